@@ -1,0 +1,48 @@
+"""Shared helpers for the parity tests (test infrastructure; may import oracle/)."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import vargp_oracle as orc
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+PARAM_KEYS = ['z', 'u_mean', 'u_tril_vec', 'log_mean', 'log_logvar', 'prior_log_mean', 'prior_log_logvar']
+GRAD_KEYS = ['z', 'u_mean', 'u_tril_vec', 'log_mean', 'log_logvar']
+
+# Tolerances (north star: ELBO rtol 1e-4 in fp32)
+RTOL_SCALAR = 1e-4
+ATOL_PRED, RTOL_PRED = 1e-3, 1e-3
+ATOL_PROBS = 1e-4
+REL_L2_GRAD = 1e-3
+
+
+def load_case(name):
+    """-> (g, params, prev, x, y, noise) with tensors rebuilt from the fixture (or regenerated
+    from the seed for the full-size case that stores outputs only)."""
+    g = np.load(os.path.join(GOLDEN, f'{name}.npz'))
+    S, F_, C, M, D, B, n_prev, seed = [int(v) for v in g['meta']]
+    if 'x' in g.files:
+        params = {k: torch.from_numpy(g[f'p_{k}']) for k in PARAM_KEYS}
+        prev = [{k: torch.from_numpy(g[f'prev{i}_{k}']) for k in ['z', 'u_mean', 'u_tril_vec']}
+                for i in range(n_prev)]
+        noise = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('n_')}
+        x, y = torch.from_numpy(g['x']), torch.from_numpy(g['y'])
+    else:
+        params, prev, x, y, noise = orc.make_problem(S, F_, C, M, D, B, n_prev=n_prev, seed=seed,
+                                                     kind=str(g['kind']))
+    return g, params, prev, x, y, noise
+
+
+def rel_l2(a, b):
+    a = torch.as_tensor(a).double().flatten()
+    b = torch.as_tensor(b).double().flatten()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def to_dev(obj, dev):
+    if isinstance(obj, dict):
+        return {k: to_dev(v, dev) for k, v in obj.items()}
+    if isinstance(obj, list):
+        return [to_dev(v, dev) for v in obj]
+    return obj.to(dev)

@@ -1,0 +1,97 @@
+"""CPU: the oracle (oracle/vargp_oracle.py) against golden vectors produced by the reference
+(tests/golden/make_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vargp_oracle as orc
+from helpers import (load_case, rel_l2, RTOL_SCALAR, ATOL_PRED, RTOL_PRED, ATOL_PROBS, REL_L2_GRAD,
+                     GRAD_KEYS, GOLDEN)
+
+E2E = ['toy_t0', 'toy_t1', 'toy_t2', 'smnist_small_t0', 'smnist_small_t1']
+
+
+@pytest.fixture(scope='module')
+def ops():
+    return np.load(f'{GOLDEN}/ops.npz')
+
+
+@pytest.mark.parametrize('tag', ['toy', 'mnist'])
+def test_rbf_gram(ops, tag):
+    th, x, y = (torch.from_numpy(ops[f'rbf_{tag}_{k}']) for k in ['theta', 'x', 'y'])
+    kuu = orc.rbf_gram(th, x)
+    kuf = orc.rbf_gram(th, x, y)
+    np.testing.assert_allclose(kuu.numpy(), ops[f'rbf_{tag}_kuu'], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(kuf.numpy(), ops[f'rbf_{tag}_kuf'], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(orc.rbf_gram(th, x, y, full_gram=True).numpy(), ops[f'rbf_{tag}_kuf'],
+                               rtol=2e-5, atol=1e-6)
+    # K_uu diagonal is exactly gamma^2
+    g2 = (2 * th[:, -1]).exp()
+    assert torch.equal(kuu.diagonal(dim1=-2, dim2=-1), g2.view(-1, 1, 1).expand(kuu.shape[:-1]))
+
+
+def test_tril_pack(ops):
+    v = torch.from_numpy(ops['tril_vec'])
+    np.testing.assert_allclose(orc.vec2tril(v).numpy(), ops['tril_mat'], rtol=1e-6, atol=0)
+    np.testing.assert_allclose(orc.mat2trilvec(orc.vec2tril(v)).numpy(), ops['tril_back'], rtol=1e-6)
+
+
+def test_linear_gaussian_ops(ops):
+    t = {k: torch.from_numpy(ops[k]) for k in ops.files if k.startswith(('lg_', 'lj_', 'lmd_', 'gc_', 'kl_'))}
+    mu, Sig, Lz, LzK = orc.linear_joint(t['lg_m'], t['lg_S'], t['lg_Kzx'], t['lg_Kzz'], t['lg_V'], t['lg_b'])
+    for got, want in [(mu, 'lj_mu'), (Sig, 'lj_Sig'), (Lz, 'lj_Lz'), (LzK, 'lj_LzKzx')]:
+        np.testing.assert_allclose(got.numpy(), ops[want], rtol=2e-4, atol=2e-5)
+    mu, var, _, _ = orc.linear_marginal_diag(t['lg_m'], t['lg_S'], t['lg_Kzz'], t['lg_Kzx'],
+                                             orc.rbf_diag(t['lg_theta']))
+    np.testing.assert_allclose(mu.numpy(), ops['lmd_mu'], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(var.numpy(), ops['lmd_var'], rtol=2e-4, atol=2e-5)
+    Lz = orc.chol(t['lg_Kzz'])
+    LzK = torch.linalg.solve_triangular(Lz, t['lg_Kzx'], upper=False)
+    mu, Sig = orc.gp_cond(t['lg_m'], t['lg_Kxx'], Lz, LzK)
+    np.testing.assert_allclose(mu.numpy(), ops['gc_mu'], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(Sig.numpy(), ops['gc_Sig'], rtol=2e-4, atol=2e-5)
+    kl = orc.mvn_kl(t['lg_m'].squeeze(-1), t['kl_Lq'], torch.zeros_like(t['lg_m'].squeeze(-1)), t['kl_Lp'])
+    np.testing.assert_allclose(kl.numpy(), ops['kl_val'], rtol=1e-5)
+
+
+def test_likelihood(ops):
+    mu, var, y, eps = (torch.from_numpy(ops[f'lik_{k}']) for k in ['mu', 'var', 'y', 'eps'])
+    np.testing.assert_allclose(orc.softmax_nll(mu, var, y, eps).numpy(), ops['lik_nll'], rtol=1e-6)
+    np.testing.assert_allclose(orc.softmax_predict(mu, var, eps).numpy(), ops['lik_probs'], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize('name', E2E)
+def test_e2e_loss_grads_predict(name):
+    g, params, prev, x, y, noise = load_case(name)
+    sc, grads = orc.elbo_step(params, prev, x, y, noise, beta=float(g['beta']), n_total=float(g['n_total']))
+    for k in ['kl_hypers', 'kl_u', 'nll', 'total']:
+        np.testing.assert_allclose(sc[k].item(), float(g[k]), rtol=RTOL_SCALAR, err_msg=k)
+    for k in GRAD_KEYS:
+        assert rel_l2(grads[k], g[f'grad_{k}']) < REL_L2_GRAD, k
+    pmu, pvar, _ = orc.forward(params, prev, x, noise)
+    np.testing.assert_allclose(pmu.numpy(), g['pred_mu'], rtol=RTOL_PRED, atol=ATOL_PRED)
+    np.testing.assert_allclose(pvar.numpy(), g['pred_var'], rtol=RTOL_PRED, atol=ATOL_PRED)
+    np.testing.assert_allclose(orc.predict(params, prev, x, noise).numpy(), g['probs'], atol=ATOL_PROBS)
+
+
+def test_e2e_full_size_cfg2():
+    """Cfg2 (S3 F10 C10 M100 D784 B512): inputs regenerated from the seed, outputs from the reference."""
+    g, params, prev, x, y, noise = load_case('smnist_full_t0')
+    sc, grads = orc.elbo_step(params, prev, x, y, noise, beta=float(g['beta']), n_total=float(g['n_total']))
+    for k in ['kl_hypers', 'kl_u', 'nll', 'total']:
+        np.testing.assert_allclose(sc[k].item(), float(g[k]), rtol=RTOL_SCALAR, err_msg=k)
+    for k in GRAD_KEYS:
+        np.testing.assert_allclose(grads[k].double().norm().item(), float(g[f'gradnorm_{k}']), rtol=1e-3)
+    assert rel_l2(grads['log_mean'], g['grad_log_mean']) < REL_L2_GRAD
+    assert rel_l2(grads['u_mean'], g['grad_u_mean']) < REL_L2_GRAD
+    assert rel_l2(grads['z'][:, :4, :], g['grad_z_head']) < REL_L2_GRAD
+
+
+def test_fp64_matches_fp32():
+    """The oracle is dtype-generic; fp64 run bounds the fp32 self-noise."""
+    params, prev, x, y, noise = orc.make_problem(2, 3, 4, 8, 6, 16, n_prev=1, seed=3, kind='toy', dtype=torch.float64)
+    sc64, _ = orc.elbo_step(params, prev, x, y, noise)
+    f32 = lambda o: {k: v.float() for k, v in o.items()}
+    sc32, _ = orc.elbo_step(f32(params), [f32(p) for p in prev], x.float(), y, f32(noise))
+    for k in sc64:
+        np.testing.assert_allclose(sc32[k].item(), sc64[k].item(), rtol=1e-4)
