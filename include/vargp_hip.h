@@ -1,0 +1,163 @@
+/*
+ * libvargp_hip — C ABI of the MI355X (gfx950) kernels behind the VAR-GP ELBO hot path.
+ *
+ * The reference (uber-research/vargp) has no FFI: its hot path is Python on top of ATen call sites
+ * (SURVEY.md §2.3).  Each entry point below replaces one group of those call sites; the reference
+ * lines are cited per function.  Conventions:
+ *   - all tensors are contiguous row-major fp32 DEVICE pointers unless a leading dimension /
+ *     stride argument says otherwise; labels are int64; the caller owns every buffer, including
+ *     the workspace (size from the matching *_workspace_bytes query);
+ *   - every function only enqueues work on `stream` and never synchronises or allocates, so the
+ *     caller may capture a sequence of calls into a hipGraph;
+ *   - return value: 0 on success, negative VARGP_E* on a bad argument / launch failure
+ *     (vargp_last_error() gives the text).  Numerical failure of a Cholesky is reported through the
+ *     device-side `info` array (0 = ok, j+1 = first non-positive pivot, LAPACK style); the factor
+ *     of a failed matrix is filled with NaN so the failure cannot go unnoticed downstream.
+ */
+#ifndef VARGP_HIP_H
+#define VARGP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* vargp_stream_t; /* a hipStream_t */
+
+#define VARGP_OK 0
+#define VARGP_EINVAL (-1)
+#define VARGP_ELAUNCH (-2)
+#define VARGP_EWORKSPACE (-3)
+
+int vargp_version(void);
+const char* vargp_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Batched strided fp32 GEMM on the f32 MFMA (v_mfma_f32_32x32x2_f32):
+ *     C[b] = alpha * op(A[b]) * op(B[b]) + beta * D[b]          op(A): M x K, op(B): K x N
+ * Replaces the einsum/bmm call sites of var_gp/gp_utils.py:18,94,96,127,131,136,178,184 and the
+ * triangular_solve call sites :89,92,124-134,175-182 (solves are products with the explicit
+ * inverse factor T = L^-1 produced by vargp_chol_inv_fwd).
+ * transX = 0: X stored row-major as op(X) (ldx = row stride); transX = 1: stored as op(X)^T.
+ * Batch index b = (i0*nb[1] + i1)*nb[2] + i2, element strides per batch dim (0 = broadcast).
+ * triA/triB: structure hint for op(A)/op(B) (0 none, 1 lower-triangular, 2 upper-triangular); the
+ * stored zeros must really be zero, the hint only clips the K range.
+ * triC: 0 full; 1 compute the lower triangle and write zeros above it; 2 compute and write only
+ * tiles that touch the lower triangle (entries above the diagonal are left unspecified / untouched).
+ * D may be NULL (beta ignored) and may alias C.
+ */
+typedef struct vargp_gemm_desc {
+  int32_t M, N, K;
+  int32_t transA, transB;
+  const float* A;
+  const float* B;
+  float* C;
+  const float* D;
+  int32_t lda, ldb, ldc, ldd;
+  int32_t nb[3];
+  int64_t sA[3], sB[3], sC[3], sD[3];
+  float alpha, beta;
+  int32_t triA, triB, triC;
+} vargp_gemm_desc;
+
+int vargp_bgemm(const vargp_gemm_desc* d, vargp_stream_t stream);
+
+/* out[i] = sum_r in[r*inner + i], r < outer   (reduction of broadcast batch dims in backward) */
+int vargp_sum_outer(const float* in, float* out, int64_t outer, int64_t inner, vargp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * RBF / ARD kernel matrix (reference: RBFKernel.compute, var_gp/kernels.py:24-56).
+ *   theta[S, D+1] = [log lengthscale_1..D, log gamma];  X[C, M, D];
+ *   Y: NULL (Y = X, symmetric K_uu: the diagonal is exactly gamma^2, kernels.py:47-48,54),
+ *      or [C, N, D] (y_shared = 0), or [N, D] shared by every class (y_shared = 1; the reference
+ *      expands the minibatch over classes, var_gp/vargp.py:106);
+ *   K[S, C, M, N] = gamma_s^2 * exp(-0.5 * (|x/sig|^2 + |y/sig|^2 - 2 (x/sig).(y/sig))), no clamp.
+ * Backward (autograd of the same lines): gK[S,C,M,N] -> gX[C,M,D], gY (NULL if not wanted; for
+ * Y = NULL both sides are accumulated into gX), gtheta[S, D+1].
+ */
+size_t vargp_rbf_workspace_bytes(int S, int C, int M, int N, int D, int backward);
+int vargp_rbf_gram_fwd(const float* theta, const float* X, const float* Y, float* K, int S, int C, int M,
+                       int N, int D, int y_shared, void* ws, size_t ws_bytes, vargp_stream_t stream);
+int vargp_rbf_gram_bwd(const float* theta, const float* X, const float* Y, const float* K, const float* gK,
+                       float* gX, float* gY, float* gtheta, int S, int C, int M, int N, int D, int y_shared,
+                       void* ws, size_t ws_bytes, vargp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Batched Cholesky with jitter + explicit inverse factor (reference: gp_utils.cholesky,
+ * var_gp/gp_utils.py:5-11, and every torch.triangular_solve(., Lz) that consumes it).
+ *   A[nbatch, n, n] symmetric (lower triangle read);  L = chol(A + eps I) lower, zeros above;
+ *   T = L^-1 (lower; NULL to skip);  logdet[nbatch] = sum_i log L_ii (NULL to skip);
+ *   info[nbatch] as described at the top.
+ * Backward: gA = d/dA of <gL, L> + <gT, T> (either may be NULL), symmetric like torch's
+ * cholesky_backward.
+ */
+size_t vargp_chol_workspace_bytes(int nbatch, int n, int backward);
+int vargp_chol_inv_fwd(const float* A, float eps, float* L, float* T, float* logdet, int32_t* info, int nbatch,
+                       int n, void* ws, size_t ws_bytes, vargp_stream_t stream);
+int vargp_chol_inv_bwd(const float* L, const float* T, const float* gL, const float* gT, float* gA, int nbatch,
+                       int n, void* ws, size_t ws_bytes, vargp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Packed lower triangle <-> matrix with softplus on the diagonal (reference: vec2tril /
+ * mat2trilvec, var_gp/gp_utils.py:22-65; packing order = torch.tril_indices, row-major).
+ */
+int vargp_vec2tril_fwd(const float* vec, float* tril, int nbatch, int m, vargp_stream_t stream);
+int vargp_vec2tril_bwd(const float* vec, const float* gtril, float* gvec, int nbatch, int m,
+                       vargp_stream_t stream);
+int vargp_mat2trilvec(const float* mat, float* vec, int nbatch, int m, vargp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Predictive marginal mean / variance reductions (reference: linear_marginal_diag,
+ * var_gp/gp_utils.py:178-186):  with P = Lz^-1 Kzx [nb, M, B], W = (Lz^-1 L_S)^T P [nb, M, B],
+ * a = Lz^-1 m [nb, M]:   mu_b = sum_m P_mb a_m;  var_b = kdiag - sum_m P_mb^2 + sum_m W_mb^2,
+ * kdiag[nb] (= gamma^2 of the sample, kernels.py:58-60).
+ */
+int vargp_predictive_diag_fwd(const float* P, const float* W, const float* a, const float* kdiag, float* mu,
+                              float* var, int nbatch, int M, int B, vargp_stream_t stream);
+int vargp_predictive_diag_bwd(const float* P, const float* W, const float* a, const float* gmu,
+                              const float* gvar, float* gP, float* gW, float* ga, float* gkdiag, int nbatch,
+                              int M, int B, vargp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * KL(N(mu_q, Lq Lq^T) || N(mu_p, Lp Lp^T)) from its triangular ingredients (reference:
+ * torch.distributions kl_divergence(MVN, MVN) as called from var_gp/vargp.py:182-190):
+ *   kl = logdet_p - logdet_q + 0.5 * (|G|_F^2 + |d|^2 - M),  G = Lp^-1 Lq [nb, M, M],
+ *   d = Lp^-1 (mu_q - mu_p) [nb, M];  logdet_* = sum log diag.
+ * Forward reduces G and d; backward is gG = gkl * G, gd = gkl * d.
+ */
+int vargp_mvn_kl_fwd(const float* G, const float* d, const float* logdet_p, const float* logdet_q, float* kl,
+                     int nbatch, int M, vargp_stream_t stream);
+int vargp_mvn_kl_bwd(const float* G, const float* d, const float* gkl, float* gG, float* gd, int nbatch, int M,
+                     vargp_stream_t stream);
+/* logdet[b] = sum_i log L[b,i,i]; backward gL[b,i,i] = g[b] / L[b,i,i] (zeros elsewhere) */
+int vargp_logdet_tril_fwd(const float* L, float* logdet, int nbatch, int n, vargp_stream_t stream);
+int vargp_logdet_tril_bwd(const float* L, const float* g, float* gL, int nbatch, int n, vargp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Monte-Carlo softmax likelihood (reference: MulticlassSoftmax, var_gp/likelihoods.py:13-63).
+ *   mu, var [S, C, B]; eps [S, F, C, B]; y int64 [B].
+ *   nll   = sum_b mean_{s,f} -log_softmax_c(mu + sqrt(var) eps)[y_b]           (likelihoods.py:33-47)
+ *   probs[B, C] = mean_{s,f} softmax_c(...)                                       (likelihoods.py:49-63)
+ * nll is accumulated with atomics into *nll, which the call zeroes first.
+ */
+int vargp_softmax_nll_fwd(const float* mu, const float* var, const float* eps, const int64_t* y, float* nll,
+                          int S, int F, int C, int B, vargp_stream_t stream);
+int vargp_softmax_nll_bwd(const float* mu, const float* var, const float* eps, const int64_t* y,
+                          const float* gnll, float* gmu, float* gvar, int S, int F, int C, int B,
+                          vargp_stream_t stream);
+int vargp_softmax_predict(const float* mu, const float* var, const float* eps, float* probs, int S, int F,
+                          int C, int B, vargp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Yogi optimiser step, fused over one flat parameter buffer (reference call site:
+ * experiments/vargp.py:23,37 -> torch_optimizer.Yogi; algorithm from Zaheer et al. 2018).
+ */
+int vargp_yogi_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                    float beta2, float eps, float bias1, float bias2, vargp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VARGP_HIP_H */

@@ -1,0 +1,82 @@
+"""GPU: VARGP.loss / backward / predict on the HIP path against (a) the golden vectors produced by
+the reference and (b) the oracle on the same inputs and noise.  Tolerances: helpers.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vargp_oracle as orc
+from helpers import (load_case, rel_l2, to_dev, RTOL_SCALAR, ATOL_PRED, RTOL_PRED, ATOL_PROBS, REL_L2_GRAD,
+                     GRAD_KEYS)
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(name, ep_var_mean=True):
+    from vargp_amd import noise
+    from gpu_common import build_gp, grads_of, DEV
+    g, params, prev, x, y, nz = load_case(name)
+    S, F_ = int(g['meta'][0]), int(g['meta'][1])
+    gp = build_gp(params, prev, S, F_, ep_var_mean)
+    xd, yd = x.to(DEV), y.to(DEV)
+    with noise.inject(**to_dev(nz, DEV)):
+        kl_h, kl_u, nll = gp.loss(xd, yd)
+        total = float(g['beta']) * kl_h + kl_u + (float(g['n_total']) / x.shape[0]) * nll
+        total.backward()
+        with torch.no_grad():
+            pmu, pvar = gp(xd)
+            probs = gp.predict(xd)
+    sc = dict(kl_hypers=kl_h.item(), kl_u=kl_u.item(), nll=nll.item(), total=total.item())
+    return g, (params, prev, x, y, nz), sc, grads_of(gp), pmu.cpu(), pvar.cpu(), probs.cpu()
+
+
+@pytest.mark.parametrize('name', ['toy_t0', 'toy_t1', 'toy_t2', 'smnist_small_t0', 'smnist_small_t1'])
+def test_loss_grads_predict_vs_reference_golden(name):
+    g, _, sc, grads, pmu, pvar, probs = _run(name)
+    for k in ['kl_hypers', 'kl_u', 'nll', 'total']:
+        np.testing.assert_allclose(sc[k], float(g[k]), rtol=RTOL_SCALAR, err_msg=k)
+    for k in GRAD_KEYS:
+        assert rel_l2(grads[k].cpu(), g[f'grad_{k}']) < REL_L2_GRAD, k
+    np.testing.assert_allclose(pmu.numpy(), g['pred_mu'], rtol=RTOL_PRED, atol=ATOL_PRED)
+    np.testing.assert_allclose(pvar.numpy(), g['pred_var'], rtol=RTOL_PRED, atol=ATOL_PRED)
+    np.testing.assert_allclose(probs.numpy(), g['probs'], atol=ATOL_PROBS)
+    np.testing.assert_allclose(probs.sum(-1).numpy(), 1.0, atol=1e-5)
+
+
+def test_full_size_cfg2_vs_reference_golden_and_oracle():
+    """BASELINE config 1: Split-MNIST task 0, S3 F10 C10 M100 D784 B512."""
+    g, (params, prev, x, y, nz), sc, grads, pmu, pvar, probs = _run('smnist_full_t0')
+    for k in ['kl_hypers', 'kl_u', 'nll', 'total']:
+        np.testing.assert_allclose(sc[k], float(g[k]), rtol=RTOL_SCALAR, err_msg=k)
+    for k in GRAD_KEYS:
+        np.testing.assert_allclose(grads[k].double().norm().item(), float(g[f'gradnorm_{k}']), rtol=1e-3)
+    assert rel_l2(grads['log_mean'].cpu(), g['grad_log_mean']) < REL_L2_GRAD
+    assert rel_l2(grads['u_mean'].cpu(), g['grad_u_mean']) < REL_L2_GRAD
+    assert rel_l2(grads['z'][:, :4, :].cpu(), g['grad_z_head']) < REL_L2_GRAD
+    np.testing.assert_allclose(pmu.numpy(), g['pred_mu'], rtol=RTOL_PRED, atol=ATOL_PRED)
+    np.testing.assert_allclose(pvar.numpy(), g['pred_var'], rtol=RTOL_PRED, atol=ATOL_PRED)
+    np.testing.assert_allclose(probs.numpy(), g['probs'], atol=ATOL_PROBS)
+    # and every gradient tensor in full against the oracle on the same inputs
+    _, og = orc.elbo_step(params, prev, x, y, nz, beta=float(g['beta']), n_total=float(g['n_total']))
+    for k in GRAD_KEYS:
+        assert rel_l2(grads[k].cpu(), og[k]) < REL_L2_GRAD, k
+
+
+def test_ep_var_mean_false_matches_oracle():
+    """ep_var_mean=False exercises the u_<t sampling + gp_cond mean path (reference vargp.py:137-152)."""
+    g, (params, prev, x, y, nz), sc, grads, *_ = _run('toy_t1', ep_var_mean=False)
+    osc, og = orc.elbo_step(params, prev, x, y, nz, beta=float(g['beta']), n_total=float(g['n_total']),
+                            ep_var_mean=False)
+    for k in ['kl_hypers', 'kl_u', 'nll', 'total']:
+        np.testing.assert_allclose(sc[k], osc[k].item(), rtol=RTOL_SCALAR, err_msg=k)
+    for k in GRAD_KEYS:
+        assert rel_l2(grads[k].cpu(), og[k]) < REL_L2_GRAD, k
+
+
+def test_state_dict_keys_and_shapes():
+    from gpu_common import build_gp
+    g, params, prev, x, y, nz = load_case('toy_t1')
+    gp = build_gp(params, prev, 3, 10)
+    sd = gp.state_dict()
+    assert sorted(sd) == sorted(['z', 'u_mean', 'u_tril_vec', 'kernel.log_mean', 'kernel.log_logvar',
+                                 'kernel.prior_log_mean', 'kernel.prior_log_logvar'])
+    assert sd['z'].shape == (4, 20, 2) and sd['u_mean'].shape == (4, 20, 1) and sd['u_tril_vec'].shape == (4, 210)

@@ -1,0 +1,103 @@
+"""ctypes binding of libvargp_hip.so (the C ABI declared in include/vargp_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a tensor is not on a ROCm
+device, the call raises.  (The CPU restatement under oracle/ is test infrastructure only.)
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libvargp_hip.so')
+
+
+class GemmDesc(Structure):
+    _fields_ = [
+        ('M', c_int32), ('N', c_int32), ('K', c_int32),
+        ('transA', c_int32), ('transB', c_int32),
+        ('A', c_void_p), ('B', c_void_p), ('C', c_void_p), ('D', c_void_p),
+        ('lda', c_int32), ('ldb', c_int32), ('ldc', c_int32), ('ldd', c_int32),
+        ('nb', c_int32 * 3),
+        ('sA', c_int64 * 3), ('sB', c_int64 * 3), ('sC', c_int64 * 3), ('sD', c_int64 * 3),
+        ('alpha', c_float), ('beta', c_float),
+        ('triA', c_int32), ('triB', c_int32), ('triC', c_int32),
+    ]
+
+
+_P = c_void_p
+_SIGNATURES = {
+    'vargp_version': (c_int, []),
+    'vargp_last_error': (c_char_p, []),
+    'vargp_bgemm': (c_int, [POINTER(GemmDesc), _P]),
+    'vargp_sum_outer': (c_int, [_P, _P, c_int64, c_int64, _P]),
+    'vargp_rbf_workspace_bytes': (c_size_t, [c_int] * 6),
+    'vargp_rbf_gram_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
+    'vargp_rbf_gram_bwd': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P,
+                                   c_size_t, _P]),
+    'vargp_chol_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'vargp_chol_inv_fwd': (c_int, [_P, c_float, _P, _P, _P, _P, c_int, c_int, _P, c_size_t, _P]),
+    'vargp_chol_inv_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, c_size_t, _P]),
+    'vargp_vec2tril_fwd': (c_int, [_P, _P, c_int, c_int, _P]),
+    'vargp_vec2tril_bwd': (c_int, [_P, _P, _P, c_int, c_int, _P]),
+    'vargp_mat2trilvec': (c_int, [_P, _P, c_int, c_int, _P]),
+    'vargp_predictive_diag_fwd': (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    'vargp_predictive_diag_bwd': (c_int, [_P] * 9 + [c_int, c_int, c_int, _P]),
+    'vargp_mvn_kl_fwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P]),
+    'vargp_mvn_kl_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P]),
+    'vargp_logdet_tril_fwd': (c_int, [_P, _P, c_int, c_int, _P]),
+    'vargp_logdet_tril_bwd': (c_int, [_P, _P, _P, c_int, c_int, _P]),
+    'vargp_softmax_nll_fwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    'vargp_softmax_nll_bwd': (c_int, [_P] * 7 + [c_int, c_int, c_int, c_int, _P]),
+    'vargp_softmax_predict': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    'vargp_yogi_step': (c_int, [_P, _P, _P, _P, c_int64] + [c_float] * 6 + [_P]),
+}
+EXPORTS = sorted(_SIGNATURES)
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the HIP library has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f'{LIB_PATH} not found: build it with `make -C vargp_amd/csrc` (or __graft_entry__.build()). '
+                'vargp_amd has no CPU fallback.')
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+class VargpHipError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        raise VargpHipError(f'{what} failed (code {rc}): {lib().vargp_last_error().decode()}')
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise VargpHipError(
+                'vargp_amd ops need tensors on a ROCm device (cuda:N); there is no CPU path in the product '
+                '(the CPU restatement lives under oracle/ and is for tests only).')
+
+
+def stream_ptr():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def workspace(nbytes, device):
+    return torch.empty((int(nbytes) + 3) // 4, dtype=torch.float32, device=device)

@@ -1,0 +1,76 @@
+// Shared helpers for the libvargp_hip kernels (gfx950 / CDNA4 only: wave64, f32 MFMA, 160 KB LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/vargp_hip.h"
+
+namespace vargp {
+
+constexpr int kWave = 64;
+
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define VARGP_REQUIRE(cond, ...)            \
+  do {                                      \
+    if (!(cond)) {                          \
+      vargp::set_error(__VA_ARGS__);        \
+      return VARGP_EINVAL;                  \
+    }                                       \
+  } while (0)
+
+static inline hipStream_t as_stream(vargp_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- wave / block reductions (64-lane wavefronts) -------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+// sum over a block of NT threads (NT multiple of 64, <= 1024); result valid in every thread
+template <int NT>
+__device__ __forceinline__ float block_sum(float v, float* red /* >= NT/64 floats of LDS */) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < NT / 64; ++i) t += red[i];
+  return t;
+}
+
+// internal GEMM parameter block (superset of vargp_gemm_desc: adds the fused RBF epilogue)
+struct GemmParams {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* D;
+  int M, N, K;
+  int lda, ldb, ldc, ldd;
+  int nb1, nb2;
+  int64_t sA[3], sB[3], sC[3], sD[3];
+  float alpha, beta;
+  int triA, triB, triC;
+  // RBF epilogue: C = g2[b0] * exp(-0.5 * (na[row] + nb[col] - 2 acc)); A is scaled by kscale[k]
+  const float* kscale;  // [nb0][ks_ld] : 1/sigma^2
+  int64_t ks_ld;
+  const float* g2;      // [nb0]
+  const float* na;      // row norms, batch strides sNa
+  const float* nbv;     // col norms, batch strides sNb
+  int64_t sNa[3], sNb[3];
+  int same_xy;
+};
+
+int launch_gemm(const GemmParams& p, int transA, int transB, int nbatch, bool rbf, hipStream_t st);
+
+}  // namespace vargp

@@ -1,0 +1,284 @@
+// Batched strided fp32 GEMM on the CDNA4 f32 matrix core (v_mfma_f32_32x32x2_f32), with an optional
+// fused RBF epilogue.  One 256-thread workgroup (4 wave64, 2x2) computes a BM x BN tile; K is walked
+// in slabs of 16 staged through LDS with a register prefetch of the next slab.
+//
+// LDS images mirror the global layout of each operand so that both the staging writes and the MFMA
+// fragment reads are bank-conflict free:
+//   K-contiguous operand  -> [row][17]   (odd row stride: 32 lanes x consecutive rows hit 32 banks)
+//   M/N-contiguous operand-> [k][rows+4] (lanes read consecutive floats)
+// MFMA 32x32x2 fragment maps (cdna guide §3): lane l holds A[i=l&31][k=l>>5], B[k=l>>5][j=l&31];
+// D register r of lane l is row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31.
+#include "common.h"
+
+namespace vargp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int BK = 16;
+
+template <bool KC, int ROWS>
+struct LdsLayout {
+  static constexpr int kStride = KC ? (BK + 1) : (ROWS + 4);
+  static constexpr int kSize = KC ? ROWS * (BK + 1) : BK * (ROWS + 4);
+  __device__ static __forceinline__ int at(int r, int k) { return KC ? r * kStride + k : k * kStride + r; }
+};
+
+// Global -> registers for one ROWS x BK slab.  Element (r,k) lives at base[(r0+r)*ld + k] (KC) or
+// base[k*ld + r0 + r] (!KC).  Out-of-range elements (r >= rmax, k >= ke) read as zero.
+template <bool KC, int ROWS, bool VEC>
+__device__ __forceinline__ void load_slab(const float* __restrict__ base, int ld, int r0, int rmax, int k0,
+                                          int ke, float (&reg)[ROWS * BK / 256]) {
+  constexpr int NPT = ROWS * BK / 256;
+  const int tid = threadIdx.x;
+  if constexpr (VEC) {
+#pragma unroll
+    for (int c = 0; c < NPT / 4; ++c) {
+      const int q = tid + 256 * c;
+      int r, k;
+      if constexpr (KC) { r = q >> 2; k = (q & 3) * 4; } else { k = q / (ROWS / 4); r = (q % (ROWS / 4)) * 4; }
+      const int gr = r0 + r, gk = k0 + k;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (KC) {
+        if (gr < rmax) {
+          const float* src = base + (int64_t)gr * ld + gk;
+          if (gk + 3 < ke) v = *reinterpret_cast<const float4*>(src);
+          else {
+            if (gk < ke) v.x = src[0];
+            if (gk + 1 < ke) v.y = src[1];
+            if (gk + 2 < ke) v.z = src[2];
+          }
+        }
+      } else {
+        if (gk < ke) {
+          const float* src = base + (int64_t)gk * ld + gr;
+          if (gr + 3 < rmax) v = *reinterpret_cast<const float4*>(src);
+          else {
+            if (gr < rmax) v.x = src[0];
+            if (gr + 1 < rmax) v.y = src[1];
+            if (gr + 2 < rmax) v.z = src[2];
+          }
+        }
+      }
+      reg[4 * c + 0] = v.x; reg[4 * c + 1] = v.y; reg[4 * c + 2] = v.z; reg[4 * c + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < NPT; ++c) {
+      const int e = tid + 256 * c;
+      int r, k;
+      if constexpr (KC) { r = e / BK; k = e % BK; } else { k = e / ROWS; r = e % ROWS; }
+      const int gr = r0 + r, gk = k0 + k;
+      float v = 0.f;
+      if (gr < rmax && gk < ke) v = KC ? base[(int64_t)gr * ld + gk] : base[(int64_t)gk * ld + gr];
+      reg[c] = v;
+    }
+  }
+}
+
+// registers -> LDS (same element <-> thread map as load_slab); optional per-k scale (KC only)
+template <bool KC, int ROWS, bool VEC, bool SCALE>
+__device__ __forceinline__ void store_slab(float* __restrict__ lds, const float (&reg)[ROWS * BK / 256],
+                                           const float* __restrict__ kscale, int k0, int ke) {
+  constexpr int NPT = ROWS * BK / 256;
+  using L = LdsLayout<KC, ROWS>;
+  const int tid = threadIdx.x;
+  if constexpr (VEC) {
+#pragma unroll
+    for (int c = 0; c < NPT / 4; ++c) {
+      const int q = tid + 256 * c;
+      if constexpr (KC) {
+        const int r = q >> 2, k = (q & 3) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = reg[4 * c + e];
+          if constexpr (SCALE) v *= (k0 + k + e < ke) ? kscale[k0 + k + e] : 0.f;
+          lds[L::at(r, k + e)] = v;
+        }
+      } else {
+        const int k = q / (ROWS / 4), r = (q % (ROWS / 4)) * 4;
+        *reinterpret_cast<float4*>(&lds[L::at(r, k)]) =
+            make_float4(reg[4 * c], reg[4 * c + 1], reg[4 * c + 2], reg[4 * c + 3]);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < NPT; ++c) {
+      const int e = tid + 256 * c;
+      int r, k;
+      if constexpr (KC) { r = e / BK; k = e % BK; } else { k = e / ROWS; r = e % ROWS; }
+      float v = reg[c];
+      if constexpr (SCALE) v *= (k0 + k < ke) ? kscale[k0 + k] : 0.f;
+      lds[L::at(r, k)] = v;
+    }
+  }
+}
+
+template <int BM, int BN, bool AKC, bool BKC, bool VEC, bool RBF>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+  using LA = LdsLayout<AKC, BM>;
+  using LB = LdsLayout<BKC, BN>;
+  __shared__ __attribute__((aligned(16))) float lds[LA::kSize + LB::kSize + 8];
+  float* As = lds;
+  float* Bs = lds + ((LA::kSize + 3) & ~3);
+
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int b = blockIdx.y;
+  const int i2 = b % p.nb2, i1 = (b / p.nb2) % p.nb1, i0 = b / (p.nb2 * p.nb1);
+  const float* A = p.A + i0 * p.sA[0] + i1 * p.sA[1] + i2 * p.sA[2];
+  const float* B = p.B + i0 * p.sB[0] + i1 * p.sB[1] + i2 * p.sB[2];
+  float* C = p.C + i0 * p.sC[0] + i1 * p.sC[1] + i2 * p.sC[2];
+  const float* D = p.D ? p.D + i0 * p.sD[0] + i1 * p.sD[1] + i2 * p.sD[2] : nullptr;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+
+  // tiles strictly above the diagonal of a lower-triangular result
+  if (p.triC != 0 && n0 >= m0 + BM) {
+    if (p.triC == 1) {
+      for (int e = tid; e < BM * BN; e += 256) {
+        const int r = m0 + e / BN, c = n0 + e % BN;
+        if (r < p.M && c < p.N) C[(int64_t)r * p.ldc + c] = 0.f;
+      }
+    }
+    return;
+  }
+
+  int ks = 0, ke = p.K;
+  if (p.triA == 1) ke = min(ke, m0 + BM);
+  if (p.triA == 2) ks = max(ks, m0);
+  if (p.triB == 1) ks = max(ks, n0);
+  if (p.triB == 2) ke = min(ke, n0 + BN);
+  ks = (ks / BK) * BK;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int c = 0; c < TN; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+
+  const float* kscale = RBF ? p.kscale + i0 * p.ks_ld : nullptr;
+
+  float ra[BM * BK / 256], rb[BN * BK / 256];
+  if (ks < ke) {
+    load_slab<AKC, BM, VEC>(A, p.lda, m0, p.M, ks, ke, ra);
+    load_slab<BKC, BN, VEC>(B, p.ldb, n0, p.N, ks, ke, rb);
+  }
+  for (int k0 = ks; k0 < ke; k0 += BK) {
+    __syncthreads();  // previous slab fully consumed
+    store_slab<AKC, BM, VEC, RBF>(As, ra, kscale, k0, ke);
+    store_slab<BKC, BN, VEC, false>(Bs, rb, nullptr, k0, ke);
+    __syncthreads();
+    if (k0 + BK < ke) {
+      load_slab<AKC, BM, VEC>(A, p.lda, m0, p.M, k0 + BK, ke, ra);
+      load_slab<BKC, BN, VEC>(B, p.ldb, n0, p.N, k0 + BK, ke, rb);
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      const int k = 2 * kk + lh;
+      float af[TM], bf[TN];
+#pragma unroll
+      for (int a = 0; a < TM; ++a) af[a] = As[LA::at(wm0 + 32 * a + li, k)];
+#pragma unroll
+      for (int c = 0; c < TN; ++c) bf[c] = Bs[LB::at(wn0 + 32 * c + li, k)];
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int c = 0; c < TN; ++c)
+          acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[c], acc[a][c], 0, 0, 0);
+    }
+  }
+
+  // epilogue
+  float g2 = 0.f;
+  const float *na = nullptr, *nbv = nullptr;
+  if constexpr (RBF) {
+    g2 = p.g2[i0];
+    na = p.na + i0 * p.sNa[0] + i1 * p.sNa[1] + i2 * p.sNa[2];
+    nbv = p.nbv + i0 * p.sNb[0] + i1 * p.sNb[1] + i2 * p.sNb[2];
+  }
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+#pragma unroll
+    for (int c = 0; c < TN; ++c) {
+      const int col = n0 + wn0 + 32 * c + li;
+      float nbc = 0.f;
+      if constexpr (RBF) nbc = (col < p.N) ? nbv[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < p.M && col < p.N) {
+          float v;
+          if constexpr (RBF) {
+            const float d2 = na[row] + nbc - 2.f * acc[a][c][r];
+            v = (p.same_xy && row == col) ? g2 : g2 * expf(-0.5f * d2);
+          } else {
+            v = p.alpha * acc[a][c][r];
+            if (D) v += p.beta * D[(int64_t)row * p.ldd + col];
+            if (p.triC == 1 && col > row) v = 0.f;
+          }
+          C[(int64_t)row * p.ldc + col] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, bool VEC, bool RBF>
+static void dispatch_layout(const GemmParams& p, int transA, int transB, dim3 grid, hipStream_t st) {
+  // op(A) K-contiguous <=> transA == 0;  op(B) K-contiguous <=> transB == 1
+  const bool akc = transA == 0, bkc = transB == 1;
+  if constexpr (RBF) {
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true, VEC, true>), grid, dim3(256), 0, st, p);
+  } else {
+    if (akc && bkc) hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true, VEC, false>), grid, dim3(256), 0, st, p);
+    else if (akc && !bkc) hipLaunchKernelGGL((gemm_kernel<BM, BN, true, false, VEC, false>), grid, dim3(256), 0, st, p);
+    else if (!akc && bkc) hipLaunchKernelGGL((gemm_kernel<BM, BN, false, true, VEC, false>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_kernel<BM, BN, false, false, VEC, false>), grid, dim3(256), 0, st, p);
+  }
+}
+
+static bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+int launch_gemm(const GemmParams& p, int transA, int transB, int nbatch, bool rbf, hipStream_t st) {
+  if (p.M <= 0 || p.N <= 0 || nbatch <= 0) return VARGP_OK;
+  VARGP_REQUIRE(nbatch <= 65535, "bgemm: batch %d exceeds 65535", nbatch);
+  bool vec = aligned16(p.A) && aligned16(p.B) && (p.lda % 4 == 0) && (p.ldb % 4 == 0);
+  for (int i = 0; i < 3; ++i) vec = vec && (p.sA[i] % 4 == 0) && (p.sB[i] % 4 == 0);
+  const int64_t big_tiles = (int64_t)cdiv(p.M, 128) * cdiv(p.N, 128) * nbatch;
+  const bool big = big_tiles >= 192;
+  if (big) {
+    dim3 grid(cdiv(p.M, 128) * cdiv(p.N, 128), nbatch);
+    if (rbf) { if (vec) dispatch_layout<128, 128, true, true>(p, 0, 1, grid, st); else dispatch_layout<128, 128, false, true>(p, 0, 1, grid, st); }
+    else     { if (vec) dispatch_layout<128, 128, true, false>(p, transA, transB, grid, st); else dispatch_layout<128, 128, false, false>(p, transA, transB, grid, st); }
+  } else {
+    dim3 grid(cdiv(p.M, 64) * cdiv(p.N, 64), nbatch);
+    if (rbf) { if (vec) dispatch_layout<64, 64, true, true>(p, 0, 1, grid, st); else dispatch_layout<64, 64, false, true>(p, 0, 1, grid, st); }
+    else     { if (vec) dispatch_layout<64, 64, true, false>(p, transA, transB, grid, st); else dispatch_layout<64, 64, false, false>(p, transA, transB, grid, st); }
+  }
+  return check_launch("bgemm");
+}
+
+}  // namespace vargp
+
+extern "C" int vargp_bgemm(const vargp_gemm_desc* d, vargp_stream_t stream) {
+  using namespace vargp;
+  VARGP_REQUIRE(d != nullptr, "bgemm: null descriptor");
+  VARGP_REQUIRE(d->A && d->B && d->C, "bgemm: null operand");
+  VARGP_REQUIRE(d->M >= 0 && d->N >= 0 && d->K >= 0, "bgemm: negative dims");
+  GemmParams p{};
+  p.A = d->A; p.B = d->B; p.C = d->C; p.D = d->D;
+  p.M = d->M; p.N = d->N; p.K = d->K;
+  p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.ldd = d->ldd;
+  const int nb0 = d->nb[0] > 0 ? d->nb[0] : 1;
+  p.nb1 = d->nb[1] > 0 ? d->nb[1] : 1;
+  p.nb2 = d->nb[2] > 0 ? d->nb[2] : 1;
+  for (int i = 0; i < 3; ++i) { p.sA[i] = d->sA[i]; p.sB[i] = d->sB[i]; p.sC[i] = d->sC[i]; p.sD[i] = d->sD[i]; }
+  p.alpha = d->alpha; p.beta = d->D ? d->beta : 0.f;
+  p.triA = d->triA; p.triB = d->triB; p.triC = d->triC;
+  return launch_gemm(p, d->transA, d->transB, nb0 * p.nb1 * p.nb2, false, as_stream(stream));
+}

@@ -1,0 +1,266 @@
+// RBF / ARD kernel-matrix construction and its backward (reference: RBFKernel.compute,
+// var_gp/kernels.py:24-56).  The inner products run on the f32 MFMA through gemm.hip; this file has
+// the pre-pass (1/sigma^2, gamma^2, weighted squared row norms), the backward pre-pass
+// (W = gK o K and its row/column sums) and the backward finalisation (gX, gY, gtheta from W.Y).
+//
+//   d2_ij  = sum_d w_d (x_id - y_jd)^2 = na_i + nb_j - 2 sum_d w_d x_id y_jd,   w = exp(-2 theta_d)
+//   K_ij   = g2 exp(-d2_ij / 2),  g2 = exp(2 theta_D)
+//   with W = gK o K, r = rowsum W, c = colsum W, P = W Y, Q = W^T X:
+//   gX_i   = -sum_s w_s o (r_i x_i - P_i)          gY_j = -sum_s w_s o (c_j y_j - Q_j)
+//   gth_sd = w_sd [ sum_i x_id (r_i x_id - 2 P_id) + sum_j c_j y_jd^2 ]      gth_sD = 2 sum W
+#include "common.h"
+
+namespace vargp {
+
+struct RbfWs {
+  float *w, *g2, *na, *nb, *Wm, *W2, *r, *c, *P, *Q;
+  int64_t Dp;
+  size_t bytes;
+};
+
+static RbfWs carve(void* ws, int S, int C, int M, int N, int D, bool backward) {
+  RbfWs o{};
+  o.Dp = round_up(D, 4);
+  float* p = reinterpret_cast<float*>(ws);
+  auto take = [&](int64_t n) { float* q = p; p += round_up(n, 64); return q; };
+  o.w = take((int64_t)S * o.Dp);
+  o.g2 = take(S);
+  if (!backward) {
+    o.na = take((int64_t)S * C * M);
+    o.nb = take((int64_t)S * C * N);
+  } else {
+    o.Wm = take((int64_t)S * C * M * N);
+    o.W2 = take((int64_t)S * C * M * N);
+    o.r = take((int64_t)S * C * M);
+    o.c = take((int64_t)S * C * N);
+    o.P = take((int64_t)S * C * M * D);
+    o.Q = take((int64_t)S * C * N * D);
+  }
+  o.bytes = (size_t)((char*)p - (char*)ws);
+  return o;
+}
+
+__global__ void rbf_prep_kernel(const float* __restrict__ theta, float* __restrict__ w, float* __restrict__ g2,
+                                int D, int64_t Dp) {
+  const int s = blockIdx.x;
+  const float* th = theta + (int64_t)s * (D + 1);
+  for (int d = threadIdx.x; d < Dp; d += blockDim.x) w[s * Dp + d] = d < D ? expf(-2.f * th[d]) : 0.f;
+  if (threadIdx.x == 0) g2[s] = expf(2.f * th[D]);
+}
+
+// nrm[s][row] = sum_d w[s][d] x[row][d]^2 ; one wave per row, grid (ceil(rows/4), S)
+__global__ __launch_bounds__(256) void rbf_norm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       float* __restrict__ nrm, int64_t rows, int D, int64_t Dp) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int s = blockIdx.y, lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + row * D;
+  const float* ws = w + s * Dp;
+  float acc = 0.f;
+  for (int d = lane; d < D; d += 64) { const float v = xr[d]; acc = fmaf(v * v, ws[d], acc); }
+  acc = wave_sum(acc);
+  if (lane == 0) nrm[(int64_t)s * rows + row] = acc;
+}
+
+// W = gK o K, r = rowsum(W); one wave per row of the flattened [nrow_total, N] matrix.
+// tot[s] += sum(W) (for dlog gamma = 2 sum W), rows_per_s rows belong to each sample.
+__global__ __launch_bounds__(256) void rbf_w_rows_kernel(const float* __restrict__ K, const float* __restrict__ gK,
+                                                         float* __restrict__ W, float* __restrict__ r,
+                                                         float* __restrict__ gtheta, int64_t nrows, int N,
+                                                         int64_t rows_per_s, int D) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= nrows) return;
+  const float* k = K + row * N;
+  const float* g = gK + row * N;
+  float* wr = W + row * N;
+  float acc = 0.f;
+  for (int n = lane; n < N; n += 64) { const float v = k[n] * g[n]; wr[n] = v; acc += v; }
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    r[row] = acc;
+    atomicAdd(&gtheta[(row / rows_per_s) * (D + 1) + D], 2.f * acc);
+  }
+}
+
+// c[b][n] = sum_m W[b][m][n]; grid (ceil(N/256), nb)
+__global__ __launch_bounds__(256) void rbf_w_cols_kernel(const float* __restrict__ W, float* __restrict__ c, int M,
+                                                         int N) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const int64_t b = blockIdx.y;
+  if (n >= N) return;
+  const float* w = W + b * M * N + n;
+  float acc = 0.f;
+  for (int m = 0; m < M; ++m) acc += w[(int64_t)m * N];
+  c[b * N + n] = acc;
+}
+
+// square case (Y = X): W <- W + W^T (out of place into Ws), r <- r + c.  grid (ceil(M*M/256), nb)
+__global__ __launch_bounds__(256) void rbf_w_sym_kernel(const float* __restrict__ W, float* __restrict__ Ws, int M) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int64_t b = blockIdx.y;
+  if (e >= M * M) return;
+  const int i = e / M, j = e % M;
+  const float* w = W + b * M * M;
+  Ws[b * M * M + e] = w[e] + w[(int64_t)j * M + i];
+}
+__global__ void rbf_add_kernel(float* __restrict__ r, const float* __restrict__ c, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) r[i] += c[i];
+}
+
+// Finalise one side.  rows = points of this side (flattened over classes), S samples.
+//   g[row][d]  (+)= -sum_s w_sd (R_s,row x_row,d - P_s,row,d)            (if g != null)
+//   gtheta[s][d] += w_sd sum_row x (R x - kappa P)                         (P may be null -> 0)
+// block = 64 d-columns x 4 row lanes, RPB rows per block.
+constexpr int RPB = 32;
+__global__ __launch_bounds__(256) void rbf_final_kernel(const float* __restrict__ x, const float* __restrict__ R,
+                                                        const float* __restrict__ P, const float* __restrict__ w,
+                                                        float* __restrict__ g, float* __restrict__ gtheta,
+                                                        int64_t rows, int D, int64_t Dp, int S, float kappa,
+                                                        int accumulate) {
+  __shared__ float red[4][64];
+  const int dx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int d = blockIdx.x * 64 + dx;
+  const int64_t row0 = (int64_t)blockIdx.y * RPB;
+  const bool dok = d < D;
+  float xa[RPB / 4], ga[RPB / 4];
+#pragma unroll
+  for (int j = 0; j < RPB / 4; ++j) {
+    const int64_t row = row0 + ry + 4 * j;
+    xa[j] = (dok && row < rows) ? x[row * D + d] : 0.f;
+    ga[j] = 0.f;
+  }
+  for (int s = 0; s < S; ++s) {
+    const float wv = dok ? w[s * Dp + d] : 0.f;
+    float th = 0.f;
+#pragma unroll
+    for (int j = 0; j < RPB / 4; ++j) {
+      const int64_t row = row0 + ry + 4 * j;
+      if (row < rows) {
+        const float rr = R[(int64_t)s * rows + row];
+        const float pv = (P && dok) ? P[((int64_t)s * rows + row) * D + d] : 0.f;
+        const float rx = rr * xa[j];
+        ga[j] -= wv * (rx - pv);
+        th += xa[j] * (rx - kappa * pv);
+      }
+    }
+    __syncthreads();
+    red[ry][dx] = th;
+    __syncthreads();
+    if (ry == 0 && dok) {
+      const float t = red[0][dx] + red[1][dx] + red[2][dx] + red[3][dx];
+      atomicAdd(&gtheta[(int64_t)s * (D + 1) + d], wv * t);
+    }
+  }
+  if (g && dok) {
+#pragma unroll
+    for (int j = 0; j < RPB / 4; ++j) {
+      const int64_t row = row0 + ry + 4 * j;
+      if (row < rows) {
+        if (accumulate) g[row * D + d] += ga[j]; else g[row * D + d] = ga[j];
+      }
+    }
+  }
+}
+
+}  // namespace vargp
+
+using namespace vargp;
+
+extern "C" size_t vargp_rbf_workspace_bytes(int S, int C, int M, int N, int D, int backward) {
+  return carve(nullptr, S, C, M, N, D, backward != 0).bytes + 256;
+}
+
+extern "C" int vargp_rbf_gram_fwd(const float* theta, const float* X, const float* Y, float* K, int S, int C, int M,
+                                  int N, int D, int y_shared, void* ws, size_t ws_bytes, vargp_stream_t stream) {
+  VARGP_REQUIRE(theta && X && K && ws, "rbf_gram_fwd: null pointer");
+  VARGP_REQUIRE(S > 0 && C > 0 && M > 0 && D > 0, "rbf_gram_fwd: bad dims");
+  const bool self = (Y == nullptr);
+  if (self) { N = M; y_shared = 0; }
+  VARGP_REQUIRE(N > 0, "rbf_gram_fwd: bad N");
+  VARGP_REQUIRE(ws_bytes >= vargp_rbf_workspace_bytes(S, C, M, N, D, 0), "rbf_gram_fwd: workspace too small");
+  hipStream_t st = as_stream(stream);
+  RbfWs o = carve(ws, S, C, M, N, D, false);
+  hipLaunchKernelGGL(rbf_prep_kernel, dim3(S), dim3(256), 0, st, theta, o.w, o.g2, D, o.Dp);
+  const int64_t xrows = (int64_t)C * M, yrows = y_shared ? N : (int64_t)C * N;
+  hipLaunchKernelGGL(rbf_norm_kernel, dim3(cdiv(xrows, 4), S), dim3(256), 0, st, X, o.w, o.na, xrows, D, o.Dp);
+  if (!self)
+    hipLaunchKernelGGL(rbf_norm_kernel, dim3(cdiv(yrows, 4), S), dim3(256), 0, st, Y, o.w, o.nb, yrows, D, o.Dp);
+  // shared Y: the classes' inducing points are just more rows of one [C*M, D] x [D, N] product
+  const int Cb = y_shared ? 1 : C, Mb = y_shared ? C * M : M;
+  GemmParams p{};
+  p.A = X; p.B = self ? X : Y; p.C = K; p.D = nullptr;
+  p.M = Mb; p.N = N; p.K = D; p.lda = D; p.ldb = D; p.ldc = N; p.ldd = 0;
+  p.nb1 = Cb; p.nb2 = 1;
+  p.sA[0] = 0; p.sA[1] = (int64_t)Mb * D;
+  p.sB[0] = 0; p.sB[1] = y_shared ? 0 : (int64_t)N * D;
+  p.sC[0] = (int64_t)Cb * Mb * N; p.sC[1] = (int64_t)Mb * N;
+  p.alpha = 1.f; p.beta = 0.f;
+  p.kscale = o.w; p.ks_ld = o.Dp; p.g2 = o.g2;
+  p.na = o.na; p.sNa[0] = xrows; p.sNa[1] = Mb;
+  p.nbv = self ? o.na : o.nb; p.sNb[0] = self ? xrows : yrows; p.sNb[1] = (self || !y_shared) ? N : 0;
+  p.same_xy = self ? 1 : 0;
+  int rc = launch_gemm(p, 0, 1, S * Cb, true, st);
+  if (rc) return rc;
+  return check_launch("rbf_gram_fwd");
+}
+
+extern "C" int vargp_rbf_gram_bwd(const float* theta, const float* X, const float* Y, const float* K, const float* gK,
+                                  float* gX, float* gY, float* gtheta, int S, int C, int M, int N, int D,
+                                  int y_shared, void* ws, size_t ws_bytes, vargp_stream_t stream) {
+  VARGP_REQUIRE(theta && X && K && gK && gtheta && ws, "rbf_gram_bwd: null pointer");
+  const bool self = (Y == nullptr);
+  if (self) { N = M; y_shared = 0; gY = nullptr; }
+  VARGP_REQUIRE(ws_bytes >= vargp_rbf_workspace_bytes(S, C, M, N, D, 1), "rbf_gram_bwd: workspace too small");
+  hipStream_t st = as_stream(stream);
+  RbfWs o = carve(ws, S, C, M, N, D, true);
+  const int Cb = y_shared ? 1 : C, Mb = y_shared ? C * M : M;
+  const int64_t xrows = (int64_t)C * M, yrows = y_shared ? N : (int64_t)C * N;
+  const int nb = S * Cb;
+
+  (void)hipMemsetAsync(gtheta, 0, sizeof(float) * (size_t)S * (D + 1), st);
+  hipLaunchKernelGGL(rbf_prep_kernel, dim3(S), dim3(256), 0, st, theta, o.w, o.g2, D, o.Dp);
+  const int64_t nrows = (int64_t)S * xrows;
+  float* Wfirst = self ? o.W2 : o.Wm;  // self: raw W goes to W2, W + W^T to Wm
+  hipLaunchKernelGGL(rbf_w_rows_kernel, dim3(cdiv(nrows, 4)), dim3(256), 0, st, K, gK, Wfirst, o.r, gtheta, nrows, N,
+                     xrows, D);
+  hipLaunchKernelGGL(rbf_w_cols_kernel, dim3(cdiv(N, 256), nb), dim3(256), 0, st, Wfirst, o.c, Mb, N);
+  if (self) {
+    hipLaunchKernelGGL(rbf_w_sym_kernel, dim3(cdiv((int64_t)M * M, 256), nb), dim3(256), 0, st, Wfirst, o.Wm, M);
+    hipLaunchKernelGGL(rbf_add_kernel, dim3(cdiv(nrows, 256)), dim3(256), 0, st, o.r, o.c, nrows);
+  }
+  // P = W . Y   ([Mb, N] x [N, D]) per (s, class-batch)
+  GemmParams p{};
+  p.A = o.Wm; p.B = self ? X : Y; p.C = o.P;
+  p.M = Mb; p.N = D; p.K = N; p.lda = N; p.ldb = D; p.ldc = D;
+  p.nb1 = Cb; p.nb2 = 1;
+  p.sA[0] = (int64_t)Cb * Mb * N; p.sA[1] = (int64_t)Mb * N;
+  p.sB[0] = 0; p.sB[1] = y_shared ? 0 : (int64_t)N * D;
+  p.sC[0] = (int64_t)Cb * Mb * D; p.sC[1] = (int64_t)Mb * D;
+  p.alpha = 1.f;
+  int rc = launch_gemm(p, 0, 0, nb, false, st);
+  if (rc) return rc;
+  const dim3 gx(cdiv(D, 64), cdiv(xrows, RPB));
+  hipLaunchKernelGGL(rbf_final_kernel, gx, dim3(256), 0, st, X, o.r, o.P, o.w, gX, gtheta, xrows, D, o.Dp, S,
+                     self ? 1.f : 2.f, 0);
+  if (!self) {
+    const float* Qp = nullptr;
+    if (gY) {  // Q = W^T . X  ([N, Mb] x [Mb, D])
+      GemmParams q{};
+      q.A = o.Wm; q.B = X; q.C = o.Q;
+      q.M = N; q.N = D; q.K = Mb; q.lda = N; q.ldb = D; q.ldc = D;
+      q.nb1 = Cb; q.nb2 = 1;
+      q.sA[0] = (int64_t)Cb * Mb * N; q.sA[1] = (int64_t)Mb * N;
+      q.sB[0] = 0; q.sB[1] = (int64_t)Mb * D;
+      q.sC[0] = (int64_t)Cb * N * D; q.sC[1] = (int64_t)N * D;
+      q.alpha = 1.f;
+      rc = launch_gemm(q, 1, 0, nb, false, st);
+      if (rc) return rc;
+      Qp = o.Q;
+    }
+    const dim3 gy(cdiv(D, 64), cdiv(yrows, RPB));
+    hipLaunchKernelGGL(rbf_final_kernel, gy, dim3(256), 0, st, Y, o.c, Qp, o.w, gY, gtheta, yrows, D, o.Dp, S, 0.f, 0);
+  }
+  return check_launch("rbf_gram_bwd");
+}

@@ -1,0 +1,70 @@
+"""RBF / ARD kernel with a variational Normal over log-hyperparameters.
+
+API of the reference's `var_gp.kernels.RBFKernel` (var_gp/kernels.py:7-77); the kernel matrices are
+built by `vargp_rbf_gram_{fwd,bwd}` (f32-MFMA distance GEMM with fused exp epilogue).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import noise, ops
+
+
+class RBFKernel(nn.Module):
+    def __init__(self, in_size, prior_log_mean=None, prior_log_logvar=None, map_est=False):
+        super().__init__()
+        self.map_est = map_est
+        # variational parameters over theta = [log lengthscale_1..D, log gamma]  (kernels.py:14-17)
+        self.log_mean = nn.Parameter(math.log(0.5) + 0.05 * torch.randn(in_size + 1))
+        self.log_logvar = nn.Parameter(torch.full((in_size + 1,), -2.0))
+        # hyper-prior (kernels.py:19-22)
+        self.register_buffer('prior_log_mean', torch.zeros(in_size + 1) if prior_log_mean is None
+                             else prior_log_mean.detach().clone())
+        self.register_buffer('prior_log_logvar', torch.zeros(in_size + 1) if prior_log_logvar is None
+                             else prior_log_logvar.detach().clone())
+
+    def compute(self, kern_samples, x, y=None):
+        """kern_samples (S, D+1); x (...batch, M, D); y (...batch, N, D) or None (= x).
+        Returns (S, ...batch, M, N)  (kernels.py:24-56).  A `y` that is an expand() of one (N, D)
+        block over the batch dims (how the reference feeds the minibatch, vargp.py:106) is consumed
+        without materialising the copies."""
+        batch = x.shape[:-2]
+        M, D = x.shape[-2:]
+        X = x.reshape(-1, M, D)
+        Y, shared = None, False
+        if y is not None:
+            N = y.shape[-2]
+            if y.dim() == 2 or all(st == 0 or sz == 1 for st, sz in zip(y.stride()[:-2], y.shape[:-2])):
+                Y, shared = y[(0,) * (y.dim() - 2)], True
+            else:
+                Y = y.expand(*batch, N, D).reshape(-1, N, D)
+        K = ops.rbf_gram(kern_samples, X, Y, shared)
+        return K.reshape(kern_samples.shape[0], *batch, M, K.shape[-1])
+
+    def compute_diag(self, kern_samples):
+        """gamma^2 as (S, 1, 1)  (kernels.py:58-60)."""
+        return (2.0 * kern_samples[..., -1:]).exp().unsqueeze(-2)
+
+    def sample_hypers(self, n_hypers):
+        """reparameterised theta ~ N(log_mean, exp(log_logvar))  (kernels.py:62-68)."""
+        if self.map_est:
+            return self.log_mean.unsqueeze(0)
+        eps = noise.draw('eps_theta', (n_hypers, self.log_mean.shape[0]), self.log_mean.device)
+        return self.log_mean + eps * self.log_logvar.exp().sqrt()
+
+    def kl_hypers(self):
+        """sum_d KL(q(theta_d) || p(theta_d)), both diagonal Normals  (kernels.py:70-77).
+        785-element elementwise math: stays in torch."""
+        if self.map_est:
+            return torch.tensor(0.0, device=self.log_mean.device)
+        ratio = (self.log_logvar - self.prior_log_logvar).exp()
+        t1 = (self.log_mean - self.prior_log_mean).pow(2) / self.prior_log_logvar.exp()
+        return (0.5 * (ratio + t1 - 1.0 - (self.log_logvar - self.prior_log_logvar))).sum()
+
+
+class DeepRBFKernel(RBFKernel):
+    """Deep-kernel ablation of the reference (kernels.py:80-96): out of scope for the HIP hot path."""
+
+    def __init__(self, *a, **k):
+        raise NotImplementedError('DeepRBFKernel (dkl=True ablation) is outside the MI355X hot-path scope')

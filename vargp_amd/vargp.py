@@ -1,0 +1,184 @@
+"""VAR-GP model: API of the reference's `var_gp.vargp.VARGP` (var_gp/vargp.py:11-243) with the ELBO
+hot path on the HIP kernels (see gp_utils.py / ops.py).
+
+Differences that do not change results:
+  * the minibatch is never expanded over classes (reference vargp.py:106): the kernel-matrix op takes
+    the shared (B, D) block directly;
+  * for tasks t > 0 the prior covariance of p(u_t | u_<t, theta) does not depend on the u_<t sample,
+    so its Cholesky is computed once per (s, c) instead of n_v times (reference vargp.py:146-155), and
+    with ep_var_mean=True (the default) the KL does not depend on the u_<t sample at all,
+    so that sample is not drawn.
+"""
+import torch
+import torch.nn as nn
+
+from . import gp_utils, noise, ops
+from .gp_utils import vec2tril, mat2trilvec, cholesky, rev_cholesky, gp_cond, linear_joint, linear_marginal_diag
+from .kernels import RBFKernel, DeepRBFKernel
+from .likelihoods import MulticlassSoftmax
+from .ops import LOWER
+
+
+class VARGP(nn.Module):
+    def __init__(self, z_init, kernel, likelihood, n_var_samples=1, ep_var_mean=True, prev_params=None):
+        super().__init__()
+        self.var_mean_mask = float(ep_var_mean)
+        # frozen earlier tasks: plain dicts, not buffers (same as the reference, vargp.py:17-20);
+        # u_tril is materialised lazily on first use because that needs the device the params live on
+        self.prev_params = [dict(z=p['z'], u_mean=p['u_mean'], u_tril_vec=p['u_tril_vec'])
+                            for p in (prev_params or [])]
+        self.M = z_init.size(-2)
+        self.kernel = kernel
+        self.n_v = n_var_samples
+        self.likelihood = likelihood
+
+        self.z = nn.Parameter(z_init.detach().clone())
+        out_size = self.z.size(0)
+        self.u_mean = nn.Parameter(torch.empty(out_size, self.M, 1).normal_(0., .5))
+        # packed identity (vargp.py:32-33): diagonal entries 1 (softplus(1) = 1.3133 effective)
+        eye_vec = torch.zeros(self.M * (self.M + 1) // 2)
+        idx = torch.arange(self.M)
+        eye_vec[idx * (idx + 1) // 2 + idx] = 1.0
+        self.u_tril_vec = nn.Parameter(eye_vec.unsqueeze(0).repeat(out_size, 1))
+
+    # ------------------------------------------------------------------------------------------
+    def _prev(self, i):
+        """previous task i as device tensors with its u_tril (vec2tril once, cached)."""
+        p = self.prev_params[i]
+        dev = self.z.device
+        if 'u_tril' not in p or p['u_tril'].device != dev:
+            for k in ('z', 'u_mean', 'u_tril_vec'):
+                p[k] = p[k].detach().to(dev)
+            with torch.no_grad():
+                p['u_tril'] = vec2tril(p['u_tril_vec'])
+        return p
+
+    def compute_q(self, theta, cache=None):
+        """Fold previous tasks into q(u_<t | theta) and q(u_<=t | theta)  (vargp.py:35-88).
+        Returns mu_lt, S_lt, mu_leq_t, S_leq_t, z_leq_t."""
+        n_hypers = theta.size(0)
+        p0 = self._prev(0)
+        z_lt = p0['z']
+        mu_lt = p0['u_mean'].unsqueeze(0).expand(n_hypers, -1, -1, -1)
+        S_lt = rev_cholesky(p0['u_tril']).unsqueeze(0).expand(n_hypers, -1, -1, -1)
+
+        for i in range(1, len(self.prev_params)):
+            p = self._prev(i)
+            Kzx = self.kernel.compute(theta, z_lt, p['z'])
+            Kzz = self.kernel.compute(theta, z_lt)
+            V = rev_cholesky(p['u_tril']).unsqueeze(0)
+            b = p['u_mean'].unsqueeze(0)
+            mu_lt, S_lt = linear_joint(mu_lt, S_lt, Kzx, Kzz, V, b)
+            z_lt = torch.cat([z_lt, p['z']], dim=-2)
+
+        Kzx = self.kernel.compute(theta, z_lt, self.z)
+        Kzz = self.kernel.compute(theta, z_lt)
+        V = rev_cholesky(vec2tril(self.u_tril_vec, self.M)).unsqueeze(0)
+        b = self.u_mean.unsqueeze(0)
+        cache_leq_t = dict()
+        mu_leq_t, S_leq_t = linear_joint(mu_lt, S_lt, Kzx, Kzz, V, b, cache=cache_leq_t)
+        z_leq_t = torch.cat([z_lt, self.z], dim=-2)
+
+        if isinstance(cache, dict):
+            cache['Lz_lt'] = cache_leq_t['Lz']
+            cache['Tz_lt'] = cache_leq_t['Tz']
+            cache['Lz_lt_Kz_lt_z_t'] = cache_leq_t['Lz_Kzx']
+        return mu_lt, S_lt, mu_leq_t, S_leq_t, z_leq_t
+
+    def compute_pf_diag(self, theta, x, mu_leq_t, S_leq_t, z_leq_t, cache=None):
+        """p(f) = int p(f | u_<=t) q(u_<=t): mean and variance diagonals (S, C, B)  (vargp.py:90-113)."""
+        Kzz = self.kernel.compute(theta, z_leq_t)
+        Kzx = self.kernel.compute(theta, z_leq_t, x)          # x (B, D) shared by all classes
+        Kxx_diag = self.kernel.compute_diag(theta)
+        return linear_marginal_diag(mu_leq_t, S_leq_t, Kzz, Kzx, Kxx_diag, cache=cache)
+
+    def forward(self, x, loss_cache=False):
+        """x (B, D) -> pred_mu, pred_var (S, C, B); fills `loss_cache` with the KL ingredients if it is
+        a dict  (vargp.py:115-175)."""
+        theta = self.kernel.sample_hypers(self.n_v)
+
+        if self.prev_params:
+            cache_q = dict()
+            mu_lt, S_lt, mu_leq_t, S_leq_t, z_leq_t = self.compute_q(theta, cache=cache_q)
+            pred_mu, pred_var = self.compute_pf_diag(theta, x, mu_leq_t, S_leq_t, z_leq_t)
+
+            if isinstance(loss_cache, dict):
+                Lz_Kzx = cache_q.pop('Lz_lt_Kz_lt_z_t').unsqueeze(0)          # (1, S, C, M<, M)
+                Tz = cache_q.pop('Tz_lt').unsqueeze(0)
+                Kzz = self.kernel.compute(theta, self.z).unsqueeze(0)
+                # prior covariance Kzz - (Lz^-1 Kzx)^T (Lz^-1 Kzx): independent of u_<t
+                prior_cov_t = ops.matmul(Lz_Kzx.mT, Lz_Kzx, D=Kzz, alpha=-1.0, beta=1.0)
+                prior_L, prior_T = ops.chol_inv(prior_cov_t)
+                if self.var_mean_mask == 1.0:
+                    # var_mu - prior_mu = u_mean exactly; prior_mu itself is not needed
+                    prior_mu_t = torch.zeros(1, 1, 1, 1, device=x.device)
+                    var_mu_t = self.u_mean.squeeze(-1).unsqueeze(0).unsqueeze(0)
+                else:
+                    # u_<t ~ N(mu_<t, S_<t): Cholesky without jitter (MultivariateNormal, vargp.py:137-138)
+                    Ls = ops.chol(S_lt, 0.0)
+                    n_lt = mu_lt.shape[-2]
+                    eps_u = noise.draw('eps_u', (self.n_v, theta.size(0), self.z.size(0), n_lt), x.device,
+                                       sample_dim=1)
+                    u_lt = mu_lt.unsqueeze(0) + ops.matmul(Ls.unsqueeze(0), eps_u.unsqueeze(-1), triA=LOWER)
+                    Lz_u = ops.matmul(Tz, u_lt, triA=LOWER)
+                    prior_mu_t = ops.matmul(Lz_Kzx.mT, Lz_u).squeeze(-1)       # (n_v, S, C, M)
+                    var_mu_t = prior_mu_t * self.var_mean_mask + self.u_mean.squeeze(-1).unsqueeze(0).unsqueeze(0)
+                var_L_cov_t = vec2tril(self.u_tril_vec, self.M).unsqueeze(0).unsqueeze(0)
+                loss_cache.update(dict(var_mu_t=var_mu_t, var_L_cov_t=var_L_cov_t, prior_mu_t=prior_mu_t,
+                                       prior_L_cov_t=prior_L, prior_T_cov_t=prior_T))
+        else:
+            cache_pf = dict()
+            mu_leq_t = self.u_mean
+            L_cov_leq_t = vec2tril(self.u_tril_vec, self.M)
+            pred_mu, pred_var = self.compute_pf_diag(theta, x, mu_leq_t, rev_cholesky(L_cov_leq_t), self.z,
+                                                     cache=cache_pf)
+            if isinstance(loss_cache, dict):
+                mu_t = mu_leq_t.squeeze(-1).unsqueeze(0).unsqueeze(0)            # q(u_1)
+                L_cov_t = L_cov_leq_t.unsqueeze(0).unsqueeze(0)
+                prior_mu_t = torch.zeros(1, 1, 1, 1, device=x.device)            # p(u_1) = N(0, Lz Lz^T)
+                loss_cache.update(dict(var_mu_t=mu_t, var_L_cov_t=L_cov_t, prior_mu_t=prior_mu_t,
+                                       prior_L_cov_t=cache_pf.pop('Lz').unsqueeze(0),
+                                       prior_T_cov_t=cache_pf.pop('Tz').unsqueeze(0)))
+        return pred_mu, pred_var
+
+    def loss(self, x, y):
+        """(kl_hypers, kl_u, nll); the caller combines beta*kl_hypers + kl_u + (N/B)*nll
+        (vargp.py:177-194, experiments/vargp.py:34)."""
+        loss_cache = dict()
+        pred_mu, pred_var = self(x, loss_cache=loss_cache)
+        nll = self.likelihood.loss(pred_mu, pred_var, y)
+        kl = gp_utils.mvn_kl(loss_cache.pop('var_mu_t'), loss_cache.pop('var_L_cov_t'),
+                             loss_cache.pop('prior_mu_t'), loss_cache.pop('prior_L_cov_t'),
+                             Tp=loss_cache.pop('prior_T_cov_t'))
+        kl_u = kl.sum(dim=-1).mean(dim=0).mean(dim=0)
+        kl_hypers = self.kernel.kl_hypers()
+        return kl_hypers, kl_u, nll
+
+    def predict(self, x):
+        pred_mu, pred_var = self(x)
+        return self.likelihood.predict(pred_mu, pred_var)
+
+    @staticmethod
+    def create_clf(dataset, M=20, n_f=10, n_var_samples=3, prev_params=None,
+                   ep_var_mean=True, map_est_hypers=False, dkl=False):
+        """Factory used by the experiment driver (vargp.py:200-243): inducing points at random data
+        points per class, hyper-prior = previous task's hyper-posterior (popped from prev_params[-1],
+        which is mutated like the reference does)."""
+        if dkl:
+            raise NotImplementedError('dkl=True (DeepRBFKernel ablation) is outside the MI355X hot-path scope')
+        N = len(dataset)
+        out_size = torch.unique(dataset.targets).size(0)
+        z = torch.stack([dataset[torch.randperm(N)[:M]][0] for _ in range(out_size)])
+
+        prior_log_mean, prior_log_logvar = None, None
+        if prev_params:
+            prior_log_mean = prev_params[-1].get('kernel.log_mean')
+            prior_log_logvar = prev_params[-1].get('kernel.log_logvar')
+            for p in prev_params:
+                for k in [k for k in p if k.startswith('kernel')]:
+                    p.pop(k)
+        kernel = RBFKernel(z.size(-1), prior_log_mean=prior_log_mean, prior_log_logvar=prior_log_logvar,
+                           map_est=map_est_hypers)
+        likelihood = MulticlassSoftmax(n_f=n_f)
+        return VARGP(z, kernel, likelihood, n_var_samples=n_var_samples, ep_var_mean=ep_var_mean,
+                     prev_params=prev_params)
