@@ -1,0 +1,182 @@
+#!/usr/bin/env python
+"""ELBO steps/s of the VAR-GP hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload at N=1: BASELINE config 1 — Split-MNIST task 0 shape, S=3 hyper-samples, F=10, C=10, M=100,
+D=784, B=512, synthetic data resident in HBM.  One step = zero_grad + VARGP.loss + combine + backward
++ (N>1: one RCCL all-reduce) + Yogi step, exactly as experiments/vargp.py:29-37 does it.
+N>1 is sample-parallel WEAK scaling: every rank evaluates its own 3 of the 3N hyper-samples, so the
+job does N Cfg2-steps worth of work per global step and `value` = N * global_steps / time.
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+S, F_, C, M, D, B = 3, 10, 10, 100, 784, 512
+N_TOTAL, BETA, LR = 12000, 10.0, 3e-3
+MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32 matrix peak
+DOMINANT_TAG = 'rbf_kuf_gemm'
+DOMINANT_FLOPS = 2.0 * S * C * M * B * D          # algorithmic flops of one K_uf launch
+
+
+def make_model(device, seed=0):
+    from vargp_amd.kernels import RBFKernel
+    from vargp_amd.likelihoods import MulticlassSoftmax
+    from vargp_amd.synthetic import mnist_like
+    from vargp_amd.vargp import VARGP
+    torch.manual_seed(seed)
+    xall, yall = mnist_like(4096, D, C, kind='gauss', seed=1)
+    z = torch.stack([xall[yall == c][:M] for c in range(C)])
+    gp = VARGP(z, RBFKernel(D), MulticlassSoftmax(n_f=F_), n_var_samples=S).to(device)
+    return gp, xall[:B].to(device), yall[:B].to(device)
+
+
+def snapshot(gp):
+    p = dict(z=gp.z, u_mean=gp.u_mean, u_tril_vec=gp.u_tril_vec, log_mean=gp.kernel.log_mean,
+             log_logvar=gp.kernel.log_logvar, prior_log_mean=gp.kernel.prior_log_mean,
+             prior_log_logvar=gp.kernel.prior_log_logvar)
+    return {k: v.detach().cpu().clone() for k, v in p.items()}
+
+
+def cpu_baseline(p, x, y, budget_s=15.0, max_steps=30):
+    """The oracle (CPU port of the reference algorithm, incl. its full B x B Gram) timed on the host
+    cores on the same shapes: zero_grad + loss + backward + a plain SGD-style update."""
+    from oracle import vargp_oracle as orc
+    threads = min(os.cpu_count(), 32)     # more threads than this only slows torch's CPU kernels down here
+    torch.set_num_threads(threads)
+    xc, yc = x.cpu(), y.cpu()
+    times = []
+    t_start = time.perf_counter()
+    for i in range(max_steps):
+        nz = dict(eps_theta=torch.randn(S, D + 1), eps_f=torch.randn(S, F_, C, B))
+        t0 = time.perf_counter()
+        _, g = orc.elbo_step(p, [], xc, yc, nz, beta=BETA, n_total=N_TOTAL, full_gram=True)
+        for k in g:
+            p[k] = p[k] - 1e-4 * g[k]
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_start > budget_s and i >= 3:
+            break
+    times = sorted(times[1:]) if len(times) > 1 else times
+    med = times[len(times) // 2]
+    return dict(value=1.0 / med, unit='ELBO steps/s', cores=threads, kind='port',
+                sample=f'{len(times)} steps of the same Cfg2 workload (S{S} F{F_} C{C} M{M} D{D} B{B}), median')
+
+
+def elbo_check(gp, x, y):
+    """ELBO (total loss) of the HIP path vs the CPU oracle on identical inputs and noise."""
+    from oracle import vargp_oracle as orc
+    from vargp_amd import noise
+    nz = dict(eps_theta=torch.randn(S, D + 1), eps_f=torch.randn(S, F_, C, B))
+    with torch.no_grad(), noise.inject(**{k: v.to(x.device) for k, v in nz.items()}):
+        kl_h, kl_u, nll = gp.loss(x, y)
+    tot = (BETA * kl_h + kl_u + (N_TOTAL / B) * nll).item()
+    with torch.no_grad():
+        a, b, c = orc.loss(snapshot(gp), [], x.cpu(), y.cpu(), nz)
+    ref = (BETA * a + b + (N_TOTAL / B) * c).item()
+    return abs(tot - ref) / abs(ref)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--eager', action='store_true', help='do not replay the step from a captured hipGraph')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=device)
+
+    from vargp_amd import _lib, ops
+    from vargp_amd.train import ElboTrainer
+    ops.set_cholesky_error_mode('defer')
+    ops.reset_linalg_errors()
+    gp, x, y = make_model(device)
+    rtol = elbo_check(gp, x, y) if rank == 0 else None
+    p0 = snapshot(gp) if rank == 0 else None     # the CPU baseline runs the same (initial) model
+    trainer = ElboTrainer(gp, lr=LR, beta=BETA, n_total=N_TOTAL)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    use_graph = not args.eager and world == 1
+    if use_graph:
+        trainer.capture(x, y)
+        run = trainer.step_graph
+    else:
+        run = lambda: trainer.step(x, y)
+    for _ in range(args.warmup):
+        run()
+    sync()
+    if not use_graph:
+        _lib.prof_enable(True)
+        _lib.prof_read('')                  # drop anything recorded so far
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = run()
+    sync()
+    dt = time.perf_counter() - t0
+    if use_graph:
+        # hipEvents cannot bracket a kernel inside a replayed graph: time the dominant kernel with
+        # events over the same number of eager steps right after the timed region (same launches).
+        _lib.prof_enable(True)
+        _lib.prof_read('')
+        for _ in range(min(args.steps, 50)):
+            trainer.step(x, y)
+        sync()
+    _lib.prof_enable(False)
+    kern_ms, kern_n = _lib.prof_read(DOMINANT_TAG)
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    finite = all(torch.isfinite(v).item() for v in out)
+    errs = ops.linalg_error_count()
+
+    if rank == 0:
+        value = world * args.steps / dt
+        avg_s = kern_ms / max(kern_n, 1) * 1e-3
+        achieved = DOMINANT_FLOPS / avg_s / 1e12 if kern_n else None
+        res = dict(metric='ELBO steps/sec', value=value, unit='ELBO steps/s (Cfg2 step: S=3 hyper-samples per GPU)',
+                   n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * dt / args.steps,
+                   higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+                   config=dict(workload='Split-MNIST task-0 ELBO step (BASELINE config 1)', S_per_gpu=S,
+                               S_total=S * world, F=F_, C=C, M=M, D=D, B=B, N=N_TOTAL, beta=BETA,
+                               optimizer='yogi', parallelism=f'sample-parallel x{world}',
+                               launch='hipGraph replay' if use_graph else 'eager'),
+                   elbo_rtol_vs_cpu=rtol, finite=bool(finite), cholesky_failures=errs,
+                   final_loss=dict(kl_hypers=out[0].item(), kl_u=out[1].item(), nll=out[2].item()),
+                   roofline=dict(bound='mfma', kernel='gemm_kernel<RBF> (K_uf = rbf(z, x), vargp_rbf_gram_fwd)',
+                                 achieved=achieved, peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
+                                 frac=(achieved / MFMA_F32_PEAK_TFLOPS) if achieved else None,
+                                 launches=kern_n, avg_us=avg_s * 1e6, traffic=None))
+        if world == 1 and not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(p0, x, y)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -153,9 +153,39 @@ int vargp_softmax_predict(const float* mu, const float* var, const float* eps, f
 /* ------------------------------------------------------------------------------------------------
  * Yogi optimiser step, fused over one flat parameter buffer (reference call site:
  * experiments/vargp.py:23,37 -> torch_optimizer.Yogi; algorithm from Zaheer et al. 2018).
+ * bias1/bias2 = 1 - beta^t; if `step` (device pointer to the step count t as a float) is not NULL
+ * the corrections are computed on the device from it instead, which keeps a captured graph valid.
  */
 int vargp_yogi_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
-                    float beta2, float eps, float bias1, float bias2, vargp_stream_t stream);
+                    float beta2, float eps, float bias1, float bias2, const float* step, vargp_stream_t stream);
+
+/* same update for up to 8 tensors in one launch; `step` (device float, the step count t) is required */
+int vargp_yogi_step_multi(int ntensors, float* const* p, const float* const* g, float* const* m, float* const* v,
+                          const int64_t* n, float lr, float beta1, float beta2, float eps, const float* step,
+                          vargp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Variational kernel hyper-parameters (reference: RBFKernel.sample_hypers / kl_hypers,
+ * var_gp/kernels.py:62-77).  D1 = D + 1.
+ *   sample: theta[S, D1] = mean + eps * exp(logvar / 2)           (Normal.rsample)
+ *   kl:     sum_d KL(N(mean_d, e^logvar_d) || N(prior_mean_d, e^prior_logvar_d))
+ */
+int vargp_hyper_sample_fwd(const float* mean, const float* logvar, const float* eps, float* theta, int S, int D1,
+                           vargp_stream_t stream);
+int vargp_hyper_sample_bwd(const float* logvar, const float* eps, const float* gtheta, float* gmean,
+                           float* glogvar, int S, int D1, vargp_stream_t stream);
+int vargp_hyper_kl_fwd(const float* mean, const float* logvar, const float* prior_mean, const float* prior_logvar,
+                       float* kl, int D1, vargp_stream_t stream);
+int vargp_hyper_kl_bwd(const float* mean, const float* logvar, const float* prior_mean, const float* prior_logvar,
+                       const float* gkl, float* gmean, float* glogvar, int D1, vargp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Measurement hooks (no reference counterpart): when enabled, the heavy launches are bracketed by
+ * hipEvents on their own stream, tagged "rbf_kuf_gemm", "rbf_kuu_gemm", "rbf_kuf_bwd_gemm",
+ * "rbf_kuu_bwd_gemm", "chol_inv_small", "bgemm".  vargp_prof_read sums and clears one tag.
+ */
+int vargp_prof_enable(int on);
+int vargp_prof_read(const char* tag, double* total_ms, int64_t* launches);
 
 #ifdef __cplusplus
 }

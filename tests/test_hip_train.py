@@ -1,0 +1,98 @@
+"""GPU: optimiser kernel, hyper-parameter ops, and the captured-graph training step."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vargp_oracle as orc
+from helpers import rel_l2, load_case, to_dev
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _yogi_ref(p, g, m, v, t, lr, b1=0.9, b2=0.999, eps=1e-3):
+    """Zaheer et al. 2018, as implemented by torch_optimizer.Yogi (recalled; parity unpinned)."""
+    m = b1 * m + (1 - b1) * g
+    g2 = g * g
+    v = v - (1 - b2) * torch.sign(v - g2) * g2
+    denom = v.sqrt() / np.sqrt(1 - b2 ** t) + eps
+    return p - (lr / (1 - b1 ** t)) * m / denom, m, v
+
+
+def test_yogi_matches_published_algorithm():
+    from vargp_amd.optim import Yogi
+    torch.manual_seed(0)
+    ps = [torch.randn(37, 5), torch.randn(1000), torch.randn(3, 3, 3)]
+    params = [torch.nn.Parameter(p.clone().to(DEV)) for p in ps]
+    opt = Yogi(params, lr=1e-2)
+    ref = [(p.double(), torch.full_like(p, 1e-6).double(), torch.full_like(p, 1e-6).double()) for p in ps]
+    for t in range(1, 6):
+        gs = [torch.randn_like(p) for p in ps]
+        for p, g in zip(params, gs):
+            p.grad = g.to(DEV)
+        opt.step()
+        ref = [_yogi_ref(p, g.double(), m, v, t, 1e-2) for (p, m, v), g in zip(ref, gs)]
+    for p, (rp, _, _) in zip(params, ref):
+        assert rel_l2(p.detach().cpu(), rp) < 1e-5
+
+
+def test_hyper_ops():
+    from vargp_amd import ops
+    D1, S = 785, 3
+    m, v, m0, v0 = (orc.hash_normal((D1,), 1).float() * 0.3, -2 + 0.1 * orc.hash_normal((D1,), 2).float(),
+                    0.1 * orc.hash_normal((D1,), 3).float(), 0.1 * orc.hash_normal((D1,), 4).float())
+    eps = orc.hash_normal((S, D1), 5).float()
+    md, vd = m.to(DEV).requires_grad_(True), v.to(DEV).requires_grad_(True)
+    th = ops.hyper_sample(md, vd, eps.to(DEV))
+    kl = ops.hyper_kl(md, vd, m0.to(DEV), v0.to(DEV))
+    w = orc.hash_normal((S, D1), 6).float()
+    ((th * w.to(DEV)).sum() + 3.0 * kl).backward()
+    m64, v64 = m.double().requires_grad_(True), v.double().requires_grad_(True)
+    th64 = orc.sample_hypers(m64, v64, eps.double())
+    kl64 = orc.kl_hypers(m64, v64, m0.double(), v0.double())
+    ((th64 * w.double()).sum() + 3.0 * kl64).backward()
+    assert rel_l2(th.detach().cpu(), th64.detach()) < 1e-6
+    np.testing.assert_allclose(kl.item(), kl64.item(), rtol=1e-5)
+    assert rel_l2(md.grad.cpu(), m64.grad) < 1e-5 and rel_l2(vd.grad.cpu(), v64.grad) < 1e-5
+
+
+def test_graph_step_equals_eager_step():
+    """A step replayed from a captured hipGraph produces the same parameters as the eager step."""
+    import copy
+    from vargp_amd import noise, ops
+    from vargp_amd.train import ElboTrainer
+    from gpu_common import build_gp
+    g, params, prev, x, y, nz = load_case('smnist_small_t0')
+    xd, yd = x.to(DEV), y.to(DEV)
+    ops.set_cholesky_error_mode('defer')
+    ops.reset_linalg_errors()
+    try:
+        results = []
+        for mode in ('eager', 'graph'):
+            gp = build_gp(params, prev, 3, 10)
+            tr = ElboTrainer(gp, lr=1e-3, beta=10.0, n_total=12000)
+            with noise.inject(**to_dev(nz, DEV)):
+                if mode == 'graph':
+                    snap = copy.deepcopy(gp.state_dict())
+                    tr.capture(xd, yd, warmup=2)
+                    gp.load_state_dict(snap)            # undo the warm-up / capture steps
+                    for grp in tr.optim.param_groups:
+                        grp['step'].zero_()
+                    for st in tr.optim.state.values():
+                        st['exp_avg'].fill_(1e-6)
+                        st['exp_avg_sq'].fill_(1e-6)
+                    for _ in range(3):
+                        out = tr.step_graph()
+                else:
+                    for _ in range(3):
+                        out = tr.step(xd, yd)
+            torch.cuda.synchronize()
+            results.append(({k: v.detach().cpu().clone() for k, v in gp.state_dict().items()},
+                            [o.item() for o in out]))
+        (sd_e, out_e), (sd_g, out_g) = results
+        np.testing.assert_allclose(out_g, out_e, rtol=1e-5)
+        for k in sd_e:
+            assert rel_l2(sd_g[k], sd_e[k]) < 1e-5, k
+        assert ops.linalg_error_count() == 0
+    finally:
+        ops.set_cholesky_error_mode('raise')

@@ -51,7 +51,14 @@ _SIGNATURES = {
     'vargp_softmax_nll_fwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     'vargp_softmax_nll_bwd': (c_int, [_P] * 7 + [c_int, c_int, c_int, c_int, _P]),
     'vargp_softmax_predict': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
-    'vargp_yogi_step': (c_int, [_P, _P, _P, _P, c_int64] + [c_float] * 6 + [_P]),
+    'vargp_yogi_step_multi': (c_int, [c_int, _P, _P, _P, _P, _P] + [c_float] * 4 + [_P, _P]),
+    'vargp_hyper_sample_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
+    'vargp_hyper_sample_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P]),
+    'vargp_hyper_kl_fwd': (c_int, [_P, _P, _P, _P, _P, c_int, _P]),
+    'vargp_hyper_kl_bwd': (c_int, [_P] * 7 + [c_int, _P]),
+    'vargp_prof_enable': (c_int, [c_int]),
+    'vargp_prof_read': (c_int, [c_char_p, POINTER(ctypes.c_double), POINTER(c_int64)]),
+    'vargp_yogi_step': (c_int, [_P, _P, _P, _P, c_int64] + [c_float] * 6 + [_P, _P]),
 }
 EXPORTS = sorted(_SIGNATURES)
 
@@ -101,3 +108,14 @@ def ptr(t):
 
 def workspace(nbytes, device):
     return torch.empty((int(nbytes) + 3) // 4, dtype=torch.float32, device=device)
+
+
+def prof_enable(on=True):
+    lib().vargp_prof_enable(int(on))
+
+
+def prof_read(tag):
+    """-> (total_ms, launches) of the launches tagged `tag` since the last read."""
+    ms, n = ctypes.c_double(0.0), c_int64(0)
+    lib().vargp_prof_read(tag.encode(), ctypes.byref(ms), ctypes.byref(n))
+    return ms.value, n.value

@@ -1,12 +1,9 @@
 // Batched Cholesky (+ jitter) with explicit inverse factor T = L^-1 and log-determinant
 // (reference: gp_utils.cholesky, var_gp/gp_utils.py:5-11, plus every triangular_solve against it).
 //
-// n <= 128: one 256-thread workgroup per matrix, matrix resident in LDS (odd row stride).
-//   factorisation: right-looking with deferred column scaling (one barrier per column):
-//       a_ik -= a_ij a_kj / d_j  (j < k <= i),  L_ij = a_ij / sqrt(d_j)
-//   inverse: forward substitution, one lane group per column of T; groups never interact, so the
-//   sweep needs no workgroup barrier.
-// n > 128: blocked right-looking on 128-wide panels; the diagonal blocks use the LDS kernel, the
+// n <= 100: one workgroup per matrix; fp64 in-place Gauss-Jordan on the packed triangle held in registers
+//   yields L and T = L^-1 together (see chol_inv_small_kernel).
+// n > 100: blocked right-looking on 96-wide panels; the diagonal blocks use the LDS kernel, the
 //   panel solves and trailing updates are MFMA GEMMs (gemm.hip).
 // Backward (any n) is five GEMMs (see vargp_chol_inv_bwd).
 #include "common.h"
@@ -14,42 +11,100 @@
 
 namespace vargp {
 
-constexpr int kNbSmall = 128;
+constexpr int kSmallMax = 100;  // largest n the register-resident kernel takes (packed triangle <= 512*10)
+constexpr int kNbSmall = 96;    // panel width of the blocked algorithm (multiple of 32, <= kSmallMax)
 
-__global__ __launch_bounds__(256) void chol_inv_small_kernel(const float* __restrict__ A, int lda, int64_t strideA,
+// Packed lower-triangular index.
+__device__ __forceinline__ int pk(int i, int j) { return i * (i + 1) / 2 + j; }
+
+// One workgroup per matrix, n <= kSmallMax.  In-place Gauss-Jordan on [A | I] restricted to the lower
+// triangle, which yields L = chol(A) and T = L^-1 from one elimination.  The triangle lives in
+// REGISTERS, row-wise: thread (r, part) = (tid / P, tid % P) owns the entries e = k*P + part (k < K) of
+// row r, so nothing about a slot has to be looked up at run time:
+//   slot (i,e) holds A_ie until column e has been eliminated (step e), afterwards entry (i,e) of the
+//   unit-lower inverse.  Step j:
+//     publish  the pivot vector p to LDS: column j of A comes from slot j/P of the threads with
+//              part == j%P (a wave-uniform slot index), the inverse's row j from the P threads of row j;
+//              p[j] := 1, the pivot d_j goes to its own word; slot (i,j) restarts from 0;
+//     barrier; rows i > j do  v <- v + (-p[i]/d_j) * p[e]  on every slot: one LDS read + one FMA per
+//              slot, no predicates (slots beyond the diagonal only ever hold garbage nobody reads);
+//              rows i <= j are finished and their waves drop out.
+//   end: L_ie = A_ie(final) / sqrt(d_e), T_ie = v_ie / sqrt(d_i), T_ii = 1/sqrt(d_i).
+// F = double: factor and explicit inverse are then at least as accurate as fp32 LAPACK potrf + trsm on
+// ill-conditioned K_uu; the chain of n dependent pivots, not the flops, bounds the kernel.
+constexpr int kCholP = 5;
+template <typename F, int K>
+__global__ __launch_bounds__(512) void chol_inv_small_kernel(const float* __restrict__ A, int lda, int64_t strideA,
                                                              float eps, float* __restrict__ L, int ldl,
                                                              int64_t strideL, float* __restrict__ T, int ldt,
                                                              int64_t strideT, float* __restrict__ logdet,
                                                              int32_t* __restrict__ info, int info_base, int n,
                                                              int logdet_accumulate) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int LD = n | 1;
-  float* sa = smem;            // n x LD  working matrix / L
-  float* sd = sa + n * LD;     // n       sqrt of pivots
-  float* st = sd + ((n + 3) & ~3);  // n x LD  T (only if T != null)
-  __shared__ float red[4];
+  constexpr int P = kCholP;
+  __shared__ F pbuf[2][K * P + 8];
+  __shared__ F dpiv[2];
+  __shared__ F sd[K * P + 8];
+  __shared__ float Lp[(K * P) * (K * P + 1) / 2];   // final (unscaled) columns of A, packed
+  __shared__ float red[8];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, NT = blockDim.x;
+  const int r = tid / P, part = tid % P;
   const int64_t b = blockIdx.x;
   A += b * strideA;
   L += b * strideL;
   if (T) T += b * strideT;
+  const bool mine = r < n;
 
-  for (int e = tid; e < n * n; e += 256) {
-    const int i = e / n, j = e % n;
-    if (j <= i) sa[i * LD + j] = A[(int64_t)i * lda + j] + (i == j ? eps : 0.f);
+  F v[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int e = k * P + part;
+    v[k] = F(0);
+    if (mine && e <= r) v[k] = (F)A[(int64_t)r * lda + e] + (e == r ? (F)eps : F(0));
   }
 
   int fail = 0;
   for (int j = 0; j < n; ++j) {
+    F* p = pbuf[j & 1];
+    const int ks = j / P, ps = j % P;
+    // column j of A (and the pivot): slot ks of the threads with part == ps.  k == ks is wave-uniform and the
+    // body only READS v[k], so the unrolled chain stays a handful of scalar compares.
+    if (part == ps && mine && r >= j) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        if (k == ks) {
+          asm volatile("" ::: "memory");                 // keep this a real (scalar) branch, not 20 selects
+          if (r == j) { dpiv[j & 1] = v[k]; p[j] = F(1); }
+          else { p[r] = v[k]; Lp[pk(r, j)] = (float)v[k]; }
+        }
+      }
+    }
+    if (__builtin_amdgcn_ballot_w64(r == j) != 0) {     // only the wave that holds row j: inverse row j
+      if (r == j) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const int e = k * P + part;
+          if (e < j) p[e] = v[k];
+        }
+      }
+    }
     __syncthreads();
-    const float d = sa[j * LD + j];
-    if (!(d > 0.f)) { fail = j + 1; break; }  // uniform: every thread reads the same pivot
-    const float inv = 1.f / d;
-    for (int k = j + 1 + lane; k < n; k += 64) {
-      const float ckj = sa[k * LD + j] * inv;
-      for (int i = j + 1 + wave; i < n; i += 4) {
-        if (i >= k) sa[i * LD + k] = fmaf(-sa[i * LD + j], ckj, sa[i * LD + k]);
+    const F d = dpiv[j & 1];
+    if (!(d > F(0))) { fail = j + 1; break; }           // uniform
+    if (tid == 0) sd[j] = d;
+    {
+      // rows i <= j are finished: they run the same FMAs with m = 0 (no divergent copy of the row)
+      const F m = (mine && r > j) ? -p[r] / d : F(0);
+      const F* pp = p + part;
+      const bool pivcol = part == ps;
+#pragma unroll
+      for (int k = 0; k < K; ++k) v[k] = fma(m, pp[k * P], v[k]);
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        if (k == ks) {                                   // slot (i,j) restarts as an inverse entry: 0 + m * 1
+          asm volatile("" ::: "memory");
+          v[k] = pivcol ? m : v[k];
+        }
       }
     }
   }
@@ -57,7 +112,7 @@ __global__ __launch_bounds__(256) void chol_inv_small_kernel(const float* __rest
   if (fail) {
     if (tid == 0 && info) { if (info[b] == 0) info[b] = info_base + fail; }
     const float qnan = __builtin_nanf("");
-    for (int e = tid; e < n * n; e += 256) {
+    for (int e = tid; e < n * n; e += NT) {
       const int i = e / n, j = e % n;
       L[(int64_t)i * ldl + j] = qnan;
       if (T) T[(int64_t)i * ldt + j] = qnan;
@@ -65,70 +120,51 @@ __global__ __launch_bounds__(256) void chol_inv_small_kernel(const float* __rest
     if (logdet && tid == 0) logdet[b] = qnan;
     return;
   }
-  for (int j = tid; j < n; j += 256) sd[j] = sqrtf(sa[j * LD + j]);
-  __syncthreads();
   float ld_acc = 0.f;
-  for (int e = tid; e < n * n; e += 256) {
-    const int i = e / n, j = e % n;
-    float v = 0.f;
-    if (j < i) v = sa[i * LD + j] / sd[j];
-    else if (j == i) { v = sd[j]; ld_acc += logf(v); }
-    if (j <= i) sa[i * LD + j] = v;
-    L[(int64_t)i * ldl + j] = v;
-  }
-  if (logdet) {
-    const float tot = block_sum<256>(ld_acc, red);
-    if (tid == 0) { if (logdet_accumulate) logdet[b] += tot; else logdet[b] = tot; }
-  }
-  if (!T) return;
-  __syncthreads();
-
-  // T = L^-1, column c handled by P adjacent lanes of one wave
-  int np2 = 16;
-  while (np2 < n) np2 <<= 1;
-  const int P = 256 / np2;
-  const int c = tid / P, part = tid % P;
-  if (c < n) {
-    for (int i = 0; i < n; ++i) {
-      if (i < c) {
-        if (part == 0) st[i * LD + c] = 0.f;
-      } else {
-        float acc = 0.f;
-        for (int k = c + part; k < i; k += P) acc = fmaf(sa[i * LD + k], st[k * LD + c], acc);
-        for (int off = P >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-        const float t = ((i == c ? 1.f : 0.f) - acc) / sa[i * LD + i];
-        if (part == 0) st[i * LD + c] = t;
+  if (mine) {
+    const F si = sqrt(sd[r]);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int e = k * P + part;
+      if (e < r) {
+        L[(int64_t)r * ldl + e] = (float)((F)Lp[pk(r, e)] / sqrt(sd[e]));
+        if (T) T[(int64_t)r * ldt + e] = (float)(v[k] / si);
+      } else if (e == r) {
+        L[(int64_t)r * ldl + e] = (float)si;
+        if (T) T[(int64_t)r * ldt + e] = (float)(F(1) / si);
+        ld_acc += (float)log(si);
+      } else if (e < n) {
+        L[(int64_t)r * ldl + e] = 0.f;
+        if (T) T[(int64_t)r * ldt + e] = 0.f;
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
     }
   }
-  __syncthreads();
-  for (int e = tid; e < n * n; e += 256) {
-    const int i = e / n, j = e % n;
-    T[(int64_t)i * ldt + j] = (j <= i) ? st[i * LD + j] : 0.f;
+  if (logdet) {
+    ld_acc = wave_sum(ld_acc);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = ld_acc;
+    __syncthreads();
+    if (tid == 0) {
+      float tot = 0.f;
+      for (int w = 0; w < (NT + 63) / 64; ++w) tot += red[w];
+      if (logdet_accumulate) logdet[b] += tot; else logdet[b] = tot;
+    }
   }
-}
-
-static size_t small_lds_bytes(int n, bool want_T) {
-  const int LD = n | 1;
-  return sizeof(float) * ((size_t)n * LD + ((n + 3) & ~3) + (want_T ? (size_t)n * LD : 0));
 }
 
 static int launch_small(const float* A, int lda, int64_t sA, float eps, float* L, int ldl, int64_t sL, float* T,
                         int ldt, int64_t sT, float* logdet, int32_t* info, int info_base, int nbatch, int n,
                         int ld_acc, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(chol_inv_small_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) {
-      set_error("chol: cannot raise dynamic LDS limit");
-      return VARGP_ELAUNCH;
-    }
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(chol_inv_small_kernel, dim3(nbatch), dim3(256), small_lds_bytes(n, T != nullptr), st, A, lda, sA,
-                     eps, L, ldl, sL, T, ldt, sT, logdet, info, info_base, n, ld_acc);
+  ProfScope prof("chol_inv_small", st);
+  const int nt = (int)round_up((int64_t)n * kCholP, 64);
+#define VARGP_CHOL_LAUNCH(K)                                                                                     \
+  hipLaunchKernelGGL((chol_inv_small_kernel<double, K>), dim3(nbatch), dim3(nt), 0, st, A, lda, sA, eps, L, ldl, sL, \
+                     T, ldt, sT, logdet, info, info_base, n, ld_acc)
+  if (n <= 20) VARGP_CHOL_LAUNCH(4);
+  else if (n <= 40) VARGP_CHOL_LAUNCH(8);
+  else if (n <= 65) VARGP_CHOL_LAUNCH(13);
+  else VARGP_CHOL_LAUNCH(20);   // n <= 100
+#undef VARGP_CHOL_LAUNCH
   return check_launch("chol_inv_small");
 }
 
@@ -184,7 +220,7 @@ using namespace vargp;
 extern "C" size_t vargp_chol_workspace_bytes(int nbatch, int n, int backward) {
   const size_t nn = (size_t)nbatch * n * n * sizeof(float);
   if (backward) return 2 * nn + 256;
-  if (n <= kNbSmall) return 256;
+  if (n <= kSmallMax) return 256;
   return nn + (size_t)nbatch * n * kNbSmall * sizeof(float) + 256;
 }
 
@@ -195,7 +231,7 @@ extern "C" int vargp_chol_inv_fwd(const float* A, float eps, float* L, float* T,
   hipStream_t st = as_stream(stream);
   const int64_t nn = (int64_t)n * n;
   if (info) (void)hipMemsetAsync(info, 0, sizeof(int32_t) * nbatch, st);
-  if (n <= kNbSmall)
+  if (n <= kSmallMax)
     return launch_small(A, n, nn, eps, L, n, nn, T, n, nn, logdet, info, 0, nbatch, n, 0, st);
 
   VARGP_REQUIRE(ws && ws_bytes >= vargp_chol_workspace_bytes(nbatch, n, 0), "chol_inv_fwd: workspace too small");

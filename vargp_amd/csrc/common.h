@@ -71,6 +71,16 @@ struct GemmParams {
   int same_xy;
 };
 
-int launch_gemm(const GemmParams& p, int transA, int transB, int nbatch, bool rbf, hipStream_t st);
+int launch_gemm(const GemmParams& p, int transA, int transB, int nbatch, bool rbf, hipStream_t st,
+                const char* tag = "bgemm");
+
+// Optional per-kernel timing with hipEvents on the launch stream (vargp_prof_* in the C ABI).
+// Disabled (one branch) unless vargp_prof_enable(1); skipped while the stream is being captured.
+struct ProfScope {
+  ProfScope(const char* tag, hipStream_t st);
+  ~ProfScope();
+  int slot_;
+  hipStream_t st_;
+};
 
 }  // namespace vargp

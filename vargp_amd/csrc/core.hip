@@ -1,6 +1,9 @@
 // Error plumbing and small generic kernels (outer-sum reduction, fused Yogi step).
 #include "common.h"
 #include <stdarg.h>
+#include <string>
+#include <vector>
+#include <string.h>
 
 namespace vargp {
 
@@ -22,6 +25,26 @@ int check_launch(const char* what) {
   return VARGP_OK;
 }
 
+// ---- per-kernel event timing ---------------------------------------------------------------
+struct ProfRec { std::string tag; hipEvent_t a, b; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+
+ProfScope::ProfScope(const char* tag, hipStream_t st) : slot_(-1), st_(st) {
+  if (!g_prof_on) return;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return;
+  ProfRec r;
+  r.tag = tag;
+  if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+  (void)hipEventRecord(r.a, st);
+  g_prof.push_back(r);
+  slot_ = (int)g_prof.size() - 1;
+}
+ProfScope::~ProfScope() {
+  if (slot_ >= 0) (void)hipEventRecord(g_prof[slot_].b, st_);
+}
+
 __global__ void sum_outer_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t outer, int64_t inner) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= inner) return;
@@ -33,9 +56,10 @@ __global__ void sum_outer_kernel(const float* __restrict__ in, float* __restrict
 // Yogi (Zaheer et al. 2018): v <- v - (1-b2) sign(v - g^2) g^2 ; p <- p - lr/bias1 * m / (sqrt(v/bias2) + eps)
 __global__ void yogi_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float bias1,
-                            float bias2) {
+                            float bias2, const float* __restrict__ step) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (step) { const float t = step[0]; bias1 = 1.f - powf(b1, t); bias2 = 1.f - powf(b2, t); }
   const float gi = g[i], g2 = gi * gi;
   const float mi = b1 * m[i] + (1.f - b1) * gi;
   float vi = v[i];
@@ -46,6 +70,34 @@ __global__ void yogi_kernel(float* __restrict__ p, const float* __restrict__ g, 
   v[i] = vi;
   const float denom = sqrtf(vi) / sqrtf(bias2) + eps;
   p[i] -= (lr / bias1) * mi / denom;
+}
+
+struct YogiPack {
+  float* p[8];
+  const float* g[8];
+  float* m[8];
+  float* v[8];
+  int64_t n[8];
+};
+__global__ void yogi_multi_kernel(YogiPack pk, float lr, float b1, float b2, float eps, const float* __restrict__ step) {
+  const int t = blockIdx.y;
+  const int64_t n = pk.n[t];
+  float* __restrict__ p = pk.p[t];
+  const float* __restrict__ g = pk.g[t];
+  float* __restrict__ m = pk.m[t];
+  float* __restrict__ v = pk.v[t];
+  const float tt = step[0];
+  const float bias1 = 1.f - powf(b1, tt), sb2 = sqrtf(1.f - powf(b2, tt));
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i], g2 = gi * gi;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    float vi = v[i];
+    const float df = vi - g2;
+    vi -= (1.f - b2) * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * g2;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= (lr / bias1) * mi / (sqrtf(vi) / sb2 + eps);
+  }
 }
 
 }  // namespace vargp
@@ -62,9 +114,51 @@ extern "C" int vargp_sum_outer(const float* in, float* out, int64_t outer, int64
 }
 
 extern "C" int vargp_yogi_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
-                               float beta2, float eps, float bias1, float bias2, vargp_stream_t stream) {
+                               float beta2, float eps, float bias1, float bias2, const float* step,
+                               vargp_stream_t stream) {
   VARGP_REQUIRE(p && g && m && v && n > 0, "yogi_step: bad arguments");
   hipLaunchKernelGGL(yogi_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), p, g, m, v, n, lr, beta1,
-                     beta2, eps, bias1, bias2);
+                     beta2, eps, bias1, bias2, step);
   return check_launch("yogi_step");
+}
+
+extern "C" int vargp_prof_enable(int on) {
+  g_prof_on = on != 0;
+  return VARGP_OK;
+}
+// Sum the elapsed time of every recorded launch whose tag equals `tag` (all tags if NULL/""), then
+// drop those records.  Synchronises on the recorded events.
+extern "C" int vargp_prof_read(const char* tag, double* total_ms, int64_t* launches) {
+  double tot = 0.0;
+  int64_t n = 0;
+  std::vector<ProfRec> keep;
+  for (auto& r : g_prof) {
+    if (tag && tag[0] && r.tag != tag) { keep.push_back(r); continue; }
+    float ms = 0.f;
+    if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { tot += ms; ++n; }
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  g_prof.swap(keep);
+  if (total_ms) *total_ms = tot;
+  if (launches) *launches = n;
+  return VARGP_OK;
+}
+
+// up to 8 parameter tensors in ONE launch (the VAR-GP model has 5); step = device pointer to t
+extern "C" int vargp_yogi_step_multi(int ntensors, float* const* p, const float* const* g, float* const* m,
+                                     float* const* v, const int64_t* n, float lr, float beta1, float beta2, float eps,
+                                     const float* step, vargp_stream_t stream) {
+  VARGP_REQUIRE(ntensors > 0 && ntensors <= 8 && p && g && m && v && n && step, "yogi_step_multi: bad arguments");
+  YogiPack pk{};
+  int64_t nmax = 0;
+  for (int i = 0; i < ntensors; ++i) {
+    pk.p[i] = p[i]; pk.g[i] = g[i]; pk.m[i] = m[i]; pk.v[i] = v[i]; pk.n[i] = n[i];
+    if (n[i] > nmax) nmax = n[i];
+  }
+  int bx = cdiv(nmax, 256);
+  if (bx > 2048) bx = 2048;
+  hipLaunchKernelGGL(yogi_multi_kernel, dim3(bx, ntensors), dim3(256), 0, as_stream(stream), pk, lr, beta1, beta2, eps,
+                     step);
+  return check_launch("yogi_step_multi");
 }

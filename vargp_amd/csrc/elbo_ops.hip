@@ -43,25 +43,36 @@ __global__ void mat2trilvec_kernel(const float* __restrict__ mat, float* __restr
 }
 
 // ---- predictive diag (var_gp/gp_utils.py:178-186) ---------------------------------------------
-// grid (ceil(B/256), nb): one thread per minibatch column, coalesced across the column index
+// grid (ceil(B/64), nb): 64 columns x 4 row lanes per block, coalesced across the column index
 __global__ __launch_bounds__(256) void pdiag_fwd_kernel(const float* __restrict__ P, const float* __restrict__ W,
                                                         const float* __restrict__ a, const float* __restrict__ kd,
                                                         float* __restrict__ mu, float* __restrict__ var, int M, int B) {
-  const int col = blockIdx.x * 256 + threadIdx.x;
+  __shared__ float red[3][4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cx;
   const int64_t b = blockIdx.y;
-  if (col >= B) return;
-  const float* p = P + b * M * B + col;
-  const float* w = W + b * M * B + col;
-  const float* av = a + b * M;
   float m0 = 0.f, d1 = 0.f, d2 = 0.f;
-  for (int m = 0; m < M; ++m) {
-    const float pv = p[(int64_t)m * B], wv = w[(int64_t)m * B];
-    m0 = fmaf(pv, av[m], m0);
-    d1 = fmaf(pv, pv, d1);
-    d2 = fmaf(wv, wv, d2);
+  if (col < B) {
+    const float* p = P + b * M * B + col;
+    const float* w = W + b * M * B + col;
+    const float* av = a + b * M;
+#pragma unroll 4
+    for (int m = ry; m < M; m += 4) {
+      const float pv = p[(int64_t)m * B], wv = w[(int64_t)m * B];
+      m0 = fmaf(pv, av[m], m0);
+      d1 = fmaf(pv, pv, d1);
+      d2 = fmaf(wv, wv, d2);
+    }
   }
-  mu[b * B + col] = m0;
-  var[b * B + col] = kd[b] - d1 + d2;
+  red[0][ry][cx] = m0; red[1][ry][cx] = d1; red[2][ry][cx] = d2;
+  __syncthreads();
+  if (ry == 0 && col < B) {
+    m0 = red[0][0][cx] + red[0][1][cx] + red[0][2][cx] + red[0][3][cx];
+    d1 = red[1][0][cx] + red[1][1][cx] + red[1][2][cx] + red[1][3][cx];
+    d2 = red[2][0][cx] + red[2][1][cx] + red[2][2][cx] + red[2][3][cx];
+    mu[b * B + col] = m0;
+    var[b * B + col] = kd[b] - d1 + d2;
+  }
 }
 // grid (M, nb): one block per row; gP, gW elementwise, ga row reduction; block m == 0 also reduces gkd
 __global__ __launch_bounds__(256) void pdiag_bwd_kernel(const float* __restrict__ P, const float* __restrict__ W,
@@ -188,6 +199,57 @@ __global__ __launch_bounds__(256) void softmax_nll_bwd_kernel(const float* __res
   gmu[e] = sc * a0;
   gvar[e] = sc * a1 * 0.5f / sd;
 }
+// C <= CMAX: one thread per (s, b) keeps the class vector in registers (no recomputation per class)
+template <int CMAX>
+__global__ __launch_bounds__(256) void softmax_nll_bwd_small_kernel(const float* __restrict__ mu,
+                                                                    const float* __restrict__ var,
+                                                                    const float* __restrict__ eps,
+                                                                    const int64_t* __restrict__ y,
+                                                                    const float* __restrict__ gnll,
+                                                                    float* __restrict__ gmu, float* __restrict__ gvar,
+                                                                    int S, int F, int C, int B) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)S * B) return;
+  const int b = e % B, s = e / B;
+  const int yb = (int)y[b];
+  float m[CMAX], sd[CMAX], a0[CMAX], a1[CMAX];
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) {
+    const int64_t i = ((int64_t)s * C + c) * B + b;
+    m[c] = c < C ? mu[i] : 0.f;
+    sd[c] = c < C ? sqrtf(var[i]) : 0.f;
+    a0[c] = 0.f; a1[c] = 0.f;
+  }
+  for (int f = 0; f < F; ++f) {
+    float ev[CMAX], v[CMAX], mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+      ev[c] = c < C ? eps[(((int64_t)s * F + f) * C + c) * B + b] : 0.f;
+      v[c] = c < C ? m[c] + sd[c] * ev[c] : -INFINITY;
+      mx = fmaxf(mx, v[c]);
+    }
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) { v[c] = c < C ? expf(v[c] - mx) : 0.f; se += v[c]; }
+    const float inv = 1.f / se;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+      const float p = v[c] * inv - (c == yb ? 1.f : 0.f);
+      a0[c] += p;
+      a1[c] = fmaf(p, ev[c], a1[c]);
+    }
+  }
+  const float sc = gnll[0] / (float)(S * F);
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) {
+    if (c < C) {
+      const int64_t i = ((int64_t)s * C + c) * B + b;
+      gmu[i] = sc * a0[c];
+      gvar[i] = sc * a1[c] * 0.5f / sd[c];
+    }
+  }
+}
+
 // probs[b, c] = mean_{s,f} softmax_c ; one thread per (b, c)
 __global__ __launch_bounds__(256) void softmax_predict_kernel(const float* __restrict__ mu, const float* __restrict__ var,
                                                               const float* __restrict__ eps, float* __restrict__ probs,
@@ -205,6 +267,54 @@ __global__ __launch_bounds__(256) void softmax_predict_kernel(const float* __res
     }
   }
   probs[(int64_t)b * C + c] = acc / (float)(S * F);
+}
+
+// ---- variational hyper-parameters (var_gp/kernels.py:62-77) -----------------------------------
+// theta[s,d] = mean[d] + eps[s,d] * exp(0.5 * logvar[d])
+__global__ void hyper_sample_fwd_kernel(const float* __restrict__ mean, const float* __restrict__ logvar,
+                                        const float* __restrict__ eps, float* __restrict__ theta, int S, int D1) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= S * D1) return;
+  const int d = e % D1;
+  theta[e] = mean[d] + eps[e] * expf(0.5f * logvar[d]);
+}
+__global__ void hyper_sample_bwd_kernel(const float* __restrict__ logvar, const float* __restrict__ eps,
+                                        const float* __restrict__ gtheta, float* __restrict__ gmean,
+                                        float* __restrict__ glogvar, int S, int D1) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= D1) return;
+  const float hs = 0.5f * expf(0.5f * logvar[d]);
+  float gm = 0.f, gv = 0.f;
+  for (int s = 0; s < S; ++s) {
+    const float g = gtheta[s * D1 + d];
+    gm += g;
+    gv = fmaf(g * hs, eps[s * D1 + d], gv);
+  }
+  gmean[d] = gm;
+  glogvar[d] = gv;
+}
+// kl = sum_d 0.5 * (exp(v - v0) + (m - m0)^2 / exp(v0) - 1 - (v - v0));  single block
+__global__ __launch_bounds__(256) void hyper_kl_fwd_kernel(const float* __restrict__ m, const float* __restrict__ v,
+                                                           const float* __restrict__ m0, const float* __restrict__ v0,
+                                                           float* __restrict__ kl, int D1) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int d = threadIdx.x; d < D1; d += 256) {
+    const float dv = v[d] - v0[d], dm = m[d] - m0[d];
+    acc += 0.5f * (expf(dv) + dm * dm * expf(-v0[d]) - 1.f - dv);
+  }
+  const float t = block_sum<256>(acc, red);
+  if (threadIdx.x == 0) kl[0] = t;
+}
+__global__ void hyper_kl_bwd_kernel(const float* __restrict__ m, const float* __restrict__ v,
+                                    const float* __restrict__ m0, const float* __restrict__ v0,
+                                    const float* __restrict__ gkl, float* __restrict__ gm, float* __restrict__ gv,
+                                    int D1) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= D1) return;
+  const float g = gkl[0];
+  gm[d] = g * (m[d] - m0[d]) * expf(-v0[d]);
+  gv[d] = g * 0.5f * (expf(v[d] - v0[d]) - 1.f);
 }
 
 }  // namespace vargp
@@ -236,7 +346,7 @@ extern "C" int vargp_predictive_diag_fwd(const float* P, const float* W, const f
                                          float* var, int nbatch, int M, int B, vargp_stream_t stream) {
   VARGP_REQUIRE(P && W && a && kdiag && mu && var && nbatch > 0 && M > 0 && B > 0, "predictive_diag_fwd: bad arguments");
   VARGP_REQUIRE(nbatch <= 65535, "predictive_diag_fwd: batch too large");
-  hipLaunchKernelGGL(pdiag_fwd_kernel, dim3(cdiv(B, 256), nbatch), dim3(256), 0, as_stream(stream), P, W, a, kdiag, mu,
+  hipLaunchKernelGGL(pdiag_fwd_kernel, dim3(cdiv(B, 64), nbatch), dim3(256), 0, as_stream(stream), P, W, a, kdiag, mu,
                      var, M, B);
   return check_launch("predictive_diag_fwd");
 }
@@ -288,8 +398,13 @@ extern "C" int vargp_softmax_nll_bwd(const float* mu, const float* var, const fl
                                      const float* gnll, float* gmu, float* gvar, int S, int F, int C, int B,
                                      vargp_stream_t stream) {
   VARGP_REQUIRE(mu && var && eps && y && gnll && gmu && gvar, "softmax_nll_bwd: null pointer");
-  const int64_t total = (int64_t)S * C * B;
-  hipLaunchKernelGGL(softmax_nll_bwd_kernel, GRID1(total), mu, var, eps, y, gnll, gmu, gvar, S, F, C, B);
+  if (C <= 16) {
+    const int64_t total = (int64_t)S * B;
+    hipLaunchKernelGGL(softmax_nll_bwd_small_kernel<16>, GRID1(total), mu, var, eps, y, gnll, gmu, gvar, S, F, C, B);
+  } else {
+    const int64_t total = (int64_t)S * C * B;
+    hipLaunchKernelGGL(softmax_nll_bwd_kernel, GRID1(total), mu, var, eps, y, gnll, gmu, gvar, S, F, C, B);
+  }
   return check_launch("softmax_nll_bwd");
 }
 extern "C" int vargp_softmax_predict(const float* mu, const float* var, const float* eps, float* probs, int S, int F,
@@ -298,4 +413,32 @@ extern "C" int vargp_softmax_predict(const float* mu, const float* var, const fl
   const int64_t total = (int64_t)C * B;
   hipLaunchKernelGGL(softmax_predict_kernel, GRID1(total), mu, var, eps, probs, S, F, C, B);
   return check_launch("softmax_predict");
+}
+
+extern "C" int vargp_hyper_sample_fwd(const float* mean, const float* logvar, const float* eps, float* theta, int S,
+                                      int D1, vargp_stream_t stream) {
+  VARGP_REQUIRE(mean && logvar && eps && theta && S > 0 && D1 > 0, "hyper_sample_fwd: bad arguments");
+  hipLaunchKernelGGL(hyper_sample_fwd_kernel, GRID1((int64_t)S * D1), mean, logvar, eps, theta, S, D1);
+  return check_launch("hyper_sample_fwd");
+}
+extern "C" int vargp_hyper_sample_bwd(const float* logvar, const float* eps, const float* gtheta, float* gmean,
+                                      float* glogvar, int S, int D1, vargp_stream_t stream) {
+  VARGP_REQUIRE(logvar && eps && gtheta && gmean && glogvar && S > 0 && D1 > 0, "hyper_sample_bwd: bad arguments");
+  hipLaunchKernelGGL(hyper_sample_bwd_kernel, GRID1((int64_t)D1), logvar, eps, gtheta, gmean, glogvar, S, D1);
+  return check_launch("hyper_sample_bwd");
+}
+extern "C" int vargp_hyper_kl_fwd(const float* mean, const float* logvar, const float* prior_mean,
+                                  const float* prior_logvar, float* kl, int D1, vargp_stream_t stream) {
+  VARGP_REQUIRE(mean && logvar && prior_mean && prior_logvar && kl && D1 > 0, "hyper_kl_fwd: bad arguments");
+  hipLaunchKernelGGL(hyper_kl_fwd_kernel, dim3(1), dim3(256), 0, as_stream(stream), mean, logvar, prior_mean,
+                     prior_logvar, kl, D1);
+  return check_launch("hyper_kl_fwd");
+}
+extern "C" int vargp_hyper_kl_bwd(const float* mean, const float* logvar, const float* prior_mean,
+                                  const float* prior_logvar, const float* gkl, float* gmean, float* glogvar, int D1,
+                                  vargp_stream_t stream) {
+  VARGP_REQUIRE(mean && logvar && prior_mean && prior_logvar && gkl && gmean && glogvar, "hyper_kl_bwd: null pointer");
+  hipLaunchKernelGGL(hyper_kl_bwd_kernel, GRID1((int64_t)D1), mean, logvar, prior_mean, prior_logvar, gkl, gmean,
+                     glogvar, D1);
+  return check_launch("hyper_kl_bwd");
 }

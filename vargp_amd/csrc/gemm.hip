@@ -13,9 +13,8 @@
 namespace vargp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int BK = 16;
 
-template <bool KC, int ROWS>
+template <bool KC, int ROWS, int BK>
 struct LdsLayout {
   static constexpr int kStride = KC ? (BK + 1) : (ROWS + 4);
   static constexpr int kSize = KC ? ROWS * (BK + 1) : BK * (ROWS + 4);
@@ -24,7 +23,7 @@ struct LdsLayout {
 
 // Global -> registers for one ROWS x BK slab.  Element (r,k) lives at base[(r0+r)*ld + k] (KC) or
 // base[k*ld + r0 + r] (!KC).  Out-of-range elements (r >= rmax, k >= ke) read as zero.
-template <bool KC, int ROWS, bool VEC>
+template <bool KC, int ROWS, int BK, bool VEC>
 __device__ __forceinline__ void load_slab(const float* __restrict__ base, int ld, int r0, int rmax, int k0,
                                           int ke, float (&reg)[ROWS * BK / 256]) {
   constexpr int NPT = ROWS * BK / 256;
@@ -34,7 +33,7 @@ __device__ __forceinline__ void load_slab(const float* __restrict__ base, int ld
     for (int c = 0; c < NPT / 4; ++c) {
       const int q = tid + 256 * c;
       int r, k;
-      if constexpr (KC) { r = q >> 2; k = (q & 3) * 4; } else { k = q / (ROWS / 4); r = (q % (ROWS / 4)) * 4; }
+      if constexpr (KC) { r = q / (BK / 4); k = (q % (BK / 4)) * 4; } else { k = q / (ROWS / 4); r = (q % (ROWS / 4)) * 4; }
       const int gr = r0 + r, gk = k0 + k;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if constexpr (KC) {
@@ -74,23 +73,41 @@ __device__ __forceinline__ void load_slab(const float* __restrict__ base, int ld
   }
 }
 
+// per-k scale factors of the elements this thread stages (K-contiguous operand only): with VEC the
+// thread owns k = 4*(tid % (BK/4)) + e, e<4, in every chunk (256 % (BK/4) == 0); without, k = tid % BK.
+// Loaded together with the slab (prefetch), applied when the slab is written to LDS.
+template <int BK, bool VEC>
+__device__ __forceinline__ void load_scale(const float* __restrict__ kscale, int k0, int ke, float (&rs)[4]) {
+  const int tid = threadIdx.x;
+  if constexpr (VEC) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = k0 + (tid % (BK / 4)) * 4 + e;
+      rs[e] = (k < ke) ? kscale[k] : 0.f;
+    }
+  } else {
+    const int k = k0 + (tid % BK);
+    rs[0] = (k < ke) ? kscale[k] : 0.f;
+  }
+}
+
 // registers -> LDS (same element <-> thread map as load_slab); optional per-k scale (KC only)
-template <bool KC, int ROWS, bool VEC, bool SCALE>
+template <bool KC, int ROWS, int BK, bool VEC, bool SCALE>
 __device__ __forceinline__ void store_slab(float* __restrict__ lds, const float (&reg)[ROWS * BK / 256],
-                                           const float* __restrict__ kscale, int k0, int ke) {
+                                           const float (&rs)[4]) {
   constexpr int NPT = ROWS * BK / 256;
-  using L = LdsLayout<KC, ROWS>;
+  using L = LdsLayout<KC, ROWS, BK>;
   const int tid = threadIdx.x;
   if constexpr (VEC) {
 #pragma unroll
     for (int c = 0; c < NPT / 4; ++c) {
       const int q = tid + 256 * c;
       if constexpr (KC) {
-        const int r = q >> 2, k = (q & 3) * 4;
+        const int r = q / (BK / 4), k = (q % (BK / 4)) * 4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float v = reg[4 * c + e];
-          if constexpr (SCALE) v *= (k0 + k + e < ke) ? kscale[k0 + k + e] : 0.f;
+          if constexpr (SCALE) v *= rs[e];
           lds[L::at(r, k + e)] = v;
         }
       } else {
@@ -106,17 +123,17 @@ __device__ __forceinline__ void store_slab(float* __restrict__ lds, const float 
       int r, k;
       if constexpr (KC) { r = e / BK; k = e % BK; } else { k = e / ROWS; r = e % ROWS; }
       float v = reg[c];
-      if constexpr (SCALE) v *= (k0 + k < ke) ? kscale[k0 + k] : 0.f;
+      if constexpr (SCALE) v *= rs[0];
       lds[L::at(r, k)] = v;
     }
   }
 }
 
-template <int BM, int BN, bool AKC, bool BKC, bool VEC, bool RBF>
+template <int BM, int BN, int BK, bool AKC, bool BKC, bool VEC, bool RBF>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-  using LA = LdsLayout<AKC, BM>;
-  using LB = LdsLayout<BKC, BN>;
+  using LA = LdsLayout<AKC, BM, BK>;
+  using LB = LdsLayout<BKC, BN, BK>;
   __shared__ __attribute__((aligned(16))) float lds[LA::kSize + LB::kSize + 8];
   float* As = lds;
   float* Bs = lds + ((LA::kSize + 3) & ~3);
@@ -163,19 +180,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 
   const float* kscale = RBF ? p.kscale + i0 * p.ks_ld : nullptr;
 
-  float ra[BM * BK / 256], rb[BN * BK / 256];
+  float ra[BM * BK / 256], rb[BN * BK / 256], rs[4] = {1.f, 1.f, 1.f, 1.f};
   if (ks < ke) {
-    load_slab<AKC, BM, VEC>(A, p.lda, m0, p.M, ks, ke, ra);
-    load_slab<BKC, BN, VEC>(B, p.ldb, n0, p.N, ks, ke, rb);
+    load_slab<AKC, BM, BK, VEC>(A, p.lda, m0, p.M, ks, ke, ra);
+    load_slab<BKC, BN, BK, VEC>(B, p.ldb, n0, p.N, ks, ke, rb);
+    if constexpr (RBF) load_scale<BK, VEC>(kscale, ks, ke, rs);
   }
   for (int k0 = ks; k0 < ke; k0 += BK) {
     __syncthreads();  // previous slab fully consumed
-    store_slab<AKC, BM, VEC, RBF>(As, ra, kscale, k0, ke);
-    store_slab<BKC, BN, VEC, false>(Bs, rb, nullptr, k0, ke);
+    store_slab<AKC, BM, BK, VEC, RBF>(As, ra, rs);
+    store_slab<BKC, BN, BK, VEC, false>(Bs, rb, rs);
     __syncthreads();
     if (k0 + BK < ke) {
-      load_slab<AKC, BM, VEC>(A, p.lda, m0, p.M, k0 + BK, ke, ra);
-      load_slab<BKC, BN, VEC>(B, p.ldb, n0, p.N, k0 + BK, ke, rb);
+      load_slab<AKC, BM, BK, VEC>(A, p.lda, m0, p.M, k0 + BK, ke, ra);
+      load_slab<BKC, BN, BK, VEC>(B, p.ldb, n0, p.N, k0 + BK, ke, rb);
+      if constexpr (RBF) load_scale<BK, VEC>(kscale, k0 + BK, ke, rs);
     }
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
@@ -228,38 +247,51 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   }
 }
 
-template <int BM, int BN, bool VEC, bool RBF>
+template <int BM, int BN, int BK, bool VEC, bool RBF>
 static void dispatch_layout(const GemmParams& p, int transA, int transB, dim3 grid, hipStream_t st) {
   // op(A) K-contiguous <=> transA == 0;  op(B) K-contiguous <=> transB == 1
   const bool akc = transA == 0, bkc = transB == 1;
   if constexpr (RBF) {
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true, VEC, true>), grid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, true, true, VEC, true>), grid, dim3(256), 0, st, p);
   } else {
-    if (akc && bkc) hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true, VEC, false>), grid, dim3(256), 0, st, p);
-    else if (akc && !bkc) hipLaunchKernelGGL((gemm_kernel<BM, BN, true, false, VEC, false>), grid, dim3(256), 0, st, p);
-    else if (!akc && bkc) hipLaunchKernelGGL((gemm_kernel<BM, BN, false, true, VEC, false>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((gemm_kernel<BM, BN, false, false, VEC, false>), grid, dim3(256), 0, st, p);
+    if (akc && bkc) hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, true, true, VEC, false>), grid, dim3(256), 0, st, p);
+    else if (akc && !bkc) hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, true, false, VEC, false>), grid, dim3(256), 0, st, p);
+    else if (!akc && bkc) hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, false, true, VEC, false>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, false, false, VEC, false>), grid, dim3(256), 0, st, p);
+  }
+}
+
+template <int BM, int BN, int BK>
+static void dispatch_tile(const GemmParams& p, int transA, int transB, int nbatch, bool rbf, bool vec, hipStream_t st) {
+  dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), nbatch);
+  if (rbf) {
+    if (vec) dispatch_layout<BM, BN, BK, true, true>(p, 0, 1, grid, st);
+    else dispatch_layout<BM, BN, BK, false, true>(p, 0, 1, grid, st);
+  } else {
+    if (vec) dispatch_layout<BM, BN, BK, true, false>(p, transA, transB, grid, st);
+    else dispatch_layout<BM, BN, BK, false, false>(p, transA, transB, grid, st);
   }
 }
 
 static bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
-int launch_gemm(const GemmParams& p, int transA, int transB, int nbatch, bool rbf, hipStream_t st) {
+// Tile choice (MI355X: 256 CUs).  The f32 MFMA runs at the vector rate, so what matters is (a) filling
+// the CUs and (b) amortising the per-slab staging + 2 barriers over enough MFMAs:
+//   128x128xBK16 : 32 MFMA / slab / wave  - when that still gives >= ~1 workgroup per CU
+//   128x64 xBK32 : 32 MFMA / slab / wave  - mid-size problems (K_uf at Split-MNIST: 192 workgroups)
+//   64 x64 xBK64 :  32 MFMA / slab / wave - small problems; the K extent of the (M x M) products of the
+//                  ELBO (K <= 128) is covered by one or two slabs, i.e. one or two global-load latencies.
+int launch_gemm(const GemmParams& p, int transA, int transB, int nbatch, bool rbf, hipStream_t st, const char* tag) {
   if (p.M <= 0 || p.N <= 0 || nbatch <= 0) return VARGP_OK;
+  ProfScope prof(tag, st);
   VARGP_REQUIRE(nbatch <= 65535, "bgemm: batch %d exceeds 65535", nbatch);
   bool vec = aligned16(p.A) && aligned16(p.B) && (p.lda % 4 == 0) && (p.ldb % 4 == 0);
   for (int i = 0; i < 3; ++i) vec = vec && (p.sA[i] % 4 == 0) && (p.sB[i] % 4 == 0);
-  const int64_t big_tiles = (int64_t)cdiv(p.M, 128) * cdiv(p.N, 128) * nbatch;
-  const bool big = big_tiles >= 192;
-  if (big) {
-    dim3 grid(cdiv(p.M, 128) * cdiv(p.N, 128), nbatch);
-    if (rbf) { if (vec) dispatch_layout<128, 128, true, true>(p, 0, 1, grid, st); else dispatch_layout<128, 128, false, true>(p, 0, 1, grid, st); }
-    else     { if (vec) dispatch_layout<128, 128, true, false>(p, transA, transB, grid, st); else dispatch_layout<128, 128, false, false>(p, transA, transB, grid, st); }
-  } else {
-    dim3 grid(cdiv(p.M, 64) * cdiv(p.N, 64), nbatch);
-    if (rbf) { if (vec) dispatch_layout<64, 64, true, true>(p, 0, 1, grid, st); else dispatch_layout<64, 64, false, true>(p, 0, 1, grid, st); }
-    else     { if (vec) dispatch_layout<64, 64, true, false>(p, transA, transB, grid, st); else dispatch_layout<64, 64, false, false>(p, transA, transB, grid, st); }
-  }
+  const int64_t t128 = (int64_t)cdiv(p.M, 128) * cdiv(p.N, 128) * nbatch;
+  const int64_t t12864 = (int64_t)cdiv(p.M, 128) * cdiv(p.N, 64) * nbatch;
+  if (t128 >= 192) dispatch_tile<128, 128, 16>(p, transA, transB, nbatch, rbf, vec, st);
+  else if (t12864 >= 160 && p.M > 64) dispatch_tile<128, 64, 32>(p, transA, transB, nbatch, rbf, vec, st);
+  else dispatch_tile<64, 64, 64>(p, transA, transB, nbatch, rbf, vec, st);
   return check_launch("bgemm");
 }
 

@@ -48,6 +48,25 @@ __global__ void rbf_prep_kernel(const float* __restrict__ theta, float* __restri
   if (threadIdx.x == 0) g2[s] = expf(2.f * th[D]);
 }
 
+// Small input dimension (D <= kDirectD, e.g. the 2-D toy problem): form the squared distance directly as
+// sum_d w_d (x_d - y_d)^2 — no cancellation, no GEMM.  One thread per kernel-matrix entry.
+constexpr int kDirectD = 32;
+__global__ __launch_bounds__(256) void rbf_direct_kernel(const float* __restrict__ X, const float* __restrict__ Y,
+                                                         const float* __restrict__ w, const float* __restrict__ g2,
+                                                         float* __restrict__ K, int C, int M, int N, int D, int64_t Dp,
+                                                         int y_shared, int64_t total) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int n = e % N, m = (e / N) % M, c = (e / ((int64_t)N * M)) % C;
+  const int s = e / ((int64_t)N * M * C);
+  const float* xr = X + ((int64_t)c * M + m) * D;
+  const float* yr = Y ? (y_shared ? Y + (int64_t)n * D : Y + ((int64_t)c * N + n) * D) : X + ((int64_t)c * M + n) * D;
+  const float* ws = w + s * Dp;
+  float d2 = 0.f;
+  for (int d = 0; d < D; ++d) { const float t = xr[d] - yr[d]; d2 = fmaf(ws[d] * t, t, d2); }
+  K[e] = g2[s] * expf(-0.5f * d2);
+}
+
 // nrm[s][row] = sum_d w[s][d] x[row][d]^2 ; one wave per row, grid (ceil(rows/4), S)
 __global__ __launch_bounds__(256) void rbf_norm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        float* __restrict__ nrm, int64_t rows, int D, int64_t Dp) {
@@ -62,37 +81,33 @@ __global__ __launch_bounds__(256) void rbf_norm_kernel(const float* __restrict__
   if (lane == 0) nrm[(int64_t)s * rows + row] = acc;
 }
 
-// W = gK o K, r = rowsum(W); one wave per row of the flattened [nrow_total, N] matrix.
-// tot[s] += sum(W) (for dlog gamma = 2 sum W), rows_per_s rows belong to each sample.
-__global__ __launch_bounds__(256) void rbf_w_rows_kernel(const float* __restrict__ K, const float* __restrict__ gK,
-                                                         float* __restrict__ W, float* __restrict__ r,
-                                                         float* __restrict__ gtheta, int64_t nrows, int N,
-                                                         int64_t rows_per_s, int D) {
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (row >= nrows) return;
-  const float* k = K + row * N;
-  const float* g = gK + row * N;
-  float* wr = W + row * N;
-  float acc = 0.f;
-  for (int n = lane; n < N; n += 64) { const float v = k[n] * g[n]; wr[n] = v; acc += v; }
-  acc = wave_sum(acc);
-  if (lane == 0) {
-    r[row] = acc;
-    atomicAdd(&gtheta[(row / rows_per_s) * (D + 1) + D], 2.f * acc);
+// W = gK o K with its row sums r, column sums c and total (dlog gamma = 2 sum W) in one pass.
+// grid (ceil(N/256), ceil(Mb/32), nb): a thread owns one column of a 32-row strip; r and c are
+// accumulated with float atomics (pre-zeroed by the caller), the total with one atomic per block.
+constexpr int WROWS = 32;
+__global__ __launch_bounds__(256) void rbf_w_kernel(const float* __restrict__ K, const float* __restrict__ gK,
+                                                    float* __restrict__ W, float* __restrict__ r,
+                                                    float* __restrict__ c, float* __restrict__ gtheta, int Mb, int N,
+                                                    int Cb, int D) {
+  __shared__ float red[4];
+  const int col = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+  const int row0 = blockIdx.y * WROWS;
+  const int64_t b = blockIdx.z;
+  const bool cok = col < N;
+  const int64_t base = b * Mb * N;
+  float csum = 0.f;
+  const int rend = min(WROWS, Mb - row0);
+  for (int rr = 0; rr < rend; ++rr) {
+    const int64_t off = base + (int64_t)(row0 + rr) * N + col;
+    float v = 0.f;
+    if (cok) { v = K[off] * gK[off]; W[off] = v; }
+    csum += v;
+    const float rs = wave_sum(v);
+    if (lane == 0 && rs != 0.f) atomicAdd(&r[b * Mb + row0 + rr], rs);
   }
-}
-
-// c[b][n] = sum_m W[b][m][n]; grid (ceil(N/256), nb)
-__global__ __launch_bounds__(256) void rbf_w_cols_kernel(const float* __restrict__ W, float* __restrict__ c, int M,
-                                                         int N) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  const int64_t b = blockIdx.y;
-  if (n >= N) return;
-  const float* w = W + b * M * N + n;
-  float acc = 0.f;
-  for (int m = 0; m < M; ++m) acc += w[(int64_t)m * N];
-  c[b * N + n] = acc;
+  if (cok) atomicAdd(&c[b * N + col], csum);
+  const float tot = block_sum<256>(csum, red);
+  if (threadIdx.x == 0) atomicAdd(&gtheta[(b / Cb) * (D + 1) + D], 2.f * tot);
 }
 
 // square case (Y = X): W <- W + W^T (out of place into Ws), r <- r + c.  grid (ceil(M*M/256), nb)
@@ -183,6 +198,12 @@ extern "C" int vargp_rbf_gram_fwd(const float* theta, const float* X, const floa
   hipStream_t st = as_stream(stream);
   RbfWs o = carve(ws, S, C, M, N, D, false);
   hipLaunchKernelGGL(rbf_prep_kernel, dim3(S), dim3(256), 0, st, theta, o.w, o.g2, D, o.Dp);
+  if (D <= kDirectD) {
+    const int64_t total = (int64_t)S * C * M * N;
+    hipLaunchKernelGGL(rbf_direct_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, X, Y, o.w, o.g2, K, C, M, N, D, o.Dp,
+                       y_shared, total);
+    return check_launch("rbf_gram_fwd(direct)");
+  }
   const int64_t xrows = (int64_t)C * M, yrows = y_shared ? N : (int64_t)C * N;
   hipLaunchKernelGGL(rbf_norm_kernel, dim3(cdiv(xrows, 4), S), dim3(256), 0, st, X, o.w, o.na, xrows, D, o.Dp);
   if (!self)
@@ -201,7 +222,7 @@ extern "C" int vargp_rbf_gram_fwd(const float* theta, const float* X, const floa
   p.na = o.na; p.sNa[0] = xrows; p.sNa[1] = Mb;
   p.nbv = self ? o.na : o.nb; p.sNb[0] = self ? xrows : yrows; p.sNb[1] = (self || !y_shared) ? N : 0;
   p.same_xy = self ? 1 : 0;
-  int rc = launch_gemm(p, 0, 1, S * Cb, true, st);
+  int rc = launch_gemm(p, 0, 1, S * Cb, true, st, self ? "rbf_kuu_gemm" : "rbf_kuf_gemm");
   if (rc) return rc;
   return check_launch("rbf_gram_fwd");
 }
@@ -223,9 +244,9 @@ extern "C" int vargp_rbf_gram_bwd(const float* theta, const float* X, const floa
   hipLaunchKernelGGL(rbf_prep_kernel, dim3(S), dim3(256), 0, st, theta, o.w, o.g2, D, o.Dp);
   const int64_t nrows = (int64_t)S * xrows;
   float* Wfirst = self ? o.W2 : o.Wm;  // self: raw W goes to W2, W + W^T to Wm
-  hipLaunchKernelGGL(rbf_w_rows_kernel, dim3(cdiv(nrows, 4)), dim3(256), 0, st, K, gK, Wfirst, o.r, gtheta, nrows, N,
-                     xrows, D);
-  hipLaunchKernelGGL(rbf_w_cols_kernel, dim3(cdiv(N, 256), nb), dim3(256), 0, st, Wfirst, o.c, Mb, N);
+  (void)hipMemsetAsync(o.r, 0, sizeof(float) * (size_t)(o.P - o.r), st);   // r and c are adjacent
+  hipLaunchKernelGGL(rbf_w_kernel, dim3(cdiv(N, 256), cdiv(Mb, WROWS), nb), dim3(256), 0, st, K, gK, Wfirst, o.r, o.c,
+                     gtheta, Mb, N, Cb, D);
   if (self) {
     hipLaunchKernelGGL(rbf_w_sym_kernel, dim3(cdiv((int64_t)M * M, 256), nb), dim3(256), 0, st, Wfirst, o.Wm, M);
     hipLaunchKernelGGL(rbf_add_kernel, dim3(cdiv(nrows, 256)), dim3(256), 0, st, o.r, o.c, nrows);
@@ -239,7 +260,7 @@ extern "C" int vargp_rbf_gram_bwd(const float* theta, const float* X, const floa
   p.sB[0] = 0; p.sB[1] = y_shared ? 0 : (int64_t)N * D;
   p.sC[0] = (int64_t)Cb * Mb * D; p.sC[1] = (int64_t)Mb * D;
   p.alpha = 1.f;
-  int rc = launch_gemm(p, 0, 0, nb, false, st);
+  int rc = launch_gemm(p, 0, 0, nb, false, st, self ? "rbf_kuu_bwd_gemm" : "rbf_kuf_bwd_gemm");
   if (rc) return rc;
   const dim3 gx(cdiv(D, 64), cdiv(xrows, RPB));
   hipLaunchKernelGGL(rbf_final_kernel, gx, dim3(256), 0, st, X, o.r, o.P, o.w, gX, gtheta, xrows, D, o.Dp, S,

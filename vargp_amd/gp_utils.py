@@ -98,18 +98,20 @@ def linear_marginal_diag(m, S, Kzz, Kzx, Kxx_diag, cache=None):
     if per_column:
         var = var + Kxx_diag
     if isinstance(cache, dict):
-        cache.update(dict(Lz=Lz, Lz_Kzx=P, Tz=Tz))
+        cache.update(dict(Lz=Lz, Lz_Kzx=P, Tz=Tz, Lz_m=a))
     return mu, var
 
 
-def mvn_kl(mu_q, Lq, mu_p, Lp, Tp=None):
+def mvn_kl(mu_q, Lq, mu_p, Lp, Tp=None, d=None):
     """KL(N(mu_q, Lq Lq^T) || N(mu_p, Lp Lp^T)) over the last dim, broadcasting batch dims — what
-    torch's kl_divergence(MVN, MVN) computes for the reference (var_gp/vargp.py:182-190)."""
+    torch's kl_divergence(MVN, MVN) computes for the reference (var_gp/vargp.py:182-190).
+    Tp = Lp^-1 and d = Lp^-1 (mu_q - mu_p) may be passed in when the caller already has them."""
     if Tp is None:
         Tp = _inverse_factor(Lp)
     G = ops.matmul(Tp, Lq, triA=LOWER, triB=LOWER, triC=LOWER)
-    d = ops.matmul(Tp, (mu_q - mu_p).unsqueeze(-1), triA=LOWER).squeeze(-1)
-    bshape = G.shape[:-2]
+    if d is None:
+        d = ops.matmul(Tp, (mu_q - mu_p).unsqueeze(-1), triA=LOWER).squeeze(-1)
+    bshape = torch.broadcast_shapes(G.shape[:-2], d.shape[:-1])
     ldp = ops.logdet_tril(Lp).expand(bshape)
     ldq = ops.logdet_tril(Lq).expand(bshape)
-    return ops.mvn_kl_from_factors(G, d.expand(*bshape, -1), ldp, ldq)
+    return ops.mvn_kl_from_factors(G.expand(*bshape, -1, -1), d.expand(*bshape, -1), ldp, ldq)

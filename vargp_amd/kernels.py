@@ -51,16 +51,13 @@ class RBFKernel(nn.Module):
         if self.map_est:
             return self.log_mean.unsqueeze(0)
         eps = noise.draw('eps_theta', (n_hypers, self.log_mean.shape[0]), self.log_mean.device)
-        return self.log_mean + eps * self.log_logvar.exp().sqrt()
+        return ops.hyper_sample(self.log_mean, self.log_logvar, eps)
 
     def kl_hypers(self):
-        """sum_d KL(q(theta_d) || p(theta_d)), both diagonal Normals  (kernels.py:70-77).
-        785-element elementwise math: stays in torch."""
+        """sum_d KL(q(theta_d) || p(theta_d)), both diagonal Normals  (kernels.py:70-77)."""
         if self.map_est:
             return torch.tensor(0.0, device=self.log_mean.device)
-        ratio = (self.log_logvar - self.prior_log_logvar).exp()
-        t1 = (self.log_mean - self.prior_log_mean).pow(2) / self.prior_log_logvar.exp()
-        return (0.5 * (ratio + t1 - 1.0 - (self.log_logvar - self.prior_log_logvar))).sum()
+        return ops.hyper_kl(self.log_mean, self.log_logvar, self.prior_log_mean, self.prior_log_logvar)
 
 
 class DeepRBFKernel(RBFKernel):

@@ -25,6 +25,10 @@ def set_cholesky_error_mode(mode):
     _chol_mode = mode
 
 
+def reset_linalg_errors():
+    del _info_ring[:]
+
+
 def linalg_error_count():
     """'defer' mode: number of failed factorisations among the most recent calls (syncs)."""
     return sum(int((t != 0).sum().item()) for t in _info_ring)
@@ -442,3 +446,57 @@ def softmax_predict(mu, var, eps):
     check(lib().vargp_softmax_predict(ptr(mu), ptr(var), ptr(eps), ptr(probs), S, F, C, B, stream_ptr()),
           'vargp_softmax_predict')
     return probs
+
+
+# ------------------------------------------------------------------------------------------------
+# variational hyper-parameters
+# ------------------------------------------------------------------------------------------------
+class _HyperSample(Function):
+    @staticmethod
+    def forward(ctx, mean, logvar, eps):
+        require_device(mean, logvar, eps)
+        mean, logvar, eps = mean.contiguous(), logvar.contiguous(), eps.contiguous()
+        S, D1 = eps.shape
+        theta = torch.empty_like(eps)
+        check(lib().vargp_hyper_sample_fwd(ptr(mean), ptr(logvar), ptr(eps), ptr(theta), S, D1, stream_ptr()),
+              'vargp_hyper_sample_fwd')
+        ctx.save_for_backward(logvar, eps)
+        return theta
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        logvar, eps = ctx.saved_tensors
+        S, D1 = eps.shape
+        gm, gv = torch.empty_like(logvar), torch.empty_like(logvar)
+        check(lib().vargp_hyper_sample_bwd(ptr(logvar), ptr(eps), ptr(g.contiguous()), ptr(gm), ptr(gv), S, D1,
+                                           stream_ptr()), 'vargp_hyper_sample_bwd')
+        return gm, gv, None
+
+
+def hyper_sample(mean, logvar, eps):
+    return _HyperSample.apply(mean, logvar, eps)
+
+
+class _HyperKl(Function):
+    @staticmethod
+    def forward(ctx, mean, logvar, pmean, plogvar):
+        require_device(mean, logvar, pmean, plogvar)
+        t = [x.contiguous() for x in (mean, logvar, pmean, plogvar)]
+        kl = torch.empty((), dtype=torch.float32, device=mean.device)
+        check(lib().vargp_hyper_kl_fwd(*(ptr(x) for x in t), ptr(kl), mean.numel(), stream_ptr()), 'vargp_hyper_kl_fwd')
+        ctx.save_for_backward(*t)
+        return kl
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        t = ctx.saved_tensors
+        gm, gv = torch.empty_like(t[0]), torch.empty_like(t[1])
+        check(lib().vargp_hyper_kl_bwd(*(ptr(x) for x in t), ptr(g.contiguous()), ptr(gm), ptr(gv), t[0].numel(),
+                                       stream_ptr()), 'vargp_hyper_kl_bwd')
+        return gm, gv, None, None
+
+
+def hyper_kl(mean, logvar, prior_mean, prior_logvar):
+    return _HyperKl.apply(mean, logvar, prior_mean, prior_logvar)

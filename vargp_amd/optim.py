@@ -1,0 +1,48 @@
+"""Yogi optimiser on the fused HIP step kernel (reference call site: experiments/vargp.py:23,37 uses
+torch_optimizer.Yogi).
+
+torch_optimizer is not available in this environment and is unpinned in the reference's
+environment.yml, so the arithmetic follows the published algorithm (Zaheer et al., NeurIPS 2018) with
+the defaults torch_optimizer documents: betas (0.9, 0.999), eps 1e-3, initial_accumulator 1e-6 for
+both moment buffers.  PARITY UNPINNED for optimiser trajectories.
+"""
+import ctypes
+
+import torch
+
+from ._lib import check, lib, ptr, require_device, stream_ptr
+
+
+class Yogi(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-2, betas=(0.9, 0.999), eps=1e-3, initial_accumulator=1e-6):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, initial_accumulator=initial_accumulator))
+
+    @torch.no_grad()
+    def step(self):
+        """One fused launch for all parameter tensors of a group (<= 8).  The step count lives on the
+        device (bias corrections are computed inside the kernel), so the whole step can sit inside a
+        captured hipGraph."""
+        for group in self.param_groups:
+            b1, b2 = group['betas']
+            ps = [p for p in group['params'] if p.grad is not None]
+            if not ps:
+                continue
+            if 'step' not in group:
+                group['step'] = torch.zeros(1, dtype=torch.float32, device=ps[0].device)
+            group['step'].add_(1.0)
+            for p in ps:
+                require_device(p, p.grad)
+                st = self.state[p]
+                if not st:
+                    st['exp_avg'] = torch.full_like(p, group['initial_accumulator'])
+                    st['exp_avg_sq'] = torch.full_like(p, group['initial_accumulator'])
+            for i in range(0, len(ps), 8):
+                chunk = ps[i:i + 8]
+                k = len(chunk)
+                grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in chunk]
+                arr = lambda ts: (ctypes.c_void_p * k)(*[t.data_ptr() for t in ts])
+                sizes = (ctypes.c_int64 * k)(*[p.numel() for p in chunk])
+                check(lib().vargp_yogi_step_multi(k, arr(chunk), arr(grads), arr([self.state[p]['exp_avg'] for p in chunk]),
+                                                  arr([self.state[p]['exp_avg_sq'] for p in chunk]), sizes,
+                                                  group['lr'], b1, b2, group['eps'], ptr(group['step']), stream_ptr()),
+                      'vargp_yogi_step_multi')

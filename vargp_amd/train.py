@@ -1,0 +1,85 @@
+"""One ELBO training step as the reference's training loop performs it
+(experiments/vargp.py:29-37): zero_grad, loss, combine, backward, optimiser step — plus the
+sample-parallel multi-GPU exchange (one all-reduce of [grads | kl_u | nll]).
+
+Sample-parallel sharding: every rank holds all parameters and the same minibatch and
+evaluates `gp.n_v` of the world*gp.n_v hyper-parameter samples; the per-rank partial means combine
+linearly, so   total = beta*kl_hypers + mean_r kl_u_r + (N/B) mean_r nll_r.
+Each rank back-propagates its share divided by the world size and ONE all-reduce(sum) over a flat
+fp32 buffer [grad(z) | grad(u_mean) | grad(u_tril_vec) | grad(log_mean) | grad(log_logvar) | kl_u | nll]
+yields identical gradients on every rank.  Gradients are views into that flat buffer, so there is no
+pack/unpack copy.
+"""
+import torch
+import torch.distributed as dist
+
+from . import noise
+from .optim import Yogi
+
+
+class ElboTrainer:
+    def __init__(self, gp, lr=1e-2, beta=1.0, n_total=None, group=None, noise_seed=1234, optimizer=None):
+        self.gp = gp
+        self.beta = float(beta)
+        self.n_total = n_total
+        self.group = group
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        self.params = [p for p in gp.parameters() if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(n + 2, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        self.scalars = self.flat[n:]
+        self.optim = optimizer if optimizer is not None else Yogi(self.params, lr=lr)
+        if self.world > 1:
+            noise.set_shard(self.rank, self.world, noise_seed, dev)
+
+        self.graph = None
+
+    # -- hipGraph capture of the whole step (zero_grad .. optimiser) --------------------------------
+    def capture(self, x, y, warmup=3):
+        """Capture one full step into a hipGraph (torch.cuda.CUDAGraph).  Needs the 'defer' Cholesky
+        error mode (no host sync inside the step).  Afterwards use step_graph()."""
+        from . import ops
+        assert ops._chol_mode == 'defer', "set_cholesky_error_mode('defer') before capturing"
+        self._sx, self._sy = x.clone(), y.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.step(self._sx, self._sy)
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        if noise._shard is not None:
+            self.graph.register_generator_state(noise._shard[2])
+        with torch.cuda.graph(self.graph):
+            self._sout = self.step(self._sx, self._sy)
+        return self
+
+    def step_graph(self, x=None, y=None):
+        """Replay the captured step (optionally on a new minibatch of the captured shape)."""
+        if x is not None:
+            self._sx.copy_(x, non_blocking=True)
+            self._sy.copy_(y, non_blocking=True)
+        self.graph.replay()
+        return self._sout
+
+    def step(self, x, y):
+        """-> (kl_hypers, kl_u, nll) as 0-dim device tensors (global values on every rank)."""
+        self.flat.zero_()
+        kl_h, kl_u, nll = self.gp.loss(x, y)
+        scale = (self.n_total if self.n_total is not None else x.size(0)) / x.size(0)
+        w = 1.0 / self.world
+        loss = (self.beta * kl_h + kl_u + scale * nll) * w
+        loss.backward()
+        with torch.no_grad():
+            self.scalars[0] = kl_u.detach() * w
+            self.scalars[1] = nll.detach() * w
+        if self.world > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        self.optim.step()
+        return kl_h.detach(), self.scalars[0], self.scalars[1]

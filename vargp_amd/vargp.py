@@ -138,7 +138,9 @@ class VARGP(nn.Module):
                 prior_mu_t = torch.zeros(1, 1, 1, 1, device=x.device)            # p(u_1) = N(0, Lz Lz^T)
                 loss_cache.update(dict(var_mu_t=mu_t, var_L_cov_t=L_cov_t, prior_mu_t=prior_mu_t,
                                        prior_L_cov_t=cache_pf.pop('Lz').unsqueeze(0),
-                                       prior_T_cov_t=cache_pf.pop('Tz').unsqueeze(0)))
+                                       prior_T_cov_t=cache_pf.pop('Tz').unsqueeze(0),
+                                       # Lz^-1 (mu_q - 0) = Lz^-1 u_mean was already needed for the mean
+                                       prior_d=cache_pf.pop('Lz_m').squeeze(-1).unsqueeze(0)))
         return pred_mu, pred_var
 
     def loss(self, x, y):
@@ -149,7 +151,7 @@ class VARGP(nn.Module):
         nll = self.likelihood.loss(pred_mu, pred_var, y)
         kl = gp_utils.mvn_kl(loss_cache.pop('var_mu_t'), loss_cache.pop('var_L_cov_t'),
                              loss_cache.pop('prior_mu_t'), loss_cache.pop('prior_L_cov_t'),
-                             Tp=loss_cache.pop('prior_T_cov_t'))
+                             Tp=loss_cache.pop('prior_T_cov_t'), d=loss_cache.pop('prior_d', None))
         kl_u = kl.sum(dim=-1).mean(dim=0).mean(dim=0)
         kl_hypers = self.kernel.kl_hypers()
         return kl_hypers, kl_u, nll
