@@ -1,0 +1,105 @@
+"""CPU, world_size 2 over gloo: the sample-parallel exchange of vargp_amd.train.ElboTrainer
+(noise sharding + one all-reduce of [grads | kl_u | nll]) reproduces the single-process result for
+the full sample set.  The local compute is the oracle here (no GPU in this container); on the GPU box
+the same trainer drives the HIP model (bench.py --gpus N)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import vargp_oracle as orc
+
+S_LOCAL, WORLD, F_, C, M, D, B = 2, 2, 3, 4, 6, 5, 16
+SEED = 77
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _problem(n_prev):
+    return orc.make_problem(S_LOCAL * WORLD, F_, C, M, D, B, n_prev=n_prev, seed=9, kind='toy')
+
+
+def _worker(rank, port, n_prev, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD))
+    dist.init_process_group('gloo', rank=rank, world_size=WORLD)
+    try:
+        from vargp_amd import noise
+        from vargp_amd.train import ElboTrainer
+        torch.set_num_threads(1)
+        params, prev, x, y, _ = _problem(n_prev)
+        names = ['z', 'u_mean', 'u_tril_vec', 'log_mean', 'log_logvar']
+        leaves = {k: torch.nn.Parameter(params[k].clone()) for k in names}
+        full = dict(params, **leaves)
+        Mt_prev = n_prev * M
+
+        def loss_fn(xb, yb):
+            nz = dict(eps_theta=noise.draw('eps_theta', (S_LOCAL, D + 1), 'cpu'))
+            if n_prev:
+                nz['eps_u'] = noise.draw('eps_u', (S_LOCAL * WORLD, S_LOCAL, C, Mt_prev), 'cpu', sample_dim=1)
+            nz['eps_f'] = noise.draw('eps_f', (S_LOCAL, F_, C, B), 'cpu')
+            return orc.loss(full, prev, xb, yb, nz)
+
+        tr = ElboTrainer(None, beta=2.0, n_total=64, noise_seed=SEED, params=[leaves[k] for k in names],
+                         loss_fn=loss_fn, optimizer=lambda ps: torch.optim.SGD(ps, lr=0.0))
+        assert tr.world == WORLD and tr.rank == rank
+        kl_h, kl_u, nll = tr.step(x, y)
+        if rank == 0:
+            out.put(dict(kl_h=kl_h.item(), kl_u=kl_u.item(), nll=nll.item(),
+                         grads={k: leaves[k].grad.detach().clone().numpy() for k in names}))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n_prev', [0, 1])
+def test_sample_parallel_matches_single_process(n_prev):
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, port, n_prev, out)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    got = out.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+
+    # single process, all S_LOCAL*WORLD samples, same global noise (same generator seed, same draw order)
+    params, prev, x, y, _ = _problem(n_prev)
+    gen = torch.Generator().manual_seed(SEED)
+    S = S_LOCAL * WORLD
+    nz = dict(eps_theta=torch.randn(S, D + 1, generator=gen))
+    if n_prev:
+        # each rank draws (n_v, world*S_local, ...) and keeps its slice of dim 1; n_v = S_total here
+        nz['eps_u'] = torch.randn(S, S, C, n_prev * M, generator=gen)
+    nz['eps_f'] = torch.randn(S, F_, C, B, generator=gen)
+    sc, grads = orc.elbo_step(params, prev, x, y, nz, beta=2.0, n_total=64)
+    np.testing.assert_allclose(got['kl_h'], sc['kl_hypers'].item(), rtol=1e-5)
+    np.testing.assert_allclose(got['kl_u'], sc['kl_u'].item(), rtol=2e-5)
+    np.testing.assert_allclose(got['nll'], sc['nll'].item(), rtol=2e-5)
+    for k, g in grads.items():
+        err = np.linalg.norm(got['grads'][k] - g.numpy()) / np.linalg.norm(g.numpy())
+        assert err < 1e-4, (k, err)
+
+
+def test_noise_shards_tile_the_global_draw():
+    from vargp_amd import noise
+    try:
+        parts = []
+        for r in range(3):
+            noise.set_shard(r, 3, 11, 'cpu')
+            parts.append((noise.draw('eps_theta', (2, 7), 'cpu'), noise.draw('eps_f', (2, 3, 4, 5), 'cpu')))
+        gen = torch.Generator().manual_seed(11)
+        a, b = torch.randn(6, 7, generator=gen), torch.randn(6, 3, 4, 5, generator=gen)
+        assert torch.equal(torch.cat([p[0] for p in parts]), a)
+        assert torch.equal(torch.cat([p[1] for p in parts]), b)
+    finally:
+        noise.clear_shard()

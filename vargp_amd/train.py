@@ -18,14 +18,19 @@ from .optim import Yogi
 
 
 class ElboTrainer:
-    def __init__(self, gp, lr=1e-2, beta=1.0, n_total=None, group=None, noise_seed=1234, optimizer=None):
+    """`gp` is a vargp_amd VARGP module.  For tests of the exchange logic on CPU (gloo) the model can be
+    replaced by any `loss_fn(x, y) -> (kl_hypers, kl_u, nll)` over an explicit `params` list."""
+
+    def __init__(self, gp=None, lr=1e-2, beta=1.0, n_total=None, group=None, noise_seed=1234, optimizer=None,
+                 params=None, loss_fn=None):
         self.gp = gp
+        self.loss_fn = loss_fn if loss_fn is not None else gp.loss
         self.beta = float(beta)
         self.n_total = n_total
         self.group = group
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
-        self.params = [p for p in gp.parameters() if p.requires_grad]
+        self.params = list(params) if params is not None else [p for p in gp.parameters() if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(n + 2, dtype=torch.float32, device=dev)
@@ -35,6 +40,8 @@ class ElboTrainer:
             off += p.numel()
         self.scalars = self.flat[n:]
         self.optim = optimizer if optimizer is not None else Yogi(self.params, lr=lr)
+        if callable(self.optim) and not hasattr(self.optim, 'step'):
+            self.optim = self.optim(self.params)
         if self.world > 1:
             noise.set_shard(self.rank, self.world, noise_seed, dev)
 
@@ -71,7 +78,7 @@ class ElboTrainer:
     def step(self, x, y):
         """-> (kl_hypers, kl_u, nll) as 0-dim device tensors (global values on every rank)."""
         self.flat.zero_()
-        kl_h, kl_u, nll = self.gp.loss(x, y)
+        kl_h, kl_u, nll = self.loss_fn(x, y)
         scale = (self.n_total if self.n_total is not None else x.size(0)) / x.size(0)
         w = 1.0 / self.world
         loss = (self.beta * kl_h + kl_u + scale * nll) * w
