@@ -1,0 +1,103 @@
+// Standalone kernel micro-benchmarks against libvargp_hip.so (no torch): used for tuning under rocprofv3.
+//   ./bench_kernels [case] [iters]      case: all | kuf | gemm4k | small | chol | kufbwd
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/vargp_hip.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+static float* dev_rand(size_t n, float scale, unsigned seed) {
+  std::vector<float> h(n);
+  unsigned s = seed * 2654435761u + 12345u;
+  for (size_t i = 0; i < n; ++i) { s = s * 1664525u + 1013904223u; h[i] = scale * ((float)(s >> 8) / 8388608.f - 1.f); }
+  float* d; CK(hipMalloc(&d, n * sizeof(float)));
+  CK(hipMemcpy(d, h.data(), n * sizeof(float), hipMemcpyHostToDevice));
+  return d;
+}
+template <class F> static double time_us(F f, int iters) {
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  for (int i = 0; i < 3; ++i) f();
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(a, 0));
+  for (int i = 0; i < iters; ++i) f();
+  CK(hipEventRecord(b, 0));
+  CK(hipEventSynchronize(b));
+  float ms; CK(hipEventElapsedTime(&ms, a, b));
+  return 1e3 * ms / iters;
+}
+static void gemm(const float* A, const float* B, float* C, int M, int N, int K, int tA, int tB, int nb, long sA, long sB, long sC,
+                 int triA = 0, int triB = 0) {
+  vargp_gemm_desc d; memset(&d, 0, sizeof(d));
+  d.M = M; d.N = N; d.K = K; d.transA = tA; d.transB = tB; d.A = A; d.B = B; d.C = C; d.D = nullptr;
+  d.lda = tA ? M : K; d.ldb = tB ? K : N; d.ldc = N; d.nb[0] = nb; d.nb[1] = 1; d.nb[2] = 1;
+  d.sA[0] = sA; d.sB[0] = sB; d.sC[0] = sC; d.alpha = 1.f; d.triA = triA; d.triB = triB;
+  int rc = vargp_bgemm(&d, nullptr);
+  if (rc) { printf("bgemm failed: %s\n", vargp_last_error()); exit(1); }
+}
+
+int main(int argc, char** argv) {
+  std::string which = argc > 1 ? argv[1] : "all";
+  int iters = argc > 2 ? atoi(argv[2]) : 50;
+  auto want = [&](const char* n) { return which == "all" || which == n; };
+  if (want("kuf")) {   // Cfg2 K_uf: S3 C10 M100 B512 D784
+    const int S = 3, C = 10, M = 100, B = 512, D = 784;
+    float* th = dev_rand((size_t)S * (D + 1), 0.05f, 1);
+    float* z = dev_rand((size_t)C * M * D, 0.02f, 2);
+    float* x = dev_rand((size_t)B * D, 0.02f, 3);
+    float* K; CK(hipMalloc(&K, (size_t)S * C * M * B * 4));
+    size_t wsb = vargp_rbf_workspace_bytes(S, C, M, B, D, 0);
+    void* ws; CK(hipMalloc(&ws, wsb));
+    double us = time_us([&] { vargp_rbf_gram_fwd(th, z, x, K, S, C, M, B, D, 1, ws, wsb, nullptr); }, iters);
+    printf("kuf   rbf_gram_fwd(all 4 launches) %8.1f us  -> %.1f TFLOP/s on 2.408e9 flop\n", us, 2.408e9 / us * 1e-6);
+  }
+  if (want("kufbwd")) {   // P = W . Y  : [1000 x 512] x [512 x 784], batch 3
+    float* W = dev_rand((size_t)3 * 1000 * 512, 1.f, 4);
+    float* Y = dev_rand((size_t)512 * 784, 1.f, 5);
+    float* P; CK(hipMalloc(&P, (size_t)3 * 1000 * 784 * 4));
+    double us = time_us([&] { gemm(W, Y, P, 1000, 784, 512, 0, 0, 3, 1000L * 512, 0, 1000L * 784); }, iters);
+    printf("kufbwd [1000x512]x[512x784] b3     %8.1f us  -> %.1f TFLOP/s\n", us, 2.0 * 3 * 1000 * 784 * 512 / us * 1e-6);
+  }
+  if (want("gemm4k")) {
+    const int n = 4096;
+    float* A = dev_rand((size_t)n * n, 1.f, 6);
+    float* B = dev_rand((size_t)n * n, 1.f, 7);
+    float* C; CK(hipMalloc(&C, (size_t)n * n * 4));
+    for (int tb = 0; tb < 2; ++tb) {
+      double us = time_us([&] { gemm(A, B, C, n, n, n, 0, tb, 1, 0, 0, 0); }, 10);
+      printf("gemm4k NN/NT=%d                      %8.1f us  -> %.1f TFLOP/s\n", tb, us, 2.0 * n * n * (double)n / us * 1e-6);
+    }
+  }
+  if (want("small")) {   // the (M x M) products of the ELBO: 100x100x100 / 100x512x100, batch 30
+    float* A = dev_rand((size_t)30 * 100 * 100, 1.f, 8);
+    float* B = dev_rand((size_t)30 * 100 * 512, 1.f, 9);
+    float* C; CK(hipMalloc(&C, (size_t)30 * 100 * 512 * 4));
+    for (int tA = 0; tA < 2; ++tA) for (int tB = 0; tB < 2; ++tB) {
+      double us = time_us([&] { gemm(A, B, C, 100, 100, 100, tA, tB, 30, 10000, 10000, 10000); }, iters);
+      printf("small 100x100x100 b30 tA%d tB%d       %8.1f us\n", tA, tB, us);
+    }
+    double us = time_us([&] { gemm(A, B, C, 100, 512, 100, 0, 0, 30, 10000, 51200, 51200, 1, 0); }, iters);
+    printf("small T.Kuf 100x512x100 b30 (triA)   %8.1f us  -> %.1f TFLOP/s\n", us, 2.0 * 30 * 100 * 512 * 100 / us * 1e-6);
+    us = time_us([&] { gemm(A, B, C, 100, 512, 100, 1, 0, 30, 10000, 51200, 51200, 2, 0); }, iters);
+    printf("small G^T.P 100x512x100 b30 (triA up)%8.1f us\n", us);
+  }
+  if (want("chol")) {
+    for (int n : {20, 40, 64, 100}) {
+      const int nb = 30;
+      std::vector<float> h((size_t)nb * n * n);
+      for (int b = 0; b < nb; ++b) for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j)
+        h[((size_t)b * n + i) * n + j] = (i == j ? 1.f : 0.f) + 0.5f * expf(-0.05f * (i - j) * (i - j));
+      float *A, *L, *T; int* info;
+      CK(hipMalloc(&A, h.size() * 4)); CK(hipMalloc(&L, h.size() * 4)); CK(hipMalloc(&T, h.size() * 4)); CK(hipMalloc(&info, nb * 4));
+      CK(hipMemcpy(A, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+      double us = time_us([&] { vargp_chol_inv_fwd(A, 1e-4f, L, T, nullptr, info, nb, n, nullptr, 0, nullptr); }, iters);
+      double us2 = time_us([&] { vargp_chol_inv_fwd(A, 1e-4f, L, nullptr, nullptr, info, nb, n, nullptr, 0, nullptr); }, iters);
+      printf("chol  n=%3d batch %d  L+T %8.1f us   L only %8.1f us (incl. info memset)\n", n, nb, us, us2);
+    }
+  }
+  return 0;
+}

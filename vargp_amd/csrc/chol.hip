@@ -8,6 +8,8 @@
 // Backward (any n) is five GEMMs (see vargp_chol_inv_bwd).
 #include "common.h"
 #include <math.h>
+#include <type_traits>
+#include <stdlib.h>
 
 namespace vargp {
 
@@ -33,6 +35,7 @@ __device__ __forceinline__ int pk(int i, int j) { return i * (i + 1) / 2 + j; }
 // F = double: factor and explicit inverse are then at least as accurate as fp32 LAPACK potrf + trsm on
 // ill-conditioned K_uu; the chain of n dependent pivots, not the flops, bounds the kernel.
 constexpr int kCholP = 5;
+
 template <typename F, int K>
 __global__ __launch_bounds__(512) void chol_inv_small_kernel(const float* __restrict__ A, int lda, int64_t strideA,
                                                              float eps, float* __restrict__ L, int ldl,
@@ -157,9 +160,16 @@ static int launch_small(const float* A, int lda, int64_t sA, float eps, float* L
                         int ld_acc, hipStream_t st) {
   ProfScope prof("chol_inv_small", st);
   const int nt = (int)round_up((int64_t)n * kCholP, 64);
+  static const bool f32 = [] { const char* e = getenv("VARGP_CHOL_F32"); return e && atoi(e) != 0; }();   // tuning aid
 #define VARGP_CHOL_LAUNCH(K)                                                                                     \
-  hipLaunchKernelGGL((chol_inv_small_kernel<double, K>), dim3(nbatch), dim3(nt), 0, st, A, lda, sA, eps, L, ldl, sL, \
-                     T, ldt, sT, logdet, info, info_base, n, ld_acc)
+  do {                                                                                                           \
+    if (f32)                                                                                                     \
+      hipLaunchKernelGGL((chol_inv_small_kernel<float, K>), dim3(nbatch), dim3(nt), 0, st, A, lda, sA, eps, L, ldl, \
+                         sL, T, ldt, sT, logdet, info, info_base, n, ld_acc);                                    \
+    else                                                                                                         \
+      hipLaunchKernelGGL((chol_inv_small_kernel<double, K>), dim3(nbatch), dim3(nt), 0, st, A, lda, sA, eps, L, ldl, \
+                         sL, T, ldt, sT, logdet, info, info_base, n, ld_acc);                                    \
+  } while (0)
   if (n <= 20) VARGP_CHOL_LAUNCH(4);
   else if (n <= 40) VARGP_CHOL_LAUNCH(8);
   else if (n <= 65) VARGP_CHOL_LAUNCH(13);

@@ -9,6 +9,7 @@
 // MFMA 32x32x2 fragment maps (cdna guide §3): lane l holds A[i=l&31][k=l>>5], B[k=l>>5][j=l&31];
 // D register r of lane l is row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31.
 #include "common.h"
+#include <stdlib.h>
 
 namespace vargp {
 
@@ -129,14 +130,106 @@ __device__ __forceinline__ void store_slab(float* __restrict__ lds, const float 
   }
 }
 
+// ---- the same staging, one piece at a time (a piece = one float4 chunk with VEC, one float without),
+// so that the main loop can drop pieces into the shadow of individual MFMAs ----------------------------
+template <bool KC, int ROWS, int BK, bool VEC>
+struct Pieces { static constexpr int kCount = VEC ? ROWS * BK / 256 / 4 : ROWS * BK / 256; };
+
+template <bool KC, int ROWS, int BK, bool VEC>
+__device__ __forceinline__ void load_piece(const float* __restrict__ base, int ld, int r0, int rmax, int k0, int ke,
+                                           int c, float (&reg)[ROWS * BK / 256]) {
+  const int tid = threadIdx.x;
+  if constexpr (VEC) {
+    const int q = tid + 256 * c;
+    int r, k;
+    if constexpr (KC) { r = q / (BK / 4); k = (q % (BK / 4)) * 4; } else { k = q / (ROWS / 4); r = (q % (ROWS / 4)) * 4; }
+    const int gr = r0 + r, gk = k0 + k;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (KC) {
+      if (gr < rmax) {
+        const float* src = base + (int64_t)gr * ld + gk;
+        if (gk + 3 < ke) v = *reinterpret_cast<const float4*>(src);
+        else { if (gk < ke) v.x = src[0]; if (gk + 1 < ke) v.y = src[1]; if (gk + 2 < ke) v.z = src[2]; }
+      }
+    } else {
+      if (gk < ke) {
+        const float* src = base + (int64_t)gk * ld + gr;
+        if (gr + 3 < rmax) v = *reinterpret_cast<const float4*>(src);
+        else { if (gr < rmax) v.x = src[0]; if (gr + 1 < rmax) v.y = src[1]; if (gr + 2 < rmax) v.z = src[2]; }
+      }
+    }
+    reg[4 * c + 0] = v.x; reg[4 * c + 1] = v.y; reg[4 * c + 2] = v.z; reg[4 * c + 3] = v.w;
+  } else {
+    const int e = tid + 256 * c;
+    int r, k;
+    if constexpr (KC) { r = e / BK; k = e % BK; } else { k = e / ROWS; r = e % ROWS; }
+    const int gr = r0 + r, gk = k0 + k;
+    float v = 0.f;
+    if (gr < rmax && gk < ke) v = KC ? base[(int64_t)gr * ld + gk] : base[(int64_t)gk * ld + gr];
+    reg[c] = v;
+  }
+}
+
+// Loop-invariant element offset of a VEC piece's float4 relative to the slab origin, with the row index
+// clamped into the operand.  A clamped (duplicated) row/column only feeds output rows/columns >= M/N,
+// which are never stored, so the fast path needs no masks and no zero-fill.
+template <bool KC, int ROWS, int BK>
+__device__ __forceinline__ int piece_offset(int ld, int r0, int rmax, int c) {
+  const int q = threadIdx.x + 256 * c;
+  if constexpr (KC) {
+    const int r = q / (BK / 4), k = (q % (BK / 4)) * 4;
+    return min(r0 + r, rmax - 1) * ld + k;
+  } else {
+    const int k = q / (ROWS / 4), r = (q % (ROWS / 4)) * 4;
+    return k * ld + min(r0 + r, rmax - 4);       // requires rmax % 4 == 0 && rmax >= 4
+  }
+}
+template <int ROWS, int BK>
+__device__ __forceinline__ void load_piece_fast(const float* __restrict__ slab_base, int off, int c,
+                                                float (&reg)[ROWS * BK / 256]) {
+  const float4 v = *reinterpret_cast<const float4*>(slab_base + off);
+  reg[4 * c + 0] = v.x; reg[4 * c + 1] = v.y; reg[4 * c + 2] = v.z; reg[4 * c + 3] = v.w;
+}
+
+template <bool KC, int ROWS, int BK, bool VEC, bool SCALE>
+__device__ __forceinline__ void store_piece(float* __restrict__ lds, const float (&reg)[ROWS * BK / 256],
+                                            const float (&rs)[4], int c) {
+  using L = LdsLayout<KC, ROWS, BK>;
+  const int tid = threadIdx.x;
+  if constexpr (VEC) {
+    const int q = tid + 256 * c;
+    if constexpr (KC) {
+      const int r = q / (BK / 4), k = (q % (BK / 4)) * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = reg[4 * c + e];
+        if constexpr (SCALE) v *= rs[e];
+        lds[L::at(r, k + e)] = v;
+      }
+    } else {
+      const int k = q / (ROWS / 4), r = (q % (ROWS / 4)) * 4;
+      *reinterpret_cast<float4*>(&lds[L::at(r, k)]) =
+          make_float4(reg[4 * c], reg[4 * c + 1], reg[4 * c + 2], reg[4 * c + 3]);
+    }
+  } else {
+    const int e = tid + 256 * c;
+    int r, k;
+    if constexpr (KC) { r = e / BK; k = e % BK; } else { k = e / ROWS; r = e % ROWS; }
+    float v = reg[c];
+    if constexpr (SCALE) v *= rs[0];
+    lds[L::at(r, k)] = v;
+  }
+}
+
 template <int BM, int BN, int BK, bool AKC, bool BKC, bool VEC, bool RBF>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   using LA = LdsLayout<AKC, BM, BK>;
   using LB = LdsLayout<BKC, BN, BK>;
-  __shared__ __attribute__((aligned(16))) float lds[LA::kSize + LB::kSize + 8];
-  float* As = lds;
-  float* Bs = lds + ((LA::kSize + 3) & ~3);
+  // two LDS stages: slab s is consumed from stage s&1 while slab s+1 is written to the other one,
+  // so one barrier per slab is enough and the staging writes overlap the MFMAs
+  constexpr int kStage = ((LA::kSize + 3) & ~3) + ((LB::kSize + 3) & ~3);
+  __shared__ __attribute__((aligned(16))) float lds[2 * kStage];
 
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
@@ -185,31 +278,95 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     load_slab<AKC, BM, BK, VEC>(A, p.lda, m0, p.M, ks, ke, ra);
     load_slab<BKC, BN, BK, VEC>(B, p.ldb, n0, p.N, ks, ke, rb);
     if constexpr (RBF) load_scale<BK, VEC>(kscale, ks, ke, rs);
-  }
-  for (int k0 = ks; k0 < ke; k0 += BK) {
-    __syncthreads();  // previous slab fully consumed
-    store_slab<AKC, BM, BK, VEC, RBF>(As, ra, rs);
-    store_slab<BKC, BN, BK, VEC, false>(Bs, rb, rs);
-    __syncthreads();
-    if (k0 + BK < ke) {
-      load_slab<AKC, BM, BK, VEC>(A, p.lda, m0, p.M, k0 + BK, ke, ra);
-      load_slab<BKC, BN, BK, VEC>(B, p.ldb, n0, p.N, k0 + BK, ke, rb);
-      if constexpr (RBF) load_scale<BK, VEC>(kscale, k0 + BK, ke, rs);
+    store_slab<AKC, BM, BK, VEC, RBF>(lds, ra, rs);
+    store_slab<BKC, BN, BK, VEC, false>(lds + ((LA::kSize + 3) & ~3), rb, rs);
+    if (ks + BK < ke) {
+      load_slab<AKC, BM, BK, VEC>(A, p.lda, m0, p.M, ks + BK, ke, ra);
+      load_slab<BKC, BN, BK, VEC>(B, p.ldb, n0, p.N, ks + BK, ke, rb);
+      if constexpr (RBF) load_scale<BK, VEC>(kscale, ks + BK, ke, rs);
     }
+  }
+  __syncthreads();
+  // Main loop.  One wave per SIMD issues in order, so everything that is not an MFMA has to sit in the
+  // shadow of one: per k-step the body issues the fragment reads two steps ahead, the step's MFMAs, and
+  // a slice of the staging work (first half of the slab: registers -> other LDS stage for slab s+1;
+  // second half: global -> registers for slab s+2).
+  constexpr int KS = BK / 2;
+  constexpr int NPA = Pieces<AKC, BM, BK, VEC>::kCount, NPB = Pieces<BKC, BN, BK, VEC>::kCount, NP = NPA + NPB;
+  constexpr int HALF = KS / 2;
+  constexpr int PER = (NP + HALF - 1) / HALF;     // pieces per k-step inside a half
+  int offA[VEC ? NPA : 1], offB[VEC ? NPB : 1];
+  bool fastwg = false;      // uniform: this workgroup may stage full slabs with bare float4 loads
+  if constexpr (VEC) {
+    fastwg = (AKC || (p.M % 4 == 0 && p.M >= 4)) && (BKC || (p.N % 4 == 0 && p.N >= 4));
 #pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
+    for (int c = 0; c < NPA; ++c) offA[c] = fastwg ? piece_offset<AKC, BM, BK>(p.lda, m0, p.M, c) : 0;
+#pragma unroll
+    for (int c = 0; c < NPB; ++c) offB[c] = fastwg ? piece_offset<BKC, BN, BK>(p.ldb, n0, p.N, c) : 0;
+  }
+  int stage = 0;
+  for (int k0 = ks; k0 < ke; k0 += BK) {
+    const float* As = lds + stage * kStage;
+    const float* Bs = As + ((LA::kSize + 3) & ~3);
+    float* An = lds + (stage ^ 1) * kStage;
+    float* Bn = An + ((LA::kSize + 3) & ~3);
+    const bool has1 = k0 + BK < ke, has2 = k0 + 2 * BK < ke;
+    float af[KS][TM], bf[KS][TN];
+    auto frag = [&](int kk) {
       const int k = 2 * kk + lh;
-      float af[TM], bf[TN];
 #pragma unroll
-      for (int a = 0; a < TM; ++a) af[a] = As[LA::at(wm0 + 32 * a + li, k)];
+      for (int a = 0; a < TM; ++a) af[kk][a] = As[LA::at(wm0 + 32 * a + li, k)];
 #pragma unroll
-      for (int c = 0; c < TN; ++c) bf[c] = Bs[LB::at(wn0 + 32 * c + li, k)];
+      for (int c = 0; c < TN; ++c) bf[kk][c] = Bs[LB::at(wn0 + 32 * c + li, k)];
+    };
+    frag(0);
+    if (KS > 1) frag(1);
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      if (kk + 2 < KS) frag(kk + 2);
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int c = 0; c < TN; ++c)
-          acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[c], acc[a][c], 0, 0, 0);
+          acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][a], bf[kk][c], acc[a][c], 0, 0, 0);
+      if (kk < HALF) {
+        if (has1) {
+#pragma unroll
+          for (int u = 0; u < PER; ++u) {
+            const int pc = kk * PER + u;
+            if (pc < NPA) store_piece<AKC, BM, BK, VEC, RBF>(An, ra, rs, pc);
+            else if (pc < NP) store_piece<BKC, BN, BK, VEC, false>(Bn, rb, rs, pc - NPA);
+          }
+        }
+      } else {
+        if (has2) {
+          const int kn = k0 + 2 * BK;
+          const bool full = VEC && fastwg && (kn + BK <= ke);     // uniform: no guards needed at all
+          if (full) {
+            if constexpr (VEC) {
+              const float* Au = A + (int64_t)kn * (AKC ? 1 : p.lda);
+              const float* Bu = B + (int64_t)kn * (BKC ? 1 : p.ldb);
+#pragma unroll
+              for (int u = 0; u < PER; ++u) {
+                const int pc = (kk - HALF) * PER + u;
+                if (pc < NPA) load_piece_fast<BM, BK>(Au, offA[pc], pc, ra);
+                else if (pc < NP) load_piece_fast<BN, BK>(Bu, offB[pc - NPA], pc - NPA, rb);
+              }
+            }
+          } else {
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+              const int pc = (kk - HALF) * PER + u;
+              if (pc < NPA) load_piece<AKC, BM, BK, VEC>(A, p.lda, m0, p.M, kn, ke, pc, ra);
+              else if (pc < NP) load_piece<BKC, BN, BK, VEC>(B, p.ldb, n0, p.N, kn, ke, pc - NPA, rb);
+            }
+          }
+          if constexpr (RBF) { if (kk == KS - 1) load_scale<BK, VEC>(kscale, k0 + 2 * BK, ke, rs); }
+        }
+      }
     }
+    __syncthreads();
+    stage ^= 1;
   }
 
   // epilogue
@@ -289,8 +446,12 @@ int launch_gemm(const GemmParams& p, int transA, int transB, int nbatch, bool rb
   for (int i = 0; i < 3; ++i) vec = vec && (p.sA[i] % 4 == 0) && (p.sB[i] % 4 == 0);
   const int64_t t128 = (int64_t)cdiv(p.M, 128) * cdiv(p.N, 128) * nbatch;
   const int64_t t12864 = (int64_t)cdiv(p.M, 128) * cdiv(p.N, 64) * nbatch;
-  if (t128 >= 192) dispatch_tile<128, 128, 16>(p, transA, transB, nbatch, rbf, vec, st);
-  else if (t12864 >= 160 && p.M > 64) dispatch_tile<128, 64, 32>(p, transA, transB, nbatch, rbf, vec, st);
+  static const int force = [] { const char* e = getenv("VARGP_GEMM_TILE"); return e ? atoi(e) : 0; }();   // tuning aid
+  if (force == 1) dispatch_tile<128, 128, 16>(p, transA, transB, nbatch, rbf, vec, st);
+  else if (force == 2) dispatch_tile<128, 64, 32>(p, transA, transB, nbatch, rbf, vec, st);
+  else if (force == 3) dispatch_tile<64, 64, 64>(p, transA, transB, nbatch, rbf, vec, st);
+  else if (t128 >= 512) dispatch_tile<128, 128, 16>(p, transA, transB, nbatch, rbf, vec, st);
+  else if (t12864 >= 512 && p.M > 64) dispatch_tile<128, 64, 32>(p, transA, transB, nbatch, rbf, vec, st);
   else dispatch_tile<64, 64, 64>(p, transA, transB, nbatch, rbf, vec, st);
   return check_launch("bgemm");
 }
