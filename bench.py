@@ -26,9 +26,18 @@ import torch.distributed as dist  # noqa: E402
 
 S, F_, C, M, D, B = 3, 10, 10, 100, 784, 512
 N_TOTAL, BETA, LR = 12000, 10.0, 3e-3
+N_PREV = 0
 MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32 matrix peak
 DOMINANT_TAG = 'rbf_kuf_gemm'
-DOMINANT_FLOPS = 2.0 * S * C * M * B * D          # algorithmic flops of one K_uf launch
+
+# Secondary workloads (not the driver's default line): other BASELINE configs, same step definition.
+WORKLOADS = {
+    'smnist': dict(S=3, M=100, n_prev=0, desc='Split-MNIST task-0 ELBO step (BASELINE config 1)'),
+    'smnist_s64': dict(S=64, M=100, n_prev=0, desc='Split-MNIST task-0, 64 hyper-samples on ONE GPU (BASELINE config 3 unsharded)'),
+    'pmnist_t0': dict(S=10, M=200, n_prev=0, desc='Permuted-MNIST task 0, M=200, S=10 (BASELINE config 2)'),
+    'pmnist_t1': dict(S=10, M=200, n_prev=1, desc='Permuted-MNIST task 1 (Mt=400), M=200, S=10'),
+    'pmnist_t4': dict(S=10, M=200, n_prev=4, desc='Permuted-MNIST task 4 (Mt=1000), M=200, S=10'),
+}
 
 
 def make_model(device, seed=0):
@@ -37,10 +46,54 @@ def make_model(device, seed=0):
     from vargp_amd.synthetic import mnist_like
     from vargp_amd.vargp import VARGP
     torch.manual_seed(seed)
-    xall, yall = mnist_like(4096, D, C, kind='gauss', seed=1)
-    z = torch.stack([xall[yall == c][:M] for c in range(C)])
-    gp = VARGP(z, RBFKernel(D), MulticlassSoftmax(n_f=F_), n_var_samples=S).to(device)
+    xall, yall = mnist_like(max(4096, 16 * M * (N_PREV + 1)), D, C, kind='gauss', seed=1)
+    per_class = [xall[yall == c] for c in range(C)]
+    prev = []
+    for t in range(N_PREV):       # frozen earlier tasks with the initial variational parameters
+        zt = torch.stack([pc[(t + 1) * M:(t + 2) * M] for pc in per_class])
+        eye = torch.zeros(M * (M + 1) // 2)
+        idx = torch.arange(M)
+        eye[idx * (idx + 1) // 2 + idx] = 1.0
+        prev.append(dict(z=zt.to(device), u_mean=(0.5 * torch.randn(C, M, 1)).to(device),
+                         u_tril_vec=eye.repeat(C, 1).to(device)))
+    z = torch.stack([pc[:M] for pc in per_class])
+    gp = VARGP(z, RBFKernel(D), MulticlassSoftmax(n_f=F_), n_var_samples=S, prev_params=prev).to(device)
     return gp, xall[:B].to(device), yall[:B].to(device)
+
+
+def stress(args, device):
+    """BASELINE config 4: N=1e6, D=784, M=2048, C=10, S=1 predictive sweep, K_uf tiled over N in HBM."""
+    from vargp_amd import _lib
+    from vargp_amd.kernels import RBFKernel
+    from vargp_amd.likelihoods import MulticlassSoftmax
+    from vargp_amd.vargp import VARGP
+    n, m, tile = args.stress_n, 2048, 8192
+    torch.manual_seed(0)
+    x = torch.randn(n, D, device=device) * (0.25 / D) ** 0.5
+    z = torch.stack([x[c * m:(c + 1) * m] + 0.01 * torch.randn(m, D, device=device) for c in range(C)])
+    gp = VARGP(z.cpu(), RBFKernel(D), MulticlassSoftmax(n_f=F_), n_var_samples=1).to(device)
+    with torch.no_grad():
+        gp.predict(x[:2 * tile], tile=tile)                    # warm-up
+        torch.cuda.synchronize()
+        _lib.prof_enable(True)
+        _lib.prof_read('')
+        t0 = time.perf_counter()
+        probs = gp.predict(x, tile=tile)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        _lib.prof_enable(False)
+    kern_ms, kern_n = _lib.prof_read(DOMINANT_TAG)
+    flops = 2.0 * C * m * tile * D
+    avg_s = kern_ms / max(kern_n, 1) * 1e-3
+    res = dict(metric='predictive points/sec (stress)', value=n / dt, unit='points/s', n_gpus=1, steps=1, warmup=1,
+               ms_per_step=1e3 * dt, higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32',
+               data='synthetic', finite=bool(torch.isfinite(probs).all().item()),
+               config=dict(workload='BASELINE config 4: predictive sweep N=%d D=784 M=2048 C=10 S=1, tile %d' % (n, tile)),
+               roofline=dict(bound='mfma', kernel='gemm_kernel<RBF> K_uf tile [10*2048 x 784] x [784 x 8192]',
+                             achieved=flops / avg_s / 1e12 if kern_n else None, peak=MFMA_F32_PEAK_TFLOPS,
+                             unit='TFLOP/s', frac=flops / avg_s / 1e12 / MFMA_F32_PEAK_TFLOPS if kern_n else None,
+                             launches=kern_n, avg_us=avg_s * 1e6, traffic=None))
+    print(json.dumps(res))
 
 
 def snapshot(gp):
@@ -79,11 +132,14 @@ def elbo_check(gp, x, y):
     from oracle import vargp_oracle as orc
     from vargp_amd import noise
     nz = dict(eps_theta=torch.randn(S, D + 1), eps_f=torch.randn(S, F_, C, B))
+    prev = [{k: p[k].detach().cpu() for k in ('z', 'u_mean', 'u_tril_vec')} for p in gp.prev_params]
+    if prev:
+        nz['eps_u'] = torch.randn(S, S, C, N_PREV * M)     # KL does not depend on it (ep_var_mean=True)
     with torch.no_grad(), noise.inject(**{k: v.to(x.device) for k, v in nz.items()}):
         kl_h, kl_u, nll = gp.loss(x, y)
     tot = (BETA * kl_h + kl_u + (N_TOTAL / B) * nll).item()
     with torch.no_grad():
-        a, b, c = orc.loss(snapshot(gp), [], x.cpu(), y.cpu(), nz)
+        a, b, c = orc.loss(snapshot(gp), prev, x.cpu(), y.cpu(), nz)
     ref = (BETA * a + b + (N_TOTAL / B) * c).item()
     return abs(tot - ref) / abs(ref)
 
@@ -95,7 +151,14 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eager', action='store_true', help='do not replay the step from a captured hipGraph')
+    ap.add_argument('--workload', default='smnist', choices=sorted(WORKLOADS) + ['stress'],
+                    help='default: the BASELINE metric workload; the others are secondary measurements')
+    ap.add_argument('--stress-n', type=int, default=1000000)
     args = ap.parse_args()
+    global S, M, N_PREV
+    if args.workload != 'stress':
+        S, M, N_PREV = (WORKLOADS[args.workload][k] for k in ('S', 'M', 'n_prev'))
+    dominant_flops = 2.0 * S * C * M * (N_PREV + 1) * B * D     # one K_uf launch of compute_pf_diag
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -108,10 +171,12 @@ def main():
 
     from vargp_amd import _lib, ops
     from vargp_amd.train import ElboTrainer
+    if args.workload == 'stress':
+        return stress(args, device)
     ops.set_cholesky_error_mode('defer')
     ops.reset_linalg_errors()
     gp, x, y = make_model(device)
-    rtol = elbo_check(gp, x, y) if rank == 0 else None
+    rtol = elbo_check(gp, x, y) if (rank == 0 and S * (N_PREV + 1) * M <= 4000) else None
     p0 = snapshot(gp) if rank == 0 else None     # the CPU baseline runs the same (initial) model
     trainer = ElboTrainer(gp, lr=LR, beta=BETA, n_total=N_TOTAL)
 
@@ -157,11 +222,11 @@ def main():
     if rank == 0:
         value = world * args.steps / dt
         avg_s = kern_ms / max(kern_n, 1) * 1e-3
-        achieved = DOMINANT_FLOPS / avg_s / 1e12 if kern_n else None
+        achieved = dominant_flops / avg_s / 1e12 if kern_n else None
         res = dict(metric='ELBO steps/sec', value=value, unit='ELBO steps/s (Cfg2 step: S=3 hyper-samples per GPU)',
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * dt / args.steps,
                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
-                   config=dict(workload='Split-MNIST task-0 ELBO step (BASELINE config 1)', S_per_gpu=S,
+                   config=dict(workload=WORKLOADS[args.workload]['desc'], S_per_gpu=S, Mt=M * (N_PREV + 1),
                                S_total=S * world, F=F_, C=C, M=M, D=D, B=B, N=N_TOTAL, beta=BETA,
                                optimizer='yogi', parallelism=f'sample-parallel x{world}',
                                launch='hipGraph replay' if use_graph else 'eager'),
@@ -171,7 +236,7 @@ def main():
                                  achieved=achieved, peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
                                  frac=(achieved / MFMA_F32_PEAK_TFLOPS) if achieved else None,
                                  launches=kern_n, avg_us=avg_s * 1e6, traffic=None))
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == 'smnist':
             res['cpu_baseline'] = cpu_baseline(p0, x, y)
         print(json.dumps(res))
     if world > 1:

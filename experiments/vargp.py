@@ -1,0 +1,210 @@
+#!/usr/bin/env python
+"""Continual-learning driver for VAR-GP on MI355X — counterpart of the reference's
+`experiments/vargp.py` (train :14-73, toy :76-104, split_mnist :107-140, permuted_mnist :143-186).
+
+Same commands, flags and defaults:
+
+    python experiments/vargp.py toy      [--epochs 5000 --M 20 --lr 1e-2 --beta 1.0 ...]
+    python experiments/vargp.py s-mnist  [--epochs 500  --M 60 --lr 3e-3 --beta 10.0 ...]
+    python experiments/vargp.py p-mnist  [--n_tasks 10 --epochs 1000 --M 100 --lr 3.7e-3 --beta 1.64 ...]
+
+Differences: wandb / tensorboard / fire are optional (a JSONL logger under --log_dir is always written);
+MNIST is read from IDX files under --data_dir if present, else an MNIST-shaped synthetic surrogate is used
+(no network); --graph replays the training step from a captured hipGraph.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import torch  # noqa: E402
+from torch.utils.data import ConcatDataset, DataLoader  # noqa: E402
+
+import vargp_amd  # noqa: E402
+from vargp_amd.datasets import PermutedMNIST, SplitMNIST, ToyDataset  # noqa: E402
+from vargp_amd.train import ElboTrainer  # noqa: E402
+from vargp_amd.train_utils import EarlyStopper, compute_accuracy, set_seeds  # noqa: E402
+from vargp_amd.vargp import VARGP  # noqa: E402
+
+
+class JsonlLogger:
+    """add_scalar()-compatible logger (the reference uses a tensorboard SummaryWriter)."""
+
+    def __init__(self, log_dir):
+        os.makedirs(log_dir, exist_ok=True)
+        self.log_dir = log_dir
+        self._f = open(os.path.join(log_dir, 'scalars.jsonl'), 'a')
+
+    def add_scalar(self, key, value, global_step=None):
+        self._f.write(json.dumps(dict(key=key, value=float(value), step=global_step, t=time.time())) + '\n')
+        self._f.flush()
+
+    def close(self):
+        self._f.close()
+
+
+def train(task_id, train_set, val_set, test_set, ep_var_mean=True, map_est_hypers=False, dkl=False,
+          epochs=1, M=20, n_f=10, n_var_samples=3, batch_size=512, lr=1e-2, beta=1.0,
+          eval_interval=10, patience=20, prev_params=None, logger=None, device=None, graph=False):
+    gp = VARGP.create_clf(train_set, M=M, n_f=n_f, n_var_samples=n_var_samples, prev_params=prev_params,
+                          ep_var_mean=ep_var_mean, map_est_hypers=map_est_hypers, dkl=dkl).to(device)
+    stopper = EarlyStopper(patience=patience)
+    N = len(train_set)
+    trainer = ElboTrainer(gp, lr=lr, beta=beta, n_total=N)          # Yogi, as the reference (:23)
+    loader = DataLoader(train_set, batch_size=batch_size, shuffle=True)
+    captured_for = None
+
+    for e in range(epochs):
+        for x, y in loader:
+            x, y = x.to(device), y.to(device)
+            if graph and x.size(0) == min(batch_size, N):
+                if captured_for != x.size(0):
+                    trainer.capture(x, y)
+                    captured_for = x.size(0)
+                kl_hypers, kl_u, lik = trainer.step_graph(x, y)
+            else:
+                kl_hypers, kl_u, lik = trainer.step(x, y)
+
+        if (e + 1) % eval_interval == 0:
+            acc_summary = {
+                f'task{task_id}/train/acc': compute_accuracy(train_set, gp, device=device),
+                f'task{task_id}/val/acc': compute_accuracy(val_set, gp, device=device),
+                f'task{task_id}/test/acc': compute_accuracy(test_set, gp, device=device),
+            }
+            loss_summary = {
+                f'task{task_id}/loss/kl_hypers': kl_hypers.item(),
+                f'task{task_id}/loss/kl_u': kl_u.item(),
+                f'task{task_id}/loss/lik': lik.item(),
+            }
+            if logger is not None:
+                for k, v in dict(**loss_summary, **acc_summary).items():
+                    logger.add_scalar(k, v, global_step=e + 1)
+            stopper(acc_summary[f'task{task_id}/val/acc'],
+                    dict(state_dict=gp.state_dict(), acc_summary=acc_summary, step=e + 1))
+            if stopper.is_done():
+                break
+
+    info = stopper.info() or dict(state_dict=gp.state_dict(), acc_summary={}, step=epochs)
+    if logger is not None:
+        for k, v in info.get('acc_summary').items():
+            logger.add_scalar(f'{k}_best', v, global_step=info.get('step'))
+        torch.save(info.get('state_dict'), os.path.join(logger.log_dir, f'ckpt{task_id}.pt'))
+    return info.get('state_dict')
+
+
+def _setup(args):
+    set_seeds(args.seed)
+    vargp_amd.set_cholesky_error_mode('defer' if args.graph else 'raise')
+    device = 'cuda' if torch.cuda.is_available() else None
+    if device is None:
+        raise SystemExit('vargp_amd needs a ROCm GPU (there is no CPU path)')
+    return device, JsonlLogger(args.log_dir)
+
+
+def toy(args):
+    device, logger = _setup(args)
+    toy_train = ToyDataset()
+    toy_val = ToyDataset(X=toy_train.data.clone(), Y=toy_train.targets.clone())
+    toy_test = ToyDataset(X=toy_train.data.clone(), Y=toy_train.targets.clone())
+    prev_params = []
+    for t in range(2):
+        toy_train.filter_by_class([2 * t, 2 * t + 1])
+        toy_val.filter_by_class(range(2 * t + 2))
+        toy_test.filter_by_class(range(2 * t + 2))
+        sd = train(t, toy_train, toy_val, toy_test, epochs=args.epochs, M=args.M, lr=args.lr, beta=args.beta,
+                   batch_size=args.batch_size, ep_var_mean=args.ep_var_mean, map_est_hypers=args.map_est_hypers,
+                   dkl=args.dkl, prev_params=prev_params, logger=logger, device=device, patience=-1,
+                   eval_interval=args.eval_interval, graph=args.graph)
+        prev_params.append(sd)
+    logger.close()
+
+
+def split_mnist(args):
+    device, logger = _setup(args)
+    syn = dict(synthetic=args.synthetic, n_synth=args.n_synth)
+    mnist_train = SplitMNIST(args.data_dir, train=True, **syn)
+    mnist_val = SplitMNIST(args.data_dir, train=True, **syn)
+    mnist_test = SplitMNIST(args.data_dir, train=False, synthetic=args.synthetic,
+                            n_synth=args.n_synth // 6 if args.n_synth else None)
+    idx = torch.randperm(len(mnist_train))
+    n_val = max(len(idx) // 6, 1)
+    mnist_train.filter_by_idx(idx[:-n_val])
+    mnist_val.filter_by_idx(idx[-n_val:])
+    prev_params = []
+    for t in range(5):
+        mnist_train.filter_by_class([2 * t, 2 * t + 1])
+        mnist_val.filter_by_class(range(2 * t + 2))
+        mnist_test.filter_by_class(range(2 * t + 2))
+        sd = train(t, mnist_train, mnist_val, mnist_test, epochs=args.epochs, M=args.M, lr=args.lr, beta=args.beta,
+                   batch_size=args.batch_size, ep_var_mean=args.ep_var_mean, map_est_hypers=args.map_est_hypers,
+                   dkl=args.dkl, prev_params=prev_params, logger=logger, device=device,
+                   eval_interval=args.eval_interval, graph=args.graph)
+        prev_params.append(sd)
+    logger.close()
+
+
+def permuted_mnist(args):
+    device, logger = _setup(args)
+    syn = dict(synthetic=args.synthetic, n_synth=args.n_synth)
+    tasks = [torch.arange(784)] + PermutedMNIST.create_tasks(n=args.n_tasks - 1)   # first task is unpermuted
+    base = PermutedMNIST(args.data_dir, train=True, **syn)
+    idx = torch.randperm(len(base))
+    n_val = max(len(idx) // 6, 1)
+    train_idx, val_idx = idx[:-n_val], idx[-n_val:]
+    mnist_val, mnist_test, prev_params = [], [], []
+    for t in range(len(tasks)):
+        mnist_train = PermutedMNIST(args.data_dir, train=True, **syn)
+        mnist_train.filter_by_idx(train_idx)
+        mnist_train.set_task(tasks[t])
+        mnist_val.append(PermutedMNIST(args.data_dir, train=True, **syn))
+        mnist_val[-1].filter_by_idx(val_idx)
+        mnist_val[-1].set_task(tasks[t])
+        mnist_test.append(PermutedMNIST(args.data_dir, train=False, synthetic=args.synthetic,
+                                        n_synth=args.n_synth // 6 if args.n_synth else None))
+        mnist_test[-1].set_task(tasks[t])
+        sd = train(t, mnist_train, ConcatDataset(mnist_val), ConcatDataset(mnist_test), epochs=args.epochs, M=args.M,
+                   lr=args.lr, beta=args.beta, batch_size=args.batch_size, ep_var_mean=args.ep_var_mean,
+                   map_est_hypers=args.map_est_hypers, dkl=args.dkl, prev_params=prev_params, logger=logger,
+                   device=device, eval_interval=args.eval_interval, graph=args.graph)
+        prev_params.append(sd)
+    logger.close()
+
+
+def main(argv=None):
+    defaults = {   # reference defaults: experiments/vargp.py:76-78,107-109,143-145
+        'toy': dict(epochs=5000, M=20, lr=1e-2, beta=1.0),
+        's-mnist': dict(epochs=500, M=60, lr=3e-3, beta=10.0),
+        'p-mnist': dict(epochs=1000, M=100, lr=3.7e-3, beta=1.64),
+    }
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    sub = ap.add_subparsers(dest='cmd', required=True)
+    for name, d in defaults.items():
+        sp = sub.add_parser(name, aliases=[name.replace('-', '_')])
+        sp.add_argument('--data_dir', default=os.environ.get('USER_DATADIR', '/tmp'))
+        sp.add_argument('--epochs', type=int, default=d['epochs'])
+        sp.add_argument('--M', type=int, default=d['M'])
+        sp.add_argument('--lr', type=float, default=d['lr'])
+        sp.add_argument('--batch_size', type=int, default=512)
+        sp.add_argument('--beta', type=float, default=d['beta'])
+        sp.add_argument('--ep_var_mean', type=lambda v: str(v).lower() not in ('0', 'false'), default=True)
+        sp.add_argument('--map_est_hypers', type=lambda v: str(v).lower() not in ('0', 'false'), default=False)
+        sp.add_argument('--dkl', type=lambda v: str(v).lower() not in ('0', 'false'), default=False)
+        sp.add_argument('--seed', type=int, default=None)
+        sp.add_argument('--eval_interval', type=int, default=10)
+        sp.add_argument('--log_dir', default=os.path.join('runs', f'{name}-{int(time.time())}'))
+        sp.add_argument('--synthetic', action='store_true', default=None,
+                        help='force the MNIST-shaped synthetic surrogate (default: only if IDX files are missing)')
+        sp.add_argument('--n_synth', type=int, default=None, help='size of the synthetic training set')
+        sp.add_argument('--graph', action='store_true', help='replay the training step from a captured hipGraph')
+        if name == 'p-mnist':
+            sp.add_argument('--n_tasks', type=int, default=10)
+    args = ap.parse_args(argv)
+    {'toy': toy, 's-mnist': split_mnist, 's_mnist': split_mnist, 'p-mnist': permuted_mnist,
+     'p_mnist': permuted_mnist}[args.cmd](args)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,41 @@
+"""GPU: the experiment driver end to end (toy, 2 tasks) and a short synthetic Split-MNIST run."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(args, tmp_path):
+    log = tmp_path / 'run'
+    cmd = [sys.executable, os.path.join(ROOT, 'experiments', 'vargp.py')] + args + ['--log_dir', str(log)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rows = [json.loads(l) for l in open(log / 'scalars.jsonl')]
+    return log, {(r['key'], r['step']): r['value'] for r in rows}
+
+
+def test_toy_two_tasks_learn_and_checkpoint(tmp_path):
+    # (the reference trains 5000 epochs; ~1500 full-batch steps are enough to separate the blobs)
+    log, sc = _run(['toy', '--epochs', '1500', '--eval_interval', '500', '--seed', '1'], tmp_path)
+    assert sc[('task0/train/acc', 1500)] > 0.8         # classes 0/1 of the 4-way classifier
+    assert sc[('task1/test/acc', 1500)] > 0.5          # all 4 classes after the second task (chance 0.25)
+    sd0, sd1 = torch.load(log / 'ckpt0.pt'), torch.load(log / 'ckpt1.pt')
+    assert sorted(sd0) == sorted(['z', 'u_mean', 'u_tril_vec', 'kernel.log_mean', 'kernel.log_logvar',
+                                  'kernel.prior_log_mean', 'kernel.prior_log_logvar'])
+    # task 1's hyper-prior is task 0's hyper-posterior (create_clf, reference vargp.py:214-217)
+    assert torch.allclose(sd1['kernel.prior_log_mean'].cpu(), sd0['kernel.log_mean'].cpu())
+
+
+def test_split_mnist_synthetic_graph_mode(tmp_path):
+    log, sc = _run(['s-mnist', '--synthetic', '--n_synth', '3000', '--epochs', '4', '--eval_interval', '2', '--M', '20',
+                    '--graph', '--seed', '2'], tmp_path)
+    assert all(v == v for v in sc.values())            # no NaN anywhere (losses, accuracies)
+    assert sc[('task0/loss/lik', 4)] < sc[('task0/loss/lik', 2)] * 1.5
+    assert os.path.exists(log / 'ckpt4.pt')            # all five tasks ran and checkpointed

@@ -92,3 +92,24 @@ def test_state_dict_keys_and_shapes():
     assert sorted(sd) == sorted(['z', 'u_mean', 'u_tril_vec', 'kernel.log_mean', 'kernel.log_logvar',
                                  'kernel.prior_log_mean', 'kernel.prior_log_logvar'])
     assert sd['z'].shape == (4, 20, 2) and sd['u_mean'].shape == (4, 20, 1) and sd['u_tril_vec'].shape == (4, 210)
+
+
+def test_continual_chain_blocked_cholesky_vs_oracle():
+    """Task 3 of a continual chain with Mt = 160 > 100: the K_uu / S_<=t factorisations go through the
+    blocked (panel + MFMA GEMM) Cholesky path, and compute_q folds three previous tasks."""
+    from vargp_amd import noise
+    from gpu_common import build_gp, grads_of, DEV
+    S, F_, C, M, D, B = 2, 3, 3, 40, 20, 32
+    params, prev, x, y, nz = orc.make_problem(S, F_, C, M, D, B, n_prev=3, seed=21, kind='gauss')
+    gp = build_gp(params, prev, S, F_)
+    with noise.inject(**to_dev(nz, DEV)):
+        kl_h, kl_u, nll = gp.loss(x.to(DEV), y.to(DEV))
+        (2.0 * kl_h + kl_u + 10.0 * nll).backward()
+        with torch.no_grad():
+            probs = gp.predict(x.to(DEV))
+    sc, og = orc.elbo_step(params, prev, x, y, nz, beta=2.0, n_total=10 * B)
+    for k, v in [('kl_hypers', kl_h), ('kl_u', kl_u), ('nll', nll)]:
+        np.testing.assert_allclose(v.item(), sc[k].item(), rtol=RTOL_SCALAR, err_msg=k)
+    for k, g in grads_of(gp).items():
+        assert rel_l2(g.cpu(), og[k]) < REL_L2_GRAD, k
+    np.testing.assert_allclose(probs.cpu().numpy(), orc.predict(params, prev, x, nz).numpy(), atol=ATOL_PROBS)

@@ -160,16 +160,9 @@ static int launch_small(const float* A, int lda, int64_t sA, float eps, float* L
                         int ld_acc, hipStream_t st) {
   ProfScope prof("chol_inv_small", st);
   const int nt = (int)round_up((int64_t)n * kCholP, 64);
-  static const bool f32 = [] { const char* e = getenv("VARGP_CHOL_F32"); return e && atoi(e) != 0; }();   // tuning aid
 #define VARGP_CHOL_LAUNCH(K)                                                                                     \
-  do {                                                                                                           \
-    if (f32)                                                                                                     \
-      hipLaunchKernelGGL((chol_inv_small_kernel<float, K>), dim3(nbatch), dim3(nt), 0, st, A, lda, sA, eps, L, ldl, \
-                         sL, T, ldt, sT, logdet, info, info_base, n, ld_acc);                                    \
-    else                                                                                                         \
-      hipLaunchKernelGGL((chol_inv_small_kernel<double, K>), dim3(nbatch), dim3(nt), 0, st, A, lda, sA, eps, L, ldl, \
-                         sL, T, ldt, sT, logdet, info, info_base, n, ld_acc);                                    \
-  } while (0)
+  hipLaunchKernelGGL((chol_inv_small_kernel<double, K>), dim3(nbatch), dim3(nt), 0, st, A, lda, sA, eps, L, ldl, sL, \
+                     T, ldt, sT, logdet, info, info_base, n, ld_acc)
   if (n <= 20) VARGP_CHOL_LAUNCH(4);
   else if (n <= 40) VARGP_CHOL_LAUNCH(8);
   else if (n <= 65) VARGP_CHOL_LAUNCH(13);

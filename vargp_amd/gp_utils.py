@@ -80,15 +80,20 @@ def linear_joint(m, S, Kzx, Kzz, V, b, cache=None):
     return mu, Sigma
 
 
-def linear_marginal_diag(m, S, Kzz, Kzx, Kxx_diag, cache=None):
-    """Diagonal of the marginal of N(z; m, S) N(y; A z, V): mu = A m,
-    var = Kxx_diag - diag(Kxz Kzz^-1 Kzx) + diag(A (S + eps I) A^T)   (gp_utils.py:150-191).
-    m (.., M, 1); S (.., M, M); Kzz (.., M, M); Kzx (.., M, B); Kxx_diag broadcastable to (.., 1)."""
+def marginal_prepare(m, S, Kzz):
+    """The x-independent part of linear_marginal_diag: Lz = chol(Kzz + eps I), Tz = Lz^-1, a = Lz^-1 m,
+    G = Lz^-1 chol(S + eps I).  Reusable across minibatch tiles that share the hyper-sample."""
     Lz, Tz = ops.chol_inv(Kzz)
     a = ops.matmul(Tz, m, triA=LOWER)                      # Lz^-1 m
-    P = ops.matmul(Tz, Kzx, triA=LOWER)                    # Lz^-1 Kzx
     LS = ops.chol(S)                                       # chol(S + eps I), gp_utils.py:182
     G = ops.matmul(Tz, LS, triA=LOWER, triB=LOWER, triC=LOWER)   # Lz^-1 L_S (lower)
+    return dict(Lz=Lz, Tz=Tz, Lz_m=a, G=G)
+
+
+def marginal_apply(prep, Kzx, Kxx_diag):
+    """mu, var (.., B) for one block of columns Kzx (.., M, B) given marginal_prepare()'s factors."""
+    Tz, a, G = prep['Tz'], prep['Lz_m'], prep['G']
+    P = ops.matmul(Tz, Kzx, triA=LOWER)                    # Lz^-1 Kzx
     W = ops.matmul(G.mT, P, triA=UPPER)
     bshape = P.shape[:-2]
     per_column = Kxx_diag.shape[-1] != 1          # a full (.., B) prior diagonal instead of gamma^2
@@ -97,8 +102,17 @@ def linear_marginal_diag(m, S, Kzz, Kzx, Kxx_diag, cache=None):
     mu, var = ops.predictive_diag(P, W, a.squeeze(-1).expand(*bshape, -1), kd)
     if per_column:
         var = var + Kxx_diag
+    return mu, var, P
+
+
+def linear_marginal_diag(m, S, Kzz, Kzx, Kxx_diag, cache=None):
+    """Diagonal of the marginal of N(z; m, S) N(y; A z, V): mu = A m,
+    var = Kxx_diag - diag(Kxz Kzz^-1 Kzx) + diag(A (S + eps I) A^T)   (gp_utils.py:150-191).
+    m (.., M, 1); S (.., M, M); Kzz (.., M, M); Kzx (.., M, B); Kxx_diag broadcastable to (.., 1)."""
+    prep = marginal_prepare(m, S, Kzz)
+    mu, var, P = marginal_apply(prep, Kzx, Kxx_diag)
     if isinstance(cache, dict):
-        cache.update(dict(Lz=Lz, Lz_Kzx=P, Tz=Tz, Lz_m=a))
+        cache.update(dict(Lz=prep['Lz'], Lz_Kzx=P, Tz=prep['Tz'], Lz_m=prep['Lz_m']))
     return mu, var
 
 

@@ -14,6 +14,16 @@ def mnist_like(n, d=784, n_classes=10, kind='gauss', seed=0):
     y = torch.arange(n) % n_classes
     if kind == 'mnist':
         x = torch.rand(n, d, generator=g) * (torch.rand(n, d, generator=g) < 0.19)
+    elif kind == 'mnist_classes':
+        # learnable surrogate with MNIST-like geometry: every class has 16 sparse "stroke" prototypes (19 % of
+        # the pixels on); a sample is one prototype with half of its pixels dropped, a few spurious pixels and
+        # random intensities, so same-class points are far from identical (no near-singular K_uu)
+        n_proto = 16
+        protos = (torch.rand(n_classes, n_proto, d, generator=g) < 0.19).float()
+        which = torch.randint(0, n_proto, (n,), generator=g)
+        keep = (torch.rand(n, d, generator=g) < 0.5).float()
+        extra = (torch.rand(n, d, generator=g) < 0.03).float()
+        x = ((protos[y, which] * keep + extra).clamp(0, 1) * (0.5 + 0.5 * torch.rand(n, d, generator=g)))
     else:
         x = torch.randn(n, d, generator=g) * math.sqrt(0.25 / d)
         centers = torch.randn(n_classes, d, generator=g) * math.sqrt(0.25 / d)

@@ -156,9 +156,27 @@ class VARGP(nn.Module):
         kl_hypers = self.kernel.kl_hypers()
         return kl_hypers, kl_u, nll
 
-    def predict(self, x):
-        pred_mu, pred_var = self(x)
-        return self.likelihood.predict(pred_mu, pred_var)
+    def predict(self, x, tile=None):
+        """Class probabilities (B, C)  (vargp.py:196-198).  With `tile`, a large x is swept in blocks of
+        `tile` points that share ONE hyper-sample and ONE set of x-independent factors (K_uu, its Cholesky
+        / inverse, Lz^-1 m, Lz^-1 L_S): the same result as a single call on all of x, in bounded memory."""
+        if tile is None or x.size(0) <= tile:
+            pred_mu, pred_var = self(x)
+            return self.likelihood.predict(pred_mu, pred_var)
+        theta = self.kernel.sample_hypers(self.n_v)
+        if self.prev_params:
+            _, _, mu_leq_t, S_leq_t, z_leq_t = self.compute_q(theta)
+        else:
+            mu_leq_t, z_leq_t = self.u_mean, self.z
+            S_leq_t = rev_cholesky(vec2tril(self.u_tril_vec, self.M))
+        prep = gp_utils.marginal_prepare(mu_leq_t, S_leq_t, self.kernel.compute(theta, z_leq_t))
+        Kxx_diag = self.kernel.compute_diag(theta)
+        out = []
+        for i in range(0, x.size(0), tile):
+            xt = x[i:i + tile]
+            mu, var, _ = gp_utils.marginal_apply(prep, self.kernel.compute(theta, z_leq_t, xt), Kxx_diag)
+            out.append(self.likelihood.predict(mu, var))
+        return torch.cat(out, dim=0)
 
     @staticmethod
     def create_clf(dataset, M=20, n_f=10, n_var_samples=3, prev_params=None,
