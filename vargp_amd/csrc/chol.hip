@@ -19,23 +19,24 @@ constexpr int kNbSmall = 96;    // panel width of the blocked algorithm (multipl
 // Packed lower-triangular index.
 __device__ __forceinline__ int pk(int i, int j) { return i * (i + 1) / 2 + j; }
 
-// One workgroup per matrix, n <= kSmallMax.  In-place Gauss-Jordan on [A | I] restricted to the lower
-// triangle, which yields L = chol(A) and T = L^-1 from one elimination.  The triangle lives in
-// REGISTERS, row-wise: thread (r, part) = (tid / P, tid % P) owns the entries e = k*P + part (k < K) of
-// row r, so nothing about a slot has to be looked up at run time:
-//   slot (i,e) holds A_ie until column e has been eliminated (step e), afterwards entry (i,e) of the
-//   unit-lower inverse.  Step j:
-//     publish  the pivot vector p to LDS: column j of A comes from slot j/P of the threads with
-//              part == j%P (a wave-uniform slot index), the inverse's row j from the P threads of row j;
-//              p[j] := 1, the pivot d_j goes to its own word; slot (i,j) restarts from 0;
-//     barrier; rows i > j do  v <- v + (-p[i]/d_j) * p[e]  on every slot: one LDS read + one FMA per
-//              slot, no predicates (slots beyond the diagonal only ever hold garbage nobody reads);
-//              rows i <= j are finished and their waves drop out.
+// One workgroup per matrix, n <= kSmallMax.  In-place Gauss-Jordan on [A | I], which yields L = chol(A)
+// and T = L^-1 from one elimination.  The matrix lives in REGISTERS, row-wise and FULL (both triangles):
+// thread (r, part) = (tid / P, tid % P) owns the entries e = k*P + part (k < K) of row r.
+//   slot (i,e) holds the Schur-complement entry A_ie until column e has been eliminated (step e), afterwards
+//   entry (i,e) of the unit-lower inverse.  Because the Schur complement stays symmetric, at step j ROW j
+//   of the register file is the whole pivot vector: inverse row j for e < j, the pivot d_j at e = j, column
+//   j of A (= row j) for e > j.  So a step is
+//     publish  the P threads of row j copy their K slots to LDS, no predicates (p[j] := 1, d_j aside);
+//     barrier; every row i > j does  v <- v + (-p[i]/d_j) * p[e]  on all its slots: one LDS read + one FMA
+//              per slot; slot (i,j) restarts from 0 and becomes the inverse entry; rows i <= j are finished
+//              (they run the same FMAs with a zero multiplier).
+//   The slot holding column j, j / P, is wave-uniform and changes every P steps: the elimination runs in
+//   groups of P statically unrolled steps with that slot kept in a named register, so no register array
+//   is ever indexed dynamically.
 //   end: L_ie = A_ie(final) / sqrt(d_e), T_ie = v_ie / sqrt(d_i), T_ii = 1/sqrt(d_i).
 // F = double: factor and explicit inverse are then at least as accurate as fp32 LAPACK potrf + trsm on
 // ill-conditioned K_uu; the chain of n dependent pivots, not the flops, bounds the kernel.
 constexpr int kCholP = 5;
-
 template <typename F, int K>
 __global__ __launch_bounds__(512) void chol_inv_small_kernel(const float* __restrict__ A, int lda, int64_t strideA,
                                                              float eps, float* __restrict__ L, int ldl,
@@ -63,52 +64,49 @@ __global__ __launch_bounds__(512) void chol_inv_small_kernel(const float* __rest
   for (int k = 0; k < K; ++k) {
     const int e = k * P + part;
     v[k] = F(0);
-    if (mine && e <= r) v[k] = (F)A[(int64_t)r * lda + e] + (e == r ? (F)eps : F(0));
+    if (mine && e < n) {   // only the lower triangle of the input is trusted: mirror it
+      const int hi = r > e ? r : e, lo = r > e ? e : r;
+      v[k] = (F)A[(int64_t)hi * lda + lo] + (e == r ? (F)eps : F(0));
+    }
   }
 
   int fail = 0;
-  for (int j = 0; j < n; ++j) {
-    F* p = pbuf[j & 1];
-    const int ks = j / P, ps = j % P;
-    // column j of A (and the pivot): slot ks of the threads with part == ps.  k == ks is wave-uniform and the
-    // body only READS v[k], so the unrolled chain stays a handful of scalar compares.
-    if (part == ps && mine && r >= j) {
+  for (int jb = 0; jb * P < n && !fail; ++jb) {
+    F vcur = F(0);       // slot jb of this thread: the entries (r, jb*P + part), i.e. this group's pivot columns
 #pragma unroll
-      for (int k = 0; k < K; ++k) {
-        if (k == ks) {
-          asm volatile("" ::: "memory");                 // keep this a real (scalar) branch, not 20 selects
-          if (r == j) { dpiv[j & 1] = v[k]; p[j] = F(1); }
-          else { p[r] = v[k]; Lp[pk(r, j)] = (float)v[k]; }
+    for (int k = 0; k < K; ++k) {
+      if (k == jb) { asm volatile("" ::: "memory"); vcur = v[k]; }
+    }
+#pragma unroll
+    for (int ps = 0; ps < P; ++ps) {
+      const int j = jb * P + ps;
+      if (j >= n || fail) break;                           // uniform
+      F* p = pbuf[j & 1];
+      if (__builtin_amdgcn_ballot_w64(r == j) != 0) {       // only the wave that holds row j
+        if (r == j) {
+#pragma unroll
+          for (int k = 0; k < K; ++k) p[k * P + part] = v[k];
+          p[jb * P + part] = vcur;                          // the live copy of slot jb
+          if (part == ps) { dpiv[j & 1] = vcur; p[j] = F(1); }
         }
       }
-    }
-    if (__builtin_amdgcn_ballot_w64(r == j) != 0) {     // only the wave that holds row j: inverse row j
-      if (r == j) {
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-          const int e = k * P + part;
-          if (e < j) p[e] = v[k];
-        }
-      }
-    }
-    __syncthreads();
-    const F d = dpiv[j & 1];
-    if (!(d > F(0))) { fail = j + 1; break; }           // uniform
-    if (tid == 0) sd[j] = d;
-    {
-      // rows i <= j are finished: they run the same FMAs with m = 0 (no divergent copy of the row)
-      const F m = (mine && r > j) ? -p[r] / d : F(0);
+      __syncthreads();
+      const F d = dpiv[j & 1];
+      if (!(d > F(0))) { fail = j + 1; break; }             // uniform
+      if (tid == 0) sd[j] = d;
+      const bool below = mine && r > j;
+      const F pr = p[r];                                    // A_rj (= A_jr)
+      if (below && part == 0) Lp[pk(r, j)] = (float)pr;     // park column j of A (unscaled L column)
+      const F m = below ? -pr / d : F(0);
       const F* pp = p + part;
-      const bool pivcol = part == ps;
 #pragma unroll
       for (int k = 0; k < K; ++k) v[k] = fma(m, pp[k * P], v[k]);
+      // the group's slot: same update, except that (i,j) itself restarts as an inverse entry (0 + m * 1)
+      vcur = (part == ps) ? m : fma(m, pp[jb * P], vcur);
+    }
 #pragma unroll
-      for (int k = 0; k < K; ++k) {
-        if (k == ks) {                                   // slot (i,j) restarts as an inverse entry: 0 + m * 1
-          asm volatile("" ::: "memory");
-          v[k] = pivcol ? m : v[k];
-        }
-      }
+    for (int k = 0; k < K; ++k) {
+      if (k == jb) { asm volatile("" ::: "memory"); v[k] = vcur; }
     }
   }
   __syncthreads();
