@@ -82,7 +82,8 @@ int vargp_rbf_gram_fwd(const float* theta, const float* X, const float* Y, float
                        int N, int D, int y_shared, void* ws, size_t ws_bytes, vargp_stream_t stream);
 int vargp_rbf_gram_bwd(const float* theta, const float* X, const float* Y, const float* K, const float* gK,
                        float* gX, float* gY, float* gtheta, int S, int C, int M, int N, int D, int y_shared,
-                       void* ws, size_t ws_bytes, vargp_stream_t stream);
+                       int accumulate /* add into gX / gY / gtheta instead of overwriting */, void* ws, size_t ws_bytes,
+                       vargp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Batched Cholesky with jitter + explicit inverse factor (reference: gp_utils.cholesky,
@@ -113,12 +114,15 @@ int vargp_mat2trilvec(const float* mat, float* vec, int nbatch, int m, vargp_str
  * var_gp/gp_utils.py:178-186):  with P = Lz^-1 Kzx [nb, M, B], W = (Lz^-1 L_S)^T P [nb, M, B],
  * a = Lz^-1 m [nb, M]:   mu_b = sum_m P_mb a_m;  var_b = kdiag - sum_m P_mb^2 + sum_m W_mb^2,
  * kdiag[nb] (= gamma^2 of the sample, kernels.py:58-60).
+ * a_stride: element stride between consecutive a_m (1 = contiguous [nb, M]; the fused path reads a as a
+ * column of a wider matrix), a_bstride: stride between batches.  ga is always written contiguous [nb, M].
  */
-int vargp_predictive_diag_fwd(const float* P, const float* W, const float* a, const float* kdiag, float* mu,
-                              float* var, int nbatch, int M, int B, vargp_stream_t stream);
-int vargp_predictive_diag_bwd(const float* P, const float* W, const float* a, const float* gmu,
-                              const float* gvar, float* gP, float* gW, float* ga, float* gkdiag, int nbatch,
-                              int M, int B, vargp_stream_t stream);
+int vargp_predictive_diag_fwd(const float* P, const float* W, const float* a, int64_t a_stride, int64_t a_bstride,
+                              const float* kdiag, float* mu, float* var, int nbatch, int M, int B,
+                              vargp_stream_t stream);
+int vargp_predictive_diag_bwd(const float* P, const float* W, const float* a, int64_t a_stride, int64_t a_bstride,
+                              const float* gmu, const float* gvar, float* gP, float* gW, float* ga, float* gkdiag,
+                              int nbatch, int M, int B, vargp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * KL(N(mu_q, Lq Lq^T) || N(mu_p, Lp Lp^T)) from its triangular ingredients (reference:
@@ -158,6 +162,20 @@ int vargp_softmax_predict(const float* mu, const float* var, const float* eps, f
  */
 int vargp_yogi_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                     float beta2, float eps, float bias1, float bias2, const float* step, vargp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Glue of the fused task-0 ELBO (vargp_amd/fused.py; reference var_gp/vargp.py:156-190): the small
+ * right-hand sides that share Lz^-1 are packed per class as R[c] = [m | 0 0 0 | L_S | Lu] (M x (4+2M));
+ * Q[s,c] = Lz^-1[s,c] R[c] then holds a = Lz^-1 m, G = Lz^-1 L_S and G2 = Lz^-1 Lu, and
+ * kl_u = (1/S) sum_{s,c} [ sum log diag Lz - sum log diag Lu + 0.5 (|G2|_F^2 + |a|^2 - M) ].
+ */
+int vargp_pack_rsmall(const float* m, const float* LS, const float* Lu, float* R, int C, int M, vargp_stream_t stream);
+int vargp_kl_t0_fwd(const float* Q, const float* Lz, const float* Lu, float* kl_u, int S, int C, int M,
+                    vargp_stream_t stream);
+int vargp_kl_t0_bwd(const float* Q, const float* Lz, const float* Lu, const float* ga, const float* gkl, float* gQ,
+                    float* gLz, float* gLu, int S, int C, int M, vargp_stream_t stream);
+/* gtheta[s, D] += 2 gamma_s^2 sum_c gkd[s, c]  (chain rule through kdiag = gamma^2, kernels.py:58-60) */
+int vargp_kdiag_bwd(const float* theta, const float* gkd, float* gtheta, int S, int C, int D, vargp_stream_t stream);
 
 /* same update for up to 8 tensors in one launch; `step` (device float, the step count t) is required */
 int vargp_yogi_step_multi(int ntensors, float* const* p, const float* const* g, float* const* m, float* const* v,

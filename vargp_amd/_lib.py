@@ -34,7 +34,7 @@ _SIGNATURES = {
     'vargp_sum_outer': (c_int, [_P, _P, c_int64, c_int64, _P]),
     'vargp_rbf_workspace_bytes': (c_size_t, [c_int] * 6),
     'vargp_rbf_gram_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
-    'vargp_rbf_gram_bwd': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P,
+    'vargp_rbf_gram_bwd': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P,
                                    c_size_t, _P]),
     'vargp_chol_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'vargp_chol_inv_fwd': (c_int, [_P, c_float, _P, _P, _P, _P, c_int, c_int, _P, c_size_t, _P]),
@@ -42,8 +42,8 @@ _SIGNATURES = {
     'vargp_vec2tril_fwd': (c_int, [_P, _P, c_int, c_int, _P]),
     'vargp_vec2tril_bwd': (c_int, [_P, _P, _P, c_int, c_int, _P]),
     'vargp_mat2trilvec': (c_int, [_P, _P, c_int, c_int, _P]),
-    'vargp_predictive_diag_fwd': (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
-    'vargp_predictive_diag_bwd': (c_int, [_P] * 9 + [c_int, c_int, c_int, _P]),
+    'vargp_predictive_diag_fwd': (c_int, [_P, _P, _P, c_int64, c_int64, _P, _P, _P, c_int, c_int, c_int, _P]),
+    'vargp_predictive_diag_bwd': (c_int, [_P, _P, _P, c_int64, c_int64] + [_P] * 6 + [c_int, c_int, c_int, _P]),
     'vargp_mvn_kl_fwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P]),
     'vargp_mvn_kl_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P]),
     'vargp_logdet_tril_fwd': (c_int, [_P, _P, c_int, c_int, _P]),
@@ -56,6 +56,10 @@ _SIGNATURES = {
     'vargp_hyper_sample_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P]),
     'vargp_hyper_kl_fwd': (c_int, [_P, _P, _P, _P, _P, c_int, _P]),
     'vargp_hyper_kl_bwd': (c_int, [_P] * 7 + [c_int, _P]),
+    'vargp_pack_rsmall': (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
+    'vargp_kl_t0_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    'vargp_kl_t0_bwd': (c_int, [_P] * 8 + [c_int, c_int, c_int, _P]),
+    'vargp_kdiag_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
     'vargp_prof_enable': (c_int, [c_int]),
     'vargp_prof_read': (c_int, [c_char_p, POINTER(ctypes.c_double), POINTER(c_int64)]),
     'vargp_yogi_step': (c_int, [_P, _P, _P, _P, c_int64] + [c_float] * 6 + [_P, _P]),

@@ -45,7 +45,8 @@ __global__ void mat2trilvec_kernel(const float* __restrict__ mat, float* __restr
 // ---- predictive diag (var_gp/gp_utils.py:178-186) ---------------------------------------------
 // grid (ceil(B/64), nb): 64 columns x 4 row lanes per block, coalesced across the column index
 __global__ __launch_bounds__(256) void pdiag_fwd_kernel(const float* __restrict__ P, const float* __restrict__ W,
-                                                        const float* __restrict__ a, const float* __restrict__ kd,
+                                                        const float* __restrict__ a, int64_t a_stride,
+                                                        int64_t a_bstride, const float* __restrict__ kd,
                                                         float* __restrict__ mu, float* __restrict__ var, int M, int B) {
   __shared__ float red[3][4][64];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
@@ -55,11 +56,11 @@ __global__ __launch_bounds__(256) void pdiag_fwd_kernel(const float* __restrict_
   if (col < B) {
     const float* p = P + b * M * B + col;
     const float* w = W + b * M * B + col;
-    const float* av = a + b * M;
+    const float* av = a + b * a_bstride;
 #pragma unroll 4
     for (int m = ry; m < M; m += 4) {
       const float pv = p[(int64_t)m * B], wv = w[(int64_t)m * B];
-      m0 = fmaf(pv, av[m], m0);
+      m0 = fmaf(pv, av[m * a_stride], m0);
       d1 = fmaf(pv, pv, d1);
       d2 = fmaf(wv, wv, d2);
     }
@@ -76,7 +77,8 @@ __global__ __launch_bounds__(256) void pdiag_fwd_kernel(const float* __restrict_
 }
 // grid (M, nb): one block per row; gP, gW elementwise, ga row reduction; block m == 0 also reduces gkd
 __global__ __launch_bounds__(256) void pdiag_bwd_kernel(const float* __restrict__ P, const float* __restrict__ W,
-                                                        const float* __restrict__ a, const float* __restrict__ gmu,
+                                                        const float* __restrict__ a, int64_t a_stride,
+                                                        int64_t a_bstride, const float* __restrict__ gmu,
                                                         const float* __restrict__ gvar, float* __restrict__ gP,
                                                         float* __restrict__ gW, float* __restrict__ ga,
                                                         float* __restrict__ gkd, int M, int B) {
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(256) void pdiag_bwd_kernel(const float* __restrict_
   const int m = blockIdx.x;
   const int64_t b = blockIdx.y;
   const int64_t off = (b * M + m) * B;
-  const float am = a[b * M + m];
+  const float am = a[b * a_bstride + m * a_stride];
   float acc = 0.f, accv = 0.f;
   for (int col = threadIdx.x; col < B; col += 256) {
     const float gm = gmu[b * B + col], gv = gvar[b * B + col];
@@ -342,21 +344,22 @@ extern "C" int vargp_mat2trilvec(const float* mat, float* vec, int nbatch, int m
   return check_launch("mat2trilvec");
 }
 
-extern "C" int vargp_predictive_diag_fwd(const float* P, const float* W, const float* a, const float* kdiag, float* mu,
-                                         float* var, int nbatch, int M, int B, vargp_stream_t stream) {
+extern "C" int vargp_predictive_diag_fwd(const float* P, const float* W, const float* a, int64_t a_stride,
+                                         int64_t a_bstride, const float* kdiag, float* mu, float* var, int nbatch,
+                                         int M, int B, vargp_stream_t stream) {
   VARGP_REQUIRE(P && W && a && kdiag && mu && var && nbatch > 0 && M > 0 && B > 0, "predictive_diag_fwd: bad arguments");
   VARGP_REQUIRE(nbatch <= 65535, "predictive_diag_fwd: batch too large");
-  hipLaunchKernelGGL(pdiag_fwd_kernel, dim3(cdiv(B, 64), nbatch), dim3(256), 0, as_stream(stream), P, W, a, kdiag, mu,
-                     var, M, B);
+  hipLaunchKernelGGL(pdiag_fwd_kernel, dim3(cdiv(B, 64), nbatch), dim3(256), 0, as_stream(stream), P, W, a, a_stride,
+                     a_bstride, kdiag, mu, var, M, B);
   return check_launch("predictive_diag_fwd");
 }
-extern "C" int vargp_predictive_diag_bwd(const float* P, const float* W, const float* a, const float* gmu,
-                                         const float* gvar, float* gP, float* gW, float* ga, float* gkdiag, int nbatch,
-                                         int M, int B, vargp_stream_t stream) {
+extern "C" int vargp_predictive_diag_bwd(const float* P, const float* W, const float* a, int64_t a_stride,
+                                         int64_t a_bstride, const float* gmu, const float* gvar, float* gP, float* gW,
+                                         float* ga, float* gkdiag, int nbatch, int M, int B, vargp_stream_t stream) {
   VARGP_REQUIRE(P && W && a && gmu && gvar && gP && gW && ga && gkdiag, "predictive_diag_bwd: null pointer");
   VARGP_REQUIRE(nbatch <= 65535 && M <= 65535 * 32, "predictive_diag_bwd: dims too large");
-  hipLaunchKernelGGL(pdiag_bwd_kernel, dim3(M, nbatch), dim3(256), 0, as_stream(stream), P, W, a, gmu, gvar, gP, gW, ga,
-                     gkdiag, M, B);
+  hipLaunchKernelGGL(pdiag_bwd_kernel, dim3(M, nbatch), dim3(256), 0, as_stream(stream), P, W, a, a_stride, a_bstride, gmu,
+                     gvar, gP, gW, ga, gkdiag, M, B);
   return check_launch("predictive_diag_bwd");
 }
 

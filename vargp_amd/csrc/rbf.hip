@@ -229,7 +229,7 @@ extern "C" int vargp_rbf_gram_fwd(const float* theta, const float* X, const floa
 
 extern "C" int vargp_rbf_gram_bwd(const float* theta, const float* X, const float* Y, const float* K, const float* gK,
                                   float* gX, float* gY, float* gtheta, int S, int C, int M, int N, int D,
-                                  int y_shared, void* ws, size_t ws_bytes, vargp_stream_t stream) {
+                                  int y_shared, int accumulate, void* ws, size_t ws_bytes, vargp_stream_t stream) {
   VARGP_REQUIRE(theta && X && K && gK && gtheta && ws, "rbf_gram_bwd: null pointer");
   const bool self = (Y == nullptr);
   if (self) { N = M; y_shared = 0; gY = nullptr; }
@@ -240,7 +240,7 @@ extern "C" int vargp_rbf_gram_bwd(const float* theta, const float* X, const floa
   const int64_t xrows = (int64_t)C * M, yrows = y_shared ? N : (int64_t)C * N;
   const int nb = S * Cb;
 
-  (void)hipMemsetAsync(gtheta, 0, sizeof(float) * (size_t)S * (D + 1), st);
+  if (!accumulate) (void)hipMemsetAsync(gtheta, 0, sizeof(float) * (size_t)S * (D + 1), st);
   hipLaunchKernelGGL(rbf_prep_kernel, dim3(S), dim3(256), 0, st, theta, o.w, o.g2, D, o.Dp);
   const int64_t nrows = (int64_t)S * xrows;
   float* Wfirst = self ? o.W2 : o.Wm;  // self: raw W goes to W2, W + W^T to Wm
@@ -264,7 +264,7 @@ extern "C" int vargp_rbf_gram_bwd(const float* theta, const float* X, const floa
   if (rc) return rc;
   const dim3 gx(cdiv(D, 64), cdiv(xrows, RPB));
   hipLaunchKernelGGL(rbf_final_kernel, gx, dim3(256), 0, st, X, o.r, o.P, o.w, gX, gtheta, xrows, D, o.Dp, S,
-                     self ? 1.f : 2.f, 0);
+                     self ? 1.f : 2.f, accumulate);
   if (!self) {
     const float* Qp = nullptr;
     if (gY) {  // Q = W^T . X  ([N, Mb] x [Mb, D])
@@ -281,7 +281,8 @@ extern "C" int vargp_rbf_gram_bwd(const float* theta, const float* X, const floa
       Qp = o.Q;
     }
     const dim3 gy(cdiv(D, 64), cdiv(yrows, RPB));
-    hipLaunchKernelGGL(rbf_final_kernel, gy, dim3(256), 0, st, Y, o.c, Qp, o.w, gY, gtheta, yrows, D, o.Dp, S, 0.f, 0);
+    hipLaunchKernelGGL(rbf_final_kernel, gy, dim3(256), 0, st, Y, o.c, Qp, o.w, gY, gtheta, yrows, D, o.Dp, S, 0.f,
+                       accumulate);
   }
   return check_launch("rbf_gram_bwd");
 }

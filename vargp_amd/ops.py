@@ -77,6 +77,7 @@ def bgemm(A, B, alpha=1.0, D=None, beta=0.0, triA=NONE, triB=NONE, triC=NONE, ou
         Ae, tA, lda = _mat_layout(Ae)
         Be, tB, ldb = _mat_layout(Be)
     C = out if out is not None else torch.empty(*bshape, M, N, dtype=torch.float32, device=A.device)
+    assert tuple(C.shape) == (*bshape, M, N) and (C.stride(-1) == 1 or N == 1), 'bgemm: bad `out`'
     Cv = C.reshape(-1, M, N) if len(bshape) > 3 else C
     nbs, sA = _batch3(Ae.shape[:-2], Ae.stride()[:-2])
     _, sB = _batch3(Be.shape[:-2], Be.stride()[:-2])
@@ -85,7 +86,7 @@ def bgemm(A, B, alpha=1.0, D=None, beta=0.0, triA=NONE, triB=NONE, triC=NONE, ou
     d.M, d.N, d.K = M, N, K
     d.transA, d.transB = tA, tB
     d.A, d.B, d.C = Ae.data_ptr(), Be.data_ptr(), Cv.data_ptr()
-    d.lda, d.ldb, d.ldc = lda, ldb, max(N, 1)
+    d.lda, d.ldb, d.ldc = lda, ldb, (max(Cv.stride(-2), N) if M > 1 else max(N, 1))
     keep = [Ae, Be]
     if D is not None:
         De = D.expand(*bshape, M, N)
@@ -197,7 +198,7 @@ class _RbfGram(Function):
         gtheta = torch.empty_like(theta)
         ws = workspace(lib().vargp_rbf_workspace_bytes(S, C, M, N, D, 1), X.device)
         check(lib().vargp_rbf_gram_bwd(ptr(theta), ptr(X), ptr(Y), ptr(K), ptr(gK), ptr(gX), ptr(gY), ptr(gtheta),
-                                       S, C, M, N, D, ctx.y_shared, ptr(ws), ws.numel() * 4, stream_ptr()),
+                                       S, C, M, N, D, ctx.y_shared, 0, ptr(ws), ws.numel() * 4, stream_ptr()),
               'vargp_rbf_gram_bwd')
         return gtheta, gX, gY, None
 
@@ -325,7 +326,7 @@ class _PredictiveDiag(Function):
         nb = P.numel() // (M * B)
         mu = torch.empty(*P.shape[:-2], B, dtype=torch.float32, device=P.device)
         var = torch.empty_like(mu)
-        check(lib().vargp_predictive_diag_fwd(ptr(P), ptr(W), ptr(a), ptr(kdiag), ptr(mu), ptr(var), nb, M, B,
+        check(lib().vargp_predictive_diag_fwd(ptr(P), ptr(W), ptr(a), 1, M, ptr(kdiag), ptr(mu), ptr(var), nb, M, B,
                                               stream_ptr()), 'vargp_predictive_diag_fwd')
         ctx.save_for_backward(P, W, a)
         return mu, var
@@ -338,7 +339,7 @@ class _PredictiveDiag(Function):
         nb = P.numel() // (M * B)
         gP, gW, ga = torch.empty_like(P), torch.empty_like(W), torch.empty_like(a)
         gk = torch.empty(P.shape[:-2], dtype=torch.float32, device=P.device)
-        check(lib().vargp_predictive_diag_bwd(ptr(P), ptr(W), ptr(a), ptr(gmu.contiguous()), ptr(gvar.contiguous()),
+        check(lib().vargp_predictive_diag_bwd(ptr(P), ptr(W), ptr(a), 1, M, ptr(gmu.contiguous()), ptr(gvar.contiguous()),
                                               ptr(gP), ptr(gW), ptr(ga), ptr(gk), nb, M, B, stream_ptr()),
               'vargp_predictive_diag_bwd')
         return gP, gW, ga, gk

@@ -77,9 +77,22 @@ class ElboTrainer:
 
     def step(self, x, y):
         """-> (kl_hypers, kl_u, nll) as 0-dim device tensors (global values on every rank)."""
+        scale = (self.n_total if self.n_total is not None else x.size(0)) / x.size(0)
+        if self.world == 1:
+            # single GPU: let autograd hand the gradients over (no zero-fill, no accumulate kernels)
+            for p in self.params:
+                p.grad = None
+            kl_h, kl_u, nll = self.loss_fn(x, y)
+            (self.beta * kl_h + kl_u + scale * nll).backward()
+            self.optim.step()
+            return kl_h.detach(), kl_u.detach(), nll.detach()
+        if self.params[0].grad is None or self.params[0].grad.data_ptr() != self.flat.data_ptr():
+            off = 0
+            for p in self.params:                      # (re-)attach the gradient views of the flat buffer
+                p.grad = self.flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
         self.flat.zero_()
         kl_h, kl_u, nll = self.loss_fn(x, y)
-        scale = (self.n_total if self.n_total is not None else x.size(0)) / x.size(0)
         w = 1.0 / self.world
         loss = (self.beta * kl_h + kl_u + scale * nll) * w
         loss.backward()

@@ -12,7 +12,7 @@ Differences that do not change results:
 import torch
 import torch.nn as nn
 
-from . import gp_utils, noise, ops
+from . import fused, gp_utils, noise, ops
 from .gp_utils import vec2tril, mat2trilvec, cholesky, rev_cholesky, gp_cond, linear_joint, linear_marginal_diag
 from .kernels import RBFKernel, DeepRBFKernel
 from .likelihoods import MulticlassSoftmax
@@ -23,6 +23,7 @@ class VARGP(nn.Module):
     def __init__(self, z_init, kernel, likelihood, n_var_samples=1, ep_var_mean=True, prev_params=None):
         super().__init__()
         self.var_mean_mask = float(ep_var_mean)
+        self.fused_first_task = True     # VARGP.loss of a first-task model runs as one fused node (fused.py)
         # frozen earlier tasks: plain dicts, not buffers (same as the reference, vargp.py:17-20);
         # u_tril is materialised lazily on first use because that needs the device the params live on
         self.prev_params = [dict(z=p['z'], u_mean=p['u_mean'], u_tril_vec=p['u_tril_vec'])
@@ -146,6 +147,12 @@ class VARGP(nn.Module):
     def loss(self, x, y):
         """(kl_hypers, kl_u, nll); the caller combines beta*kl_hypers + kl_u + (N/B)*nll
         (vargp.py:177-194, experiments/vargp.py:34)."""
+        if not self.prev_params and self.fused_first_task:
+            # first task: one fused autograd node (fused.py) instead of the composed per-op graph
+            theta = self.kernel.sample_hypers(self.n_v)
+            eps_f = noise.draw('eps_f', (theta.size(0), self.likelihood.n_f, self.z.size(0), x.size(0)), x.device)
+            nll, kl_u = fused.elbo_t0(theta, self.z, self.u_mean, self.u_tril_vec, x, y, eps_f)
+            return self.kernel.kl_hypers(), kl_u, nll
         loss_cache = dict()
         pred_mu, pred_var = self(x, loss_cache=loss_cache)
         nll = self.likelihood.loss(pred_mu, pred_var, y)
