@@ -55,6 +55,29 @@ int main(int argc, char** argv) {
     double us = time_us([&] { vargp_rbf_gram_fwd(th, z, x, K, S, C, M, B, D, 1, ws, wsb, nullptr); }, iters);
     printf("kuf   rbf_gram_fwd(all 4 launches) %8.1f us  -> %.1f TFLOP/s on 2.408e9 flop\n", us, 2.408e9 / us * 1e-6);
   }
+  if (which == "kufD") {   // K_uf with varying input dimension D: separates the per-launch fixed cost from the K loop
+    const int S = 3, C = 10, M = 100, B = 512;
+    for (int D : {16, 64, 128, 256, 512, 784, 1568}) {
+      float* th = dev_rand((size_t)S * (D + 1), 0.05f, 1);
+      float* z = dev_rand((size_t)C * M * D, 0.02f, 2);
+      float* x = dev_rand((size_t)B * D, 0.02f, 3);
+      float* K; CK(hipMalloc(&K, (size_t)S * C * M * B * 4));
+      size_t wsb = vargp_rbf_workspace_bytes(S, C, M, B, D, 0);
+      void* ws; CK(hipMalloc(&ws, wsb));
+      vargp_prof_enable(1);
+      double us = time_us([&] { vargp_rbf_gram_fwd(th, z, x, K, S, C, M, B, D, 1, ws, wsb, nullptr); }, iters);
+      double ms; long long n; vargp_prof_read("rbf_kuf_gemm", &ms, (int64_t*)&n);
+      vargp_prof_enable(0);
+      printf("kufD D=%5d total %7.1f us   gemm launch (events) %7.1f us\n", D, us, 1e3 * ms / (double)n);
+    }
+  }
+  if (want("kufplain")) {   // same shape as K_uf but plain NT GEMM (no scale, no exp epilogue)
+    float* Z = dev_rand((size_t)1000 * 784, 1.f, 4);
+    float* X = dev_rand((size_t)512 * 784, 1.f, 5);
+    float* P; CK(hipMalloc(&P, (size_t)3 * 1000 * 512 * 4));
+    double us = time_us([&] { gemm(Z, X, P, 1000, 512, 784, 0, 1, 3, 0, 0, 1000L * 512); }, iters);
+    printf("kufplain [1000x784]x[512x784]^T b3 %8.1f us  -> %.1f TFLOP/s\n", us, 2.0 * 3 * 1000 * 784 * 512 / us * 1e-6);
+  }
   if (want("kufbwd")) {   // P = W . Y  : [1000 x 512] x [512 x 784], batch 3
     float* W = dev_rand((size_t)3 * 1000 * 512, 1.f, 4);
     float* Y = dev_rand((size_t)512 * 784, 1.f, 5);

@@ -201,7 +201,8 @@ __global__ __launch_bounds__(256) void softmax_nll_bwd_kernel(const float* __res
   gmu[e] = sc * a0;
   gvar[e] = sc * a1 * 0.5f / sd;
 }
-// C <= CMAX: one thread per (s, b) keeps the class vector in registers (no recomputation per class)
+// C <= CMAX: one thread per (s, f, b) keeps the class vector in registers and adds its share of the two
+// gradients with float atomics (gmu / gvar pre-zeroed by the launcher); S*F*B threads instead of S*B
 template <int CMAX>
 __global__ __launch_bounds__(256) void softmax_nll_bwd_small_kernel(const float* __restrict__ mu,
                                                                     const float* __restrict__ var,
@@ -211,43 +212,30 @@ __global__ __launch_bounds__(256) void softmax_nll_bwd_small_kernel(const float*
                                                                     float* __restrict__ gmu, float* __restrict__ gvar,
                                                                     int S, int F, int C, int B) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= (int64_t)S * B) return;
-  const int b = e % B, s = e / B;
+  if (e >= (int64_t)S * F * B) return;
+  const int b = e % B, f = (e / B) % F, s = e / ((int64_t)B * F);
   const int yb = (int)y[b];
-  float m[CMAX], sd[CMAX], a0[CMAX], a1[CMAX];
+  float sd[CMAX], ev[CMAX], v[CMAX], mx = -INFINITY;
 #pragma unroll
   for (int c = 0; c < CMAX; ++c) {
     const int64_t i = ((int64_t)s * C + c) * B + b;
-    m[c] = c < C ? mu[i] : 0.f;
-    sd[c] = c < C ? sqrtf(var[i]) : 0.f;
-    a0[c] = 0.f; a1[c] = 0.f;
+    sd[c] = c < C ? sqrtf(var[i]) : 1.f;
+    ev[c] = c < C ? eps[(((int64_t)s * F + f) * C + c) * B + b] : 0.f;
+    v[c] = c < C ? mu[i] + sd[c] * ev[c] : -INFINITY;
+    mx = fmaxf(mx, v[c]);
   }
-  for (int f = 0; f < F; ++f) {
-    float ev[CMAX], v[CMAX], mx = -INFINITY;
+  float se = 0.f;
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c) {
-      ev[c] = c < C ? eps[(((int64_t)s * F + f) * C + c) * B + b] : 0.f;
-      v[c] = c < C ? m[c] + sd[c] * ev[c] : -INFINITY;
-      mx = fmaxf(mx, v[c]);
-    }
-    float se = 0.f;
-#pragma unroll
-    for (int c = 0; c < CMAX; ++c) { v[c] = c < C ? expf(v[c] - mx) : 0.f; se += v[c]; }
-    const float inv = 1.f / se;
-#pragma unroll
-    for (int c = 0; c < CMAX; ++c) {
-      const float p = v[c] * inv - (c == yb ? 1.f : 0.f);
-      a0[c] += p;
-      a1[c] = fmaf(p, ev[c], a1[c]);
-    }
-  }
-  const float sc = gnll[0] / (float)(S * F);
+  for (int c = 0; c < CMAX; ++c) { v[c] = c < C ? expf(v[c] - mx) : 0.f; se += v[c]; }
+  const float sc = gnll[0] / (float)(S * F) / se;
+  const float sc1 = gnll[0] / (float)(S * F);
 #pragma unroll
   for (int c = 0; c < CMAX; ++c) {
     if (c < C) {
       const int64_t i = ((int64_t)s * C + c) * B + b;
-      gmu[i] = sc * a0[c];
-      gvar[i] = sc * a1[c] * 0.5f / sd[c];
+      const float p = v[c] * sc - (c == yb ? sc1 : 0.f);
+      atomicAdd(&gmu[i], p);
+      atomicAdd(&gvar[i], p * ev[c] * 0.5f / sd[c]);
     }
   }
 }
@@ -402,7 +390,9 @@ extern "C" int vargp_softmax_nll_bwd(const float* mu, const float* var, const fl
                                      vargp_stream_t stream) {
   VARGP_REQUIRE(mu && var && eps && y && gnll && gmu && gvar, "softmax_nll_bwd: null pointer");
   if (C <= 16) {
-    const int64_t total = (int64_t)S * B;
+    const int64_t total = (int64_t)S * F * B;
+    (void)hipMemsetAsync(gmu, 0, sizeof(float) * (size_t)S * C * B, as_stream(stream));
+    (void)hipMemsetAsync(gvar, 0, sizeof(float) * (size_t)S * C * B, as_stream(stream));
     hipLaunchKernelGGL(softmax_nll_bwd_small_kernel<16>, GRID1(total), mu, var, eps, y, gnll, gmu, gvar, S, F, C, B);
   } else {
     const int64_t total = (int64_t)S * C * B;

@@ -25,27 +25,30 @@ __global__ void pack_rsmall_kernel(const float* __restrict__ m, const float* __r
   R[e] = v;
 }
 
-// one block per (s, c); kl_u accumulated with one atomic per block (pre-zeroed by the caller)
+// grid (ceil(M / kKlRows), S*C): a block reduces kKlRows rows of one (s, c); kl_u accumulated with one atomic per
+// block (pre-zeroed by the caller)
+constexpr int kKlRows = 8;
 __global__ __launch_bounds__(256) void kl_t0_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ Lz,
                                                         const float* __restrict__ Lu, float* __restrict__ kl_u, int S,
                                                         int C, int M) {
   __shared__ float red[4];
   const int NR = 4 + 2 * M;
-  const int64_t b = blockIdx.x;          // s * C + c
+  const int64_t b = blockIdx.y;          // s * C + c
   const int c = b % C;
+  const int i0 = blockIdx.x * kKlRows, i1 = min(M, i0 + kKlRows);
   const float* q = Q + b * M * NR;
   float acc = 0.f;
-  for (int e = threadIdx.x; e < M * M; e += 256) {
-    const int i = e / M, j = e % M;
+  for (int e = threadIdx.x; e < (i1 - i0) * M; e += 256) {
+    const int i = i0 + e / M, j = e % M;
     if (j <= i) { const float v = q[(int64_t)i * NR + 4 + M + j]; acc = fmaf(v, v, acc); }
   }
-  for (int i = threadIdx.x; i < M; i += 256) {
+  for (int i = i0 + threadIdx.x; i < i1; i += 256) {
     const float a = q[(int64_t)i * NR];
     acc = fmaf(a, a, acc);
-    acc += 2.f * (logf(Lz[(b * M + i) * M + i]) - logf(Lu[((int64_t)c * M + i) * M + i]));
+    acc += 2.f * (logf(Lz[(b * M + i) * M + i]) - logf(Lu[((int64_t)c * M + i) * M + i])) - 1.f;
   }
   const float t = block_sum<256>(acc, red);
-  if (threadIdx.x == 0) atomicAdd(kl_u, 0.5f * (t - (float)M) / (float)S);
+  if (threadIdx.x == 0) atomicAdd(kl_u, 0.5f * t / (float)S);
 }
 
 // gQ[:, 0] = ga + g a / S ; gQ[:, 1..3] = 0 ; gQ[:, 4+M..] = g tril(G2) / S  (the G block is written by a GEMM);
@@ -56,18 +59,20 @@ __global__ __launch_bounds__(256) void kl_t0_bwd_kernel(const float* __restrict_
                                                         float* __restrict__ gLz, float* __restrict__ gLu, int S, int C,
                                                         int M) {
   const int NR = 4 + 2 * M;
-  const int64_t b = blockIdx.x;
+  const int64_t b = blockIdx.y;
   const int s = b / C, c = b % C;
+  const int i0 = blockIdx.x * kKlRows, i1 = min(M, i0 + kKlRows);
   const float g = gkl[0] / (float)S;
   const float* q = Q + b * M * NR;
   float* gq = gQ + b * M * NR;
-  for (int e = threadIdx.x; e < M * M; e += 256) {
-    const int i = e / M, j = e % M;
+  for (int e0 = threadIdx.x; e0 < (i1 - i0) * M; e0 += 256) {
+    const int i = i0 + e0 / M, j = e0 % M;
+    const int e = i * M + j;
     gq[(int64_t)i * NR + 4 + M + j] = (j <= i) ? g * q[(int64_t)i * NR + 4 + M + j] : 0.f;
     gLz[b * M * M + e] = (i == j) ? g / Lz[b * M * M + e] : 0.f;
     if (s == 0) gLu[(int64_t)c * M * M + e] = (i == j) ? -gkl[0] / Lu[(int64_t)c * M * M + e] : 0.f;
   }
-  for (int i = threadIdx.x; i < M; i += 256) {
+  for (int i = i0 + threadIdx.x; i < i1; i += 256) {
     gq[(int64_t)i * NR] = ga[b * M + i] + g * q[(int64_t)i * NR];
     gq[(int64_t)i * NR + 1] = 0.f; gq[(int64_t)i * NR + 2] = 0.f; gq[(int64_t)i * NR + 3] = 0.f;
   }
@@ -98,14 +103,15 @@ extern "C" int vargp_kl_t0_fwd(const float* Q, const float* Lz, const float* Lu,
                                vargp_stream_t stream) {
   VARGP_REQUIRE(Q && Lz && Lu && kl_u && S > 0 && C > 0 && M > 0, "kl_t0_fwd: bad arguments");
   (void)hipMemsetAsync(kl_u, 0, sizeof(float), as_stream(stream));
-  hipLaunchKernelGGL(kl_t0_fwd_kernel, dim3(S * C), dim3(256), 0, as_stream(stream), Q, Lz, Lu, kl_u, S, C, M);
+  hipLaunchKernelGGL(kl_t0_fwd_kernel, dim3(cdiv(M, kKlRows), S * C), dim3(256), 0, as_stream(stream), Q, Lz, Lu, kl_u, S, C,
+                     M);
   return check_launch("kl_t0_fwd");
 }
 extern "C" int vargp_kl_t0_bwd(const float* Q, const float* Lz, const float* Lu, const float* ga, const float* gkl,
                                float* gQ, float* gLz, float* gLu, int S, int C, int M, vargp_stream_t stream) {
   VARGP_REQUIRE(Q && Lz && Lu && ga && gkl && gQ && gLz && gLu, "kl_t0_bwd: null pointer");
-  hipLaunchKernelGGL(kl_t0_bwd_kernel, dim3(S * C), dim3(256), 0, as_stream(stream), Q, Lz, Lu, ga, gkl, gQ, gLz, gLu,
-                     S, C, M);
+  hipLaunchKernelGGL(kl_t0_bwd_kernel, dim3(cdiv(M, kKlRows), S * C), dim3(256), 0, as_stream(stream), Q, Lz, Lu, ga, gkl,
+                     gQ, gLz, gLu, S, C, M);
   return check_launch("kl_t0_bwd");
 }
 extern "C" int vargp_kdiag_bwd(const float* theta, const float* gkd, float* gtheta, int S, int C, int D,

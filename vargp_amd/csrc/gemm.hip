@@ -274,43 +274,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   const float* kscale = RBF ? p.kscale + i0 * p.ks_ld : nullptr;
 
   float ra[BM * BK / 256], rb[BN * BK / 256], rs[4] = {1.f, 1.f, 1.f, 1.f};
-  if (ks < ke) {
-    load_slab<AKC, BM, BK, VEC>(A, p.lda, m0, p.M, ks, ke, ra);
-    load_slab<BKC, BN, BK, VEC>(B, p.ldb, n0, p.N, ks, ke, rb);
-    if constexpr (RBF) load_scale<BK, VEC>(kscale, ks, ke, rs);
-    store_slab<AKC, BM, BK, VEC, RBF>(lds, ra, rs);
-    store_slab<BKC, BN, BK, VEC, false>(lds + ((LA::kSize + 3) & ~3), rb, rs);
-    if (ks + BK < ke) {
-      load_slab<AKC, BM, BK, VEC>(A, p.lda, m0, p.M, ks + BK, ke, ra);
-      load_slab<BKC, BN, BK, VEC>(B, p.ldb, n0, p.N, ks + BK, ke, rb);
-      if constexpr (RBF) load_scale<BK, VEC>(kscale, ks + BK, ke, rs);
-    }
-  }
-  __syncthreads();
-  // Main loop.  One wave per SIMD issues in order, so everything that is not an MFMA has to sit in the
-  // shadow of one: per k-step the body issues the fragment reads two steps ahead, the step's MFMAs, and
-  // a slice of the staging work (first half of the slab: registers -> other LDS stage for slab s+1;
-  // second half: global -> registers for slab s+2).
+  float* const stage0 = lds;
+  constexpr int kBoff = (LA::kSize + 3) & ~3;
   constexpr int KS = BK / 2;
-  constexpr int NPA = Pieces<AKC, BM, BK, VEC>::kCount, NPB = Pieces<BKC, BN, BK, VEC>::kCount, NP = NPA + NPB;
-  constexpr int HALF = KS / 2;
-  constexpr int PER = (NP + HALF - 1) / HALF;     // pieces per k-step inside a half
-  int offA[VEC ? NPA : 1], offB[VEC ? NPB : 1];
-  bool fastwg = false;      // uniform: this workgroup may stage full slabs with bare float4 loads
-  if constexpr (VEC) {
-    fastwg = (AKC || (p.M % 4 == 0 && p.M >= 4)) && (BKC || (p.N % 4 == 0 && p.N >= 4));
-#pragma unroll
-    for (int c = 0; c < NPA; ++c) offA[c] = fastwg ? piece_offset<AKC, BM, BK>(p.lda, m0, p.M, c) : 0;
-#pragma unroll
-    for (int c = 0; c < NPB; ++c) offB[c] = fastwg ? piece_offset<BKC, BN, BK>(p.ldb, n0, p.N, c) : 0;
-  }
-  int stage = 0;
-  for (int k0 = ks; k0 < ke; k0 += BK) {
-    const float* As = lds + stage * kStage;
-    const float* Bs = As + ((LA::kSize + 3) & ~3);
-    float* An = lds + (stage ^ 1) * kStage;
-    float* Bn = An + ((LA::kSize + 3) & ~3);
-    const bool has1 = k0 + BK < ke, has2 = k0 + 2 * BK < ke;
+
+  // MFMAs of one slab held in LDS stage `As/Bs`.  Fragment reads run PF k-steps ahead of their MFMAs (one wave
+  // per SIMD: nothing else hides the LDS latency); `between(kk)` is called after the MFMAs of k-step kk so the
+  // caller can drop staging work into their shadow.
+  constexpr int PF = (TM * TN >= 4) ? 2 : (TM * TN == 2 ? 3 : 6);
+  auto slab_mfma = [&](const float* As, const float* Bs, auto&& between) {
     float af[KS][TM], bf[KS][TN];
     auto frag = [&](int kk) {
       const int k = 2 * kk + lh;
@@ -319,54 +291,109 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 #pragma unroll
       for (int c = 0; c < TN; ++c) bf[kk][c] = Bs[LB::at(wn0 + 32 * c + li, k)];
     };
-    frag(0);
-    if (KS > 1) frag(1);
+#pragma unroll
+    for (int kk = 0; kk < PF && kk < KS; ++kk) frag(kk);
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
-      if (kk + 2 < KS) frag(kk + 2);
+      if (kk + PF < KS) frag(kk + PF);
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int c = 0; c < TN; ++c)
           acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][a], bf[kk][c], acc[a][c], 0, 0, 0);
-      if (kk < HALF) {
-        if (has1) {
+      between(kk);
+    }
+  };
+
+  const int nfull = (ke > ks) ? (ke - ks) / BK : 0;      // slabs that need no k guard
+  bool fastwg = false;                                      // uniform: bare float4 staging is legal for this workgroup
+  if constexpr (VEC) fastwg = nfull >= 1 && (AKC || (p.M % 4 == 0 && p.M >= 4)) && (BKC || (p.N % 4 == 0 && p.N >= 4));
+  int kdone = ks;                                           // first k not yet accumulated
+
+  if constexpr (VEC) {
+    if (fastwg) {
+      // ---- pipelined main loop over the full slabs: NO control flow around the loads/stores (a branch there
+      // makes the compiler drain vmcnt before every load).  Loads past the last full slab re-read that slab and
+      // the matching stores go to the idle LDS stage, where nobody reads them.
+      constexpr int NPA = Pieces<AKC, BM, BK, true>::kCount, NPB = Pieces<BKC, BN, BK, true>::kCount, NP = NPA + NPB;
+      constexpr int HALF = KS / 2;
+      constexpr int PER = (NP + HALF - 1) / HALF;           // pieces per k-step inside a half
+      int offA[NPA], offB[NPB];
 #pragma unroll
-          for (int u = 0; u < PER; ++u) {
-            const int pc = kk * PER + u;
-            if (pc < NPA) store_piece<AKC, BM, BK, VEC, RBF>(An, ra, rs, pc);
-            else if (pc < NP) store_piece<BKC, BN, BK, VEC, false>(Bn, rb, rs, pc - NPA);
-          }
-        }
-      } else {
-        if (has2) {
-          const int kn = k0 + 2 * BK;
-          const bool full = VEC && fastwg && (kn + BK <= ke);     // uniform: no guards needed at all
-          if (full) {
-            if constexpr (VEC) {
-              const float* Au = A + (int64_t)kn * (AKC ? 1 : p.lda);
-              const float* Bu = B + (int64_t)kn * (BKC ? 1 : p.ldb);
+      for (int c = 0; c < NPA; ++c) offA[c] = piece_offset<AKC, BM, BK>(p.lda, m0, p.M, c);
 #pragma unroll
-              for (int u = 0; u < PER; ++u) {
-                const int pc = (kk - HALF) * PER + u;
-                if (pc < NPA) load_piece_fast<BM, BK>(Au, offA[pc], pc, ra);
-                else if (pc < NP) load_piece_fast<BN, BK>(Bu, offB[pc - NPA], pc - NPA, rb);
-              }
+      for (int c = 0; c < NPB; ++c) offB[c] = piece_offset<BKC, BN, BK>(p.ldb, n0, p.N, c);
+      const int64_t stepA = AKC ? BK : (int64_t)BK * p.lda, stepB = BKC ? BK : (int64_t)BK * p.ldb;
+      const float* A0 = A + (AKC ? ks : (int64_t)ks * p.lda);
+      const float* B0 = B + (BKC ? ks : (int64_t)ks * p.ldb);
+      // Two register sets: while slab sl is multiplied out of LDS, slab sl+1 goes registers(set X) -> idle LDS
+      // stage and slab sl+2 goes global -> registers(set Y).  A load therefore has more than a whole slab of
+      // MFMAs before its data is needed (one wave per SIMD cannot hide a global-load latency any other way).
+      float ra2[BM * BK / 256], rb2[BN * BK / 256], rs2[4] = {1.f, 1.f, 1.f, 1.f};
+      auto load_set = [&](int slab, float (&xa)[BM * BK / 256], float (&xb)[BN * BK / 256], float (&xs)[4]) {
+        const float* Au = A0 + slab * stepA;
+        const float* Bu = B0 + slab * stepB;
+#pragma unroll
+        for (int c = 0; c < NPA; ++c) load_piece_fast<BM, BK>(Au, offA[c], c, xa);
+#pragma unroll
+        for (int c = 0; c < NPB; ++c) load_piece_fast<BN, BK>(Bu, offB[c], c, xb);
+        if constexpr (RBF) load_scale<BK, true>(kscale, ks + slab * BK, ke, xs);
+      };
+      load_set(0, ra, rb, rs);
+      store_slab<AKC, BM, BK, true, RBF>(stage0, ra, rs);
+      store_slab<BKC, BN, BK, true, false>(stage0 + kBoff, rb, rs);
+      load_set(min(1, nfull - 1), ra, rb, rs);              // slab 1 -> set X
+      __syncthreads();
+      int stage = 0;
+      constexpr int LSTEP = (KS >= 2 * NP) ? 1 : 2;        // pieces loaded per k-step so that all fit into KS/2 steps
+      auto iteration = [&](int sl, float (&xa)[BM * BK / 256], float (&xb)[BN * BK / 256], float (&xs)[4],
+                           float (&ya)[BM * BK / 256], float (&yb)[BN * BK / 256], float (&ys)[4]) {
+        const float* As = lds + stage * kStage;
+        float* An = lds + (stage ^ 1) * kStage;
+        const int nxt = min(sl + 2, nfull - 1);
+        const float* Au = A0 + nxt * stepA;
+        const float* Bu = B0 + nxt * stepB;
+        slab_mfma(As, As + kBoff, [&](int kk) {
+          // first half of the slab: global (slab sl+2) -> set Y, LSTEP pieces per k-step
+#pragma unroll
+          for (int u = 0; u < LSTEP; ++u) {
+            const int pc = kk * LSTEP + u;
+            if (kk < HALF) {
+              if (pc < NPA) load_piece_fast<BM, BK>(Au, offA[pc], pc, ya);
+              else if (pc < NP) load_piece_fast<BN, BK>(Bu, offB[pc - NPA], pc - NPA, yb);
             }
-          } else {
+          }
+          if constexpr (RBF) { if (kk == HALF - 1) load_scale<BK, true>(kscale, ks + nxt * BK, ke, ys); }
+          // second half: set X (slab sl+1, loaded during the previous slab) -> idle LDS stage
+          if (kk >= HALF) {
 #pragma unroll
             for (int u = 0; u < PER; ++u) {
               const int pc = (kk - HALF) * PER + u;
-              if (pc < NPA) load_piece<AKC, BM, BK, VEC>(A, p.lda, m0, p.M, kn, ke, pc, ra);
-              else if (pc < NP) load_piece<BKC, BN, BK, VEC>(B, p.ldb, n0, p.N, kn, ke, pc - NPA, rb);
+              if (pc < NPA) store_piece<AKC, BM, BK, true, RBF>(An, xa, xs, pc);
+              else if (pc < NP) store_piece<BKC, BN, BK, true, false>(An + kBoff, xb, xs, pc - NPA);
             }
           }
-          if constexpr (RBF) { if (kk == KS - 1) load_scale<BK, VEC>(kscale, k0 + 2 * BK, ke, rs); }
-        }
+        });
+        __syncthreads();
+        stage ^= 1;
+      };
+      for (int sl = 0; sl < nfull; sl += 2) {
+        iteration(sl, ra, rb, rs, ra2, rb2, rs2);
+        if (sl + 1 < nfull) iteration(sl + 1, ra2, rb2, rs2, ra, rb, rs);
       }
+      kdone = ks + nfull * BK;
     }
+  }
+  // ---- generic guarded slabs: everything when the fast path does not apply, otherwise only the K tail
+  for (int k0 = kdone; k0 < ke; k0 += BK) {
+    load_slab<AKC, BM, BK, VEC>(A, p.lda, m0, p.M, k0, ke, ra);
+    load_slab<BKC, BN, BK, VEC>(B, p.ldb, n0, p.N, k0, ke, rb);
+    if constexpr (RBF) load_scale<BK, VEC>(kscale, k0, ke, rs);
+    __syncthreads();                                        // previous slab fully consumed
+    store_slab<AKC, BM, BK, VEC, RBF>(stage0, ra, rs);
+    store_slab<BKC, BN, BK, VEC, false>(stage0 + kBoff, rb, rs);
     __syncthreads();
-    stage ^= 1;
+    slab_mfma(stage0, stage0 + kBoff, [](int) {});
   }
 
   // epilogue

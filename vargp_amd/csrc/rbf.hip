@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void rbf_norm_kernel(const float* __restrict__
 // W = gK o K with its row sums r, column sums c and total (dlog gamma = 2 sum W) in one pass.
 // grid (ceil(N/256), ceil(Mb/32), nb): a thread owns one column of a 32-row strip; r and c are
 // accumulated with float atomics (pre-zeroed by the caller), the total with one atomic per block.
-constexpr int WROWS = 32;
+constexpr int WROWS = 8;
 __global__ __launch_bounds__(256) void rbf_w_kernel(const float* __restrict__ K, const float* __restrict__ gK,
                                                     float* __restrict__ W, float* __restrict__ r,
                                                     float* __restrict__ c, float* __restrict__ gtheta, int Mb, int N,
