@@ -1,45 +1,39 @@
-"""Diagnostic: toy accuracy trajectory and NaN hunt on the synthetic Split-MNIST surrogate."""
+"""Diagnostic: which shapes break hipGraph replay of the fused step?"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from vargp_amd.datasets import ToyDataset, SplitMNIST
+from vargp_amd.kernels import RBFKernel
+from vargp_amd.likelihoods import MulticlassSoftmax
 from vargp_amd.train import ElboTrainer
-from vargp_amd.train_utils import set_seeds, compute_accuracy
 from vargp_amd.vargp import VARGP
+from vargp_amd.synthetic import mnist_like
 import vargp_amd
 from vargp_amd import ops
 
 dev = 'cuda'
-set_seeds(1)
-ds = ToyDataset()
-ds.filter_by_class([0, 1])
-gp = VARGP.create_clf(ds, M=20, n_f=10, n_var_samples=3).to(dev)
-tr = ElboTrainer(gp, lr=1e-2, beta=1.0, n_total=len(ds))
-x, y = ds[torch.arange(len(ds))]
-x, y = x.to(dev), y.to(dev)
-for it in range(3001):
-    out = tr.step(x, y)
-    if it % 500 == 0:
-        print('toy', it, [round(o.item(), 2) for o in out], 'acc', compute_accuracy(ds, gp, device=dev))
-
-set_seeds(2)
 vargp_amd.set_cholesky_error_mode('defer')
-ds = SplitMNIST('/nonexistent', train=True, synthetic=True, n_synth=3000)
-ds.filter_by_class([0, 1])
-xa, ya = ds[torch.arange(len(ds))]
-d2 = torch.cdist(xa[:200], xa[:200]).pow(2)
-print('smnist-syn: n', len(ds), 'same-class d2 median', d2[ya[:200, None] == ya[None, :200]].median().item(),
-      'diff-class', d2[ya[:200, None] != ya[None, :200]].median().item())
-gp = VARGP.create_clf(ds, M=20, n_f=10, n_var_samples=3).to(dev)
-tr = ElboTrainer(gp, lr=3e-3, beta=10.0, n_total=len(ds))
-for it in range(40):
-    idx = torch.randperm(len(ds))[:512]
-    out = tr.step(xa[idx].to(dev), ya[idx].to(dev))
-    vals = [o.item() for o in out]
-    if it % 5 == 0 or any(v != v for v in vals):
-        with torch.no_grad():
-            mu, var = gp(xa[:512].to(dev))
-        print('smnist', it, [round(v, 2) for v in vals], 'chol failures', ops.linalg_error_count(), 'min var %.3e' % var.min().item(),
-              'nan var', torch.isnan(var).any().item(), 'acc', None if any(v != v for v in vals) else compute_accuracy(ds, gp, device=dev))
-    if any(v != v for v in vals):
-        break
+fused = os.environ.get('FUSED', '1') == '1'
+from vargp_amd import fused as _f
+if os.environ.get('KEEP'):
+    _f._DEBUG_KEEP = {}
+for (C, M, B, D) in [(10, 16, 32, 784)]:
+    torch.manual_seed(0)
+    xall, yall = mnist_like(4096, D, C, kind='gauss', seed=1)
+    z = torch.stack([xall[yall == c][:M] for c in range(C)])
+    gp = VARGP(z, RBFKernel(D), MulticlassSoftmax(n_f=10), n_var_samples=3).to(dev)
+    gp.fused_first_task = fused
+    tr = ElboTrainer(gp, lr=3e-3, beta=10.0, n_total=12000)
+    x, y = xall[:B].to(dev), yall[:B].to(dev)
+    tr.capture(x, y)
+    res = []
+    for it in range(3):
+        out = tr.step_graph(x, y)
+        torch.cuda.synchronize()
+        res.append({n: int((~torch.isfinite(p.grad)).sum()) for n, p in gp.named_parameters()})
+        res[-1]['out'] = [round(o.item(), 2) for o in out]
+        if _f._DEBUG_KEEP and it == 1:
+            print('after replay 1:', {k: int((~torch.isfinite(v)).sum()) for k, v in _f._DEBUG_KEEP.items() if v.is_floating_point() and int((~torch.isfinite(v)).sum())})
+            print('   max abs:', {k: '%.2e' % v.abs().max().item() for k, v in _f._DEBUG_KEEP.items() if v.is_floating_point() and v.numel()})
+    print('fused', fused, 'C M B D', (C, M, B, D), 'grads finite per replay', res)
+    if _f._DEBUG_KEEP:
+        print({k: int((~torch.isfinite(v)).sum()) for k, v in _f._DEBUG_KEEP.items() if v.is_floating_point()})

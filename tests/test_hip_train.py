@@ -96,3 +96,31 @@ def test_graph_step_equals_eager_step():
         assert ops.linalg_error_count() == 0
     finally:
         ops.set_cholesky_error_mode('raise')
+
+
+@pytest.mark.parametrize('C,M,B,D', [(4, 20, 100, 2), (10, 16, 32, 784), (10, 20, 496, 784)])
+def test_graph_replays_stay_finite(C, M, B, D):
+    """Regression: every buffer a captured step accumulates into must be re-zeroed by a node of the graph
+    (hipMemsetAsync pairs were lost on replay; zeroing is done by a kernel now)."""
+    from vargp_amd import ops
+    from vargp_amd.kernels import RBFKernel
+    from vargp_amd.likelihoods import MulticlassSoftmax
+    from vargp_amd.synthetic import mnist_like
+    from vargp_amd.train import ElboTrainer
+    from vargp_amd.vargp import VARGP
+    ops.set_cholesky_error_mode('defer')
+    try:
+        torch.manual_seed(0)
+        xall, yall = mnist_like(4096, D, C, kind='gauss', seed=1)
+        z = torch.stack([xall[yall == c][:M] for c in range(C)])
+        gp = VARGP(z, RBFKernel(D), MulticlassSoftmax(n_f=10), n_var_samples=3).to(DEV)
+        tr = ElboTrainer(gp, lr=3e-3, beta=10.0, n_total=12000)
+        x, y = xall[:B].to(DEV), yall[:B].to(DEV)
+        tr.capture(x, y)
+        for _ in range(4):
+            out = tr.step_graph(x, y)
+            torch.cuda.synchronize()
+            assert all(torch.isfinite(o).item() for o in out)
+            assert all(bool(torch.isfinite(p.grad).all()) for p in gp.parameters())
+    finally:
+        ops.set_cholesky_error_mode('raise')

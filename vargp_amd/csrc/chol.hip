@@ -231,7 +231,7 @@ extern "C" int vargp_chol_inv_fwd(const float* A, float eps, float* L, float* T,
   VARGP_REQUIRE(nbatch > 0 && n > 0, "chol_inv_fwd: bad dims");
   hipStream_t st = as_stream(stream);
   const int64_t nn = (int64_t)n * n;
-  if (info) (void)hipMemsetAsync(info, 0, sizeof(int32_t) * nbatch, st);
+  if (info) zero_async(info, sizeof(int32_t) * nbatch, st);
   if (n <= kSmallMax)
     return launch_small(A, n, nn, eps, L, n, nn, T, n, nn, logdet, info, 0, nbatch, n, 0, st);
 
@@ -240,10 +240,10 @@ extern "C" int vargp_chol_inv_fwd(const float* A, float eps, float* L, float* T,
   float* tmp = W + (int64_t)nbatch * nn;
   const int64_t stmp = (int64_t)n * kNbSmall;
   hipLaunchKernelGGL(copy_jitter_kernel, dim3(cdiv(nn, 256), nbatch), dim3(256), 0, st, A, W, n, eps);
-  (void)hipMemsetAsync(L, 0, sizeof(float) * nbatch * nn, st);
+  zero_async(L, sizeof(float) * nbatch * nn, st);
   // the blocked inverse needs the factor even if the caller does not want T: use tmp-free path
   float* Tout = T;
-  if (Tout) (void)hipMemsetAsync(Tout, 0, sizeof(float) * nbatch * nn, st);
+  if (Tout) zero_async(Tout, sizeof(float) * nbatch * nn, st);
   int rc;
   for (int k0 = 0; k0 < n; k0 += kNbSmall) {
     const int kb = (n - k0 < kNbSmall) ? n - k0 : kNbSmall;

@@ -10,6 +10,9 @@ namespace vargp {
 constexpr int kWave = 64;
 
 void set_error(const char* fmt, ...);
+// Zero `bytes` (multiple of 4) at `p` with a kernel.  Used instead of hipMemsetAsync everywhere: two adjacent
+// memset nodes in a captured hipGraph were observed to lose the first one on replay (ROCm 7.2).
+void zero_async(void* p, size_t bytes, hipStream_t st);
 int check_launch(const char* what);
 
 #define VARGP_REQUIRE(cond, ...)            \
@@ -69,6 +72,7 @@ struct GemmParams {
   const float* nbv;     // col norms, batch strides sNb
   int64_t sNa[3], sNb[3];
   int same_xy;
+  int nofast;   // tuning aid: force the guarded (non-pipelined) slab loop
 };
 
 int launch_gemm(const GemmParams& p, int transA, int transB, int nbatch, bool rbf, hipStream_t st,

@@ -25,6 +25,17 @@ int check_launch(const char* what) {
   return VARGP_OK;
 }
 
+__global__ void zero_kernel(uint32_t* __restrict__ p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+void zero_async(void* p, size_t bytes, hipStream_t st) {
+  const size_t n = bytes / 4;
+  if (n == 0) return;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(zero_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<uint32_t*>(p), n);
+}
+
 // ---- per-kernel event timing ---------------------------------------------------------------
 struct ProfRec { std::string tag; hipEvent_t a, b; };
 static bool g_prof_on = false;

@@ -380,7 +380,7 @@ extern "C" int vargp_logdet_tril_bwd(const float* L, const float* g, float* gL, 
 extern "C" int vargp_softmax_nll_fwd(const float* mu, const float* var, const float* eps, const int64_t* y, float* nll,
                                      int S, int F, int C, int B, vargp_stream_t stream) {
   VARGP_REQUIRE(mu && var && eps && y && nll && S > 0 && F > 0 && C > 0 && B > 0, "softmax_nll_fwd: bad arguments");
-  (void)hipMemsetAsync(nll, 0, sizeof(float), as_stream(stream));
+  zero_async(nll, sizeof(float), as_stream(stream));
   const int64_t total = (int64_t)S * F * B;
   hipLaunchKernelGGL(softmax_nll_fwd_kernel, GRID1(total), mu, var, eps, y, nll, S, F, C, B);
   return check_launch("softmax_nll_fwd");
@@ -391,8 +391,8 @@ extern "C" int vargp_softmax_nll_bwd(const float* mu, const float* var, const fl
   VARGP_REQUIRE(mu && var && eps && y && gnll && gmu && gvar, "softmax_nll_bwd: null pointer");
   if (C <= 16) {
     const int64_t total = (int64_t)S * F * B;
-    (void)hipMemsetAsync(gmu, 0, sizeof(float) * (size_t)S * C * B, as_stream(stream));
-    (void)hipMemsetAsync(gvar, 0, sizeof(float) * (size_t)S * C * B, as_stream(stream));
+    zero_async(gmu, sizeof(float) * (size_t)S * C * B, as_stream(stream));
+    zero_async(gvar, sizeof(float) * (size_t)S * C * B, as_stream(stream));
     hipLaunchKernelGGL(softmax_nll_bwd_small_kernel<16>, GRID1(total), mu, var, eps, y, gnll, gmu, gvar, S, F, C, B);
   } else {
     const int64_t total = (int64_t)S * C * B;

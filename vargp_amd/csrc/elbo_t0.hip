@@ -102,7 +102,7 @@ extern "C" int vargp_pack_rsmall(const float* m, const float* LS, const float* L
 extern "C" int vargp_kl_t0_fwd(const float* Q, const float* Lz, const float* Lu, float* kl_u, int S, int C, int M,
                                vargp_stream_t stream) {
   VARGP_REQUIRE(Q && Lz && Lu && kl_u && S > 0 && C > 0 && M > 0, "kl_t0_fwd: bad arguments");
-  (void)hipMemsetAsync(kl_u, 0, sizeof(float), as_stream(stream));
+  zero_async(kl_u, sizeof(float), as_stream(stream));
   hipLaunchKernelGGL(kl_t0_fwd_kernel, dim3(cdiv(M, kKlRows), S * C), dim3(256), 0, as_stream(stream), Q, Lz, Lu, kl_u, S, C,
                      M);
   return check_launch("kl_t0_fwd");

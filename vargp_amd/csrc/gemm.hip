@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 
   const int nfull = (ke > ks) ? (ke - ks) / BK : 0;      // slabs that need no k guard
   bool fastwg = false;                                      // uniform: bare float4 staging is legal for this workgroup
-  if constexpr (VEC) fastwg = nfull >= 1 && (AKC || (p.M % 4 == 0 && p.M >= 4)) && (BKC || (p.N % 4 == 0 && p.N >= 4));
+  if constexpr (VEC) fastwg = !p.nofast && nfull >= 1 && (AKC || (p.M % 4 == 0 && p.M >= 4)) && (BKC || (p.N % 4 == 0 && p.N >= 4));
   int kdone = ks;                                           // first k not yet accumulated
 
   if constexpr (VEC) {
@@ -467,6 +467,8 @@ static bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 
 //                  ELBO (K <= 128) is covered by one or two slabs, i.e. one or two global-load latencies.
 int launch_gemm(const GemmParams& p, int transA, int transB, int nbatch, bool rbf, hipStream_t st, const char* tag) {
   if (p.M <= 0 || p.N <= 0 || nbatch <= 0) return VARGP_OK;
+  static const int nofast = [] { const char* e = getenv("VARGP_GEMM_NOFAST"); return e ? atoi(e) : 0; }();   // tuning aid
+  const_cast<GemmParams&>(p).nofast = nofast;
   ProfScope prof(tag, st);
   VARGP_REQUIRE(nbatch <= 65535, "bgemm: batch %d exceeds 65535", nbatch);
   bool vec = aligned16(p.A) && aligned16(p.B) && (p.lda % 4 == 0) && (p.ldb % 4 == 0);

@@ -240,11 +240,11 @@ extern "C" int vargp_rbf_gram_bwd(const float* theta, const float* X, const floa
   const int64_t xrows = (int64_t)C * M, yrows = y_shared ? N : (int64_t)C * N;
   const int nb = S * Cb;
 
-  if (!accumulate) (void)hipMemsetAsync(gtheta, 0, sizeof(float) * (size_t)S * (D + 1), st);
+  if (!accumulate) zero_async(gtheta, sizeof(float) * (size_t)S * (D + 1), st);
   hipLaunchKernelGGL(rbf_prep_kernel, dim3(S), dim3(256), 0, st, theta, o.w, o.g2, D, o.Dp);
   const int64_t nrows = (int64_t)S * xrows;
   float* Wfirst = self ? o.W2 : o.Wm;  // self: raw W goes to W2, W + W^T to Wm
-  (void)hipMemsetAsync(o.r, 0, sizeof(float) * (size_t)(o.P - o.r), st);   // r and c are adjacent
+  zero_async(o.r, sizeof(float) * (size_t)(o.P - o.r), st);   // r and c are adjacent
   hipLaunchKernelGGL(rbf_w_kernel, dim3(cdiv(N, 256), cdiv(Mb, WROWS), nb), dim3(256), 0, st, K, gK, Wfirst, o.r, o.c,
                      gtheta, Mb, N, Cb, D);
   if (self) {

@@ -22,6 +22,9 @@ from ._lib import check, lib, ptr, require_device, stream_ptr, workspace
 from .ops import JITTER, LOWER, UPPER, bgemm
 
 
+_DEBUG_KEEP = None
+
+
 def _rbf_fwd(theta, X, Y, shared, out):
     S, (C, M, D) = theta.shape[0], X.shape
     N = M if Y is None else Y.shape[-2]
@@ -136,6 +139,8 @@ class _ElboT0(Function):
         _rbf_bwd(theta, z, None, False, KS, gKS, gz, gtheta, accumulate=False)
         _rbf_bwd(theta, z, x, True, Kuf, gKuf, gz, gtheta, accumulate=True)
         check(lib().vargp_kdiag_bwd(ptr(theta), ptr(gkd), ptr(gtheta), S, C, D, st), 'vargp_kdiag_bwd')
+        if _DEBUG_KEEP is not None:   # diagnostics: keep every backward intermediate alive for inspection
+            _DEBUG_KEEP.update({k: v for k, v in locals().items() if isinstance(v, torch.Tensor)})
         return gtheta, gz, g_u_mean, g_vec, None, None, None
 
 
