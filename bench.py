@@ -185,7 +185,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    use_graph = not args.eager and world == 1
+    use_graph = not args.eager
     if use_graph:
         trainer.capture(x, y)
         run = trainer.step_graph
@@ -229,7 +229,8 @@ def main():
                    config=dict(workload=WORKLOADS[args.workload]['desc'], S_per_gpu=S, Mt=M * (N_PREV + 1),
                                S_total=S * world, F=F_, C=C, M=M, D=D, B=B, N=N_TOTAL, beta=BETA,
                                optimizer='yogi', parallelism=f'sample-parallel x{world}',
-                               launch='hipGraph replay' if use_graph else 'eager'),
+                               launch=('hipGraph replay' + (' (2 graphs around the all-reduce)' if world > 1 else '')) if use_graph
+                               else 'eager'),
                    elbo_rtol_vs_cpu=rtol, finite=bool(finite), cholesky_failures=errs,
                    final_loss=dict(kl_hypers=out[0].item(), kl_u=out[1].item(), nll=out[2].item()),
                    roofline=dict(bound='mfma', kernel='gemm_kernel<RBF> (K_uf = rbf(z, x), vargp_rbf_gram_fwd)',

@@ -1,0 +1,102 @@
+"""GPU: the sample-parallel trainer with the real HIP model, two ranks sharing cuda:0 (gloo moves the flat
+gradient buffer; on a multi-GPU node the same code runs over RCCL): the 2-rank result — eager and with the
+two-graph capture around the all-reduce — equals the single-process result for all 2*S_local samples."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+S_LOCAL, WORLD, F_, C, M, D, B = 2, 2, 4, 4, 12, 16, 64
+SEED = 31
+
+
+def _model(S):
+    from vargp_amd.kernels import RBFKernel
+    from vargp_amd.likelihoods import MulticlassSoftmax
+    from vargp_amd.synthetic import mnist_like
+    from vargp_amd.vargp import VARGP
+    torch.manual_seed(0)
+    xall, yall = mnist_like(1024, D, C, kind='gauss', seed=1)
+    z = torch.stack([xall[yall == c][:M] for c in range(C)])
+    gp = VARGP(z, RBFKernel(D), MulticlassSoftmax(n_f=F_), n_var_samples=S).to('cuda:0')
+    return gp, xall[:B].to('cuda:0'), yall[:B].to('cuda:0')
+
+
+def _run(gp, x, y, use_graph, steps=3):
+    from vargp_amd import ops
+    from vargp_amd.train import ElboTrainer
+    tr = ElboTrainer(gp, lr=1e-3, beta=2.0, n_total=10 * B, noise_seed=SEED)
+    if use_graph:
+        import copy
+        snap = copy.deepcopy(gp.state_dict())
+        tr.capture(x, y, warmup=1)
+        gp.load_state_dict(snap)                       # undo the warm-up step
+        for grp in tr.optim.param_groups:
+            grp['step'].zero_()
+        for st in tr.optim.state.values():
+            st['exp_avg'].fill_(1e-6)
+            st['exp_avg_sq'].fill_(1e-6)
+        from vargp_amd import noise
+        if noise._shard is not None:                   # restart the shared noise stream as well
+            noise._shard[2].manual_seed(SEED)
+    outs = []
+    for _ in range(steps):
+        out = tr.step_graph(x, y) if use_graph else tr.step(x, y)
+        outs.append([o.item() for o in out])
+    torch.cuda.synchronize()
+    return outs, {k: v.detach().cpu().clone() for k, v in gp.state_dict().items()}
+
+
+def _worker(rank, port, use_graph, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD))
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=WORLD)
+    try:
+        from vargp_amd import ops
+        ops.set_cholesky_error_mode('defer')
+        gp, x, y = _model(S_LOCAL)
+        outs, sd = _run(gp, x, y, use_graph)
+        if rank == 0:
+            q.put((outs, {k: v.numpy() for k, v in sd.items()}))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_two_ranks_equal_single_process(use_graph):
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, port, use_graph, q)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    outs2, sd2 = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+
+    # single process, all samples, same global noise stream
+    from vargp_amd import noise, ops
+    ops.set_cholesky_error_mode('defer')
+    try:
+        noise.set_shard(0, 1, SEED, 'cuda:0')
+        gp, x, y = _model(S_LOCAL * WORLD)
+        from vargp_amd.train import ElboTrainer
+        tr = ElboTrainer(gp, lr=1e-3, beta=2.0, n_total=10 * B)
+        outs1 = [[o.item() for o in tr.step(x, y)] for _ in range(3)]
+        sd1 = {k: v.detach().cpu().numpy() for k, v in gp.state_dict().items()}
+    finally:
+        noise.clear_shard()
+        ops.set_cholesky_error_mode('raise')
+    np.testing.assert_allclose(np.array(outs2), np.array(outs1), rtol=2e-4)
+    for k in sd1:
+        err = np.linalg.norm(sd2[k] - sd1[k]) / max(np.linalg.norm(sd1[k]), 1e-30)
+        assert err < 1e-4, (k, err)

@@ -47,10 +47,13 @@ class ElboTrainer:
 
         self.graph = None
 
-    # -- hipGraph capture of the whole step (zero_grad .. optimiser) --------------------------------
+    # -- hipGraph capture of the step --------------------------------------------------------------
     def capture(self, x, y, warmup=3):
-        """Capture one full step into a hipGraph (torch.cuda.CUDAGraph).  Needs the 'defer' Cholesky
-        error mode (no host sync inside the step).  Afterwards use step_graph()."""
+        """Capture the step into hipGraphs (torch.cuda.CUDAGraph).  Needs the 'defer' Cholesky error mode (no
+        host sync inside the step).  One GPU: a single graph (zero-grad .. optimiser).  Sample-parallel: two
+        graphs around the RCCL all-reduce, which stays an ordinary (un-captured) call:
+            graph A = zero flat buffer, loss, backward, scalars   ->   all_reduce(flat)   ->   graph B = optimiser.
+        Afterwards use step_graph()."""
         from . import ops
         assert ops._chol_mode == 'defer', "set_cholesky_error_mode('defer') before capturing"
         self._sx, self._sy = x.clone(), y.clone()
@@ -63,8 +66,15 @@ class ElboTrainer:
         self.graph = torch.cuda.CUDAGraph()
         if noise._shard is not None:
             self.graph.register_generator_state(noise._shard[2])
-        with torch.cuda.graph(self.graph):
-            self._sout = self.step(self._sx, self._sy)
+        if self.world == 1:
+            with torch.cuda.graph(self.graph):
+                self._sout = self.step(self._sx, self._sy)
+        else:
+            with torch.cuda.graph(self.graph):
+                self._sout = self._local_part(self._sx, self._sy)
+            self.graph_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_opt, pool=self.graph.pool()):
+                self.optim.step()
         return self
 
     def step_graph(self, x=None, y=None):
@@ -73,6 +83,9 @@ class ElboTrainer:
             self._sx.copy_(x, non_blocking=True)
             self._sy.copy_(y, non_blocking=True)
         self.graph.replay()
+        if self.world > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            self.graph_opt.replay()
         return self._sout
 
     def step(self, x, y):
@@ -86,6 +99,15 @@ class ElboTrainer:
             (self.beta * kl_h + kl_u + scale * nll).backward()
             self.optim.step()
             return kl_h.detach(), kl_u.detach(), nll.detach()
+        out = self._local_part(x, y)
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        self.optim.step()
+        return out
+
+    def _local_part(self, x, y):
+        """This rank's share: gradients of (beta kl_h + kl_u_r + (N/B) nll_r) / world accumulated into the flat
+        buffer, whose tail carries kl_u_r / world and nll_r / world."""
+        scale = (self.n_total if self.n_total is not None else x.size(0)) / x.size(0)
         if self.params[0].grad is None or self.params[0].grad.data_ptr() != self.flat.data_ptr():
             off = 0
             for p in self.params:                      # (re-)attach the gradient views of the flat buffer
@@ -99,7 +121,4 @@ class ElboTrainer:
         with torch.no_grad():
             self.scalars[0] = kl_u.detach() * w
             self.scalars[1] = nll.detach() * w
-        if self.world > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-        self.optim.step()
         return kl_h.detach(), self.scalars[0], self.scalars[1]
