@@ -25,18 +25,37 @@ from .ops import JITTER, LOWER, UPPER, bgemm
 _DEBUG_KEEP = None
 
 
-def _rbf_fwd(theta, X, Y, shared, out):
+_side_streams = {}
+
+
+def _side_stream(device):
+    """Second HIP stream per device: the K_uf kernel-matrix work (forward and backward) has no dependency on
+    the K_uu -> Cholesky chain, which is a latency-bound sequence on a few CUs, so the two run concurrently.
+    Forks and joins are stream waits, which a hipGraph capture records as graph edges."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _side_streams:
+        _side_streams[idx] = torch.cuda.Stream(device=device)
+    return _side_streams[idx]
+
+
+def _rbf_ws(theta, X, Y, backward):
     S, (C, M, D) = theta.shape[0], X.shape
     N = M if Y is None else Y.shape[-2]
-    ws = workspace(lib().vargp_rbf_workspace_bytes(S, C, M, N, D, 0), X.device)
+    return workspace(lib().vargp_rbf_workspace_bytes(S, C, M, N, D, int(backward)), X.device)
+
+
+def _rbf_fwd(theta, X, Y, shared, out, ws=None):
+    S, (C, M, D) = theta.shape[0], X.shape
+    N = M if Y is None else Y.shape[-2]
+    ws = ws if ws is not None else _rbf_ws(theta, X, Y, False)
     check(lib().vargp_rbf_gram_fwd(ptr(theta), ptr(X), ptr(Y), ptr(out), S, C, M, N, D, int(shared), ptr(ws),
                                    ws.numel() * 4, stream_ptr()), 'vargp_rbf_gram_fwd')
 
 
-def _rbf_bwd(theta, X, Y, shared, K, gK, gX, gtheta, accumulate):
+def _rbf_bwd(theta, X, Y, shared, K, gK, gX, gtheta, accumulate, ws=None):
     S, (C, M, D) = theta.shape[0], X.shape
     N = M if Y is None else Y.shape[-2]
-    ws = workspace(lib().vargp_rbf_workspace_bytes(S, C, M, N, D, 1), X.device)
+    ws = ws if ws is not None else _rbf_ws(theta, X, Y, True)
     check(lib().vargp_rbf_gram_bwd(ptr(theta), ptr(X), ptr(Y), ptr(K), ptr(gK), ptr(gX), None, ptr(gtheta),
                                    S, C, M, N, D, int(shared), int(accumulate), ptr(ws), ws.numel() * 4, stream_ptr()),
           'vargp_rbf_gram_bwd')
@@ -51,6 +70,15 @@ class _ElboT0(Function):
         SC, NR, dev, st = S * C, 4 + 2 * M, z.device, stream_ptr()
         f32 = dict(dtype=torch.float32, device=dev)
 
+        # fork: K_uf = rbf(z, x) on the side stream (buffers allocated here, on the main stream, and kept
+        # alive past the join)
+        main, side = torch.cuda.current_stream(), _side_stream(dev)
+        Kuf = torch.empty(S, C, M, B, **f32)
+        ws_uf = _rbf_ws(theta, z, x, False)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            _rbf_fwd(theta, z, x, True, Kuf, ws_uf)
+
         Lu = torch.empty(C, M, M, **f32)
         check(lib().vargp_vec2tril_fwd(ptr(u_tril_vec), ptr(Lu), C, M, st), 'vargp_vec2tril_fwd')
         # K_uu for every (s, c) and S_u = Lu Lu^T for every c, one batch -> one factorisation
@@ -64,11 +92,11 @@ class _ElboT0(Function):
         ops._note_chol_errors(info)
         Lz, Tz, LS = LL[:SC].view(S, C, M, M), TT[:SC].view(S, C, M, M), LL[SC:]
 
-        Kuf = torch.empty(S, C, M, B, **f32)
-        _rbf_fwd(theta, z, x, True, Kuf)
         R = torch.empty(C, M, NR, **f32)
         check(lib().vargp_pack_rsmall(ptr(u_mean), ptr(LS), ptr(Lu), ptr(R), C, M, st), 'vargp_pack_rsmall')
         Q = bgemm(Tz, R, triA=LOWER)                      # (S, C, M, NR) = [a | 0 0 0 | G | G2]
+        main.wait_stream(side)                            # join: K_uf is needed from here on
+        del ws_uf
         P = bgemm(Tz, Kuf, triA=LOWER)                    # Lz^-1 K_uf
         G = Q[..., 4:4 + M]
         W = bgemm(G.mT, P, triA=UPPER)                    # (Lz^-1 L_S)^T Lz^-1 K_uf
@@ -120,8 +148,15 @@ class _ElboT0(Function):
         bgemm(gQ, R.mT, triC=LOWER, out=gT)                       # T is lower-triangular: so is its gradient
         bgemm(gP, Kuf.mT, D=gT, beta=1.0, triC=LOWER, out=gT)
         gTT[SC:].zero_()
-        gR = ops._reduce_to(bgemm(Tz.mT, gQ, triA=UPPER), R.shape)
         gKuf = bgemm(Tz.mT, gP, triA=UPPER)
+        # fork: d K_uf -> (z, theta) on the side stream while the main stream runs the Cholesky backward chain
+        main, side = torch.cuda.current_stream(), _side_stream(dev)
+        gz, gtheta = torch.empty_like(z), torch.empty_like(theta)
+        ws_uf = _rbf_ws(theta, z, x, True)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            _rbf_bwd(theta, z, x, True, Kuf, gKuf, gz, gtheta, accumulate=False, ws=ws_uf)
+        gR = ops._reduce_to(bgemm(Tz.mT, gQ, triA=UPPER), R.shape)
         g_u_mean = gR[..., 0:1].contiguous()
         gLL[SC:].copy_(gR[..., 4:4 + M])
         gLu.add_(gR[..., 4 + M:])
@@ -135,9 +170,9 @@ class _ElboT0(Function):
         g_vec = torch.empty_like(u_tril_vec)
         check(lib().vargp_vec2tril_bwd(ptr(u_tril_vec), ptr(gLu), ptr(g_vec), C, M, st), 'vargp_vec2tril_bwd')
         # kernel matrices -> z, theta (second call accumulates), plus the gamma^2 of the predictive variance
-        gz, gtheta = torch.empty_like(z), torch.empty_like(theta)
-        _rbf_bwd(theta, z, None, False, KS, gKS, gz, gtheta, accumulate=False)
-        _rbf_bwd(theta, z, x, True, Kuf, gKuf, gz, gtheta, accumulate=True)
+        main.wait_stream(side)                            # join, then accumulate the K_uu part on top
+        del ws_uf
+        _rbf_bwd(theta, z, None, False, KS, gKS, gz, gtheta, accumulate=True)
         check(lib().vargp_kdiag_bwd(ptr(theta), ptr(gkd), ptr(gtheta), S, C, D, st), 'vargp_kdiag_bwd')
         if _DEBUG_KEEP is not None:   # diagnostics: keep every backward intermediate alive for inspection
             _DEBUG_KEEP.update({k: v for k, v in locals().items() if isinstance(v, torch.Tensor)})
