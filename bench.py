@@ -96,6 +96,15 @@ def stress(args, device):
     print(json.dumps(res))
 
 
+def measured_traffic():
+    """HBM bytes of one K_uf launch from the committed rocprofv3 PMC passes (profiles/README.md); None if absent."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')) as f:
+            return json.load(f)['traffic_bytes']
+    except Exception:
+        return None
+
+
 def snapshot(gp):
     p = dict(z=gp.z, u_mean=gp.u_mean, u_tril_vec=gp.u_tril_vec, log_mean=gp.kernel.log_mean,
              log_logvar=gp.kernel.log_logvar, prior_log_mean=gp.kernel.prior_log_mean,
@@ -236,7 +245,10 @@ def main():
                    roofline=dict(bound='mfma', kernel='gemm_kernel<RBF> (K_uf = rbf(z, x), vargp_rbf_gram_fwd)',
                                  achieved=achieved, peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
                                  frac=(achieved / MFMA_F32_PEAK_TFLOPS) if achieved else None,
-                                 launches=kern_n, avg_us=avg_s * 1e6, traffic=None))
+                                 launches=kern_n, avg_us=avg_s * 1e6,
+                                 traffic=measured_traffic() if args.workload == 'smnist' else None))
+        if N_PREV > 0:      # the tag also covers compute_q's cross-kernel launches of other shapes: not comparable
+            res['roofline'] = None
         if world == 1 and not args.no_cpu_baseline and args.workload == 'smnist':
             res['cpu_baseline'] = cpu_baseline(p0, x, y)
         print(json.dumps(res))
