@@ -28,7 +28,7 @@ S, F_, C, M, D, B = 3, 10, 10, 100, 784, 512
 N_TOTAL, BETA, LR = 12000, 10.0, 3e-3
 N_PREV = 0
 MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32 matrix peak
-DOMINANT_TAG = 'rbf_kuf_gemm'
+DOMINANT_TAG = 'rbf_kuf'       # the K_uf distance GEMM incl. its split-K combine pass (vargp_rbf_gram_fwd)
 
 # Secondary workloads (not the driver's default line): other BASELINE configs, same step definition.
 WORKLOADS = {

@@ -199,8 +199,9 @@ int vargp_hyper_kl_bwd(const float* mean, const float* logvar, const float* prio
 
 /* ------------------------------------------------------------------------------------------------
  * Measurement hooks (no reference counterpart): when enabled, the heavy launches are bracketed by
- * hipEvents on their own stream, tagged "rbf_kuf_gemm", "rbf_kuu_gemm", "rbf_kuf_bwd_gemm",
- * "rbf_kuu_bwd_gemm", "chol_inv_small", "bgemm".  vargp_prof_read sums and clears one tag.
+ * hipEvents on their own stream, tagged "rbf_kuf" / "rbf_kuu" (distance GEMM incl. the split-K combine pass),
+ * "rbf_kuf_gemm", "rbf_kuu_gemm", "rbf_kuf_bwd_gemm", "rbf_kuu_bwd_gemm", "chol_inv_small", "bgemm".
+ * vargp_prof_read sums and clears one tag.
  */
 int vargp_prof_enable(int on);
 int vargp_prof_read(const char* tag, double* total_ms, int64_t* launches);

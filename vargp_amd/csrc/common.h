@@ -73,10 +73,16 @@ struct GemmParams {
   int64_t sNa[3], sNb[3];
   int same_xy;
   int nofast;   // tuning aid: force the guarded (non-pipelined) slab loop
+  // split-K: blockIdx.z = split index; each split covers a BK-aligned share of [0, K) and writes its partial
+  // product (plain epilogue, alpha only) to C + split * sSplit; a second kernel combines the partials
+  int splitk;
+  int64_t sSplit;
 };
 
 int launch_gemm(const GemmParams& p, int transA, int transB, int nbatch, bool rbf, hipStream_t st,
                 const char* tag = "bgemm");
+// number of K splits launch_gemm will use for an RBF product of this shape (1 = fused epilogue, no partials)
+int rbf_splitk(int M, int N, int K, int nbatch);
 
 // Optional per-kernel timing with hipEvents on the launch stream (vargp_prof_* in the C ABI).
 // Disabled (one branch) unless vargp_prof_enable(1); skipped while the stream is being captured.

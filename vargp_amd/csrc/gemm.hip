@@ -257,6 +257,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   }
 
   int ks = 0, ke = p.K;
+  if (p.splitk > 1) {                        // this workgroup's BK-aligned share of K
+    const int nslab = (p.K + BK - 1) / BK;
+    const int per = (nslab + p.splitk - 1) / p.splitk;
+    ks = min(p.K, (int)blockIdx.z * per * BK);
+    ke = min(p.K, ((int)blockIdx.z + 1) * per * BK);
+    C += (int64_t)blockIdx.z * p.sSplit;
+  }
   if (p.triA == 1) ke = min(ke, m0 + BM);
   if (p.triA == 2) ks = max(ks, m0);
   if (p.triB == 1) ks = max(ks, n0);
@@ -417,8 +424,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
         if (row < p.M && col < p.N) {
           float v;
           if constexpr (RBF) {
-            const float d2 = na[row] + nbc - 2.f * acc[a][c][r];
-            v = (p.same_xy && row == col) ? g2 : g2 * expf(-0.5f * d2);
+            if (p.splitk > 1) {
+              v = acc[a][c][r];               // partial inner product; rbf_combine_kernel finishes the job
+            } else {
+              const float d2 = na[row] + nbc - 2.f * acc[a][c][r];
+              v = (p.same_xy && row == col) ? g2 : g2 * expf(-0.5f * d2);
+            }
           } else {
             v = p.alpha * acc[a][c][r];
             if (D) v += p.beta * D[(int64_t)row * p.ldd + col];
@@ -447,7 +458,7 @@ static void dispatch_layout(const GemmParams& p, int transA, int transB, dim3 gr
 
 template <int BM, int BN, int BK>
 static void dispatch_tile(const GemmParams& p, int transA, int transB, int nbatch, bool rbf, bool vec, hipStream_t st) {
-  dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), nbatch);
+  dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), nbatch, p.splitk > 1 ? p.splitk : 1);
   if (rbf) {
     if (vec) dispatch_layout<BM, BN, BK, true, true>(p, 0, 1, grid, st);
     else dispatch_layout<BM, BN, BK, false, true>(p, 0, 1, grid, st);
@@ -465,6 +476,17 @@ static bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 
 //   128x64 xBK32 : 32 MFMA / slab / wave  - mid-size problems (K_uf at Split-MNIST: 192 workgroups)
 //   64 x64 xBK64 :  32 MFMA / slab / wave - small problems; the K extent of the (M x M) products of the
 //                  ELBO (K <= 128) is covered by one or two slabs, i.e. one or two global-load latencies.
+// Split-K for mid-size RBF products is implemented (partials + rbf_combine_kernel) but OFF by default: at the
+// Split-MNIST K_uf shape (384 tiles of 64x64 on 256 CUs) two splits measured 69.8 us against 61.6 us unsplit.
+// The per-slab cost of a wave is its 32 MFMAs plus ~1000 cycles of VALU/LDS issue that do not overlap them, and
+// waves sharing a SIMD serialise, so more, shorter workgroups only add prologue/epilogue and the combine pass.
+// VARGP_RBF_SPLITK=2 turns it on for experiments.
+int rbf_splitk(int M, int N, int K, int nbatch) {
+  (void)M; (void)N; (void)K; (void)nbatch;
+  static const int force = [] { const char* e = getenv("VARGP_RBF_SPLITK"); return e ? atoi(e) : 0; }();
+  return force >= 2 ? 2 : 1;      // the workspace holds at most two partials
+}
+
 int launch_gemm(const GemmParams& p, int transA, int transB, int nbatch, bool rbf, hipStream_t st, const char* tag) {
   if (p.M <= 0 || p.N <= 0 || nbatch <= 0) return VARGP_OK;
   static const int nofast = [] { const char* e = getenv("VARGP_GEMM_NOFAST"); return e ? atoi(e) : 0; }();   // tuning aid

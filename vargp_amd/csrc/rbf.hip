@@ -13,7 +13,7 @@
 namespace vargp {
 
 struct RbfWs {
-  float *w, *g2, *na, *nb, *Wm, *W2, *r, *c, *P, *Q;
+  float *w, *g2, *na, *nb, *part, *Wm, *W2, *r, *c, *P, *Q;
   int64_t Dp;
   size_t bytes;
 };
@@ -28,6 +28,7 @@ static RbfWs carve(void* ws, int S, int C, int M, int N, int D, bool backward) {
   if (!backward) {
     o.na = take((int64_t)S * C * M);
     o.nb = take((int64_t)S * C * N);
+    o.part = take((int64_t)2 * S * C * M * N);      // split-K partial products (at most 2 splits)
   } else {
     o.Wm = take((int64_t)S * C * M * N);
     o.W2 = take((int64_t)S * C * M * N);
@@ -65,6 +66,26 @@ __global__ __launch_bounds__(256) void rbf_direct_kernel(const float* __restrict
   float d2 = 0.f;
   for (int d = 0; d < D; ++d) { const float t = xr[d] - yr[d]; d2 = fmaf(ws[d] * t, t, d2); }
   K[e] = g2[s] * expf(-0.5f * d2);
+}
+
+// K = g2 exp(-0.5 (na + nb - 2 (ab_0 + ab_1 ...))) from split-K partial inner products; same arithmetic as the fused
+// GEMM epilogue.  One thread per entry of the flattened [nb0][rows][N] result.
+__global__ __launch_bounds__(256) void rbf_combine_kernel(const float* __restrict__ part, int nsplit, int64_t sSplit,
+                                                          const float* __restrict__ na, const float* __restrict__ nbv,
+                                                          const float* __restrict__ g2, float* __restrict__ K,
+                                                          int64_t rows_per_s, int N, int64_t nb_stride_s,
+                                                          int64_t nb_stride_c, int Mb, int same_xy, int64_t total) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int col = e % N;
+  const int64_t row = e / N;                 // s * rows_per_s + (c * Mb + m)
+  const int64_t s = row / rows_per_s, rc = row % rows_per_s;
+  const int64_t c = rc / Mb;
+  const int m = rc % Mb;
+  float ab = 0.f;
+  for (int k = 0; k < nsplit; ++k) ab += part[k * sSplit + e];
+  const float d2 = na[row] + nbv[s * nb_stride_s + c * nb_stride_c + col] - 2.f * ab;
+  K[e] = (same_xy && m == col) ? g2[s] : g2[s] * expf(-0.5f * d2);
 }
 
 // nrm[s][row] = sum_d w[s][d] x[row][d]^2 ; one wave per row, grid (ceil(rows/4), S)
@@ -222,8 +243,25 @@ extern "C" int vargp_rbf_gram_fwd(const float* theta, const float* X, const floa
   p.na = o.na; p.sNa[0] = xrows; p.sNa[1] = Mb;
   p.nbv = self ? o.na : o.nb; p.sNb[0] = self ? xrows : yrows; p.sNb[1] = (self || !y_shared) ? N : 0;
   p.same_xy = self ? 1 : 0;
-  int rc = launch_gemm(p, 0, 1, S * Cb, true, st, self ? "rbf_kuu_gemm" : "rbf_kuf_gemm");
-  if (rc) return rc;
+  const int nsplit = rbf_splitk(Mb, N, D, S * Cb);
+  int rc;
+  {
+    ProfScope whole(self ? "rbf_kuu" : "rbf_kuf", st);    // distance GEMM (+ combine pass if K was split)
+    if (nsplit > 1) {
+      p.splitk = nsplit;
+      p.sSplit = (int64_t)S * Cb * Mb * N;
+      p.C = o.part;
+      rc = launch_gemm(p, 0, 1, S * Cb, true, st, self ? "rbf_kuu_gemm" : "rbf_kuf_gemm");
+      if (rc) return rc;
+      const int64_t total = (int64_t)S * Cb * Mb * N;
+      hipLaunchKernelGGL(rbf_combine_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, o.part, nsplit, p.sSplit, o.na,
+                         self ? o.na : o.nb, o.g2, K, (int64_t)Cb * Mb, N, self ? xrows : yrows,
+                         (self || !y_shared) ? (int64_t)N : 0, Mb, self ? 1 : 0, total);
+    } else {
+      rc = launch_gemm(p, 0, 1, S * Cb, true, st, self ? "rbf_kuu_gemm" : "rbf_kuf_gemm");
+      if (rc) return rc;
+    }
+  }
   return check_launch("rbf_gram_fwd");
 }
 
