@@ -2,14 +2,21 @@
 // fused RBF epilogue.  One 256-thread workgroup (4 wave64, 2x2) computes a BM x BN tile; K is walked
 // in slabs of 16 staged through LDS with a register prefetch of the next slab.
 //
-// LDS images mirror the global layout of each operand so that both the staging writes and the MFMA
+// LDS images mirror the global layout of each operand so that staging is one 16-byte write per float4 and the MFMA
 // fragment reads are bank-conflict free:
-//   K-contiguous operand  -> [row][17]   (odd row stride: 32 lanes x consecutive rows hit 32 banks)
-//   M/N-contiguous operand-> [k][rows+4] (lanes read consecutive floats)
+//   K-contiguous operand  -> [row][BK], unpadded, 16-byte chunk c of row r stored at chunk c ^ f(r) (XOR swizzle):
+//                            a lane reads its row's 4 consecutive k with ONE ds_read_b128 (the 16 lanes of a
+//                            b128 group have distinct r & 15, hence distinct slots), staging writes are b128;
+//   M/N-contiguous operand-> [k][rows+4] (lanes read consecutive floats, b128 staging writes).
 // MFMA 32x32x2 fragment maps (cdna guide §3): lane l holds A[i=l&31][k=l>>5], B[k=l>>5][j=l&31];
 // D register r of lane l is row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31.
+// The k index an MFMA sums over is free as long as A and B agree: within a group of 8 k the half-wave h = l>>5
+// owns k = 8g + 4h + j, j = 0..3, i.e. one float4 per lane feeds four MFMAs.
+// On gfx950 the f32 MFMA and the VALU/LDS/SALU issue of a SIMD do not overlap (measured: a slab costs its MFMA
+// cycles PLUS the issue cycles of everything else), so the kernel is written to minimise non-MFMA instructions.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace vargp {
 
@@ -17,9 +24,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <bool KC, int ROWS, int BK>
 struct LdsLayout {
-  static constexpr int kStride = KC ? (BK + 1) : (ROWS + 4);
-  static constexpr int kSize = KC ? ROWS * (BK + 1) : BK * (ROWS + 4);
-  __device__ static __forceinline__ int at(int r, int k) { return KC ? r * kStride + k : k * kStride + r; }
+  static constexpr int kStride = KC ? BK : (ROWS + 4);
+  static constexpr int kSize = KC ? ROWS * BK : BK * (ROWS + 4);
+  __device__ static __forceinline__ int at(int r, int k) {
+    // chunk swizzle: rows that share a 256-byte bank row (64/BK of them) keep their chunk order, the next group of
+    // rows is rotated by one more: 16 lanes with distinct (row & 15) always hit 16 distinct 16-byte slots
+    if constexpr (KC) return r * BK + ((((k >> 2) ^ (r / (64 / BK))) & (BK / 4 - 1)) << 2) + (k & 3);
+    else return k * kStride + r;
+  }
 };
 
 // Global -> registers for one ROWS x BK slab.  Element (r,k) lives at base[(r0+r)*ld + k] (KC) or
@@ -105,12 +117,9 @@ __device__ __forceinline__ void store_slab(float* __restrict__ lds, const float 
       const int q = tid + 256 * c;
       if constexpr (KC) {
         const int r = q / (BK / 4), k = (q % (BK / 4)) * 4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float v = reg[4 * c + e];
-          if constexpr (SCALE) v *= rs[e];
-          lds[L::at(r, k + e)] = v;
-        }
+        float4 v = make_float4(reg[4 * c], reg[4 * c + 1], reg[4 * c + 2], reg[4 * c + 3]);
+        if constexpr (SCALE) { v.x *= rs[0]; v.y *= rs[1]; v.z *= rs[2]; v.w *= rs[3]; }
+        *reinterpret_cast<float4*>(&lds[L::at(r, k)]) = v;
       } else {
         const int k = q / (ROWS / 4), r = (q % (ROWS / 4)) * 4;
         *reinterpret_cast<float4*>(&lds[L::at(r, k)]) =
@@ -184,10 +193,26 @@ __device__ __forceinline__ int piece_offset(int ld, int r0, int rmax, int c) {
     return k * ld + min(r0 + r, rmax - 4);       // requires rmax % 4 == 0 && rmax >= 4
   }
 }
+// One float4 through a buffer descriptor: per-thread byte offset `voff` is loop invariant, the slab advance is the
+// scalar `soff`, so a load costs no VALU address arithmetic at all (cdna guide T8).
+// (hipcc 7.2 lowers __builtin_amdgcn_raw_buffer_load_b128 to a ONE-dword load; the intrinsic is therefore declared
+// directly, with the descriptor as four plain SGPR words.)
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ f32x4 llvm_amdgcn_raw_buffer_load_f32x4(i32x4 srsrc, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ __forceinline__ i32x4 make_rsrc(const void* base, int bytes) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+  i32x4 r;
+  r.x = (int)(a & 0xffffffffull);
+  r.y = (int)((a >> 32) & 0xffffull);      // stride 0: raw buffer
+  r.z = bytes;                              // num_records: loads past it return 0
+  r.w = 0x00020000;
+  return r;
+}
 template <int ROWS, int BK>
-__device__ __forceinline__ void load_piece_fast(const float* __restrict__ slab_base, int off, int c,
-                                                float (&reg)[ROWS * BK / 256]) {
-  const float4 v = *reinterpret_cast<const float4*>(slab_base + off);
+__device__ __forceinline__ void load_piece_fast(i32x4 rsrc, int voff, int soff, int c, float (&reg)[ROWS * BK / 256]) {
+  const f32x4 v = llvm_amdgcn_raw_buffer_load_f32x4(rsrc, voff, soff, 0);
   reg[4 * c + 0] = v.x; reg[4 * c + 1] = v.y; reg[4 * c + 2] = v.z; reg[4 * c + 3] = v.w;
 }
 
@@ -200,12 +225,9 @@ __device__ __forceinline__ void store_piece(float* __restrict__ lds, const float
     const int q = tid + 256 * c;
     if constexpr (KC) {
       const int r = q / (BK / 4), k = (q % (BK / 4)) * 4;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float v = reg[4 * c + e];
-        if constexpr (SCALE) v *= rs[e];
-        lds[L::at(r, k + e)] = v;
-      }
+      float4 v = make_float4(reg[4 * c], reg[4 * c + 1], reg[4 * c + 2], reg[4 * c + 3]);
+      if constexpr (SCALE) { v.x *= rs[0]; v.y *= rs[1]; v.z *= rs[2]; v.w *= rs[3]; }
+      *reinterpret_cast<float4*>(&lds[L::at(r, k)]) = v;
     } else {
       const int k = q / (ROWS / 4), r = (q % (ROWS / 4)) * 4;
       *reinterpret_cast<float4*>(&lds[L::at(r, k)]) =
@@ -283,38 +305,60 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   float ra[BM * BK / 256], rb[BN * BK / 256], rs[4] = {1.f, 1.f, 1.f, 1.f};
   float* const stage0 = lds;
   constexpr int kBoff = (LA::kSize + 3) & ~3;
-  constexpr int KS = BK / 2;
+  constexpr int NG = BK / 8;      // groups of 8 k: per group one float4 per lane and operand feeds 4 x TM*TN MFMAs
 
-  // MFMAs of one slab held in LDS stage `As/Bs`.  Fragment reads run PF k-steps ahead of their MFMAs (one wave
-  // per SIMD: nothing else hides the LDS latency); `between(kk)` is called after the MFMAs of k-step kk so the
-  // caller can drop staging work into their shadow.
-  constexpr int PF = (TM * TN >= 4) ? 2 : (TM * TN == 2 ? 3 : 6);
+  // MFMAs of one slab held in LDS stage `As/Bs`.  Fragment reads run PF groups ahead of their MFMAs (one wave per
+  // SIMD: nothing else hides the LDS latency); `between(g)` is called after the MFMAs of group g so the caller
+  // can place staging work there.
+  constexpr int PF = (NG >= 4) ? 2 : 1;
   auto slab_mfma = [&](const float* As, const float* Bs, auto&& between) {
-    float af[KS][TM], bf[KS][TN];
-    auto frag = [&](int kk) {
-      const int k = 2 * kk + lh;
+    float af[NG][TM][4], bf[NG][TN][4];
+    auto frag = [&](int g) {
+      const int k = 8 * g + 4 * lh;
 #pragma unroll
-      for (int a = 0; a < TM; ++a) af[kk][a] = As[LA::at(wm0 + 32 * a + li, k)];
+      for (int a = 0; a < TM; ++a) {
+        if constexpr (AKC) {
+          const float4 v = *reinterpret_cast<const float4*>(&As[LA::at(wm0 + 32 * a + li, k)]);
+          af[g][a][0] = v.x; af[g][a][1] = v.y; af[g][a][2] = v.z; af[g][a][3] = v.w;
+        } else {
 #pragma unroll
-      for (int c = 0; c < TN; ++c) bf[kk][c] = Bs[LB::at(wn0 + 32 * c + li, k)];
+          for (int j = 0; j < 4; ++j) af[g][a][j] = As[LA::at(wm0 + 32 * a + li, k + j)];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < TN; ++c) {
+        if constexpr (BKC) {
+          const float4 v = *reinterpret_cast<const float4*>(&Bs[LB::at(wn0 + 32 * c + li, k)]);
+          bf[g][c][0] = v.x; bf[g][c][1] = v.y; bf[g][c][2] = v.z; bf[g][c][3] = v.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bf[g][c][j] = Bs[LB::at(wn0 + 32 * c + li, k + j)];
+        }
+      }
     };
 #pragma unroll
-    for (int kk = 0; kk < PF && kk < KS; ++kk) frag(kk);
+    for (int g = 0; g < PF && g < NG; ++g) frag(g);
 #pragma unroll
-    for (int kk = 0; kk < KS; ++kk) {
-      if (kk + PF < KS) frag(kk + PF);
+    for (int g = 0; g < NG; ++g) {
+      if (g + PF < NG) frag(g + PF);
 #pragma unroll
-      for (int a = 0; a < TM; ++a)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int c = 0; c < TN; ++c)
-          acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][a], bf[kk][c], acc[a][c], 0, 0, 0);
-      between(kk);
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int c = 0; c < TN; ++c)
+            acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][a][j], bf[g][c][j], acc[a][c], 0, 0, 0);
+      between(g);
     }
   };
 
   const int nfull = (ke > ks) ? (ke - ks) / BK : 0;      // slabs that need no k guard
   bool fastwg = false;                                      // uniform: bare float4 staging is legal for this workgroup
-  if constexpr (VEC) fastwg = !p.nofast && nfull >= 1 && (AKC || (p.M % 4 == 0 && p.M >= 4)) && (BKC || (p.N % 4 == 0 && p.N >= 4));
+  const int64_t extA = AKC ? ((int64_t)(p.M - 1) * p.lda + p.K) : ((int64_t)(p.K - 1) * p.lda + p.M);
+  const int64_t extB = BKC ? ((int64_t)(p.N - 1) * p.ldb + p.K) : ((int64_t)(p.K - 1) * p.ldb + p.N);
+  if constexpr (VEC)
+    fastwg = !p.nofast && nfull >= 1 && (AKC || (p.M % 4 == 0 && p.M >= 4)) && (BKC || (p.N % 4 == 0 && p.N >= 4)) &&
+             extA < (1ll << 29) && extB < (1ll << 29);     // 32-bit byte offsets into each operand
   int kdone = ks;                                           // first k not yet accumulated
 
   if constexpr (VEC) {
@@ -323,27 +367,30 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
       // makes the compiler drain vmcnt before every load).  Loads past the last full slab re-read that slab and
       // the matching stores go to the idle LDS stage, where nobody reads them.
       constexpr int NPA = Pieces<AKC, BM, BK, true>::kCount, NPB = Pieces<BKC, BN, BK, true>::kCount, NP = NPA + NPB;
-      constexpr int HALF = KS / 2;
-      constexpr int PER = (NP + HALF - 1) / HALF;           // pieces per k-step inside a half
+      constexpr int HALF = (NG >= 2) ? NG / 2 : 1;         // groups [0, HALF): global loads, [HALF, NG): LDS stores
+      constexpr int PERL = (NP + HALF - 1) / HALF;          // pieces loaded per group
+      constexpr int PERS = (NP + (NG - HALF > 0 ? NG - HALF : 1) - 1) / (NG - HALF > 0 ? NG - HALF : 1);
       int offA[NPA], offB[NPB];
 #pragma unroll
       for (int c = 0; c < NPA; ++c) offA[c] = piece_offset<AKC, BM, BK>(p.lda, m0, p.M, c);
 #pragma unroll
       for (int c = 0; c < NPB; ++c) offB[c] = piece_offset<BKC, BN, BK>(p.ldb, n0, p.N, c);
-      const int64_t stepA = AKC ? BK : (int64_t)BK * p.lda, stepB = BKC ? BK : (int64_t)BK * p.ldb;
-      const float* A0 = A + (AKC ? ks : (int64_t)ks * p.lda);
-      const float* B0 = B + (BKC ? ks : (int64_t)ks * p.ldb);
+      const int stepA = 4 * (AKC ? BK : BK * p.lda), stepB = 4 * (BKC ? BK : BK * p.ldb);     // bytes per slab
+      const i32x4 rsA = make_rsrc(A + (AKC ? ks : (int64_t)ks * p.lda), (int)(4 * extA));
+      const i32x4 rsB = make_rsrc(B + (BKC ? ks : (int64_t)ks * p.ldb), (int)(4 * extB));
+#pragma unroll
+      for (int c = 0; c < NPA; ++c) offA[c] *= 4;
+#pragma unroll
+      for (int c = 0; c < NPB; ++c) offB[c] *= 4;
       // Two register sets: while slab sl is multiplied out of LDS, slab sl+1 goes registers(set X) -> idle LDS
       // stage and slab sl+2 goes global -> registers(set Y).  A load therefore has more than a whole slab of
       // MFMAs before its data is needed (one wave per SIMD cannot hide a global-load latency any other way).
       float ra2[BM * BK / 256], rb2[BN * BK / 256], rs2[4] = {1.f, 1.f, 1.f, 1.f};
       auto load_set = [&](int slab, float (&xa)[BM * BK / 256], float (&xb)[BN * BK / 256], float (&xs)[4]) {
-        const float* Au = A0 + slab * stepA;
-        const float* Bu = B0 + slab * stepB;
 #pragma unroll
-        for (int c = 0; c < NPA; ++c) load_piece_fast<BM, BK>(Au, offA[c], c, xa);
+        for (int c = 0; c < NPA; ++c) load_piece_fast<BM, BK>(rsA, offA[c], slab * stepA, c, xa);
 #pragma unroll
-        for (int c = 0; c < NPB; ++c) load_piece_fast<BN, BK>(Bu, offB[c], c, xb);
+        for (int c = 0; c < NPB; ++c) load_piece_fast<BN, BK>(rsB, offB[c], slab * stepB, c, xb);
         if constexpr (RBF) load_scale<BK, true>(kscale, ks + slab * BK, ke, xs);
       };
       load_set(0, ra, rb, rs);
@@ -351,42 +398,39 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
       store_slab<BKC, BN, BK, true, false>(stage0 + kBoff, rb, rs);
       load_set(min(1, nfull - 1), ra, rb, rs);              // slab 1 -> set X
       __syncthreads();
-      int stage = 0;
-      constexpr int LSTEP = (KS >= 2 * NP) ? 1 : 2;        // pieces loaded per k-step so that all fit into KS/2 steps
-      auto iteration = [&](int sl, float (&xa)[BM * BK / 256], float (&xb)[BN * BK / 256], float (&xs)[4],
+      // The loop is unrolled by two, so the LDS stage each half works on is a compile-time constant and every LDS
+      // address is a loop-invariant register plus an immediate.
+      auto iteration = [&](auto stage_c, int sl, float (&xa)[BM * BK / 256], float (&xb)[BN * BK / 256], float (&xs)[4],
                            float (&ya)[BM * BK / 256], float (&yb)[BN * BK / 256], float (&ys)[4]) {
+        constexpr int stage = decltype(stage_c)::value;
         const float* As = lds + stage * kStage;
         float* An = lds + (stage ^ 1) * kStage;
         const int nxt = min(sl + 2, nfull - 1);
-        const float* Au = A0 + nxt * stepA;
-        const float* Bu = B0 + nxt * stepB;
-        slab_mfma(As, As + kBoff, [&](int kk) {
-          // first half of the slab: global (slab sl+2) -> set Y, LSTEP pieces per k-step
+        const int soA = nxt * stepA, soB = nxt * stepB;
+        slab_mfma(As, As + kBoff, [&](int g) {
+          if (g < HALF) {                                   // global (slab sl+2) -> register set Y
 #pragma unroll
-          for (int u = 0; u < LSTEP; ++u) {
-            const int pc = kk * LSTEP + u;
-            if (kk < HALF) {
-              if (pc < NPA) load_piece_fast<BM, BK>(Au, offA[pc], pc, ya);
-              else if (pc < NP) load_piece_fast<BN, BK>(Bu, offB[pc - NPA], pc - NPA, yb);
+            for (int u = 0; u < PERL; ++u) {
+              const int pc = g * PERL + u;
+              if (pc < NPA) load_piece_fast<BM, BK>(rsA, offA[pc], soA, pc, ya);
+              else if (pc < NP) load_piece_fast<BN, BK>(rsB, offB[pc - NPA], soB, pc - NPA, yb);
             }
+            if constexpr (RBF) { if (g == HALF - 1) load_scale<BK, true>(kscale, ks + nxt * BK, ke, ys); }
           }
-          if constexpr (RBF) { if (kk == HALF - 1) load_scale<BK, true>(kscale, ks + nxt * BK, ke, ys); }
-          // second half: set X (slab sl+1, loaded during the previous slab) -> idle LDS stage
-          if (kk >= HALF) {
+          if (g >= HALF) {                                  // register set X (slab sl+1) -> idle LDS stage
 #pragma unroll
-            for (int u = 0; u < PER; ++u) {
-              const int pc = (kk - HALF) * PER + u;
+            for (int u = 0; u < PERS; ++u) {
+              const int pc = (g - HALF) * PERS + u;
               if (pc < NPA) store_piece<AKC, BM, BK, true, RBF>(An, xa, xs, pc);
               else if (pc < NP) store_piece<BKC, BN, BK, true, false>(An + kBoff, xb, xs, pc - NPA);
             }
           }
         });
         __syncthreads();
-        stage ^= 1;
       };
       for (int sl = 0; sl < nfull; sl += 2) {
-        iteration(sl, ra, rb, rs, ra2, rb2, rs2);
-        if (sl + 1 < nfull) iteration(sl + 1, ra2, rb2, rs2, ra, rb, rs);
+        iteration(std::integral_constant<int, 0>{}, sl, ra, rb, rs, ra2, rb2, rs2);
+        if (sl + 1 < nfull) iteration(std::integral_constant<int, 1>{}, sl + 1, ra2, rb2, rs2, ra, rb, rs);
       }
       kdone = ks + nfull * BK;
     }
