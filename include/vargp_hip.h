@@ -205,6 +205,9 @@ int vargp_hyper_kl_bwd(const float* mean, const float* logvar, const float* prio
  */
 int vargp_prof_enable(int on);
 int vargp_prof_read(const char* tag, double* total_ms, int64_t* launches);
+/* Re-launch the most recent K_uf distance GEMM `iters` times back to back between one pair of hipEvents on
+ * `stream` and return the average per-launch time in microseconds (its buffers must still be alive). */
+int vargp_prof_replay_kuf(int iters, double* avg_us, vargp_stream_t stream);
 
 #ifdef __cplusplus
 }

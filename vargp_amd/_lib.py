@@ -62,6 +62,7 @@ _SIGNATURES = {
     'vargp_kdiag_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
     'vargp_prof_enable': (c_int, [c_int]),
     'vargp_prof_read': (c_int, [c_char_p, POINTER(ctypes.c_double), POINTER(c_int64)]),
+    'vargp_prof_replay_kuf': (c_int, [c_int, POINTER(ctypes.c_double), _P]),
     'vargp_yogi_step': (c_int, [_P, _P, _P, _P, c_int64] + [c_float] * 6 + [_P, _P]),
 }
 EXPORTS = sorted(_SIGNATURES)
@@ -123,3 +124,10 @@ def prof_read(tag):
     ms, n = ctypes.c_double(0.0), c_int64(0)
     lib().vargp_prof_read(tag.encode(), ctypes.byref(ms), ctypes.byref(n))
     return ms.value, n.value
+
+
+def prof_replay_kuf(iters=50):
+    """Average time (us) of the most recent K_uf distance GEMM re-launched back to back (see vargp_hip.h)."""
+    us = ctypes.c_double(0.0)
+    check(lib().vargp_prof_replay_kuf(int(iters), ctypes.byref(us), stream_ptr()), 'vargp_prof_replay_kuf')
+    return us.value

@@ -16,6 +16,7 @@
 // cycles PLUS the issue cycles of everything else), so the kernel is written to minimise non-MFMA instructions.
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 
 namespace vargp {
@@ -531,8 +532,13 @@ int rbf_splitk(int M, int N, int K, int nbatch) {
   return force >= 2 ? 2 : 1;      // the workspace holds at most two partials
 }
 
+// last launch per tag, kept for vargp_prof_replay (measurement only)
+struct SavedGemm { GemmParams p; int transA, transB, nbatch; bool rbf; bool valid; };
+static SavedGemm g_saved_kuf{};
+
 int launch_gemm(const GemmParams& p, int transA, int transB, int nbatch, bool rbf, hipStream_t st, const char* tag) {
   if (p.M <= 0 || p.N <= 0 || nbatch <= 0) return VARGP_OK;
+  if (tag[0] == 'r' && strcmp(tag, "rbf_kuf_gemm") == 0) g_saved_kuf = SavedGemm{p, transA, transB, nbatch, rbf, true};
   static const int nofast = [] { const char* e = getenv("VARGP_GEMM_NOFAST"); return e ? atoi(e) : 0; }();   // tuning aid
   const_cast<GemmParams&>(p).nofast = nofast;
   ProfScope prof(tag, st);
@@ -552,6 +558,28 @@ int launch_gemm(const GemmParams& p, int transA, int transB, int nbatch, bool rb
 }
 
 }  // namespace vargp
+
+// Re-launch the most recent K_uf distance GEMM (tag "rbf_kuf_gemm") `iters` times back to back between ONE pair of
+// hipEvents and return the average kernel time: per-launch event pairs include the dispatch gap, this does not.
+// The buffers of that launch must still be alive (bench.py holds them).  Synchronises.
+extern "C" int vargp_prof_replay_kuf(int iters, double* avg_us, vargp_stream_t stream) {
+  using namespace vargp;
+  VARGP_REQUIRE(g_saved_kuf.valid && iters > 0 && avg_us, "prof_replay_kuf: nothing recorded");
+  hipStream_t st = as_stream(stream);
+  hipEvent_t a, b;
+  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return VARGP_ELAUNCH;
+  for (int i = 0; i < 3; ++i) launch_gemm(g_saved_kuf.p, g_saved_kuf.transA, g_saved_kuf.transB, g_saved_kuf.nbatch, g_saved_kuf.rbf, st, "replay");
+  (void)hipEventRecord(a, st);
+  for (int i = 0; i < iters; ++i) launch_gemm(g_saved_kuf.p, g_saved_kuf.transA, g_saved_kuf.transB, g_saved_kuf.nbatch, g_saved_kuf.rbf, st, "replay");
+  (void)hipEventRecord(b, st);
+  (void)hipEventSynchronize(b);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, a, b);
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  *avg_us = 1e3 * ms / iters;
+  return check_launch("prof_replay_kuf");
+}
 
 extern "C" int vargp_bgemm(const vargp_gemm_desc* d, vargp_stream_t stream) {
   using namespace vargp;
