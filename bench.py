@@ -196,7 +196,21 @@ def main():
 
     use_graph = not args.eager
     if use_graph:
-        trainer.capture(x, y)
+        try:
+            trainer.capture(x, y)
+        except Exception as e:                      # never lose the bench line to a capture problem: run eagerly instead
+            if world > 1:                           # (every rank takes the same decision)
+                flag = torch.tensor([1.0], device=device)
+                dist.all_reduce(flag)
+            print(f'[bench] hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager steps', file=sys.stderr)
+            use_graph = False
+        else:
+            if world > 1:
+                flag = torch.tensor([0.0], device=device)
+                dist.all_reduce(flag)
+                if flag.item() > 0:                 # some other rank failed to capture
+                    use_graph = False
+    if use_graph:
         run = trainer.step_graph
     else:
         run = lambda: trainer.step(x, y)

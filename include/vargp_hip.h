@@ -164,18 +164,38 @@ int vargp_yogi_step(float* p, const float* g, float* m, float* v, int64_t n, flo
                     float beta2, float eps, float bias1, float bias2, const float* step, vargp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Glue of the fused task-0 ELBO (vargp_amd/fused.py; reference var_gp/vargp.py:156-190): the small
- * right-hand sides that share Lz^-1 are packed per class as R[c] = [m | 0 0 0 | L_S | Lu] (M x (4+2M));
- * Q[s,c] = Lz^-1[s,c] R[c] then holds a = Lz^-1 m, G = Lz^-1 L_S and G2 = Lz^-1 Lu, and
- * kl_u = (1/S) sum_{s,c} [ sum log diag Lz - sum log diag Lu + 0.5 (|G2|_F^2 + |a|^2 - M) ].
+ * The first-task ELBO as one native program (vargp_amd/csrc/elbo_t0.hip).
+ * Replaces, for a model without previous tasks, the whole of VARGP.loss (var_gp/vargp.py:156-194:
+ * RBFKernel.sample_hypers / kl_hypers kernels.py:62-77, RBFKernel.compute kernels.py:24-56, cholesky and
+ * linear_marginal_diag gp_utils.py:5-11,150-191, the MVN KL vargp.py:182-190, MulticlassSoftmax.loss
+ * likelihoods.py:13-45) and its autograd backward (loss.backward(), experiments/vargp.py:35).
+ *
+ * Shapes: log_mean, log_logvar, prior_* (D+1); eps_theta (S, D+1); z (C, M, D); u_mean (C, M); u_tril_vec
+ * (C, M(M+1)/2); x (B, D); y (B) int64; eps_f (S, F, C, B).  map_est != 0: theta = log_mean, S must be 1, kl_hypers = 0
+ * (log_logvar / prior_* / eps_theta may be NULL).
+ * fwd writes scalars[0..2] = (kl_hypers, kl_u, nll) and info[0 .. S*C + C) (Cholesky status of K_uu[s,c] + eps I, then of
+ * S_u[c] + eps I; 0 = ok, k = leading minor k not positive, results NaN-filled).
+ * bwd needs the workspace exactly as fwd left it; seeds (device, 3 floats) = d total / d (kl_hypers, kl_u, nll).  It
+ * OVERWRITES the five gradient buffers (shapes of the parameters).  Neither call allocates or synchronises.
  */
-int vargp_pack_rsmall(const float* m, const float* LS, const float* Lu, float* R, int C, int M, vargp_stream_t stream);
-int vargp_kl_t0_fwd(const float* Q, const float* Lz, const float* Lu, float* kl_u, int S, int C, int M,
-                    vargp_stream_t stream);
-int vargp_kl_t0_bwd(const float* Q, const float* Lz, const float* Lu, const float* ga, const float* gkl, float* gQ,
-                    float* gLz, float* gLu, int S, int C, int M, vargp_stream_t stream);
-/* gtheta[s, D] += 2 gamma_s^2 sum_c gkd[s, c]  (chain rule through kdiag = gamma^2, kernels.py:58-60) */
-int vargp_kdiag_bwd(const float* theta, const float* gkd, float* gtheta, int S, int C, int D, vargp_stream_t stream);
+typedef struct vargp_elbo_t0_desc {
+  int32_t S, C, M, D, B, F;
+  int32_t map_est;
+  float jitter;
+  const float *log_mean, *log_logvar, *prior_log_mean, *prior_log_logvar;
+  const float *z, *u_mean, *u_tril_vec;
+  const float* x;
+  const int64_t* y;
+  const float *eps_theta, *eps_f;
+  float* scalars;
+  int32_t* info;
+  void* ws;
+  size_t ws_bytes;
+} vargp_elbo_t0_desc;
+size_t vargp_elbo_t0_workspace_bytes(int S, int C, int M, int D, int B, int F);
+int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t stream);
+int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds, float* g_log_mean, float* g_log_logvar, float* g_z,
+                      float* g_u_mean, float* g_u_tril_vec, vargp_stream_t stream);
 
 /* same update for up to 8 tensors in one launch; `step` (device float, the step count t) is required */
 int vargp_yogi_step_multi(int ntensors, float* const* p, const float* const* g, float* const* m, float* const* v,

@@ -117,8 +117,9 @@ def test_continual_chain_blocked_cholesky_vs_oracle():
 
 @pytest.mark.parametrize('name', ['toy_t0', 'smnist_small_t0', 'smnist_full_t0'])
 def test_fused_first_task_equals_composed_path(name):
-    """vargp_amd/fused.py (one autograd node, batched factorisations, packed right-hand sides) against the
-    composed per-op path on the same inputs: same kernels, so agreement is at rounding level."""
+    """The native first-task program (csrc/elbo_t0.hip: one autograd node, batched factorisations, one operand for
+    everything multiplied by Lz^-1, fused glue kernels) against the composed per-op path on the same inputs: same
+    GEMM / Cholesky kernels and formulas, different summation order in the small reductions."""
     from vargp_amd import noise
     from gpu_common import build_gp, grads_of, DEV
     g, params, prev, x, y, nz = load_case(name)
@@ -131,6 +132,6 @@ def test_fused_first_task_equals_composed_path(name):
             kl_h, kl_u, nll = gp.loss(x.to(DEV), y.to(DEV))
             (float(g['beta']) * kl_h + kl_u + (float(g['n_total']) / x.shape[0]) * nll).backward()
         res.append(((kl_h.item(), kl_u.item(), nll.item()), {k: v.cpu() for k, v in grads_of(gp).items()}))
-    np.testing.assert_allclose(res[0][0], res[1][0], rtol=2e-6)
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=1e-5)
     for k in GRAD_KEYS:
-        assert rel_l2(res[0][1][k], res[1][1][k]) < 2e-5, k
+        assert rel_l2(res[0][1][k], res[1][1][k]) < 1e-4, k

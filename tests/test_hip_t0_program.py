@@ -1,0 +1,104 @@
+"""GPU: the native first-task ELBO program (vargp_elbo_t0_fwd / _bwd) against the fp64 oracle on shapes that hit
+its edge paths, and the trainer's direct use of it against the autograd route."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vargp_oracle as orc
+from helpers import rel_l2, to_dev, RTOL_SCALAR, REL_L2_GRAD
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _problem(S, F_, C, M, D, B, seed, kind='gauss'):
+    params, prev, x, y, nz = orc.make_problem(S, F_, C, M, D, B, n_prev=0, seed=seed, kind=kind)
+    return params, prev, x, y, nz
+
+
+# (S, F, C, M, D, B): odd M (padded small-column block), B not a multiple of 4 (padded row stride, scalar GEMM
+# loads), C > 16 (generic softmax kernels), D <= 32 (direct distance form), M > 100 (blocked Cholesky)
+SHAPES = [(2, 3, 3, 33, 40, 50), (3, 2, 4, 20, 64, 37), (2, 2, 18, 12, 36, 24), (2, 3, 2, 20, 2, 64),
+          (1, 2, 2, 130, 48, 40)]
+
+
+@pytest.mark.parametrize('shape', SHAPES, ids=[str(s) for s in SHAPES])
+def test_program_matches_fp64_oracle(shape):
+    from vargp_amd import noise
+    from gpu_common import build_gp, grads_of
+    S, F_, C, M, D, B = shape
+    params, prev, x, y, nz = _problem(S, F_, C, M, D, B, seed=31)
+    gp = build_gp(params, prev, S, F_)
+    with noise.inject(**to_dev(nz, DEV)):
+        kl_h, kl_u, nll = gp.loss(x.to(DEV), y.to(DEV))
+        (2.0 * kl_h + kl_u + 7.0 * nll).backward()
+    sc, og = orc.elbo_step(params, prev, x, y, nz, beta=2.0, n_total=7 * B)
+    for k, v in [('kl_hypers', kl_h), ('kl_u', kl_u), ('nll', nll)]:
+        np.testing.assert_allclose(v.item(), sc[k].item(), rtol=RTOL_SCALAR, err_msg=k)
+    for k, g in grads_of(gp).items():
+        assert rel_l2(g.cpu(), og[k]) < REL_L2_GRAD, k
+
+
+def test_program_map_est():
+    """map_est: theta = log_mean, no hyper-KL; against the composed per-op path."""
+    from vargp_amd import noise
+    from gpu_common import build_gp, grads_of
+    S, F_, C, M, D, B = 1, 3, 3, 24, 40, 32
+    params, prev, x, y, nz = _problem(S, F_, C, M, D, B, seed=5)
+    res = []
+    for fused in (True, False):
+        gp = build_gp(params, prev, S, F_)
+        gp.kernel.map_est = True
+        gp.fused_first_task = fused
+        with noise.inject(eps_f=nz['eps_f'].to(DEV)):
+            kl_h, kl_u, nll = gp.loss(x.to(DEV), y.to(DEV))
+            (kl_h + kl_u + 3.0 * nll).backward()
+        g = grads_of(gp)
+        assert g['log_logvar'] is None
+        res.append(((kl_h.item(), kl_u.item(), nll.item()), {k: v.cpu() for k, v in g.items() if v is not None}))
+    assert res[0][0][0] == 0.0
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=1e-5)
+    for k in res[1][1]:
+        assert rel_l2(res[0][1][k], res[1][1][k]) < 1e-4, k
+
+
+def test_trainer_direct_program_equals_autograd_route():
+    """ElboTrainer drives T0Program directly (seeds, gradients written into the optimiser's buffers); the same
+    steps through gp.loss -> autograd -> Yogi must give the same parameters."""
+    import vargp_amd
+    from vargp_amd import noise
+    from vargp_amd.optim import Yogi
+    from vargp_amd.train import ElboTrainer
+    from gpu_common import build_gp
+    S, F_, C, M, D, B = 2, 3, 4, 30, 48, 64
+    params, prev, x, y, nz = _problem(S, F_, C, M, D, B, seed=8, kind='mnist')
+    xd, yd = x.to(DEV), y.to(DEV)
+    beta, n_total = 1.5, 10 * B
+    gp_a, gp_b = build_gp(params, prev, S, F_), build_gp(params, prev, S, F_)
+    tr = ElboTrainer(gp_a, lr=3e-3, beta=beta, n_total=n_total)
+    assert tr._t0
+    opt = Yogi([p for p in gp_b.parameters() if p.requires_grad], lr=3e-3)
+    for it in range(3):
+        nzd = {k: (v + 0.1 * it).to(DEV) for k, v in nz.items()}
+        with noise.inject(**nzd):
+            out_a = [float(v) for v in tr.step(xd, yd)]
+            for p in gp_b.parameters():
+                p.grad = None
+            kl_h, kl_u, nll = gp_b.loss(xd, yd)
+            (beta * kl_h + kl_u + (n_total / B) * nll).backward()
+            opt.step()
+        np.testing.assert_allclose(out_a, [kl_h.item(), kl_u.item(), nll.item()], rtol=1e-5)
+    for (k, pa), (_, pb) in zip(gp_a.named_parameters(), gp_b.named_parameters()):
+        assert rel_l2(pa.detach().cpu(), pb.detach().cpu()) < 1e-5, k
+
+
+def test_program_rejects_bad_arguments():
+    from vargp_amd._lib import VargpHipError
+    from vargp_amd.fused import T0Program
+    prog = T0Program(1, 2, 8, 4, 8, 2, DEV, map_est=False)
+    z = torch.zeros(2, 8, 4, device=DEV)
+    with pytest.raises(VargpHipError):        # CPU tensor: no CPU path
+        prog.forward(torch.zeros(5), torch.zeros(5), torch.zeros(5), torch.zeros(5), z, z[..., :1], z[..., :1],
+                     torch.zeros(8, 4), torch.zeros(8, dtype=torch.int64), torch.zeros(1, 5), torch.zeros(1, 2, 2, 8))
+    with pytest.raises(AssertionError):       # backward before forward
+        prog.backward(*([torch.zeros(3, device=DEV)] * 6))

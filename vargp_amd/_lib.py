@@ -26,6 +26,19 @@ class GemmDesc(Structure):
     ]
 
 
+class ElboT0Desc(Structure):
+    _fields_ = [
+        ('S', c_int32), ('C', c_int32), ('M', c_int32), ('D', c_int32), ('B', c_int32), ('F', c_int32),
+        ('map_est', c_int32), ('jitter', c_float),
+        ('log_mean', c_void_p), ('log_logvar', c_void_p), ('prior_log_mean', c_void_p), ('prior_log_logvar', c_void_p),
+        ('z', c_void_p), ('u_mean', c_void_p), ('u_tril_vec', c_void_p),
+        ('x', c_void_p), ('y', c_void_p),
+        ('eps_theta', c_void_p), ('eps_f', c_void_p),
+        ('scalars', c_void_p), ('info', c_void_p),
+        ('ws', c_void_p), ('ws_bytes', c_size_t),
+    ]
+
+
 _P = c_void_p
 _SIGNATURES = {
     'vargp_version': (c_int, []),
@@ -56,10 +69,9 @@ _SIGNATURES = {
     'vargp_hyper_sample_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P]),
     'vargp_hyper_kl_fwd': (c_int, [_P, _P, _P, _P, _P, c_int, _P]),
     'vargp_hyper_kl_bwd': (c_int, [_P] * 7 + [c_int, _P]),
-    'vargp_pack_rsmall': (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
-    'vargp_kl_t0_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
-    'vargp_kl_t0_bwd': (c_int, [_P] * 8 + [c_int, c_int, c_int, _P]),
-    'vargp_kdiag_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
+    'vargp_elbo_t0_workspace_bytes': (c_size_t, [c_int] * 6),
+    'vargp_elbo_t0_fwd': (c_int, [POINTER(ElboT0Desc), _P]),
+    'vargp_elbo_t0_bwd': (c_int, [POINTER(ElboT0Desc)] + [_P] * 7),
     'vargp_prof_enable': (c_int, [c_int]),
     'vargp_prof_read': (c_int, [c_char_p, POINTER(ctypes.c_double), POINTER(c_int64)]),
     'vargp_prof_replay_kuf': (c_int, [c_int, POINTER(ctypes.c_double), _P]),

@@ -227,11 +227,16 @@ extern "C" size_t vargp_chol_workspace_bytes(int nbatch, int n, int backward) {
 
 extern "C" int vargp_chol_inv_fwd(const float* A, float eps, float* L, float* T, float* logdet, int32_t* info,
                                   int nbatch, int n, void* ws, size_t ws_bytes, vargp_stream_t stream) {
+  return vargp::chol_inv_fwd_impl(A, eps, L, T, logdet, info, nbatch, n, ws, ws_bytes, true, as_stream(stream));
+}
+
+// zero_info = false: the caller has already cleared the status words (the fused ELBO program does it in its prologue)
+int vargp::chol_inv_fwd_impl(const float* A, float eps, float* L, float* T, float* logdet, int32_t* info, int nbatch,
+                             int n, void* ws, size_t ws_bytes, bool zero_info, hipStream_t st) {
   VARGP_REQUIRE(A && L, "chol_inv_fwd: null pointer");
   VARGP_REQUIRE(nbatch > 0 && n > 0, "chol_inv_fwd: bad dims");
-  hipStream_t st = as_stream(stream);
   const int64_t nn = (int64_t)n * n;
-  if (info) zero_async(info, sizeof(int32_t) * nbatch, st);
+  if (info && zero_info) zero_async(info, sizeof(int32_t) * nbatch, st);
   if (n <= kSmallMax)
     return launch_small(A, n, nn, eps, L, n, nn, T, n, nn, logdet, info, 0, nbatch, n, 0, st);
 

@@ -81,8 +81,16 @@ struct GemmParams {
 
 int launch_gemm(const GemmParams& p, int transA, int transB, int nbatch, bool rbf, hipStream_t st,
                 const char* tag = "bgemm");
+int launch_gemm_pair(const GemmParams& p0, int nbatch0, const GemmParams& p1, int nbatch1, int transA, int transB,
+                     bool rbf, hipStream_t st, const char* tag0, const char* tag1);
 // number of K splits launch_gemm will use for an RBF product of this shape (1 = fused epilogue, no partials)
 int rbf_splitk(int M, int N, int K, int nbatch);
+
+constexpr int kRbfDirectD = 32;   // D <= this: kernel matrices from the direct (no-cancellation) distance form
+int rbf_direct_launch(const float* X, const float* Y, const float* w, const float* g2, float* K, int64_t ldk, int S,
+                      int C, int M, int N, int D, int64_t Dp, int y_shared, hipStream_t st);
+int chol_inv_fwd_impl(const float* A, float eps, float* L, float* T, float* logdet, int32_t* info, int nbatch, int n,
+                      void* ws, size_t ws_bytes, bool zero_info, hipStream_t st);
 
 // Optional per-kernel timing with hipEvents on the launch stream (vargp_prof_* in the C ABI).
 // Disabled (one branch) unless vargp_prof_enable(1); skipped while the stream is being captured.

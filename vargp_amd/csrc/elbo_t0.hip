@@ -1,122 +1,744 @@
-// Glue kernels of the fused task-0 ELBO path (vargp_amd/fused.py): packing the small right-hand sides that
-// share the factor T = Lz^-1 into one GEMM operand, and the MVN-KL of q(u) = N(m, Lu Lu^T) against the prior
-// p(u | theta) = N(0, Lz Lz^T) (reference: var_gp/vargp.py:156-190) computed straight from that GEMM's output.
+// The first-task ELBO as ONE native program: vargp_elbo_t0_fwd / vargp_elbo_t0_bwd sequence every kernel of
+// VARGP.loss for a model without previous tasks (reference: var_gp/vargp.py:156-194, gp_utils.py:150-191,
+// kernels.py:24-77, likelihoods.py:13-45) and of its gradient on one stream, over one caller-owned workspace.
 //
-//   Rsmall[c] = [ m_c | 0 0 0 | LS_c | Lu_c ]            (M x NR, NR = 4 + 2M), one per class
-//   Q[s,c]    = T[s,c] . Rsmall[c] = [ a | 0 0 0 | G | G2 ],  a = Lz^-1 m, G = Lz^-1 L_S, G2 = Lz^-1 Lu
-//   kl[s,c]   = sum log diag Lz - sum log diag Lu + 0.5 (|G2|_F^2 + |a|^2 - M);   kl_u = (1/S) sum_{s,c} kl[s,c]
+// Why a program and not a composition of the per-op entry points: at the reference's sizes (M = 100 inducing points
+// per class, minibatch 512) every kernel is short, so a step costs about (number of launches) x 5 us plus the GEMM and
+// Cholesky time.  The program therefore
+//   * concatenates everything that is multiplied by T = Lz^-1 into one operand
+//         RK[s,c] = [ m | 0 0 0 | L_S | Lu | pad | K_uf[s,c] ]      (M x LD, LD = NR + B rounded up to 4, NR = 4 + 2M -> 4)
+//     so that   QP = T RK = [ a | . | G | G2 | . | P ],   gT = tril(gQP RK^T)   and   gRK = T^T gQP
+//     are ONE GEMM each (a = Lz^-1 m, G = Lz^-1 L_S, G2 = Lz^-1 Lu (KL), P = Lz^-1 K_uf);
+//   * builds K_uu and K_uf with one two-problem GEMM launch (shared 1/sigma^2, gamma^2 and row norms), and their
+//     backward products W.Y likewise;
+//   * factorises K_uu (S*C matrices) and S_u = Lu Lu^T (C matrices) in one batch;
+//   * folds the glue (hyper-parameter sampling and its KL, vec2tril, S_u, zero-fills, softmax likelihood with its
+//     gradient, KL reductions, gradient unpacking) into a handful of multi-role kernels.
+// About 30 launches per step instead of about 85; numerics are those of the per-op path (same kernels and formulas).
 #include "common.h"
 
 namespace vargp {
 
-__global__ void pack_rsmall_kernel(const float* __restrict__ m, const float* __restrict__ LS,
-                                   const float* __restrict__ Lu, float* __restrict__ R, int M, int64_t total) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= total) return;
-  const int NR = 4 + 2 * M;
-  const int col = e % NR;
-  const int64_t row = e / NR;            // c * M + i
-  const int64_t c = row / M;
-  const int i = row % M;
-  float v = 0.f;
-  if (col == 0) v = m[row];
-  else if (col >= 4 && col < 4 + M) v = LS[(c * M + i) * M + (col - 4)];
-  else if (col >= 4 + M) v = Lu[(c * M + i) * M + (col - 4 - M)];
-  R[e] = v;
+constexpr int kKlRows = 8;     // rows of one (s, c) block per KL workgroup
+constexpr int kWRows = 8;      // rows per workgroup of the W = gK o K pass
+constexpr int kFinRows = 32;   // rows per workgroup of the RBF finalisation
+
+__device__ __forceinline__ float softplus_t0(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float sigmoid_t0(float x) { return 1.f / (1.f + expf(-x)); }
+
+struct T0Ws {
+  // forward results kept for the backward
+  float *theta, *w, *g2, *kd, *na, *nb, *Lu, *KS, *LL, *TT, *RK, *QP, *W, *mu, *var;
+  float *gmu, *gvar;               // accumulators zeroed by the forward prologue (softmax gradient, unscaled)
+  float *r_uf, *c_uf, *gtheta;     // accumulators zeroed by the first backward kernel
+  float *r_uu, *gW, *ga, *gkd, *gQP, *gLL, *gTT, *gRK, *gKS, *Wuu, *Puu, *Puf;
+  void* chol;
+  size_t chol_bytes;
+  int NR, LD;
+  int64_t Dp;
+  size_t bytes;
+};
+
+static T0Ws carve_t0(void* ws, int S, int C, int M, int D, int B) {
+  T0Ws o{};
+  o.NR = (int)round_up(4 + 2 * M, 4);
+  o.LD = (int)round_up(o.NR + B, 4);
+  o.Dp = round_up(D, 4);
+  const int64_t SC = (int64_t)S * C, MM = (int64_t)M * M, D1 = D + 1;
+  float* p = reinterpret_cast<float*>(ws);
+  auto take = [&](int64_t n) { float* q = p; p += round_up(n, 64); return q; };
+  o.theta = take(S * D1); o.w = take(S * o.Dp); o.g2 = take(S); o.kd = take(SC);
+  o.na = take(SC * M); o.nb = take((int64_t)S * B);
+  o.Lu = take(C * MM); o.KS = take((SC + C) * MM); o.LL = take((SC + C) * MM); o.TT = take((SC + C) * MM);
+  o.RK = take(SC * M * o.LD); o.QP = take(SC * M * o.LD); o.W = take(SC * M * B);
+  o.mu = take(SC * B); o.var = take(SC * B);
+  o.gmu = take(SC * B); o.gvar = take(SC * B);                                    // adjacent: one zero range
+  o.r_uf = take(SC * M); o.c_uf = take((int64_t)S * B); o.gtheta = take(S * D1);  // adjacent: one zero range
+  o.r_uu = take(SC * M); o.gW = take(SC * M * B); o.ga = take(SC * M); o.gkd = take(SC);
+  o.gQP = take(SC * M * o.LD); o.gLL = take((SC + C) * MM); o.gTT = take((SC + C) * MM);
+  o.gRK = take(SC * M * o.LD); o.gKS = take((SC + C) * MM); o.Wuu = take(SC * MM);
+  o.Puu = take(SC * M * D); o.Puf = take(SC * M * D);
+  const size_t cb = vargp_chol_workspace_bytes((int)(SC + C), M, 0), cbb = vargp_chol_workspace_bytes((int)(SC + C), M, 1);
+  o.chol_bytes = cb > cbb ? cb : cbb;
+  o.chol = p;
+  p += round_up((int64_t)(o.chol_bytes + 3) / 4, 64);
+  o.bytes = (size_t)((char*)p - (char*)ws);
+  return o;
 }
 
-// grid (ceil(M / kKlRows), S*C): a block reduces kKlRows rows of one (s, c); kl_u accumulated with one atomic per
-// block (pre-zeroed by the caller)
-constexpr int kKlRows = 8;
-__global__ __launch_bounds__(256) void kl_t0_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ Lz,
-                                                        const float* __restrict__ Lu, float* __restrict__ kl_u, int S,
-                                                        int C, int M) {
+// ---------------------------------------------------------------------------------------------------------------
+// forward kernels
+// ---------------------------------------------------------------------------------------------------------------
+struct ProArgs {
+  const float *mean, *logvar, *pmean, *plogvar, *eps_theta, *vec;
+  float *theta, *w, *g2, *kd, *Lu, *Su, *scalars, *zero_begin;
+  int32_t* info;
+  int64_t zero_count, Dp;
+  int S, C, M, D, ninfo, map_est, nzero_blocks;
+};
+
+// Multi-role prologue, role by block index:
+//   block 0            kl_hypers (kernels.py:70-77) -> scalars[0]; scalars[1..2] = 0 (kl_u, nll accumulate); info = 0
+//   blocks 1..S        theta_s = mean + eps_s exp(logvar/2) (kernels.py:62-68); w_s = exp(-2 theta), g2_s = exp(2 theta_D)
+//   next nzero_blocks  zero-fill of the softmax-gradient accumulators
+//   rest               Lu = vec2tril(u_tril_vec) (gp_utils.py:22-49) and S_u = Lu Lu^T straight from the packed vector
+__global__ __launch_bounds__(256) void t0_prologue_kernel(const ProArgs a) {
   __shared__ float red[4];
-  const int NR = 4 + 2 * M;
-  const int64_t b = blockIdx.y;          // s * C + c
+  const int blk = blockIdx.x, tid = threadIdx.x;
+  const int D1 = a.D + 1;
+  if (blk == 0) {
+    float acc = 0.f;
+    if (!a.map_est)
+      for (int d = tid; d < D1; d += 256) {
+        const float dv = a.logvar[d] - a.plogvar[d], dm = a.mean[d] - a.pmean[d];
+        acc += 0.5f * (expf(dv) + dm * dm * expf(-a.plogvar[d]) - 1.f - dv);
+      }
+    const float t = block_sum<256>(acc, red);
+    if (tid == 0) { a.scalars[0] = t; a.scalars[1] = 0.f; a.scalars[2] = 0.f; }
+    for (int i = tid; i < a.ninfo; i += 256) a.info[i] = 0;
+    return;
+  }
+  if (blk <= a.S) {
+    const int s = blk - 1;
+    for (int d = tid; d < D1 || d < a.Dp; d += 256) {
+      float t = 0.f;
+      if (d < D1) {
+        t = a.map_est ? a.mean[d] : a.mean[d] + a.eps_theta[s * D1 + d] * expf(0.5f * a.logvar[d]);
+        a.theta[s * D1 + d] = t;
+      }
+      if (d < a.Dp) a.w[s * a.Dp + d] = d < a.D ? expf(-2.f * t) : 0.f;
+      if (d == a.D) {
+        const float g = expf(2.f * t);
+        a.g2[s] = g;
+        for (int c = 0; c < a.C; ++c) a.kd[s * a.C + c] = g;
+      }
+    }
+    return;
+  }
+  if (blk <= a.S + a.nzero_blocks) {
+    for (int64_t i = (int64_t)(blk - a.S - 1) * 256 + tid; i < a.zero_count; i += (int64_t)a.nzero_blocks * 256)
+      a.zero_begin[i] = 0.f;
+    return;
+  }
+  const int64_t e = (int64_t)(blk - 1 - a.S - a.nzero_blocks) * 256 + tid;
+  const int M = a.M;
+  if (e >= (int64_t)a.C * M * M) return;
+  const int j = e % M, i = (e / M) % M;
+  const int64_t c = e / ((int64_t)M * M);
+  const float* v = a.vec + c * ((int64_t)M * (M + 1) / 2);
+  const int lo = i < j ? i : j, hi = i < j ? j : i;
+  const float* rh = v + (int64_t)hi * (hi + 1) / 2;
+  const float* rl = v + (int64_t)lo * (lo + 1) / 2;
+  float acc = 0.f;
+  for (int k = 0; k < lo; ++k) acc = fmaf(rh[k], rl[k], acc);
+  const float dl = softplus_t0(rl[lo]);
+  acc = fmaf(hi == lo ? dl : rh[lo], dl, acc);
+  a.Su[e] = acc;
+  a.Lu[e] = j < i ? v[(int64_t)i * (i + 1) / 2 + j] : (j == i ? dl : 0.f);
+}
+
+// weighted squared row norms of the inducing points (na) and of the minibatch (nb), one wave per row; grid (rows/4, S)
+__global__ __launch_bounds__(256) void t0_norm_kernel(const float* __restrict__ z, const float* __restrict__ x,
+                                                      const float* __restrict__ w, float* __restrict__ na,
+                                                      float* __restrict__ nb, int64_t zrows, int64_t xrows, int D,
+                                                      int64_t Dp) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int s = blockIdx.y, lane = threadIdx.x & 63;
+  if (row >= zrows + xrows) return;
+  const bool isz = row < zrows;
+  const float* xr = isz ? z + row * D : x + (row - zrows) * D;
+  const float* ws = w + s * Dp;
+  float acc = 0.f;
+  for (int d = lane; d < D; d += 64) { const float v = xr[d]; acc = fmaf(v * v, ws[d], acc); }
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    if (isz) na[(int64_t)s * zrows + row] = acc; else nb[(int64_t)s * xrows + (row - zrows)] = acc;
+  }
+}
+
+// RK[s,c,i, 0:NR] = [ m_ci | 0 0 0 | LS_c[i,:] | Lu_c[i,:] | 0.. ]  for every s (the K_uf block is written by the GEMM)
+__global__ void t0_pack_kernel(const float* __restrict__ m, const float* __restrict__ LS, const float* __restrict__ Lu,
+                               float* __restrict__ RK, int C, int M, int NR, int LD, int64_t total) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int col = e % NR;
+  const int64_t row = e / NR;            // (s * C + c) * M + i
+  const int i = row % M;
+  const int64_t c = (row / M) % C;
+  float v = 0.f;
+  if (col == 0) v = m[c * M + i];
+  else if (col >= 4 && col < 4 + M) v = LS[(c * M + i) * M + (col - 4)];
+  else if (col >= 4 + M && col < 4 + 2 * M) v = Lu[(c * M + i) * M + (col - 4 - M)];
+  RK[row * LD + col] = v;
+}
+
+// Two roles.  Blocks < npd: predictive mean / variance (gp_utils.py:178-186), 64 minibatch columns x 4 row lanes:
+//   mu = sum_m P a,  var = kd - sum_m P^2 + sum_m W^2.   Blocks >= npd: MVN-KL of q(u) = N(m, Lu Lu^T) against
+//   p(u) = N(0, Lz Lz^T) (vargp.py:182-190) from the a and G2 columns of QP, kKlRows rows of one (s, c) per block:
+//   kl[s,c] = sum log diag Lz - sum log diag Lu + 0.5 (|G2|_F^2 + |a|^2 - M),  kl_u = (1/S) sum kl[s,c]  (atomic)
+__global__ __launch_bounds__(256) void t0_pdiag_kl_fwd_kernel(const float* __restrict__ QP, const float* __restrict__ W,
+                                                              const float* __restrict__ kd, const float* __restrict__ Lz,
+                                                              const float* __restrict__ Lu, float* __restrict__ mu,
+                                                              float* __restrict__ var, float* __restrict__ kl_u, int S,
+                                                              int C, int M, int B, int NR, int LD, int nbx, int npd,
+                                                              int nkx) {
+  __shared__ float red[3][4][64];
+  if ((int)blockIdx.x < npd) {
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int col = ((int)blockIdx.x % nbx) * 64 + cx;
+    const int64_t b = blockIdx.x / nbx;
+    float m0 = 0.f, d1 = 0.f, d2 = 0.f;
+    if (col < B) {
+      const float* q = QP + b * M * LD;
+      const float* p = q + NR + col;
+      const float* w = W + b * M * B + col;
+#pragma unroll 4
+      for (int m = ry; m < M; m += 4) {
+        const float pv = p[(int64_t)m * LD], wv = w[(int64_t)m * B];
+        m0 = fmaf(pv, q[(int64_t)m * LD], m0);
+        d1 = fmaf(pv, pv, d1);
+        d2 = fmaf(wv, wv, d2);
+      }
+    }
+    red[0][ry][cx] = m0; red[1][ry][cx] = d1; red[2][ry][cx] = d2;
+    __syncthreads();
+    if (ry == 0 && col < B) {
+      m0 = red[0][0][cx] + red[0][1][cx] + red[0][2][cx] + red[0][3][cx];
+      d1 = red[1][0][cx] + red[1][1][cx] + red[1][2][cx] + red[1][3][cx];
+      d2 = red[2][0][cx] + red[2][1][cx] + red[2][2][cx] + red[2][3][cx];
+      mu[b * B + col] = m0;
+      var[b * B + col] = kd[b] - d1 + d2;
+    }
+    return;
+  }
+  const int id = (int)blockIdx.x - npd;
+  const int64_t b = id / nkx;          // s * C + c
   const int c = b % C;
-  const int i0 = blockIdx.x * kKlRows, i1 = min(M, i0 + kKlRows);
-  const float* q = Q + b * M * NR;
+  const int i0 = (id % nkx) * kKlRows, i1 = min(M, i0 + kKlRows);
+  const float* q = QP + b * M * LD;
   float acc = 0.f;
   for (int e = threadIdx.x; e < (i1 - i0) * M; e += 256) {
     const int i = i0 + e / M, j = e % M;
-    if (j <= i) { const float v = q[(int64_t)i * NR + 4 + M + j]; acc = fmaf(v, v, acc); }
+    if (j <= i) { const float v = q[(int64_t)i * LD + 4 + M + j]; acc = fmaf(v, v, acc); }
   }
   for (int i = i0 + threadIdx.x; i < i1; i += 256) {
-    const float a = q[(int64_t)i * NR];
+    const float a = q[(int64_t)i * LD];
     acc = fmaf(a, a, acc);
     acc += 2.f * (logf(Lz[(b * M + i) * M + i]) - logf(Lu[((int64_t)c * M + i) * M + i])) - 1.f;
   }
-  const float t = block_sum<256>(acc, red);
+  const float t = block_sum<256>(acc, &red[0][0][0]);
   if (threadIdx.x == 0) atomicAdd(kl_u, 0.5f * t / (float)S);
 }
 
-// gQ[:, 0] = ga + g a / S ; gQ[:, 1..3] = 0 ; gQ[:, 4+M..] = g tril(G2) / S  (the G block is written by a GEMM);
-// gLz = diag(g / (S Lz_ii)) ; gLu_diag[c, i] = -g / Lu_ii  (summed over s analytically)
-__global__ __launch_bounds__(256) void kl_t0_bwd_kernel(const float* __restrict__ Q, const float* __restrict__ Lz,
-                                                        const float* __restrict__ Lu, const float* __restrict__ ga,
-                                                        const float* __restrict__ gkl, float* __restrict__ gQ,
-                                                        float* __restrict__ gLz, float* __restrict__ gLu, int S, int C,
-                                                        int M) {
-  const int NR = 4 + 2 * M;
-  const int64_t b = blockIdx.y;
+// Monte-Carlo softmax likelihood (likelihoods.py:13-45) and its gradient in one pass, C <= CMAX: one thread per
+// (s, f, b) keeps the class vector in registers, adds -log softmax_y / (S F) to nll and its share of
+// d nll / d mu, d nll / d var to the (pre-zeroed) accumulators.  The backward only scales them by the incoming seed.
+template <int CMAX>
+__global__ __launch_bounds__(256) void t0_softmax_kernel(const float* __restrict__ mu, const float* __restrict__ var,
+                                                         const float* __restrict__ eps, const int64_t* __restrict__ y,
+                                                         float* __restrict__ nll, float* __restrict__ gmu,
+                                                         float* __restrict__ gvar, int S, int F, int C, int B) {
+  __shared__ float red[4];
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float contrib = 0.f;
+  if (e < (int64_t)S * F * B) {
+    const int b = e % B, f = (e / B) % F, s = e / ((int64_t)B * F);
+    const int yb = (int)y[b];
+    float sd[CMAX], ev[CMAX], v[CMAX], mx = -INFINITY, fy = 0.f;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+      const int64_t i = ((int64_t)s * C + c) * B + b;
+      sd[c] = c < C ? sqrtf(var[i]) : 1.f;
+      ev[c] = c < C ? eps[(((int64_t)s * F + f) * C + c) * B + b] : 0.f;
+      v[c] = c < C ? mu[i] + sd[c] * ev[c] : -INFINITY;
+      mx = fmaxf(mx, v[c]);
+      if (c == yb) fy = v[c];
+    }
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) { v[c] = c < C ? expf(v[c] - mx) : 0.f; se += v[c]; }
+    const float sc1 = 1.f / (float)(S * F), sc = sc1 / se;
+    contrib = -(fy - (mx + logf(se))) * sc1;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+      if (c < C) {
+        const int64_t i = ((int64_t)s * C + c) * B + b;
+        const float p = v[c] * sc - (c == yb ? sc1 : 0.f);
+        atomicAdd(&gmu[i], p);
+        atomicAdd(&gvar[i], p * ev[c] * 0.5f / sd[c]);
+      }
+    }
+  }
+  const float t = block_sum<256>(contrib, red);
+  if (threadIdx.x == 0) atomicAdd(nll, t);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward kernels
+// ---------------------------------------------------------------------------------------------------------------
+// KL backward into the small columns of gQP and the diagonal of gLz, plus the backward's zero-fills.
+//   gQP[:, 0] = ga + g a ; gQP[:, 1..3] = 0 ; gQP[:, 4+M .. 4+2M) = g tril(G2) ; pad columns = 0   (g = seed_kl / S)
+//   gLz = diag(g / Lz_ii) ; gT of the S_u factors = 0 ; trailing blocks zero the r / c / gtheta accumulators.
+// (the G block of gQP is written by a GEMM, the P block by t0_pdiag_bwd_kernel)
+__global__ __launch_bounds__(256) void t0_kl_bwd_kernel(const float* __restrict__ QP, const float* __restrict__ Lz,
+                                                        const float* __restrict__ ga, const float* __restrict__ seeds,
+                                                        float* __restrict__ gQP, float* __restrict__ gLz,
+                                                        float* __restrict__ gTtail, float* __restrict__ zero_begin,
+                                                        int64_t zero_count, int S, int C, int M, int NR, int LD, int nkx,
+                                                        int nkl) {
+  if ((int)blockIdx.x >= nkl) {
+    const int nz = gridDim.x - nkl;
+    for (int64_t i = (int64_t)((int)blockIdx.x - nkl) * 256 + threadIdx.x; i < zero_count; i += (int64_t)nz * 256)
+      zero_begin[i] = 0.f;
+    return;
+  }
+  const int64_t b = blockIdx.x / nkx;
   const int s = b / C, c = b % C;
-  const int i0 = blockIdx.x * kKlRows, i1 = min(M, i0 + kKlRows);
-  const float g = gkl[0] / (float)S;
-  const float* q = Q + b * M * NR;
-  float* gq = gQ + b * M * NR;
+  const int i0 = ((int)blockIdx.x % nkx) * kKlRows, i1 = min(M, i0 + kKlRows);
+  const float g = seeds[1] / (float)S;
+  const float* q = QP + b * M * LD;
+  float* gq = gQP + b * M * LD;
   for (int e0 = threadIdx.x; e0 < (i1 - i0) * M; e0 += 256) {
     const int i = i0 + e0 / M, j = e0 % M;
     const int e = i * M + j;
-    gq[(int64_t)i * NR + 4 + M + j] = (j <= i) ? g * q[(int64_t)i * NR + 4 + M + j] : 0.f;
+    gq[(int64_t)i * LD + 4 + M + j] = (j <= i) ? g * q[(int64_t)i * LD + 4 + M + j] : 0.f;
     gLz[b * M * M + e] = (i == j) ? g / Lz[b * M * M + e] : 0.f;
-    if (s == 0) gLu[(int64_t)c * M * M + e] = (i == j) ? -gkl[0] / Lu[(int64_t)c * M * M + e] : 0.f;
+    if (s == 0) gTtail[(int64_t)c * M * M + e] = 0.f;
   }
   for (int i = i0 + threadIdx.x; i < i1; i += 256) {
-    gq[(int64_t)i * NR] = ga[b * M + i] + g * q[(int64_t)i * NR];
-    gq[(int64_t)i * NR + 1] = 0.f; gq[(int64_t)i * NR + 2] = 0.f; gq[(int64_t)i * NR + 3] = 0.f;
+    gq[(int64_t)i * LD] = ga[b * M + i] + g * q[(int64_t)i * LD];
+    gq[(int64_t)i * LD + 1] = 0.f; gq[(int64_t)i * LD + 2] = 0.f; gq[(int64_t)i * LD + 3] = 0.f;
+    for (int col = 4 + 2 * M; col < NR; ++col) gq[(int64_t)i * LD + col] = 0.f;
   }
 }
 
-// gtheta[s, D] += 2 gamma_s^2 sum_c gkd[s, c]   (kdiag = gamma^2 = exp(2 theta_D), var_gp/kernels.py:58-60)
-__global__ void kdiag_bwd_kernel(const float* __restrict__ theta, const float* __restrict__ gkd,
-                                 float* __restrict__ gtheta, int S, int C, int D) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= S) return;
+// grid (M, S*C): one block per row; gP (into gQP), gW elementwise, ga row reduction; block m == 0 also reduces gkd.
+// gscale (nullable): seed multiplying the stored unscaled softmax gradients.
+__global__ __launch_bounds__(256) void t0_pdiag_bwd_kernel(const float* __restrict__ QP, const float* __restrict__ W,
+                                                           const float* __restrict__ gmu, const float* __restrict__ gvar,
+                                                           const float* __restrict__ gscale, float* __restrict__ gQP,
+                                                           float* __restrict__ gW, float* __restrict__ ga,
+                                                           float* __restrict__ gkd, int M, int B, int NR, int LD) {
+  __shared__ float red[4];
+  const int m = blockIdx.x;
+  const int64_t b = blockIdx.y;
+  const int64_t offp = (b * M + m) * LD + NR, offw = (b * M + m) * B;
+  const float am = QP[(b * M + m) * LD];
+  const float gs = gscale ? gscale[0] : 1.f;
+  float acc = 0.f, accv = 0.f;
+  for (int col = threadIdx.x; col < B; col += 256) {
+    const float gm = gs * gmu[b * B + col], gv = gs * gvar[b * B + col];
+    const float pv = QP[offp + col], wv = W[offw + col];
+    gQP[offp + col] = am * gm - 2.f * pv * gv;
+    gW[offw + col] = 2.f * wv * gv;
+    acc = fmaf(pv, gm, acc);
+    accv += gv;
+  }
+  const float t = block_sum<256>(acc, red);
+  if (threadIdx.x == 0) ga[b * M + m] = t;
+  if (m == 0) {
+    const float tv = block_sum<256>(accv, red);
+    if (threadIdx.x == 0) gkd[b] = tv;
+  }
+}
+
+// sum over s of the m and L_S columns of gRK:  g_u_mean[c,i] and gL of the S_u factors (input of the Cholesky backward)
+__global__ void t0_unpack_kernel(const float* __restrict__ gRK, float* __restrict__ g_u_mean, float* __restrict__ gLS,
+                                 int S, int C, int M, int LD, int64_t total) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int jj = e % (M + 1);
+  const int64_t ci = e / (M + 1);        // c * M + i
+  const int col = jj == 0 ? 0 : 3 + jj;
   float acc = 0.f;
-  for (int c = 0; c < C; ++c) acc += gkd[s * C + c];
-  gtheta[(int64_t)s * (D + 1) + D] += 2.f * expf(2.f * theta[(int64_t)s * (D + 1) + D]) * acc;
+  for (int s = 0; s < S; ++s) acc += gRK[((int64_t)s * C * M + ci) * LD + col];
+  if (jj == 0) g_u_mean[ci] = acc; else gLS[ci * M + (jj - 1)] = acc;
+}
+
+// gradient of the packed Cholesky vector of q(u):  gLu = sum_s gRK[.., Lu block] - seed_kl diag(1/Lu_ii) + 2 gS_u Lu,
+// through vec2tril (softplus on the diagonal).  One thread per (c, i, k <= i).
+__global__ void t0_gvec_kernel(const float* __restrict__ vec, const float* __restrict__ Lu, const float* __restrict__ gSu,
+                               const float* __restrict__ gRK, const float* __restrict__ seeds, float* __restrict__ gvec,
+                               int S, int C, int M, int LD, int64_t total) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int k = e % M, i = (e / M) % M;
+  const int64_t c = e / ((int64_t)M * M);
+  if (k > i) return;
+  const float* gs = gSu + (c * M + i) * M;
+  const float* lu = Lu + c * M * M + k;
+  float acc = 0.f;
+  for (int j = k; j < M; ++j) acc = fmaf(gs[j], lu[(int64_t)j * M], acc);
+  float g = 2.f * acc;
+  for (int s = 0; s < S; ++s) g += gRK[(((int64_t)s * C + c) * M + i) * LD + 4 + M + k];
+  const int64_t idx = c * ((int64_t)M * (M + 1) / 2) + (int64_t)i * (i + 1) / 2 + k;
+  if (i == k) {
+    g -= seeds[1] / lu[(int64_t)i * M];
+    const float x = vec[idx];
+    g *= (x > 20.f) ? 1.f : sigmoid_t0(x);
+  }
+  gvec[idx] = g;
+}
+
+// W = gK o K for both kernel matrices (see rbf.hip for the algebra).
+//   blocks < nuf : K_uf, in place on the K_uf block of gRK (row stride LD); row sums r_uf, column sums c_uf (atomics),
+//                  2 sum W into gtheta[s, D]
+//   blocks >= nuf: K_uu, one wave per row: Wuu = W + W^T, r_uu = its row sums, sum Wuu into gtheta[s, D]
+__global__ __launch_bounds__(256) void t0_w_kernel(const float* __restrict__ RK, float* __restrict__ gRK,
+                                                   const float* __restrict__ Kuu, const float* __restrict__ gKuu,
+                                                   float* __restrict__ Wuu, float* __restrict__ r_uu,
+                                                   float* __restrict__ r_uf, float* __restrict__ c_uf,
+                                                   float* __restrict__ gtheta, int S, int C, int M, int B, int D, int NR,
+                                                   int LD, int gx, int gy, int nuf) {
+  __shared__ float red[4];
+  const int lane = threadIdx.x & 63;
+  if ((int)blockIdx.x < nuf) {
+    const int id = blockIdx.x;
+    const int col = (id % gx) * 256 + threadIdx.x;
+    const int CM = C * M;
+    const int row0 = ((id / gx) % gy) * kWRows;
+    const int64_t s = id / (gx * gy);
+    const bool cok = col < B;
+    float csum = 0.f;
+    const int rend = min(kWRows, CM - row0);
+    for (int rr = 0; rr < rend; ++rr) {
+      const int64_t off = (s * CM + row0 + rr) * LD + NR + col;
+      float v = 0.f;
+      if (cok) { v = RK[off] * gRK[off]; gRK[off] = v; }
+      csum += v;
+      const float rs = wave_sum(v);
+      if (lane == 0 && rs != 0.f) atomicAdd(&r_uf[s * CM + row0 + rr], rs);
+    }
+    if (cok) atomicAdd(&c_uf[s * B + col], csum);
+    const float tot = block_sum<256>(csum, red);
+    if (threadIdx.x == 0) atomicAdd(&gtheta[s * (D + 1) + D], 2.f * tot);
+    return;
+  }
+  const int64_t rowid = (int64_t)((int)blockIdx.x - nuf) * 4 + (threadIdx.x >> 6);
+  const int64_t nrows = (int64_t)S * C * M;
+  float acc = 0.f;
+  // the 4 rows of a block may straddle two hyper-samples only if M % 4 != 0; the atomic below is per wave for that reason
+  if (rowid < nrows) {
+    const int64_t b = rowid / M;
+    const int i = rowid % M;
+    const float* K = Kuu + b * M * M;
+    const float* gK = gKuu + b * M * M;
+    for (int j = lane; j < M; j += 64) {
+      const float v = K[(int64_t)i * M + j] * gK[(int64_t)i * M + j] + K[(int64_t)j * M + i] * gK[(int64_t)j * M + i];
+      Wuu[b * M * M + (int64_t)i * M + j] = v;
+      acc += v;
+    }
+  }
+  acc = wave_sum(acc);
+  if (lane == 0 && rowid < nrows) {
+    r_uu[rowid] = acc;
+    atomicAdd(&gtheta[(rowid / ((int64_t)C * M)) * (D + 1) + D], acc);
+  }
+}
+
+// RBF finalisation (rbf.hip), both kernel matrices at once.  grid (ceil(D/64), nzy + nxy), 64 d-columns x 4 row lanes.
+//   y-blocks < nzy  (inducing points):  gz[row,d] = -sum_s w_sd ((r_uu + r_uf) z - (P_uu + P_uf))
+//                                       gtheta[s,d] += w_sd sum_row z ((r_uu z - P_uu) + (r_uf z - 2 P_uf))
+//   y-blocks >= nzy (minibatch side):   gtheta[s,d] += w_sd sum_n c_uf x^2
+__global__ __launch_bounds__(256) void t0_final_kernel(const float* __restrict__ z, const float* __restrict__ x,
+                                                       const float* __restrict__ r_uu, const float* __restrict__ r_uf,
+                                                       const float* __restrict__ c_uf, const float* __restrict__ Puu,
+                                                       const float* __restrict__ Puf, const float* __restrict__ w,
+                                                       float* __restrict__ gz, float* __restrict__ gtheta,
+                                                       int64_t zrows, int64_t xrows, int D, int64_t Dp, int S, int nzy) {
+  __shared__ float red[4][64];
+  constexpr int RJ = kFinRows / 4;
+  const int dx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int d = blockIdx.x * 64 + dx;
+  const bool dok = d < D;
+  const bool zside = (int)blockIdx.y < nzy;
+  const int64_t rows = zside ? zrows : xrows;
+  const int64_t row0 = (int64_t)(zside ? blockIdx.y : blockIdx.y - nzy) * kFinRows;
+  const float* src = zside ? z : x;
+  float xa[RJ], ga[RJ];
+#pragma unroll
+  for (int j = 0; j < RJ; ++j) {
+    const int64_t row = row0 + ry + 4 * j;
+    xa[j] = (dok && row < rows) ? src[row * D + d] : 0.f;
+    ga[j] = 0.f;
+  }
+  for (int s = 0; s < S; ++s) {
+    const float wv = dok ? w[s * Dp + d] : 0.f;
+    float th = 0.f;
+#pragma unroll
+    for (int j = 0; j < RJ; ++j) {
+      const int64_t row = row0 + ry + 4 * j;
+      if (row < rows) {
+        if (zside) {
+          const int64_t sr = (int64_t)s * rows + row;
+          const float p1 = dok ? Puu[sr * D + d] : 0.f, p2 = dok ? Puf[sr * D + d] : 0.f;
+          const float rx1 = r_uu[sr] * xa[j], rx2 = r_uf[sr] * xa[j];
+          ga[j] -= wv * ((rx1 - p1) + (rx2 - p2));
+          th += xa[j] * ((rx1 - p1) + (rx2 - 2.f * p2));
+        } else {
+          th += xa[j] * (c_uf[(int64_t)s * rows + row] * xa[j]);
+        }
+      }
+    }
+    __syncthreads();
+    red[ry][dx] = th;
+    __syncthreads();
+    if (ry == 0 && dok) {
+      const float t = red[0][dx] + red[1][dx] + red[2][dx] + red[3][dx];
+      atomicAdd(&gtheta[(int64_t)s * (D + 1) + d], wv * t);
+    }
+  }
+  if (zside && dok) {
+#pragma unroll
+    for (int j = 0; j < RJ; ++j) {
+      const int64_t row = row0 + ry + 4 * j;
+      if (row < rows) gz[row * D + d] = ga[j];
+    }
+  }
+}
+
+// gtheta (+ the gamma^2 of the predictive variance, kernels.py:58-60) -> variational hyper-parameters, plus the
+// gradient of kl_hypers scaled by its seed (kernels.py:62-77)
+__global__ void t0_hyper_bwd_kernel(const float* __restrict__ mean, const float* __restrict__ logvar,
+                                    const float* __restrict__ pmean, const float* __restrict__ plogvar,
+                                    const float* __restrict__ eps, const float* __restrict__ gtheta,
+                                    const float* __restrict__ g2, const float* __restrict__ gkd,
+                                    const float* __restrict__ seeds, float* __restrict__ gmean,
+                                    float* __restrict__ glogvar, int S, int C, int D1, int map_est) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= D1) return;
+  const float hs = map_est ? 0.f : 0.5f * expf(0.5f * logvar[d]);
+  float gm = 0.f, gv = 0.f;
+  for (int s = 0; s < S; ++s) {
+    float g = gtheta[s * D1 + d];
+    if (d == D1 - 1) {
+      float acc = 0.f;
+      for (int c = 0; c < C; ++c) acc += gkd[s * C + c];
+      g += 2.f * g2[s] * acc;
+    }
+    gm += g;
+    if (!map_est) gv = fmaf(g * hs, eps[s * D1 + d], gv);
+  }
+  if (!map_est) {
+    const float g = seeds[0];
+    gm += g * (mean[d] - pmean[d]) * expf(-plogvar[d]);
+    gv += g * 0.5f * (expf(logvar[d] - plogvar[d]) - 1.f);
+  }
+  gmean[d] = gm;
+  glogvar[d] = gv;
+}
+
+static int check_desc(const vargp_elbo_t0_desc* d, const char* who) {
+  VARGP_REQUIRE(d, "%s: null descriptor", who);
+  VARGP_REQUIRE(d->S > 0 && d->C > 0 && d->M > 0 && d->D > 0 && d->B > 0 && d->F > 0, "%s: bad dims", who);
+  VARGP_REQUIRE(d->log_mean && d->z && d->u_mean && d->u_tril_vec && d->x && d->y && d->eps_f && d->scalars && d->info &&
+                    d->ws, "%s: null pointer", who);
+  VARGP_REQUIRE(d->map_est ? d->S == 1 : (d->log_logvar && d->prior_log_mean && d->prior_log_logvar && d->eps_theta),
+                "%s: hyper-parameter arguments inconsistent with map_est", who);
+  VARGP_REQUIRE(d->ws_bytes >= vargp_elbo_t0_workspace_bytes(d->S, d->C, d->M, d->D, d->B, d->F),
+                "%s: workspace too small", who);
+  return VARGP_OK;
+}
+
+static GemmParams flat_gemm(const float* A, int lda, int64_t sA, const float* B, int ldb, int64_t sB, float* C, int ldc,
+                            int64_t sC, int M, int N, int K) {
+  GemmParams p{};
+  p.A = A; p.B = B; p.C = C; p.D = nullptr;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldd = ldc;
+  p.nb1 = 1; p.nb2 = 1;
+  p.sA[0] = sA; p.sB[0] = sB; p.sC[0] = sC; p.sD[0] = sC;
+  p.alpha = 1.f; p.beta = 0.f;
+  return p;
 }
 
 }  // namespace vargp
 
 using namespace vargp;
 
-extern "C" int vargp_pack_rsmall(const float* m, const float* LS, const float* Lu, float* R, int C, int M,
-                                 vargp_stream_t stream) {
-  VARGP_REQUIRE(m && LS && Lu && R && C > 0 && M > 0, "pack_rsmall: bad arguments");
-  const int64_t total = (int64_t)C * M * (4 + 2 * M);
-  hipLaunchKernelGGL(pack_rsmall_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), m, LS, Lu, R, M, total);
-  return check_launch("pack_rsmall");
+extern "C" size_t vargp_elbo_t0_workspace_bytes(int S, int C, int M, int D, int B, int F) {
+  (void)F;
+  return carve_t0(nullptr, S, C, M, D, B).bytes + 256;
 }
-extern "C" int vargp_kl_t0_fwd(const float* Q, const float* Lz, const float* Lu, float* kl_u, int S, int C, int M,
-                               vargp_stream_t stream) {
-  VARGP_REQUIRE(Q && Lz && Lu && kl_u && S > 0 && C > 0 && M > 0, "kl_t0_fwd: bad arguments");
-  zero_async(kl_u, sizeof(float), as_stream(stream));
-  hipLaunchKernelGGL(kl_t0_fwd_kernel, dim3(cdiv(M, kKlRows), S * C), dim3(256), 0, as_stream(stream), Q, Lz, Lu, kl_u, S, C,
-                     M);
-  return check_launch("kl_t0_fwd");
+
+extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t stream) {
+  int rc = check_desc(d, "elbo_t0_fwd");
+  if (rc) return rc;
+  hipStream_t st = as_stream(stream);
+  const int S = d->S, C = d->C, M = d->M, D = d->D, B = d->B, F = d->F, SC = S * C;
+  const T0Ws o = carve_t0(d->ws, S, C, M, D, B);
+  const int NR = o.NR, LD = o.LD;
+  const int64_t MM = (int64_t)M * M, MLD = (int64_t)M * LD;
+  const bool fused_softmax = C <= 16;
+
+  {
+    ProfScope prof("t0_prologue", st);
+    ProArgs a{};
+    a.mean = d->log_mean; a.logvar = d->log_logvar; a.pmean = d->prior_log_mean; a.plogvar = d->prior_log_logvar;
+    a.eps_theta = d->eps_theta; a.vec = d->u_tril_vec;
+    a.theta = o.theta; a.w = o.w; a.g2 = o.g2; a.kd = o.kd; a.Lu = o.Lu; a.Su = o.KS + SC * MM; a.scalars = d->scalars;
+    a.zero_begin = o.gmu; a.zero_count = o.r_uf - o.gmu; a.info = d->info; a.Dp = o.Dp;
+    a.S = S; a.C = C; a.M = M; a.D = D; a.ninfo = SC + C; a.map_est = d->map_est;
+    a.nzero_blocks = (int)std::min<int64_t>(64, cdiv(a.zero_count, 1024));
+    const int grid = 1 + S + a.nzero_blocks + cdiv((int64_t)C * MM, 256);
+    hipLaunchKernelGGL(t0_prologue_kernel, dim3(grid), dim3(256), 0, st, a);
+  }
+  // kernel matrices: K_uu -> KS[:SC], K_uf -> the trailing block of RK
+  if (D <= kRbfDirectD) {
+    rc = rbf_direct_launch(d->z, nullptr, o.w, o.g2, o.KS, M, S, C, M, M, D, o.Dp, 0, st);
+    if (rc) return rc;
+    rc = rbf_direct_launch(d->z, d->x, o.w, o.g2, o.RK + NR, LD, S, C, M, B, D, o.Dp, 1, st);
+    if (rc) return rc;
+  } else {
+    const int64_t zrows = (int64_t)C * M;
+    hipLaunchKernelGGL(t0_norm_kernel, dim3(cdiv(zrows + B, 4), S), dim3(256), 0, st, d->z, d->x, o.w, o.na, o.nb, zrows,
+                       (int64_t)B, D, o.Dp);
+    GemmParams p0{}, p1{};
+    p0.A = d->z; p0.B = d->z; p0.C = o.KS;
+    p0.M = M; p0.N = M; p0.K = D; p0.lda = D; p0.ldb = D; p0.ldc = M;
+    p0.nb1 = C; p0.nb2 = 1;
+    p0.sA[1] = (int64_t)M * D; p0.sB[1] = (int64_t)M * D;
+    p0.sC[0] = C * MM; p0.sC[1] = MM;
+    p0.alpha = 1.f;
+    p0.kscale = o.w; p0.ks_ld = o.Dp; p0.g2 = o.g2;
+    p0.na = o.na; p0.sNa[0] = zrows; p0.sNa[1] = M;
+    p0.nbv = o.na; p0.sNb[0] = zrows; p0.sNb[1] = M;
+    p0.same_xy = 1;
+    p1.A = d->z; p1.B = d->x; p1.C = o.RK + NR;
+    p1.M = C * M; p1.N = B; p1.K = D; p1.lda = D; p1.ldb = D; p1.ldc = LD;
+    p1.nb1 = 1; p1.nb2 = 1;
+    p1.sC[0] = (int64_t)C * MLD;
+    p1.alpha = 1.f;
+    p1.kscale = o.w; p1.ks_ld = o.Dp; p1.g2 = o.g2;
+    p1.na = o.na; p1.sNa[0] = zrows;
+    p1.nbv = o.nb; p1.sNb[0] = B;
+    rc = launch_gemm_pair(p0, SC, p1, S, 0, 1, true, st, "rbf_kuu_gemm", "rbf_kuf_gemm");
+    if (rc) return rc;
+  }
+  // both factorisations (K_uu + eps I for every (s, c); S_u + eps I for every c) in one batch
+  rc = chol_inv_fwd_impl(o.KS, d->jitter, o.LL, o.TT, nullptr, d->info, SC + C, M, o.chol, o.chol_bytes, false, st);
+  if (rc) return rc;
+  {
+    const int64_t total = (int64_t)SC * M * NR;
+    hipLaunchKernelGGL(t0_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, d->u_mean, o.LL + SC * MM, o.Lu, o.RK, C,
+                       M, NR, LD, total);
+  }
+  {  // QP = T RK
+    GemmParams p = flat_gemm(o.TT, M, MM, o.RK, LD, MLD, o.QP, LD, MLD, M, NR + B, M);
+    p.triA = 1;
+    rc = launch_gemm(p, 0, 0, SC, false, st, "t0_qp_gemm");
+    if (rc) return rc;
+  }
+  {  // W = G^T P
+    GemmParams p = flat_gemm(o.QP + 4, LD, MLD, o.QP + NR, LD, MLD, o.W, B, (int64_t)M * B, M, B, M);
+    p.triA = 2;
+    rc = launch_gemm(p, 1, 0, SC, false, st, "t0_w_gemm");
+    if (rc) return rc;
+  }
+  {
+    const int nbx = cdiv(B, 64), npd = nbx * SC, nkx = cdiv(M, kKlRows);
+    hipLaunchKernelGGL(t0_pdiag_kl_fwd_kernel, dim3(npd + nkx * SC), dim3(256), 0, st, o.QP, o.W, o.kd, o.LL, o.Lu, o.mu,
+                       o.var, d->scalars + 1, S, C, M, B, NR, LD, nbx, npd, nkx);
+  }
+  if (fused_softmax) {
+    const int64_t total = (int64_t)S * F * B;
+    hipLaunchKernelGGL(t0_softmax_kernel<16>, dim3(cdiv(total, 256)), dim3(256), 0, st, o.mu, o.var, d->eps_f, d->y,
+                       d->scalars + 2, o.gmu, o.gvar, S, F, C, B);
+  } else {
+    rc = vargp_softmax_nll_fwd(o.mu, o.var, d->eps_f, d->y, d->scalars + 2, S, F, C, B, stream);
+    if (rc) return rc;
+  }
+  return check_launch("elbo_t0_fwd");
 }
-extern "C" int vargp_kl_t0_bwd(const float* Q, const float* Lz, const float* Lu, const float* ga, const float* gkl,
-                               float* gQ, float* gLz, float* gLu, int S, int C, int M, vargp_stream_t stream) {
-  VARGP_REQUIRE(Q && Lz && Lu && ga && gkl && gQ && gLz && gLu, "kl_t0_bwd: null pointer");
-  hipLaunchKernelGGL(kl_t0_bwd_kernel, dim3(cdiv(M, kKlRows), S * C), dim3(256), 0, as_stream(stream), Q, Lz, Lu, ga, gkl,
-                     gQ, gLz, gLu, S, C, M);
-  return check_launch("kl_t0_bwd");
-}
-extern "C" int vargp_kdiag_bwd(const float* theta, const float* gkd, float* gtheta, int S, int C, int D,
-                               vargp_stream_t stream) {
-  VARGP_REQUIRE(theta && gkd && gtheta && S > 0 && C > 0, "kdiag_bwd: bad arguments");
-  hipLaunchKernelGGL(kdiag_bwd_kernel, dim3(cdiv(S, 64)), dim3(64), 0, as_stream(stream), theta, gkd, gtheta, S, C, D);
-  return check_launch("kdiag_bwd");
+
+extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds, float* g_log_mean, float* g_log_logvar,
+                                 float* g_z, float* g_u_mean, float* g_u_tril_vec, vargp_stream_t stream) {
+  int rc = check_desc(d, "elbo_t0_bwd");
+  if (rc) return rc;
+  VARGP_REQUIRE(seeds && g_log_mean && g_log_logvar && g_z && g_u_mean && g_u_tril_vec, "elbo_t0_bwd: null pointer");
+  hipStream_t st = as_stream(stream);
+  const int S = d->S, C = d->C, M = d->M, D = d->D, B = d->B, F = d->F, SC = S * C;
+  const T0Ws o = carve_t0(d->ws, S, C, M, D, B);
+  const int NR = o.NR, LD = o.LD;
+  const int64_t MM = (int64_t)M * M, MLD = (int64_t)M * LD, MB = (int64_t)M * B;
+  const bool fused_softmax = C <= 16;
+
+  if (!fused_softmax) {   // C > 16: gradient of the likelihood from the generic kernel (already scaled by its seed)
+    rc = vargp_softmax_nll_bwd(o.mu, o.var, d->eps_f, d->y, seeds + 2, o.gmu, o.gvar, S, F, C, B, stream);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(t0_pdiag_bwd_kernel, dim3(M, SC), dim3(256), 0, st, o.QP, o.W, o.gmu, o.gvar,
+                     fused_softmax ? seeds + 2 : nullptr, o.gQP, o.gW, o.ga, o.gkd, M, B, NR, LD);
+  {
+    const int nkx = cdiv(M, kKlRows), nkl = nkx * SC;
+    const int64_t zc = o.r_uu - o.r_uf;
+    const int nz = (int)std::min<int64_t>(64, cdiv(zc, 1024));
+    hipLaunchKernelGGL(t0_kl_bwd_kernel, dim3(nkl + nz), dim3(256), 0, st, o.QP, o.LL, o.ga, seeds, o.gQP, o.gLL,
+                       o.gTT + SC * MM, o.r_uf, zc, S, C, M, NR, LD, nkx, nkl);
+  }
+  {  // W = G^T P:  gG = P gW^T (G block of gQP),  gP += G gW
+    GemmParams p = flat_gemm(o.QP + NR, LD, MLD, o.gW, B, MB, o.gQP + 4, LD, MLD, M, M, B);
+    rc = launch_gemm(p, 0, 1, SC, false, st, "t0_gg_gemm");
+    if (rc) return rc;
+    GemmParams q = flat_gemm(o.QP + 4, LD, MLD, o.gW, B, MB, o.gQP + NR, LD, MLD, M, B, M);
+    q.triA = 1; q.D = o.gQP + NR; q.beta = 1.f;
+    rc = launch_gemm(q, 0, 0, SC, false, st, "t0_gp_gemm");
+    if (rc) return rc;
+  }
+  {  // QP = T RK:  gT = tril(gQP RK^T),  gRK = T^T gQP
+    GemmParams p = flat_gemm(o.gQP, LD, MLD, o.RK, LD, MLD, o.gTT, M, MM, M, M, NR + B);
+    p.triC = 1;
+    rc = launch_gemm(p, 0, 1, SC, false, st, "t0_gt_gemm");
+    if (rc) return rc;
+    GemmParams q = flat_gemm(o.TT, M, MM, o.gQP, LD, MLD, o.gRK, LD, MLD, M, NR + B, M);
+    q.triA = 2;
+    rc = launch_gemm(q, 1, 0, SC, false, st, "t0_grk_gemm");
+    if (rc) return rc;
+  }
+  {
+    const int64_t total = (int64_t)C * M * (M + 1);
+    hipLaunchKernelGGL(t0_unpack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, o.gRK, g_u_mean, o.gLL + SC * MM, S, C,
+                       M, LD, total);
+  }
+  rc = vargp_chol_inv_bwd(o.LL, o.TT, o.gLL, o.gTT, o.gKS, SC + C, M, o.chol, o.chol_bytes, stream);
+  if (rc) return rc;
+  {
+    const int64_t total = (int64_t)C * MM;
+    hipLaunchKernelGGL(t0_gvec_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, d->u_tril_vec, o.Lu, o.gKS + SC * MM,
+                       o.gRK, seeds, g_u_tril_vec, S, C, M, LD, total);
+  }
+  // kernel matrices -> z, theta
+  const int64_t zrows = (int64_t)C * M;
+  {
+    const int gx = cdiv(B, 256), gy = cdiv(zrows, kWRows), nuf = gx * gy * S;
+    const int nuu = cdiv((int64_t)SC * M, 4);
+    hipLaunchKernelGGL(t0_w_kernel, dim3(nuf + nuu), dim3(256), 0, st, o.RK, o.gRK, o.KS, o.gKS, o.Wuu, o.r_uu, o.r_uf,
+                       o.c_uf, o.gtheta, S, C, M, B, D, NR, LD, gx, gy, nuf);
+  }
+  {
+    GemmParams p0{}, p1{};
+    p0.A = o.Wuu; p0.B = d->z; p0.C = o.Puu;
+    p0.M = M; p0.N = D; p0.K = M; p0.lda = M; p0.ldb = D; p0.ldc = D;
+    p0.nb1 = C; p0.nb2 = 1;
+    p0.sA[0] = C * MM; p0.sA[1] = MM;
+    p0.sB[1] = (int64_t)M * D;
+    p0.sC[0] = zrows * D; p0.sC[1] = (int64_t)M * D;
+    p0.alpha = 1.f;
+    p1.A = o.gRK + NR; p1.B = d->x; p1.C = o.Puf;
+    p1.M = C * M; p1.N = D; p1.K = B; p1.lda = LD; p1.ldb = D; p1.ldc = D;
+    p1.nb1 = 1; p1.nb2 = 1;
+    p1.sA[0] = C * MLD;
+    p1.sC[0] = zrows * D;
+    p1.alpha = 1.f;
+    rc = launch_gemm_pair(p0, SC, p1, S, 0, 0, false, st, "rbf_kuu_bwd_gemm", "rbf_kuf_bwd_gemm");
+    if (rc) return rc;
+  }
+  {
+    const int nzy = cdiv(zrows, kFinRows), nxy = cdiv(B, kFinRows);
+    hipLaunchKernelGGL(t0_final_kernel, dim3(cdiv(D, 64), nzy + nxy), dim3(256), 0, st, d->z, d->x, o.r_uu, o.r_uf, o.c_uf,
+                       o.Puu, o.Puf, o.w, g_z, o.gtheta, zrows, (int64_t)B, D, o.Dp, S, nzy);
+  }
+  hipLaunchKernelGGL(t0_hyper_bwd_kernel, dim3(cdiv(D + 1, 256)), dim3(256), 0, st, d->log_mean, d->log_logvar,
+                     d->prior_log_mean, d->prior_log_logvar, d->eps_theta, o.gtheta, o.g2, o.gkd, seeds, g_log_mean,
+                     g_log_logvar, S, C, D + 1, d->map_est);
+  return check_launch("elbo_t0_bwd");
 }

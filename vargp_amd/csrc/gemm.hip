@@ -245,7 +245,7 @@ __device__ __forceinline__ void store_piece(float* __restrict__ lds, const float
 }
 
 template <int BM, int BN, int BK, bool AKC, bool BKC, bool VEC, bool RBF>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
+__device__ __forceinline__ void gemm_body(const GemmParams& p, const int tile_id, const int batch_id, const int split_id) {
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   using LA = LdsLayout<AKC, BM, BK>;
   using LB = LdsLayout<BKC, BN, BK>;
@@ -255,9 +255,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   __shared__ __attribute__((aligned(16))) float lds[2 * kStage];
 
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  const int tm = tile_id / tiles_n, tn = tile_id % tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int b = blockIdx.y;
+  const int b = batch_id;
   const int i2 = b % p.nb2, i1 = (b / p.nb2) % p.nb1, i0 = b / (p.nb2 * p.nb1);
   const float* A = p.A + i0 * p.sA[0] + i1 * p.sA[1] + i2 * p.sA[2];
   const float* B = p.B + i0 * p.sB[0] + i1 * p.sB[1] + i2 * p.sB[2];
@@ -283,9 +283,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   if (p.splitk > 1) {                        // this workgroup's BK-aligned share of K
     const int nslab = (p.K + BK - 1) / BK;
     const int per = (nslab + p.splitk - 1) / p.splitk;
-    ks = min(p.K, (int)blockIdx.z * per * BK);
-    ke = min(p.K, ((int)blockIdx.z + 1) * per * BK);
-    C += (int64_t)blockIdx.z * p.sSplit;
+    ks = min(p.K, split_id * per * BK);
+    ke = min(p.K, (split_id + 1) * per * BK);
+    C += (int64_t)split_id * p.sSplit;
   }
   if (p.triA == 1) ke = min(ke, m0 + BM);
   if (p.triA == 2) ks = max(ks, m0);
@@ -487,6 +487,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   }
 }
 
+template <int BM, int BN, int BK, bool AKC, bool BKC, bool VEC, bool RBF>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
+  gemm_body<BM, BN, BK, AKC, BKC, VEC, RBF>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Two independent problems of the same kernel flavour in ONE launch (1-D grid: the workgroups of problem 0, then
+// those of problem 1).  Mid-size problems that cannot fill the chip alone (K_uu: 120 workgroups, K_uf: 384) share it.
+struct GemmPair { GemmParams p[2]; int nwg0; int tiles[2]; };
+template <int BM, int BN, int BK, bool AKC, bool BKC, bool VEC, bool RBF>
+__global__ __launch_bounds__(256) void gemm_pair_kernel(const GemmPair pp) {
+  const int which = (int)blockIdx.x >= pp.nwg0 ? 1 : 0;       // wave-uniform
+  const int id = (int)blockIdx.x - (which ? pp.nwg0 : 0);
+  const int tiles = pp.tiles[which];
+  if (which == 0) gemm_body<BM, BN, BK, AKC, BKC, VEC, RBF>(pp.p[0], id % tiles, id / tiles, 0);
+  else gemm_body<BM, BN, BK, AKC, BKC, VEC, RBF>(pp.p[1], id % tiles, id / tiles, 0);
+}
+
 template <int BM, int BN, int BK, bool VEC, bool RBF>
 static void dispatch_layout(const GemmParams& p, int transA, int transB, dim3 grid, hipStream_t st) {
   // op(A) K-contiguous <=> transA == 0;  op(B) K-contiguous <=> transB == 1
@@ -513,7 +530,6 @@ static void dispatch_tile(const GemmParams& p, int transA, int transB, int nbatc
   }
 }
 
-static bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 // Tile choice (MI355X: 256 CUs).  The f32 MFMA runs at the vector rate, so what matters is (a) filling
 // the CUs and (b) amortising the per-slab staging + 2 barriers over enough MFMAs:
@@ -530,6 +546,35 @@ int rbf_splitk(int M, int N, int K, int nbatch) {
   (void)M; (void)N; (void)K; (void)nbatch;
   static const int force = [] { const char* e = getenv("VARGP_RBF_SPLITK"); return e ? atoi(e) : 0; }();
   return force >= 2 ? 2 : 1;      // the workspace holds at most two partials
+}
+
+static bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+static bool gemm_vec_ok(const GemmParams& p) {
+  bool vec = aligned16(p.A) && aligned16(p.B) && (p.lda % 4 == 0) && (p.ldb % 4 == 0);
+  for (int i = 0; i < 3; ++i) vec = vec && (p.sA[i] % 4 == 0) && (p.sB[i] % 4 == 0);
+  return vec;
+}
+
+// two problems, one launch; falls back to two launches when the pair kernel does not apply
+int launch_gemm_pair(const GemmParams& p0, int nbatch0, const GemmParams& p1, int nbatch1, int transA, int transB,
+                     bool rbf, hipStream_t st, const char* tag0, const char* tag1) {
+  const bool ok = gemm_vec_ok(p0) && gemm_vec_ok(p1) && ((rbf && transA == 0 && transB == 1) || (!rbf && transA == 0 && transB == 0));
+  if (!ok) {
+    int rc = launch_gemm(p0, transA, transB, nbatch0, rbf, st, tag0);
+    if (rc) return rc;
+    return launch_gemm(p1, transA, transB, nbatch1, rbf, st, tag1);
+  }
+  ProfScope prof("gemm_pair", st);
+  GemmPair pp;
+  pp.p[0] = p0; pp.p[1] = p1;
+  pp.p[0].splitk = pp.p[1].splitk = 1;
+  pp.tiles[0] = cdiv(p0.M, 64) * cdiv(p0.N, 64);
+  pp.tiles[1] = cdiv(p1.M, 64) * cdiv(p1.N, 64);
+  pp.nwg0 = pp.tiles[0] * nbatch0;
+  const int total = pp.nwg0 + pp.tiles[1] * nbatch1;
+  if (rbf) hipLaunchKernelGGL((gemm_pair_kernel<64, 64, 64, true, true, true, true>), dim3(total), dim3(256), 0, st, pp);
+  else hipLaunchKernelGGL((gemm_pair_kernel<64, 64, 64, true, false, true, false>), dim3(total), dim3(256), 0, st, pp);
+  return check_launch("gemm_pair");
 }
 
 // last launch per tag, kept for vargp_prof_replay (measurement only)

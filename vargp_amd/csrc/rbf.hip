@@ -51,11 +51,11 @@ __global__ void rbf_prep_kernel(const float* __restrict__ theta, float* __restri
 
 // Small input dimension (D <= kDirectD, e.g. the 2-D toy problem): form the squared distance directly as
 // sum_d w_d (x_d - y_d)^2 — no cancellation, no GEMM.  One thread per kernel-matrix entry.
-constexpr int kDirectD = 32;
+constexpr int kDirectD = kRbfDirectD;
 __global__ __launch_bounds__(256) void rbf_direct_kernel(const float* __restrict__ X, const float* __restrict__ Y,
                                                          const float* __restrict__ w, const float* __restrict__ g2,
-                                                         float* __restrict__ K, int C, int M, int N, int D, int64_t Dp,
-                                                         int y_shared, int64_t total) {
+                                                         float* __restrict__ K, int64_t ldk, int C, int M, int N,
+                                                         int D, int64_t Dp, int y_shared, int64_t total) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= total) return;
   const int n = e % N, m = (e / N) % M, c = (e / ((int64_t)N * M)) % C;
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void rbf_direct_kernel(const float* __restrict
   const float* ws = w + s * Dp;
   float d2 = 0.f;
   for (int d = 0; d < D; ++d) { const float t = xr[d] - yr[d]; d2 = fmaf(ws[d] * t, t, d2); }
-  K[e] = g2[s] * expf(-0.5f * d2);
+  K[(((int64_t)s * C + c) * M + m) * ldk + n] = g2[s] * expf(-0.5f * d2);
 }
 
 // K = g2 exp(-0.5 (na + nb - 2 (ab_0 + ab_1 ...))) from split-K partial inner products; same arithmetic as the fused
@@ -200,6 +200,14 @@ __global__ __launch_bounds__(256) void rbf_final_kernel(const float* __restrict_
   }
 }
 
+int rbf_direct_launch(const float* X, const float* Y, const float* w, const float* g2, float* K, int64_t ldk, int S,
+                      int C, int M, int N, int D, int64_t Dp, int y_shared, hipStream_t st) {
+  const int64_t total = (int64_t)S * C * M * N;
+  hipLaunchKernelGGL(rbf_direct_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, X, Y, w, g2, K, ldk, C, M, N, D, Dp,
+                     y_shared, total);
+  return check_launch("rbf_gram_fwd(direct)");
+}
+
 }  // namespace vargp
 
 using namespace vargp;
@@ -220,10 +228,7 @@ extern "C" int vargp_rbf_gram_fwd(const float* theta, const float* X, const floa
   RbfWs o = carve(ws, S, C, M, N, D, false);
   hipLaunchKernelGGL(rbf_prep_kernel, dim3(S), dim3(256), 0, st, theta, o.w, o.g2, D, o.Dp);
   if (D <= kDirectD) {
-    const int64_t total = (int64_t)S * C * M * N;
-    hipLaunchKernelGGL(rbf_direct_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, X, Y, o.w, o.g2, K, C, M, N, D, o.Dp,
-                       y_shared, total);
-    return check_launch("rbf_gram_fwd(direct)");
+    return rbf_direct_launch(X, Y, o.w, o.g2, K, N, S, C, M, N, D, o.Dp, y_shared, st);
   }
   const int64_t xrows = (int64_t)C * M, yrows = y_shared ? N : (int64_t)C * N;
   hipLaunchKernelGGL(rbf_norm_kernel, dim3(cdiv(xrows, 4), S), dim3(256), 0, st, X, o.w, o.na, xrows, D, o.Dp);

@@ -1,190 +1,118 @@
-"""Fused task-0 ELBO: `VARGP.loss` for a model without previous tasks as ONE autograd node whose forward
-and backward are explicit sequences of C-ABI calls (same kernels as ops.py, hand-orchestrated).
+"""First-task ELBO through the native program `vargp_elbo_t0_fwd / _bwd` (csrc/elbo_t0.hip).
 
-What the orchestration buys over composing the per-op autograd Functions (gp_utils.py):
-  * K_uu (S*C matrices) and S_u = Lu Lu^T (C matrices) are factorised by ONE vargp_chol_inv_fwd launch and
-    differentiated by ONE vargp_chol_inv_bwd call (the factorisation is a latency-bound chain of M pivots);
-  * the small right-hand sides that share Lz^-1 — u_mean, L_S = chol(S_u + eps I) and Lu — are packed into one
-    operand, so Lz^-1 m, Lz^-1 L_S and Lz^-1 Lu (KL) come out of one GEMM; the KL and its backward read them
-    in place;
-  * gradient contributions to the same tensor (T = Lz^-1 gets four) are accumulated by the GEMM epilogue
-    (C = alpha A B + beta D) instead of separate add kernels; the two RBF backward calls accumulate into one
-    z / theta gradient.
-Numerics are those of the composed path (same kernels, same order of operations inside each).
-Reference lines: var_gp/vargp.py:156-194 (forward/loss for the first task), gp_utils.py:150-191.
+`VARGP.loss` of a model without previous tasks (reference: var_gp/vargp.py:156-194) is, on this path, two C-ABI
+calls: the forward sequences ~10 kernels (hyper-parameter sampling + KL, both kernel matrices in one GEMM launch,
+one batched Cholesky/inverse, one GEMM for everything multiplied by Lz^-1, predictive moments, KL, softmax
+likelihood), the backward ~20.  This module holds
+  * `T0Program` — descriptor + workspace for one problem shape; `forward()` / `backward()` are the two calls;
+  * `elbo_t0()` — the same program as ONE autograd node, which is what `VARGP.loss` returns into the reference's
+    training loop (`loss.backward()`, experiments/vargp.py:34-35);
+`train.ElboTrainer` drives a persistent `T0Program` directly (no autograd graph, gradients written straight
+into the optimiser's buffers).
 """
+import ctypes
+
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from . import ops
-from ._lib import check, lib, ptr, require_device, stream_ptr, workspace
-from .ops import JITTER, LOWER, UPPER, bgemm
+from ._lib import ElboT0Desc, check, lib, ptr, require_device, stream_ptr, workspace
+from .ops import JITTER
 
 
-_DEBUG_KEEP = None
+def _p(t):
+    return t.data_ptr() if t is not None else None
 
 
-_side_streams = {}
+class T0Program:
+    """Descriptor + workspace of the native first-task ELBO for fixed (S, C, M, D, B, F).  The workspace carries
+    every intermediate from `forward` to `backward`; one `backward` per `forward`."""
 
+    def __init__(self, S, C, M, D, B, F, device, map_est=False):
+        self.shape = (S, C, M, D, B, F)
+        self.map_est = bool(map_est)
+        nbytes = lib().vargp_elbo_t0_workspace_bytes(S, C, M, D, B, F)
+        self.ws = workspace(nbytes, device)
+        self.scalars = torch.empty(3, dtype=torch.float32, device=device)
+        self.info = torch.empty(S * C + C, dtype=torch.int32, device=device)
+        self.desc = ElboT0Desc(S=S, C=C, M=M, D=D, B=B, F=F, map_est=int(self.map_est), jitter=JITTER,
+                               scalars=_p(self.scalars), info=_p(self.info), ws=_p(self.ws),
+                               ws_bytes=self.ws.numel() * 4)
+        self._keep = None
 
-def _side_stream(device):
-    """Second HIP stream per device: the K_uf kernel-matrix work (forward and backward) has no dependency on
-    the K_uu -> Cholesky chain, which is a latency-bound sequence on a few CUs, so the two run concurrently.
-    Forks and joins are stream waits, which a hipGraph capture records as graph edges."""
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    if idx not in _side_streams:
-        _side_streams[idx] = torch.cuda.Stream(device=device)
-    return _side_streams[idx]
+    @staticmethod
+    def shape_of(n_v, z, x, eps_f):
+        return (n_v, z.shape[0], z.shape[1], z.shape[2], x.shape[0], eps_f.shape[1])
 
+    def forward(self, log_mean, log_logvar, prior_log_mean, prior_log_logvar, z, u_mean, u_tril_vec, x, y, eps_theta,
+                eps_f):
+        """-> scalars (3,) = (kl_hypers, kl_u, nll).  All tensors contiguous fp32 on the ROCm device (y int64)."""
+        tensors = (log_mean, log_logvar, prior_log_mean, prior_log_logvar, z, u_mean, u_tril_vec, x, y, eps_theta, eps_f)
+        require_device(*tensors)
+        for t in tensors:
+            if t is not None and not t.is_contiguous():
+                raise ValueError('T0Program.forward needs contiguous tensors')
+        S, C, M, D, B, F_ = self.shape
+        assert z.shape == (C, M, D) and x.shape == (B, D) and eps_f.shape == (S, F_, C, B) and y.dtype == torch.int64
+        assert u_mean.numel() == C * M and u_tril_vec.shape == (C, M * (M + 1) // 2) and log_mean.numel() == D + 1
+        assert self.map_est or eps_theta.shape == (S, D + 1)
+        d = self.desc
+        d.log_mean, d.log_logvar = _p(log_mean), _p(log_logvar)
+        d.prior_log_mean, d.prior_log_logvar = _p(prior_log_mean), _p(prior_log_logvar)
+        d.z, d.u_mean, d.u_tril_vec, d.x, d.y = _p(z), _p(u_mean), _p(u_tril_vec), _p(x), _p(y)
+        d.eps_theta, d.eps_f = _p(eps_theta), _p(eps_f)
+        self._keep = tensors          # the descriptor holds raw pointers: keep the tensors alive until backward
+        check(lib().vargp_elbo_t0_fwd(ctypes.byref(d), stream_ptr()), 'vargp_elbo_t0_fwd')
+        ops._note_chol_errors(self.info)
+        return self.scalars
 
-def _rbf_ws(theta, X, Y, backward):
-    S, (C, M, D) = theta.shape[0], X.shape
-    N = M if Y is None else Y.shape[-2]
-    return workspace(lib().vargp_rbf_workspace_bytes(S, C, M, N, D, int(backward)), X.device)
+    def backward(self, seeds, g_log_mean, g_log_logvar, g_z, g_u_mean, g_u_tril_vec):
+        """seeds (3,) device = d total / d (kl_hypers, kl_u, nll); overwrites the five gradient buffers."""
+        require_device(seeds, g_log_mean, g_log_logvar, g_z, g_u_mean, g_u_tril_vec)
+        assert self._keep is not None, 'T0Program.backward without a forward'
+        for g in (g_log_mean, g_log_logvar, g_z, g_u_mean, g_u_tril_vec):
+            assert g.is_contiguous() and g.dtype == torch.float32
+        check(lib().vargp_elbo_t0_bwd(ctypes.byref(self.desc), ptr(seeds), ptr(g_log_mean), ptr(g_log_logvar), ptr(g_z),
+                                      ptr(g_u_mean), ptr(g_u_tril_vec), stream_ptr()), 'vargp_elbo_t0_bwd')
 
-
-def _rbf_fwd(theta, X, Y, shared, out, ws=None):
-    S, (C, M, D) = theta.shape[0], X.shape
-    N = M if Y is None else Y.shape[-2]
-    ws = ws if ws is not None else _rbf_ws(theta, X, Y, False)
-    check(lib().vargp_rbf_gram_fwd(ptr(theta), ptr(X), ptr(Y), ptr(out), S, C, M, N, D, int(shared), ptr(ws),
-                                   ws.numel() * 4, stream_ptr()), 'vargp_rbf_gram_fwd')
-
-
-def _rbf_bwd(theta, X, Y, shared, K, gK, gX, gtheta, accumulate, ws=None):
-    S, (C, M, D) = theta.shape[0], X.shape
-    N = M if Y is None else Y.shape[-2]
-    ws = ws if ws is not None else _rbf_ws(theta, X, Y, True)
-    check(lib().vargp_rbf_gram_bwd(ptr(theta), ptr(X), ptr(Y), ptr(K), ptr(gK), ptr(gX), None, ptr(gtheta),
-                                   S, C, M, N, D, int(shared), int(accumulate), ptr(ws), ws.numel() * 4, stream_ptr()),
-          'vargp_rbf_gram_bwd')
+    def theta(self):
+        """The hyper-parameter samples of the last forward, (S, D+1) (view into the workspace)."""
+        S, D = self.shape[0], self.shape[3]
+        return self.ws[:S * (D + 1)].view(S, D + 1)
 
 
 class _ElboT0(Function):
     @staticmethod
-    def forward(ctx, theta, z, u_mean, u_tril_vec, x, y, eps_f):
-        require_device(theta, z, u_mean, u_tril_vec, x, y, eps_f)
-        theta, z, u_mean, u_tril_vec, x, y, eps_f = (t.contiguous() for t in (theta, z, u_mean, u_tril_vec, x, y, eps_f))
-        S, (C, M, D), B = theta.shape[0], z.shape, x.shape[0]
-        SC, NR, dev, st = S * C, 4 + 2 * M, z.device, stream_ptr()
-        f32 = dict(dtype=torch.float32, device=dev)
-
-        # fork: K_uf = rbf(z, x) on the side stream (buffers allocated here, on the main stream, and kept
-        # alive past the join)
-        main, side = torch.cuda.current_stream(), _side_stream(dev)
-        Kuf = torch.empty(S, C, M, B, **f32)
-        ws_uf = _rbf_ws(theta, z, x, False)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            _rbf_fwd(theta, z, x, True, Kuf, ws_uf)
-
-        Lu = torch.empty(C, M, M, **f32)
-        check(lib().vargp_vec2tril_fwd(ptr(u_tril_vec), ptr(Lu), C, M, st), 'vargp_vec2tril_fwd')
-        # K_uu for every (s, c) and S_u = Lu Lu^T for every c, one batch -> one factorisation
-        KS = torch.empty(SC + C, M, M, **f32)
-        _rbf_fwd(theta, z, None, False, KS)
-        bgemm(Lu, Lu.mT, triA=LOWER, triB=UPPER, out=KS[SC:])
-        LL, TT = torch.empty_like(KS), torch.empty_like(KS)
-        info = torch.empty(SC + C, dtype=torch.int32, device=dev)
-        check(lib().vargp_chol_inv_fwd(ptr(KS), JITTER, ptr(LL), ptr(TT), None, ptr(info), SC + C, M, None, 0, st)
-              if M <= 100 else _chol_big(KS, LL, TT, info, SC + C, M), 'vargp_chol_inv_fwd')
-        ops._note_chol_errors(info)
-        Lz, Tz, LS = LL[:SC].view(S, C, M, M), TT[:SC].view(S, C, M, M), LL[SC:]
-
-        R = torch.empty(C, M, NR, **f32)
-        check(lib().vargp_pack_rsmall(ptr(u_mean), ptr(LS), ptr(Lu), ptr(R), C, M, st), 'vargp_pack_rsmall')
-        Q = bgemm(Tz, R, triA=LOWER)                      # (S, C, M, NR) = [a | 0 0 0 | G | G2]
-        main.wait_stream(side)                            # join: K_uf is needed from here on
-        del ws_uf
-        P = bgemm(Tz, Kuf, triA=LOWER)                    # Lz^-1 K_uf
-        G = Q[..., 4:4 + M]
-        W = bgemm(G.mT, P, triA=UPPER)                    # (Lz^-1 L_S)^T Lz^-1 K_uf
-
-        kd = (2.0 * theta[:, -1]).exp().unsqueeze(1).expand(S, C).contiguous()   # gamma^2 per (s, c)
-        mu, var = torch.empty(S, C, B, **f32), torch.empty(S, C, B, **f32)
-        check(lib().vargp_predictive_diag_fwd(ptr(P), ptr(W), ptr(Q), NR, M * NR, ptr(kd), ptr(mu), ptr(var), SC, M, B,
-                                              st), 'vargp_predictive_diag_fwd')
-        F_ = eps_f.shape[1]
-        nll = torch.empty((), **f32)
-        check(lib().vargp_softmax_nll_fwd(ptr(mu), ptr(var), ptr(eps_f), ptr(y), ptr(nll), S, F_, C, B, st),
-              'vargp_softmax_nll_fwd')
-        kl_u = torch.empty((), **f32)
-        check(lib().vargp_kl_t0_fwd(ptr(Q), ptr(Lz), ptr(Lu), ptr(kl_u), S, C, M, st), 'vargp_kl_t0_fwd')
-
-        ctx.save_for_backward(theta, z, u_tril_vec, x, y, eps_f, Lu, KS, LL, TT, Kuf, R, Q, P, W, mu, var)
-        return nll, kl_u
+    def forward(ctx, log_mean, log_logvar, z, u_mean, u_tril_vec, x, y, eps_theta, eps_f, prior_log_mean,
+                prior_log_logvar, map_est):
+        args = [t.contiguous() if t is not None else None
+                for t in (log_mean, log_logvar, prior_log_mean, prior_log_logvar, z, u_mean, u_tril_vec, x, y, eps_theta,
+                          eps_f)]
+        S = 1 if map_est else eps_theta.shape[0]
+        prog = T0Program(*T0Program.shape_of(S, z, x, eps_f), z.device, map_est)   # fresh workspace per graph node
+        scal = prog.forward(*args)
+        ctx.prog = prog
+        ctx.map_est = map_est
+        ctx.shapes = (log_mean.shape, z.shape, u_mean.shape, u_tril_vec.shape)
+        return scal[0], scal[1], scal[2]
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, g_nll, g_kl):
-        theta, z, u_tril_vec, x, y, eps_f, Lu, KS, LL, TT, Kuf, R, Q, P, W, mu, var = ctx.saved_tensors
-        S, (C, M, D), B = theta.shape[0], z.shape, x.shape[0]
-        SC, NR, dev, st = S * C, 4 + 2 * M, z.device, stream_ptr()
-        f32 = dict(dtype=torch.float32, device=dev)
-        F_ = eps_f.shape[1]
-        Lz, Tz = LL[:SC].view(S, C, M, M), TT[:SC].view(S, C, M, M)
-        g_nll, g_kl = g_nll.contiguous(), g_kl.contiguous()
-
-        gmu, gvar = torch.empty_like(mu), torch.empty_like(var)
-        check(lib().vargp_softmax_nll_bwd(ptr(mu), ptr(var), ptr(eps_f), ptr(y), ptr(g_nll), ptr(gmu), ptr(gvar),
-                                          S, F_, C, B, st), 'vargp_softmax_nll_bwd')
-        gP, gW = torch.empty_like(P), torch.empty_like(W)
-        ga, gkd = torch.empty(S, C, M, **f32), torch.empty(S, C, **f32)
-        check(lib().vargp_predictive_diag_bwd(ptr(P), ptr(W), ptr(Q), NR, M * NR, ptr(gmu), ptr(gvar), ptr(gP), ptr(gW),
-                                              ptr(ga), ptr(gkd), SC, M, B, st), 'vargp_predictive_diag_bwd')
-        # W = G^T P
-        gQ = torch.empty_like(Q)
-        G = Q[..., 4:4 + M]
-        bgemm(P, gW.mT, out=gQ[..., 4:4 + M])             # gG = P gW^T  (only its lower triangle is ever used)
-        bgemm(G, gW, D=gP, beta=1.0, triA=LOWER, out=gP)  # gP += G gW
-        # KL: remaining columns of gQ, diagonal gradients of Lz and Lu
-        gLL, gTT = torch.empty_like(LL), torch.empty_like(TT)
-        gLu = torch.empty_like(Lu)
-        check(lib().vargp_kl_t0_bwd(ptr(Q), ptr(Lz), ptr(Lu), ptr(ga), ptr(g_kl), ptr(gQ), ptr(gLL), ptr(gLu), S, C, M,
-                                    st), 'vargp_kl_t0_bwd')
-        # Q = T R and P = T K_uf : gT (lower), gR (summed over s), gK_uf
-        gT = gTT[:SC].view(S, C, M, M)
-        bgemm(gQ, R.mT, triC=LOWER, out=gT)                       # T is lower-triangular: so is its gradient
-        bgemm(gP, Kuf.mT, D=gT, beta=1.0, triC=LOWER, out=gT)
-        gTT[SC:].zero_()
-        gKuf = bgemm(Tz.mT, gP, triA=UPPER)
-        # fork: d K_uf -> (z, theta) on the side stream while the main stream runs the Cholesky backward chain
-        main, side = torch.cuda.current_stream(), _side_stream(dev)
-        gz, gtheta = torch.empty_like(z), torch.empty_like(theta)
-        ws_uf = _rbf_ws(theta, z, x, True)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            _rbf_bwd(theta, z, x, True, Kuf, gKuf, gz, gtheta, accumulate=False, ws=ws_uf)
-        gR = ops._reduce_to(bgemm(Tz.mT, gQ, triA=UPPER), R.shape)
-        g_u_mean = gR[..., 0:1].contiguous()
-        gLL[SC:].copy_(gR[..., 4:4 + M])
-        gLu.add_(gR[..., 4 + M:])
-        # both factorisations at once (vargp_chol_inv_bwd masks gL / gT to their lower triangles itself)
-        gKS = torch.empty_like(KS)
-        ws = workspace(lib().vargp_chol_workspace_bytes(SC + C, M, 1), dev)
-        check(lib().vargp_chol_inv_bwd(ptr(LL), ptr(TT), ptr(gLL), ptr(gTT), ptr(gKS), SC + C, M, ptr(ws),
-                                       ws.numel() * 4, st), 'vargp_chol_inv_bwd')
-        # S_u = Lu Lu^T (gS_u is symmetric): gLu += 2 gS_u Lu
-        bgemm(gKS[SC:], Lu, alpha=2.0, D=gLu, beta=1.0, triB=LOWER, out=gLu)
-        g_vec = torch.empty_like(u_tril_vec)
-        check(lib().vargp_vec2tril_bwd(ptr(u_tril_vec), ptr(gLu), ptr(g_vec), C, M, st), 'vargp_vec2tril_bwd')
-        # kernel matrices -> z, theta (second call accumulates), plus the gamma^2 of the predictive variance
-        main.wait_stream(side)                            # join, then accumulate the K_uu part on top
-        del ws_uf
-        _rbf_bwd(theta, z, None, False, KS, gKS, gz, gtheta, accumulate=True)
-        check(lib().vargp_kdiag_bwd(ptr(theta), ptr(gkd), ptr(gtheta), S, C, D, st), 'vargp_kdiag_bwd')
-        if _DEBUG_KEEP is not None:   # diagnostics: keep every backward intermediate alive for inspection
-            _DEBUG_KEEP.update({k: v for k, v in locals().items() if isinstance(v, torch.Tensor)})
-        return gtheta, gz, g_u_mean, g_vec, None, None, None
+    def backward(ctx, g_klh, g_klu, g_nll):
+        prog = ctx.prog
+        seeds = torch.stack([g_klh.reshape(()), g_klu.reshape(()), g_nll.reshape(())]).float()
+        sh_mean, sh_z, sh_um, sh_uv = ctx.shapes
+        dev = seeds.device
+        g_mean, g_logvar = torch.empty(sh_mean, device=dev), torch.empty(sh_mean, device=dev)
+        g_z, g_um, g_uv = torch.empty(sh_z, device=dev), torch.empty(sh_um, device=dev), torch.empty(sh_uv, device=dev)
+        prog.backward(seeds, g_mean, g_logvar, g_z, g_um, g_uv)
+        ctx.prog = None
+        return (g_mean, None if ctx.map_est else g_logvar, g_z, g_um, g_uv, None, None, None, None, None, None, None)
 
 
-def _chol_big(KS, LL, TT, info, nb, M):
-    ws = workspace(lib().vargp_chol_workspace_bytes(nb, M, 0), KS.device)
-    return lib().vargp_chol_inv_fwd(ptr(KS), JITTER, ptr(LL), ptr(TT), None, ptr(info), nb, M, ptr(ws), ws.numel() * 4,
-                                    stream_ptr())
-
-
-def elbo_t0(theta, z, u_mean, u_tril_vec, x, y, eps_f):
-    """-> (nll, kl_u) of VARGP.loss for a model with no previous tasks."""
-    return _ElboT0.apply(theta, z, u_mean, u_tril_vec, x, y, eps_f)
+def elbo_t0(kernel, z, u_mean, u_tril_vec, x, y, eps_theta, eps_f):
+    """-> (kl_hypers, kl_u, nll) of VARGP.loss for a model with no previous tasks; `kernel` is the RBFKernel
+    module (variational hyper-parameters and their prior)."""
+    return _ElboT0.apply(kernel.log_mean, kernel.log_logvar, z, u_mean, u_tril_vec, x, y, eps_theta, eps_f,
+                         kernel.prior_log_mean, kernel.prior_log_logvar, bool(kernel.map_est))

@@ -46,6 +46,11 @@ class ElboTrainer:
             noise.set_shard(self.rank, self.world, noise_seed, dev)
 
         self.graph = None
+        # first-task models run the native program directly (fused.T0Program): no autograd graph, gradients written
+        # straight into the optimiser's buffers
+        self._t0 = (gp is not None and loss_fn is None and params is None and hasattr(gp, 'draw_t0_noise')
+                    and not gp.prev_params and gp.fused_first_task)
+        self._prog, self._seeds, self._own_grads = None, {}, None
 
     # -- hipGraph capture of the step --------------------------------------------------------------
     def capture(self, x, y, warmup=3):
@@ -91,6 +96,14 @@ class ElboTrainer:
     def step(self, x, y):
         """-> (kl_hypers, kl_u, nll) as 0-dim device tensors (global values on every rank)."""
         scale = (self.n_total if self.n_total is not None else x.size(0)) / x.size(0)
+        if self._t0 and self.world == 1:
+            if self._own_grads is None:
+                self._own_grads = [torch.empty_like(p) for p in self.params]
+            for p, g in zip(self.params, self._own_grads):
+                p.grad = g
+            scal = self._t0_fwd_bwd(x, y, scale, 1.0)
+            self.optim.step()
+            return scal[0], scal[1], scal[2]
         if self.world == 1:
             # single GPU: let autograd hand the gradients over (no zero-fill, no accumulate kernels)
             for p in self.params:
@@ -104,6 +117,26 @@ class ElboTrainer:
         self.optim.step()
         return out
 
+    def _t0_fwd_bwd(self, x, y, scale, w):
+        """Native first-task program: scalars (kl_hypers, kl_u, nll) of this rank's samples, and the gradient of
+        w * (beta kl_hypers + kl_u + scale nll) written into every p.grad."""
+        from .fused import T0Program
+        gp, kern = self.gp, self.gp.kernel
+        x, y = x.contiguous(), y.contiguous()
+        eps_theta, eps_f = gp.draw_t0_noise(x)
+        shape = T0Program.shape_of(eps_f.shape[0], gp.z, x, eps_f)
+        if self._prog is None or self._prog.shape != shape:
+            self._prog = T0Program(*shape, x.device, kern.map_est)
+        key = (scale, w)
+        if key not in self._seeds:
+            self._seeds[key] = torch.tensor([self.beta * w, w, scale * w], dtype=torch.float32, device=x.device)
+        scal = self._prog.forward(kern.log_mean.detach(), kern.log_logvar.detach(), kern.prior_log_mean,
+                                  kern.prior_log_logvar, gp.z.detach(), gp.u_mean.detach(), gp.u_tril_vec.detach(), x, y,
+                                  None if eps_theta is None else eps_theta.contiguous(), eps_f.contiguous())
+        self._prog.backward(self._seeds[key], kern.log_mean.grad, kern.log_logvar.grad, gp.z.grad, gp.u_mean.grad,
+                            gp.u_tril_vec.grad)
+        return scal
+
     def _local_part(self, x, y):
         """This rank's share: gradients of (beta kl_h + kl_u_r + (N/B) nll_r) / world accumulated into the flat
         buffer, whose tail carries kl_u_r / world and nll_r / world."""
@@ -113,9 +146,13 @@ class ElboTrainer:
             for p in self.params:                      # (re-)attach the gradient views of the flat buffer
                 p.grad = self.flat[off:off + p.numel()].view_as(p)
                 off += p.numel()
+        w = 1.0 / self.world
+        if self._t0:
+            scal = self._t0_fwd_bwd(x, y, scale, w)      # overwrites every gradient view of the flat buffer
+            torch.mul(scal[1:3], w, out=self.scalars)
+            return scal[0], self.scalars[0], self.scalars[1]
         self.flat.zero_()
         kl_h, kl_u, nll = self.loss_fn(x, y)
-        w = 1.0 / self.world
         loss = (self.beta * kl_h + kl_u + scale * nll) * w
         loss.backward()
         with torch.no_grad():

@@ -144,15 +144,21 @@ class VARGP(nn.Module):
                                        prior_d=cache_pf.pop('Lz_m').squeeze(-1).unsqueeze(0)))
         return pred_mu, pred_var
 
+    def draw_t0_noise(self, x):
+        """(eps_theta, eps_f) of one first-task step: the hyper-parameter noise of RBFKernel.sample_hypers
+        (kernels.py:66-67; None under map_est) and the likelihood noise (likelihoods.py:26)."""
+        kern = self.kernel
+        S = 1 if kern.map_est else self.n_v
+        eps_theta = None if kern.map_est else noise.draw('eps_theta', (S, kern.log_mean.shape[0]), x.device)
+        eps_f = noise.draw('eps_f', (S, self.likelihood.n_f, self.z.size(0), x.size(0)), x.device)
+        return eps_theta, eps_f
+
     def loss(self, x, y):
         """(kl_hypers, kl_u, nll); the caller combines beta*kl_hypers + kl_u + (N/B)*nll
         (vargp.py:177-194, experiments/vargp.py:34)."""
         if not self.prev_params and self.fused_first_task:
-            # first task: one fused autograd node (fused.py) instead of the composed per-op graph
-            theta = self.kernel.sample_hypers(self.n_v)
-            eps_f = noise.draw('eps_f', (theta.size(0), self.likelihood.n_f, self.z.size(0), x.size(0)), x.device)
-            nll, kl_u = fused.elbo_t0(theta, self.z, self.u_mean, self.u_tril_vec, x, y, eps_f)
-            return self.kernel.kl_hypers(), kl_u, nll
+            # first task: the native program (csrc/elbo_t0.hip) as one autograd node
+            return fused.elbo_t0(self.kernel, self.z, self.u_mean, self.u_tril_vec, x, y, *self.draw_t0_noise(x))
         loss_cache = dict()
         pred_mu, pred_var = self(x, loss_cache=loss_cache)
         nll = self.likelihood.loss(pred_mu, pred_var, y)
