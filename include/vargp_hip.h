@@ -197,9 +197,11 @@ int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t stream);
 int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds, float* g_log_mean, float* g_log_logvar, float* g_z,
                       float* g_u_mean, float* g_u_tril_vec, vargp_stream_t stream);
 
-/* same update for up to 8 tensors in one launch; `step` (device float, the step count t) is required */
+/* Same update for up to 8 tensors in one launch.  `step` (device) = { float t; uint32 ticket (keep 0) }.
+ * step_mode 0: use t as is.  1: use t + 1.  2: use t + 1 and store it back when the launch's last block has finished
+ * (no separate "t += 1" kernel; with more than 8 tensors pass 1 for all launches but the last). */
 int vargp_yogi_step_multi(int ntensors, float* const* p, const float* const* g, float* const* m, float* const* v,
-                          const int64_t* n, float lr, float beta1, float beta2, float eps, const float* step,
+                          const int64_t* n, float lr, float beta1, float beta2, float eps, float* step, int step_mode,
                           vargp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------

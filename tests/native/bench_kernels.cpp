@@ -1,6 +1,7 @@
 // Standalone kernel micro-benchmarks against libvargp_hip.so (no torch): used for tuning under rocprofv3.
 //   ./bench_kernels [case] [iters]      case: all | kuf | gemm4k | small | chol | kufbwd
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -120,6 +121,14 @@ int main(int argc, char** argv) {
       double us = time_us([&] { vargp_chol_inv_fwd(A, 1e-4f, L, T, nullptr, info, nb, n, nullptr, 0, nullptr); }, iters);
       double us2 = time_us([&] { vargp_chol_inv_fwd(A, 1e-4f, L, nullptr, nullptr, info, nb, n, nullptr, 0, nullptr); }, iters);
       printf("chol  n=%3d batch %d  L+T %8.1f us   L only %8.1f us (incl. info memset)\n", n, nb, us, us2);
+      if (void* f = dlsym(RTLD_DEFAULT, "vargp_debug_chol_stamps")) {   // only in -DVARGP_CHOL_STAMPS builds of the library
+        unsigned long long st[8];
+        vargp_chol_inv_fwd(A, 1e-4f, L, T, nullptr, info, nb, n, nullptr, 0, nullptr);
+        hipDeviceSynchronize();
+        reinterpret_cast<void (*)(unsigned long long*)>(f)(st);
+        printf("   cycles per pivot (wave 0): loop %.0f  publish %.0f  barrier %.0f  lds-reads %.0f  fma %.0f\n",
+               st[0] / (double)n, st[1] / (double)n, st[2] / (double)n, st[3] / (double)n, st[4] / (double)n);
+      }
     }
   }
   return 0;

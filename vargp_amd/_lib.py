@@ -64,7 +64,7 @@ _SIGNATURES = {
     'vargp_softmax_nll_fwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     'vargp_softmax_nll_bwd': (c_int, [_P] * 7 + [c_int, c_int, c_int, c_int, _P]),
     'vargp_softmax_predict': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
-    'vargp_yogi_step_multi': (c_int, [c_int, _P, _P, _P, _P, _P] + [c_float] * 4 + [_P, _P]),
+    'vargp_yogi_step_multi': (c_int, [c_int, _P, _P, _P, _P, _P] + [c_float] * 4 + [_P, c_int, _P]),
     'vargp_hyper_sample_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
     'vargp_hyper_sample_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P]),
     'vargp_hyper_kl_fwd': (c_int, [_P, _P, _P, _P, _P, c_int, _P]),

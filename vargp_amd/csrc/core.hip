@@ -89,25 +89,48 @@ struct YogiPack {
   float* m[8];
   float* v[8];
   int64_t n[8];
+  int blk_end[8];   // exclusive prefix of the blocks assigned to each tensor (kYogiPerBlock elements per block)
 };
-__global__ void yogi_multi_kernel(YogiPack pk, float lr, float b1, float b2, float eps, const float* __restrict__ step) {
-  const int t = blockIdx.y;
+constexpr int kYogiPerBlock = 1024;   // 256 threads x 4 elements
+// step_mode 0: t = step[0].  1: t = step[0] + 1.  2: t = step[0] + 1 and the last block to finish stores t back
+// (ticket counter in the word after step[0]), so the optimiser needs no separate "t += 1" launch.
+__global__ __launch_bounds__(256) void yogi_multi_kernel(YogiPack pk, int ntensors, float lr, float b1, float b2, float eps,
+                                                         float* __restrict__ step, int step_mode) {
+  int t = 0;
+  while (t + 1 < ntensors && (int)blockIdx.x >= pk.blk_end[t]) ++t;
+  const int blk = (int)blockIdx.x - (t ? pk.blk_end[t - 1] : 0);
   const int64_t n = pk.n[t];
   float* __restrict__ p = pk.p[t];
   const float* __restrict__ g = pk.g[t];
   float* __restrict__ m = pk.m[t];
   float* __restrict__ v = pk.v[t];
-  const float tt = step[0];
+  const float tt = step[0] + (step_mode ? 1.f : 0.f);
   const float bias1 = 1.f - powf(b1, tt), sb2 = sqrtf(1.f - powf(b2, tt));
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const float gi = g[i], g2 = gi * gi;
-    const float mi = b1 * m[i] + (1.f - b1) * gi;
-    float vi = v[i];
-    const float df = vi - g2;
-    vi -= (1.f - b2) * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * g2;
-    m[i] = mi;
-    v[i] = vi;
-    p[i] -= (lr / bias1) * mi / (sqrtf(vi) / sb2 + eps);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int64_t i = (int64_t)blk * kYogiPerBlock + u * 256 + threadIdx.x;
+    if (i < n) {
+      const float gi = g[i], g2 = gi * gi;
+      const float mi = b1 * m[i] + (1.f - b1) * gi;
+      float vi = v[i];
+      const float df = vi - g2;
+      vi -= (1.f - b2) * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * g2;
+      m[i] = mi;
+      v[i] = vi;
+      p[i] -= (lr / bias1) * mi / (sqrtf(vi) / sb2 + eps);
+    }
+  }
+  if (step_mode == 2) {
+    __syncthreads();                      // every thread of this block has read step[0]
+    if (threadIdx.x == 0) {
+      unsigned* ticket = reinterpret_cast<unsigned*>(step + 1);
+      __threadfence();
+      if (atomicAdd(ticket, 1u) == gridDim.x - 1) {   // all other blocks have taken their ticket, i.e. read step[0]
+        step[0] = tt;
+        *ticket = 0u;
+        __threadfence();
+      }
+    }
   }
 }
 
@@ -156,20 +179,21 @@ extern "C" int vargp_prof_read(const char* tag, double* total_ms, int64_t* launc
   return VARGP_OK;
 }
 
-// up to 8 parameter tensors in ONE launch (the VAR-GP model has 5); step = device pointer to t
+// up to 8 parameter tensors in ONE launch (the VAR-GP model has 5); step = device pointer to {float t; uint32 ticket}
 extern "C" int vargp_yogi_step_multi(int ntensors, float* const* p, const float* const* g, float* const* m,
                                      float* const* v, const int64_t* n, float lr, float beta1, float beta2, float eps,
-                                     const float* step, vargp_stream_t stream) {
+                                     float* step, int step_mode, vargp_stream_t stream) {
   VARGP_REQUIRE(ntensors > 0 && ntensors <= 8 && p && g && m && v && n && step, "yogi_step_multi: bad arguments");
+  VARGP_REQUIRE(step_mode >= 0 && step_mode <= 2, "yogi_step_multi: bad step_mode");
   YogiPack pk{};
-  int64_t nmax = 0;
+  int nblk = 0;
   for (int i = 0; i < ntensors; ++i) {
     pk.p[i] = p[i]; pk.g[i] = g[i]; pk.m[i] = m[i]; pk.v[i] = v[i]; pk.n[i] = n[i];
-    if (n[i] > nmax) nmax = n[i];
+    nblk += cdiv(n[i], kYogiPerBlock);
+    pk.blk_end[i] = nblk;
   }
-  int bx = cdiv(nmax, 256);
-  if (bx > 2048) bx = 2048;
-  hipLaunchKernelGGL(yogi_multi_kernel, dim3(bx, ntensors), dim3(256), 0, as_stream(stream), pk, lr, beta1, beta2, eps,
-                     step);
+  if (nblk == 0) return VARGP_OK;
+  hipLaunchKernelGGL(yogi_multi_kernel, dim3(nblk), dim3(256), 0, as_stream(stream), pk, ntensors, lr, beta1, beta2, eps,
+                     step, step_mode);
   return check_launch("yogi_step_multi");
 }

@@ -20,7 +20,8 @@
 namespace vargp {
 
 constexpr int kKlRows = 8;     // rows of one (s, c) block per KL workgroup
-constexpr int kWRows = 8;      // rows per workgroup of the W = gK o K pass
+constexpr int kWRows = 8;      // rows per workgroup of the W = gK o K pass (K_uf role)
+constexpr int kUuRows = 16;    // rows per workgroup of the same pass, K_uu role
 constexpr int kFinRows = 32;   // rows per workgroup of the RBF finalisation
 
 __device__ __forceinline__ float softplus_t0(float x) { return x > 20.f ? x : log1pf(expf(x)); }
@@ -129,10 +130,15 @@ __global__ __launch_bounds__(256) void t0_prologue_kernel(const ProArgs a) {
   const int lo = i < j ? i : j, hi = i < j ? j : i;
   const float* rh = v + (int64_t)hi * (hi + 1) / 2;
   const float* rl = v + (int64_t)lo * (lo + 1) / 2;
-  float acc = 0.f;
-  for (int k = 0; k < lo; ++k) acc = fmaf(rh[k], rl[k], acc);
+  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;   // independent chains: the loads of a group are in flight together
+  int k = 0;
+  for (; k + 4 <= lo; k += 4) {
+    acc0 = fmaf(rh[k], rl[k], acc0); acc1 = fmaf(rh[k + 1], rl[k + 1], acc1);
+    acc2 = fmaf(rh[k + 2], rl[k + 2], acc2); acc3 = fmaf(rh[k + 3], rl[k + 3], acc3);
+  }
+  for (; k < lo; ++k) acc0 = fmaf(rh[k], rl[k], acc0);
   const float dl = softplus_t0(rl[lo]);
-  acc = fmaf(hi == lo ? dl : rh[lo], dl, acc);
+  const float acc = fmaf(hi == lo ? dl : rh[lo], dl, (acc0 + acc1) + (acc2 + acc3));
   a.Su[e] = acc;
   a.Lu[e] = j < i ? v[(int64_t)i * (i + 1) / 2 + j] : (j == i ? dl : 0.f);
 }
@@ -367,9 +373,14 @@ __global__ void t0_gvec_kernel(const float* __restrict__ vec, const float* __res
   if (k > i) return;
   const float* gs = gSu + (c * M + i) * M;
   const float* lu = Lu + c * M * M + k;
-  float acc = 0.f;
-  for (int j = k; j < M; ++j) acc = fmaf(gs[j], lu[(int64_t)j * M], acc);
-  float g = 2.f * acc;
+  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+  int j = k & ~3;                       // Lu[j][k] = 0 (stored) for j < k: start at the aligned group containing k
+  for (; j + 4 <= M; j += 4) {
+    acc0 = fmaf(gs[j], lu[(int64_t)j * M], acc0); acc1 = fmaf(gs[j + 1], lu[(int64_t)(j + 1) * M], acc1);
+    acc2 = fmaf(gs[j + 2], lu[(int64_t)(j + 2) * M], acc2); acc3 = fmaf(gs[j + 3], lu[(int64_t)(j + 3) * M], acc3);
+  }
+  for (; j < M; ++j) acc0 = fmaf(gs[j], lu[(int64_t)j * M], acc0);
+  float g = 2.f * ((acc0 + acc1) + (acc2 + acc3));
   for (int s = 0; s < S; ++s) g += gRK[(((int64_t)s * C + c) * M + i) * LD + 4 + M + k];
   const int64_t idx = c * ((int64_t)M * (M + 1) / 2) + (int64_t)i * (i + 1) / 2 + k;
   if (i == k) {
@@ -383,7 +394,7 @@ __global__ void t0_gvec_kernel(const float* __restrict__ vec, const float* __res
 // W = gK o K for both kernel matrices (see rbf.hip for the algebra).
 //   blocks < nuf : K_uf, in place on the K_uf block of gRK (row stride LD); row sums r_uf, column sums c_uf (atomics),
 //                  2 sum W into gtheta[s, D]
-//   blocks >= nuf: K_uu, one wave per row: Wuu = W + W^T, r_uu = its row sums, sum Wuu into gtheta[s, D]
+//   blocks >= nuf: K_uu, one wave per row: Wuu = W + W^T, r_uu = its row sums, sum Wuu (= 2 sum W) into gtheta[s, D]
 __global__ __launch_bounds__(256) void t0_w_kernel(const float* __restrict__ RK, float* __restrict__ gRK,
                                                    const float* __restrict__ Kuu, const float* __restrict__ gKuu,
                                                    float* __restrict__ Wuu, float* __restrict__ r_uu,
@@ -414,26 +425,28 @@ __global__ __launch_bounds__(256) void t0_w_kernel(const float* __restrict__ RK,
     if (threadIdx.x == 0) atomicAdd(&gtheta[s * (D + 1) + D], 2.f * tot);
     return;
   }
-  const int64_t rowid = (int64_t)((int)blockIdx.x - nuf) * 4 + (threadIdx.x >> 6);
-  const int64_t nrows = (int64_t)S * C * M;
-  float acc = 0.f;
-  // the 4 rows of a block may straddle two hyper-samples only if M % 4 != 0; the atomic below is per wave for that reason
-  if (rowid < nrows) {
-    const int64_t b = rowid / M;
-    const int i = rowid % M;
-    const float* K = Kuu + b * M * M;
-    const float* gK = gKuu + b * M * M;
+  // K_uu role: kUuRows consecutive rows of one (s, c) matrix per block, a wave takes every 4th of them
+  const int nchunk = (M + kUuRows - 1) / kUuRows;
+  const int id = (int)blockIdx.x - nuf;
+  const int64_t b = id / nchunk;
+  const int i0 = (id % nchunk) * kUuRows, i1 = min(M, i0 + kUuRows);
+  const float* K = Kuu + b * M * M;
+  const float* gK = gKuu + b * M * M;
+  float tot = 0.f;
+  for (int i = i0 + (threadIdx.x >> 6); i < i1; i += 4) {
+    float acc = 0.f;
     for (int j = lane; j < M; j += 64) {
       const float v = K[(int64_t)i * M + j] * gK[(int64_t)i * M + j] + K[(int64_t)j * M + i] * gK[(int64_t)j * M + i];
       Wuu[b * M * M + (int64_t)i * M + j] = v;
       acc += v;
     }
+    acc = wave_sum(acc);
+    if (lane == 0) r_uu[b * M + i] = acc;
+    tot += acc;
   }
-  acc = wave_sum(acc);
-  if (lane == 0 && rowid < nrows) {
-    r_uu[rowid] = acc;
-    atomicAdd(&gtheta[(rowid / ((int64_t)C * M)) * (D + 1) + D], acc);
-  }
+  // every lane of a wave holds the wave's total: count it once
+  const float t = block_sum<256>(lane == 0 ? tot : 0.f, red);
+  if (threadIdx.x == 0) atomicAdd(&gtheta[(b / C) * (D + 1) + D], t);
 }
 
 // RBF finalisation (rbf.hip), both kernel matrices at once.  grid (ceil(D/64), nzy + nxy), 64 d-columns x 4 row lanes.
@@ -710,7 +723,7 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
   const int64_t zrows = (int64_t)C * M;
   {
     const int gx = cdiv(B, 256), gy = cdiv(zrows, kWRows), nuf = gx * gy * S;
-    const int nuu = cdiv((int64_t)SC * M, 4);
+    const int nuu = SC * cdiv(M, kUuRows);
     hipLaunchKernelGGL(t0_w_kernel, dim3(nuf + nuu), dim3(256), 0, st, o.RK, o.gRK, o.KS, o.gKS, o.Wuu, o.r_uu, o.r_uf,
                        o.c_uf, o.gtheta, S, C, M, B, D, NR, LD, gx, gy, nuf);
   }

@@ -20,16 +20,15 @@ class Yogi(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self):
         """One fused launch for all parameter tensors of a group (<= 8).  The step count lives on the
-        device (bias corrections are computed inside the kernel), so the whole step can sit inside a
-        captured hipGraph."""
+        device (bias corrections are computed inside the kernel, which also advances the count), so the
+        whole step can sit inside a captured hipGraph."""
         for group in self.param_groups:
             b1, b2 = group['betas']
             ps = [p for p in group['params'] if p.grad is not None]
             if not ps:
                 continue
             if 'step' not in group:
-                group['step'] = torch.zeros(1, dtype=torch.float32, device=ps[0].device)
-            group['step'].add_(1.0)
+                group['step'] = torch.zeros(2, dtype=torch.float32, device=ps[0].device)   # {t, ticket word}
             for p in ps:
                 require_device(p, p.grad)
                 st = self.state[p]
@@ -44,5 +43,6 @@ class Yogi(torch.optim.Optimizer):
                 sizes = (ctypes.c_int64 * k)(*[p.numel() for p in chunk])
                 check(lib().vargp_yogi_step_multi(k, arr(chunk), arr(grads), arr([self.state[p]['exp_avg'] for p in chunk]),
                                                   arr([self.state[p]['exp_avg_sq'] for p in chunk]), sizes,
-                                                  group['lr'], b1, b2, group['eps'], ptr(group['step']), stream_ptr()),
+                                                  group['lr'], b1, b2, group['eps'], ptr(group['step']),
+                                                  2 if i + 8 >= len(ps) else 1, stream_ptr()),
                       'vargp_yogi_step_multi')
