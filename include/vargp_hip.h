@@ -172,7 +172,7 @@ int vargp_yogi_step(float* p, const float* g, float* m, float* v, int64_t n, flo
  *
  * Shapes: log_mean, log_logvar, prior_* (D+1); eps_theta (S, D+1); z (C, M, D); u_mean (C, M); u_tril_vec
  * (C, M(M+1)/2); x (B, D); y (B) int64; eps_f (S, F, C, B).  map_est != 0: theta = log_mean, S must be 1, kl_hypers = 0
- * (log_logvar / prior_* / eps_theta may be NULL).
+ * (log_logvar / prior_* / eps_theta may be NULL).  eps_theta = eps_f = NULL: native noise, see rng_* below.
  * fwd writes scalars[0..2] = (kl_hypers, kl_u, nll) and info[0 .. S*C + C) (Cholesky status of K_uu[s,c] + eps I, then of
  * S_u[c] + eps I; 0 = ok, k = leading minor k not positive, results NaN-filled).
  * bwd needs the workspace exactly as fwd left it; seeds (device, 3 floats) = d total / d (kl_hypers, kl_u, nll).  It
@@ -191,18 +191,27 @@ typedef struct vargp_elbo_t0_desc {
   int32_t* info;
   void* ws;
   size_t ws_bytes;
+  float* bump; /* optional: fwd adds 1.0f to *bump (a caller's device-side step counter rides along for free) */
+  /* Native noise: with eps_f == NULL (and eps_theta == NULL) fwd draws both noise tensors itself from a counter-based
+   * generator (Philox4x32-10 + Box-Muller) keyed by rng_seed; *rng_counter (device) is the step number, read by fwd's
+   * first kernel and incremented by a later one.  Element (s, ...) is a function of the GLOBAL sample index
+   * rng_sample_offset + s, so sample-parallel ranks (offset = rank * S, same seed and counter) see slices of one global
+   * draw.  The drawn tensors stay in the workspace (bwd reads them there). */
+  uint64_t rng_seed;
+  uint32_t* rng_counter;
+  int32_t rng_sample_offset;
 } vargp_elbo_t0_desc;
 size_t vargp_elbo_t0_workspace_bytes(int S, int C, int M, int D, int B, int F);
 int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t stream);
 int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds, float* g_log_mean, float* g_log_logvar, float* g_z,
                       float* g_u_mean, float* g_u_tril_vec, vargp_stream_t stream);
 
-/* Same update for up to 8 tensors in one launch.  `step` (device) = { float t; uint32 ticket (keep 0) }.
- * step_mode 0: use t as is.  1: use t + 1.  2: use t + 1 and store it back when the launch's last block has finished
- * (no separate "t += 1" kernel; with more than 8 tensors pass 1 for all launches but the last). */
+/* Same update for up to 8 tensors in one launch.  `step` (device float) = the step count t.
+ * step_mode 0: use t as is.  1: use t + 1 (the caller advances the stored count elsewhere, e.g. through the `bump`
+ * pointer of vargp_elbo_t0_desc, so that the optimiser needs no "t += 1" launch of its own). */
 int vargp_yogi_step_multi(int ntensors, float* const* p, const float* const* g, float* const* m, float* const* v,
-                          const int64_t* n, float lr, float beta1, float beta2, float eps, float* step, int step_mode,
-                          vargp_stream_t stream);
+                          const int64_t* n, float lr, float beta1, float beta2, float eps, const float* step,
+                          int step_mode, vargp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Variational kernel hyper-parameters (reference: RBFKernel.sample_hypers / kl_hypers,

@@ -41,9 +41,7 @@ def _run(gp, x, y, use_graph, steps=3):
         for st in tr.optim.state.values():
             st['exp_avg'].fill_(1e-6)
             st['exp_avg_sq'].fill_(1e-6)
-        from vargp_amd import noise
-        if noise._shard is not None:                   # restart the shared noise stream as well
-            noise._shard[2].manual_seed(SEED)
+        tr._rng_counter.zero_()                        # restart the shared noise stream as well
     outs = []
     for _ in range(steps):
         out = tr.step_graph(x, y) if use_graph else tr.step(x, y)
@@ -83,14 +81,14 @@ def test_two_ranks_equal_single_process(use_graph):
         p.join(timeout=120)
         assert p.exitcode == 0
 
-    # single process, all samples, same global noise stream
+    # single process, all samples, same global noise stream (the program's counter-based generator: a rank's noise
+    # is the slice [rank*S, (rank+1)*S) of the draw this process makes)
     from vargp_amd import noise, ops
     ops.set_cholesky_error_mode('defer')
     try:
-        noise.set_shard(0, 1, SEED, 'cuda:0')
         gp, x, y = _model(S_LOCAL * WORLD)
         from vargp_amd.train import ElboTrainer
-        tr = ElboTrainer(gp, lr=1e-3, beta=2.0, n_total=10 * B)
+        tr = ElboTrainer(gp, lr=1e-3, beta=2.0, n_total=10 * B, noise_seed=SEED)
         outs1 = [[o.item() for o in tr.step(x, y)] for _ in range(3)]
         sd1 = {k: v.detach().cpu().numpy() for k, v in gp.state_dict().items()}
     finally:

@@ -36,6 +36,8 @@ class ElboT0Desc(Structure):
         ('eps_theta', c_void_p), ('eps_f', c_void_p),
         ('scalars', c_void_p), ('info', c_void_p),
         ('ws', c_void_p), ('ws_bytes', c_size_t),
+        ('bump', c_void_p),
+        ('rng_seed', ctypes.c_uint64), ('rng_counter', c_void_p), ('rng_sample_offset', c_int32),
     ]
 
 

@@ -92,10 +92,9 @@ struct YogiPack {
   int blk_end[8];   // exclusive prefix of the blocks assigned to each tensor (kYogiPerBlock elements per block)
 };
 constexpr int kYogiPerBlock = 1024;   // 256 threads x 4 elements
-// step_mode 0: t = step[0].  1: t = step[0] + 1.  2: t = step[0] + 1 and the last block to finish stores t back
-// (ticket counter in the word after step[0]), so the optimiser needs no separate "t += 1" launch.
+// step_mode 0: t = step[0].  1: t = step[0] + 1 (the caller advances the stored count some other way).
 __global__ __launch_bounds__(256) void yogi_multi_kernel(YogiPack pk, int ntensors, float lr, float b1, float b2, float eps,
-                                                         float* __restrict__ step, int step_mode) {
+                                                         const float* __restrict__ step, int step_mode) {
   int t = 0;
   while (t + 1 < ntensors && (int)blockIdx.x >= pk.blk_end[t]) ++t;
   const int blk = (int)blockIdx.x - (t ? pk.blk_end[t - 1] : 0);
@@ -118,18 +117,6 @@ __global__ __launch_bounds__(256) void yogi_multi_kernel(YogiPack pk, int ntenso
       m[i] = mi;
       v[i] = vi;
       p[i] -= (lr / bias1) * mi / (sqrtf(vi) / sb2 + eps);
-    }
-  }
-  if (step_mode == 2) {
-    __syncthreads();                      // every thread of this block has read step[0]
-    if (threadIdx.x == 0) {
-      unsigned* ticket = reinterpret_cast<unsigned*>(step + 1);
-      __threadfence();
-      if (atomicAdd(ticket, 1u) == gridDim.x - 1) {   // all other blocks have taken their ticket, i.e. read step[0]
-        step[0] = tt;
-        *ticket = 0u;
-        __threadfence();
-      }
     }
   }
 }
@@ -179,12 +166,12 @@ extern "C" int vargp_prof_read(const char* tag, double* total_ms, int64_t* launc
   return VARGP_OK;
 }
 
-// up to 8 parameter tensors in ONE launch (the VAR-GP model has 5); step = device pointer to {float t; uint32 ticket}
+// up to 8 parameter tensors in ONE launch (the VAR-GP model has 5); step = device pointer to the step count t
 extern "C" int vargp_yogi_step_multi(int ntensors, float* const* p, const float* const* g, float* const* m,
                                      float* const* v, const int64_t* n, float lr, float beta1, float beta2, float eps,
-                                     float* step, int step_mode, vargp_stream_t stream) {
+                                     const float* step, int step_mode, vargp_stream_t stream) {
   VARGP_REQUIRE(ntensors > 0 && ntensors <= 8 && p && g && m && v && n && step, "yogi_step_multi: bad arguments");
-  VARGP_REQUIRE(step_mode >= 0 && step_mode <= 2, "yogi_step_multi: bad step_mode");
+  VARGP_REQUIRE(step_mode == 0 || step_mode == 1, "yogi_step_multi: bad step_mode");
   YogiPack pk{};
   int nblk = 0;
   for (int i = 0; i < ntensors; ++i) {

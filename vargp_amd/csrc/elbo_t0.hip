@@ -27,9 +27,45 @@ constexpr int kFinRows = 32;   // rows per workgroup of the RBF finalisation
 __device__ __forceinline__ float softplus_t0(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 __device__ __forceinline__ float sigmoid_t0(float x) { return 1.f / (1.f + expf(-x)); }
 
+// ---- counter-based normal generator (Philox4x32-10 + Box-Muller) ---------------------------------------------------
+// Element g of noise stream `stream` at step `step` is a pure function of (seed, stream, g, step): group g/4 is one
+// Philox block, whose four 32-bit words make two Box-Muller pairs.  A rank that evaluates samples [s0, s0 + S) of a
+// global draw simply offsets g, so every rank sees its slice of ONE global tensor without communication.
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+  c[1] = (uint32_t)p1; c[3] = (uint32_t)p0; c[0] = n0; c[2] = n2;
+}
+__device__ __forceinline__ void normal4(uint64_t seed, uint32_t stream, uint64_t group, uint32_t step, float (&out)[4]) {
+  uint32_t c[4] = {(uint32_t)group, (uint32_t)(group >> 32), stream, step};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float u0 = ((float)c[2 * h] + 1.f) * 2.3283064365386963e-10f;       // (0, 1]
+    const float u1 = (float)c[2 * h + 1] * 2.3283064365386963e-10f;            // [0, 1]
+    const float r = sqrtf(-2.f * logf(u0));
+    float sn, cs;
+    sincospif(2.f * u1, &sn, &cs);
+    out[2 * h] = r * cs; out[2 * h + 1] = r * sn;
+  }
+}
+// the single element g of a stream (recomputes its group)
+__device__ __forceinline__ float normal1(uint64_t seed, uint32_t stream, uint64_t g, uint32_t step) {
+  float v[4];
+  normal4(seed, stream, g >> 2, step, v);
+  const int l = (int)(g & 3);
+  return l == 0 ? v[0] : (l == 1 ? v[1] : (l == 2 ? v[2] : v[3]));
+}
+constexpr uint32_t kStreamTheta = 0, kStreamF = 1;
+
 struct T0Ws {
   // forward results kept for the backward
-  float *theta, *w, *g2, *kd, *na, *nb, *Lu, *KS, *LL, *TT, *RK, *QP, *W, *mu, *var;
+  float *theta, *eps_theta, *eps_f, *w, *g2, *kd, *na, *nb, *Lu, *KS, *LL, *TT, *RK, *QP, *W, *mu, *var;
   float *gmu, *gvar;               // accumulators zeroed by the forward prologue (softmax gradient, unscaled)
   float *r_uf, *c_uf, *gtheta;     // accumulators zeroed by the first backward kernel
   float *r_uu, *gW, *ga, *gkd, *gQP, *gLL, *gTT, *gRK, *gKS, *Wuu, *Puu, *Puf;
@@ -40,7 +76,7 @@ struct T0Ws {
   size_t bytes;
 };
 
-static T0Ws carve_t0(void* ws, int S, int C, int M, int D, int B) {
+static T0Ws carve_t0(void* ws, int S, int C, int M, int D, int B, int F) {
   T0Ws o{};
   o.NR = (int)round_up(4 + 2 * M, 4);
   o.LD = (int)round_up(o.NR + B, 4);
@@ -48,7 +84,9 @@ static T0Ws carve_t0(void* ws, int S, int C, int M, int D, int B) {
   const int64_t SC = (int64_t)S * C, MM = (int64_t)M * M, D1 = D + 1;
   float* p = reinterpret_cast<float*>(ws);
   auto take = [&](int64_t n) { float* q = p; p += round_up(n, 64); return q; };
-  o.theta = take(S * D1); o.w = take(S * o.Dp); o.g2 = take(S); o.kd = take(SC);
+  // theta, eps_theta, eps_f first, in this order (vargp_amd/fused.py exposes them as views)
+  o.theta = take(S * D1); o.eps_theta = take(S * D1); o.eps_f = take((int64_t)S * F * C * B);
+  o.w = take(S * o.Dp); o.g2 = take(S); o.kd = take(SC);
   o.na = take(SC * M); o.nb = take((int64_t)S * B);
   o.Lu = take(C * MM); o.KS = take((SC + C) * MM); o.LL = take((SC + C) * MM); o.TT = take((SC + C) * MM);
   o.RK = take(SC * M * o.LD); o.QP = take(SC * M * o.LD); o.W = take(SC * M * B);
@@ -72,16 +110,24 @@ static T0Ws carve_t0(void* ws, int S, int C, int M, int D, int B) {
 // ---------------------------------------------------------------------------------------------------------------
 struct ProArgs {
   const float *mean, *logvar, *pmean, *plogvar, *eps_theta, *vec;
-  float *theta, *w, *g2, *kd, *Lu, *Su, *scalars, *zero_begin;
+  float *theta, *w, *g2, *kd, *Lu, *Su, *scalars, *zero_begin, *bump;
   int32_t* info;
   int64_t zero_count, Dp;
   int S, C, M, D, ninfo, map_est, nzero_blocks;
+  // native noise (eps_theta == eps_f == NULL in the descriptor): the prologue draws it
+  int native, nrng_blocks;
+  uint64_t seed;
+  const uint32_t* rng_counter;
+  int64_t g0_theta, g0_f, n_f;
+  float *eps_theta_out, *eps_f_out;
 };
 
 // Multi-role prologue, role by block index:
-//   block 0            kl_hypers (kernels.py:70-77) -> scalars[0]; scalars[1..2] = 0 (kl_u, nll accumulate); info = 0
+//   block 0            kl_hypers (kernels.py:70-77) -> scalars[0]; scalars[1..2] = 0 (kl_u, nll accumulate); info = 0;
+//                      *bump += 1 if the caller asked for it
 //   blocks 1..S        theta_s = mean + eps_s exp(logvar/2) (kernels.py:62-68); w_s = exp(-2 theta), g2_s = exp(2 theta_D)
 //   next nzero_blocks  zero-fill of the softmax-gradient accumulators
+//   next nrng_blocks   (native noise only) the likelihood noise eps_f; eps_theta is drawn inline by blocks 1..S
 //   rest               Lu = vec2tril(u_tril_vec) (gp_utils.py:22-49) and S_u = Lu Lu^T straight from the packed vector
 __global__ __launch_bounds__(256) void t0_prologue_kernel(const ProArgs a) {
   __shared__ float red[4];
@@ -95,7 +141,10 @@ __global__ __launch_bounds__(256) void t0_prologue_kernel(const ProArgs a) {
         acc += 0.5f * (expf(dv) + dm * dm * expf(-a.plogvar[d]) - 1.f - dv);
       }
     const float t = block_sum<256>(acc, red);
-    if (tid == 0) { a.scalars[0] = t; a.scalars[1] = 0.f; a.scalars[2] = 0.f; }
+    if (tid == 0) {
+      a.scalars[0] = t; a.scalars[1] = 0.f; a.scalars[2] = 0.f;
+      if (a.bump) a.bump[0] += 1.f;
+    }
     for (int i = tid; i < a.ninfo; i += 256) a.info[i] = 0;
     return;
   }
@@ -104,7 +153,18 @@ __global__ __launch_bounds__(256) void t0_prologue_kernel(const ProArgs a) {
     for (int d = tid; d < D1 || d < a.Dp; d += 256) {
       float t = 0.f;
       if (d < D1) {
-        t = a.map_est ? a.mean[d] : a.mean[d] + a.eps_theta[s * D1 + d] * expf(0.5f * a.logvar[d]);
+        if (a.map_est) {
+          t = a.mean[d];
+        } else {
+          float e;
+          if (a.native) {
+            e = normal1(a.seed, kStreamTheta, (uint64_t)(a.g0_theta + (int64_t)s * D1 + d), a.rng_counter[0]);
+            a.eps_theta_out[s * D1 + d] = e;      // kept for the backward
+          } else {
+            e = a.eps_theta[s * D1 + d];
+          }
+          t = a.mean[d] + e * expf(0.5f * a.logvar[d]);
+        }
         a.theta[s * D1 + d] = t;
       }
       if (d < a.Dp) a.w[s * a.Dp + d] = d < a.D ? expf(-2.f * t) : 0.f;
@@ -121,7 +181,23 @@ __global__ __launch_bounds__(256) void t0_prologue_kernel(const ProArgs a) {
       a.zero_begin[i] = 0.f;
     return;
   }
-  const int64_t e = (int64_t)(blk - 1 - a.S - a.nzero_blocks) * 256 + tid;
+  if (blk <= a.S + a.nzero_blocks + a.nrng_blocks) {
+    // likelihood noise: one Philox group (4 normals) per thread, groups aligned to the GLOBAL element index
+    const uint32_t step = a.rng_counter[0];
+    const int64_t gfirst = a.g0_f >> 2, glast = (a.g0_f + a.n_f + 3) >> 2;
+    for (int64_t G = gfirst + (int64_t)(blk - a.S - a.nzero_blocks - 1) * 256 + tid; G < glast;
+         G += (int64_t)a.nrng_blocks * 256) {
+      float v[4];
+      normal4(a.seed, kStreamF, (uint64_t)G, step, v);
+#pragma unroll
+      for (int l = 0; l < 4; ++l) {
+        const int64_t i = 4 * G + l - a.g0_f;
+        if (i >= 0 && i < a.n_f) a.eps_f_out[i] = v[l];
+      }
+    }
+    return;
+  }
+  const int64_t e = (int64_t)(blk - 1 - a.S - a.nzero_blocks - a.nrng_blocks) * 256 + tid;
   const int M = a.M;
   if (e >= (int64_t)a.C * M * M) return;
   const int j = e % M, i = (e / M) % M;
@@ -187,8 +263,10 @@ __global__ __launch_bounds__(256) void t0_pdiag_kl_fwd_kernel(const float* __res
                                                               const float* __restrict__ Lu, float* __restrict__ mu,
                                                               float* __restrict__ var, float* __restrict__ kl_u, int S,
                                                               int C, int M, int B, int NR, int LD, int nbx, int npd,
-                                                              int nkx) {
+                                                              int nkx, uint32_t* rng_counter) {
   __shared__ float red[3][4][64];
+  // the noise of this step has been drawn (by the prologue, two launches back): advance the generator's step count
+  if (rng_counter && blockIdx.x == 0 && threadIdx.x == 0) rng_counter[0] += 1u;
   if ((int)blockIdx.x < npd) {
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
     const int col = ((int)blockIdx.x % nbx) * 64 + cx;
@@ -544,9 +622,13 @@ __global__ void t0_hyper_bwd_kernel(const float* __restrict__ mean, const float*
 static int check_desc(const vargp_elbo_t0_desc* d, const char* who) {
   VARGP_REQUIRE(d, "%s: null descriptor", who);
   VARGP_REQUIRE(d->S > 0 && d->C > 0 && d->M > 0 && d->D > 0 && d->B > 0 && d->F > 0, "%s: bad dims", who);
-  VARGP_REQUIRE(d->log_mean && d->z && d->u_mean && d->u_tril_vec && d->x && d->y && d->eps_f && d->scalars && d->info &&
-                    d->ws, "%s: null pointer", who);
-  VARGP_REQUIRE(d->map_est ? d->S == 1 : (d->log_logvar && d->prior_log_mean && d->prior_log_logvar && d->eps_theta),
+  VARGP_REQUIRE(d->log_mean && d->z && d->u_mean && d->u_tril_vec && d->x && d->y && d->scalars && d->info && d->ws,
+                "%s: null pointer", who);
+  const bool native = d->eps_f == nullptr;    // the program draws its own noise
+  VARGP_REQUIRE(!native || (d->rng_counter && d->eps_theta == nullptr && d->rng_sample_offset >= 0),
+                "%s: native noise needs rng_counter, eps_theta == eps_f == NULL and a sample offset >= 0", who);
+  VARGP_REQUIRE(d->map_est ? d->S == 1
+                           : (d->log_logvar && d->prior_log_mean && d->prior_log_logvar && (native || d->eps_theta)),
                 "%s: hyper-parameter arguments inconsistent with map_est", who);
   VARGP_REQUIRE(d->ws_bytes >= vargp_elbo_t0_workspace_bytes(d->S, d->C, d->M, d->D, d->B, d->F),
                 "%s: workspace too small", who);
@@ -569,8 +651,7 @@ static GemmParams flat_gemm(const float* A, int lda, int64_t sA, const float* B,
 using namespace vargp;
 
 extern "C" size_t vargp_elbo_t0_workspace_bytes(int S, int C, int M, int D, int B, int F) {
-  (void)F;
-  return carve_t0(nullptr, S, C, M, D, B).bytes + 256;
+  return carve_t0(nullptr, S, C, M, D, B, F).bytes + 256;
 }
 
 extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t stream) {
@@ -578,10 +659,12 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
   if (rc) return rc;
   hipStream_t st = as_stream(stream);
   const int S = d->S, C = d->C, M = d->M, D = d->D, B = d->B, F = d->F, SC = S * C;
-  const T0Ws o = carve_t0(d->ws, S, C, M, D, B);
+  const T0Ws o = carve_t0(d->ws, S, C, M, D, B, F);
   const int NR = o.NR, LD = o.LD;
   const int64_t MM = (int64_t)M * M, MLD = (int64_t)M * LD;
   const bool fused_softmax = C <= 16;
+  const bool native = d->eps_f == nullptr;
+  const float* eps_f = native ? o.eps_f : d->eps_f;
 
   {
     ProfScope prof("t0_prologue", st);
@@ -589,10 +672,19 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
     a.mean = d->log_mean; a.logvar = d->log_logvar; a.pmean = d->prior_log_mean; a.plogvar = d->prior_log_logvar;
     a.eps_theta = d->eps_theta; a.vec = d->u_tril_vec;
     a.theta = o.theta; a.w = o.w; a.g2 = o.g2; a.kd = o.kd; a.Lu = o.Lu; a.Su = o.KS + SC * MM; a.scalars = d->scalars;
+    a.bump = d->bump;
     a.zero_begin = o.gmu; a.zero_count = o.r_uf - o.gmu; a.info = d->info; a.Dp = o.Dp;
     a.S = S; a.C = C; a.M = M; a.D = D; a.ninfo = SC + C; a.map_est = d->map_est;
     a.nzero_blocks = (int)std::min<int64_t>(64, cdiv(a.zero_count, 1024));
-    const int grid = 1 + S + a.nzero_blocks + cdiv((int64_t)C * MM, 256);
+    if (native) {
+      const int64_t per_sample_f = (int64_t)F * C * B;
+      a.native = 1; a.seed = d->rng_seed; a.rng_counter = d->rng_counter;
+      a.g0_theta = (int64_t)d->rng_sample_offset * (D + 1); a.g0_f = (int64_t)d->rng_sample_offset * per_sample_f;
+      a.n_f = S * per_sample_f;
+      a.eps_theta_out = o.eps_theta; a.eps_f_out = o.eps_f;
+      a.nrng_blocks = (int)std::min<int64_t>(512, cdiv(a.n_f + 7, 1024));
+    }
+    const int grid = 1 + S + a.nzero_blocks + a.nrng_blocks + cdiv((int64_t)C * MM, 256);
     hipLaunchKernelGGL(t0_prologue_kernel, dim3(grid), dim3(256), 0, st, a);
   }
   // kernel matrices: K_uu -> KS[:SC], K_uf -> the trailing block of RK
@@ -650,14 +742,14 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
   {
     const int nbx = cdiv(B, 64), npd = nbx * SC, nkx = cdiv(M, kKlRows);
     hipLaunchKernelGGL(t0_pdiag_kl_fwd_kernel, dim3(npd + nkx * SC), dim3(256), 0, st, o.QP, o.W, o.kd, o.LL, o.Lu, o.mu,
-                       o.var, d->scalars + 1, S, C, M, B, NR, LD, nbx, npd, nkx);
+                       o.var, d->scalars + 1, S, C, M, B, NR, LD, nbx, npd, nkx, native ? d->rng_counter : nullptr);
   }
   if (fused_softmax) {
     const int64_t total = (int64_t)S * F * B;
-    hipLaunchKernelGGL(t0_softmax_kernel<16>, dim3(cdiv(total, 256)), dim3(256), 0, st, o.mu, o.var, d->eps_f, d->y,
+    hipLaunchKernelGGL(t0_softmax_kernel<16>, dim3(cdiv(total, 256)), dim3(256), 0, st, o.mu, o.var, eps_f, d->y,
                        d->scalars + 2, o.gmu, o.gvar, S, F, C, B);
   } else {
-    rc = vargp_softmax_nll_fwd(o.mu, o.var, d->eps_f, d->y, d->scalars + 2, S, F, C, B, stream);
+    rc = vargp_softmax_nll_fwd(o.mu, o.var, eps_f, d->y, d->scalars + 2, S, F, C, B, stream);
     if (rc) return rc;
   }
   return check_launch("elbo_t0_fwd");
@@ -670,13 +762,16 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
   VARGP_REQUIRE(seeds && g_log_mean && g_log_logvar && g_z && g_u_mean && g_u_tril_vec, "elbo_t0_bwd: null pointer");
   hipStream_t st = as_stream(stream);
   const int S = d->S, C = d->C, M = d->M, D = d->D, B = d->B, F = d->F, SC = S * C;
-  const T0Ws o = carve_t0(d->ws, S, C, M, D, B);
+  const T0Ws o = carve_t0(d->ws, S, C, M, D, B, F);
   const int NR = o.NR, LD = o.LD;
   const int64_t MM = (int64_t)M * M, MLD = (int64_t)M * LD, MB = (int64_t)M * B;
   const bool fused_softmax = C <= 16;
+  const bool native = d->eps_f == nullptr;
+  const float* eps_f = native ? o.eps_f : d->eps_f;
+  const float* eps_theta = native ? o.eps_theta : d->eps_theta;
 
   if (!fused_softmax) {   // C > 16: gradient of the likelihood from the generic kernel (already scaled by its seed)
-    rc = vargp_softmax_nll_bwd(o.mu, o.var, d->eps_f, d->y, seeds + 2, o.gmu, o.gvar, S, F, C, B, stream);
+    rc = vargp_softmax_nll_bwd(o.mu, o.var, eps_f, d->y, seeds + 2, o.gmu, o.gvar, S, F, C, B, stream);
     if (rc) return rc;
   }
   hipLaunchKernelGGL(t0_pdiag_bwd_kernel, dim3(M, SC), dim3(256), 0, st, o.QP, o.W, o.gmu, o.gvar,
@@ -751,7 +846,7 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
                        o.Puu, o.Puf, o.w, g_z, o.gtheta, zrows, (int64_t)B, D, o.Dp, S, nzy);
   }
   hipLaunchKernelGGL(t0_hyper_bwd_kernel, dim3(cdiv(D + 1, 256)), dim3(256), 0, st, d->log_mean, d->log_logvar,
-                     d->prior_log_mean, d->prior_log_logvar, d->eps_theta, o.gtheta, o.g2, o.gkd, seeds, g_log_mean,
+                     d->prior_log_mean, d->prior_log_logvar, eps_theta, o.gtheta, o.g2, o.gkd, seeds, g_log_mean,
                      g_log_logvar, S, C, D + 1, d->map_est);
   return check_launch("elbo_t0_bwd");
 }

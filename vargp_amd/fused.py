@@ -40,29 +40,61 @@ class T0Program:
                                scalars=_p(self.scalars), info=_p(self.info), ws=_p(self.ws),
                                ws_bytes=self.ws.numel() * 4)
         self._keep = None
+        self._rng = None
+
+    def set_rng(self, seed, counter, sample_offset=0):
+        """Native noise: `forward(eps_theta=None, eps_f=None)` then draws both noise tensors inside the program from a
+        Philox4x32-10 generator keyed by `seed`; `counter` (device int32/uint32 tensor of one element) is the step
+        number, advanced by every forward; `sample_offset` = index of this rank's first hyper-sample in the global
+        draw (sample-parallel ranks: rank * S)."""
+        assert counter.is_cuda and counter.numel() == 1 and counter.element_size() == 4
+        self._rng = (int(seed), counter, int(sample_offset))
+        self.desc.rng_seed, self.desc.rng_counter, self.desc.rng_sample_offset = int(seed), _p(counter), int(sample_offset)
+
+    def _view(self, index, shape):
+        # workspace layout (csrc/elbo_t0.hip, carve_t0): theta | eps_theta | eps_f | ..., each rounded up to 64 floats
+        S, C, M, D, B, F_ = self.shape
+        sizes = [S * (D + 1), S * (D + 1), S * F_ * C * B]
+        off = sum((n + 63) // 64 * 64 for n in sizes[:index])
+        n = sizes[index]
+        return self.ws[off:off + n].view(shape)
+
+    def eps_theta(self):
+        """Hyper-parameter noise drawn by the last native-noise forward, (S, D+1)."""
+        return self._view(1, (self.shape[0], self.shape[3] + 1))
+
+    def eps_f(self):
+        """Likelihood noise drawn by the last native-noise forward, (S, F, C, B)."""
+        S, C, M, D, B, F_ = self.shape
+        return self._view(2, (S, F_, C, B))
 
     @staticmethod
-    def shape_of(n_v, z, x, eps_f):
-        return (n_v, z.shape[0], z.shape[1], z.shape[2], x.shape[0], eps_f.shape[1])
+    def shape_of(n_v, z, x, n_f):
+        return (n_v, z.shape[0], z.shape[1], z.shape[2], x.shape[0], n_f)
 
     def forward(self, log_mean, log_logvar, prior_log_mean, prior_log_logvar, z, u_mean, u_tril_vec, x, y, eps_theta,
-                eps_f):
-        """-> scalars (3,) = (kl_hypers, kl_u, nll).  All tensors contiguous fp32 on the ROCm device (y int64)."""
+                eps_f, bump=None):
+        """-> scalars (3,) = (kl_hypers, kl_u, nll).  All tensors contiguous fp32 on the ROCm device (y int64).
+        eps_theta = eps_f = None: the program draws the noise itself (see set_rng).  `bump`: optional device float that the forward increments by one (an optimiser's step counter)."""
         tensors = (log_mean, log_logvar, prior_log_mean, prior_log_logvar, z, u_mean, u_tril_vec, x, y, eps_theta, eps_f)
         require_device(*tensors)
         for t in tensors:
             if t is not None and not t.is_contiguous():
                 raise ValueError('T0Program.forward needs contiguous tensors')
         S, C, M, D, B, F_ = self.shape
-        assert z.shape == (C, M, D) and x.shape == (B, D) and eps_f.shape == (S, F_, C, B) and y.dtype == torch.int64
+        assert z.shape == (C, M, D) and x.shape == (B, D) and y.dtype == torch.int64
         assert u_mean.numel() == C * M and u_tril_vec.shape == (C, M * (M + 1) // 2) and log_mean.numel() == D + 1
-        assert self.map_est or eps_theta.shape == (S, D + 1)
+        if eps_f is None:
+            assert self._rng is not None and eps_theta is None, 'native noise: call set_rng() and pass no eps tensors'
+        else:
+            assert eps_f.shape == (S, F_, C, B) and (self.map_est or eps_theta.shape == (S, D + 1))
         d = self.desc
         d.log_mean, d.log_logvar = _p(log_mean), _p(log_logvar)
         d.prior_log_mean, d.prior_log_logvar = _p(prior_log_mean), _p(prior_log_logvar)
         d.z, d.u_mean, d.u_tril_vec, d.x, d.y = _p(z), _p(u_mean), _p(u_tril_vec), _p(x), _p(y)
         d.eps_theta, d.eps_f = _p(eps_theta), _p(eps_f)
-        self._keep = tensors          # the descriptor holds raw pointers: keep the tensors alive until backward
+        d.bump = _p(bump)
+        self._keep = tensors + (bump,)   # the descriptor holds raw pointers: keep the tensors alive until backward
         check(lib().vargp_elbo_t0_fwd(ctypes.byref(d), stream_ptr()), 'vargp_elbo_t0_fwd')
         ops._note_chol_errors(self.info)
         return self.scalars
@@ -78,8 +110,7 @@ class T0Program:
 
     def theta(self):
         """The hyper-parameter samples of the last forward, (S, D+1) (view into the workspace)."""
-        S, D = self.shape[0], self.shape[3]
-        return self.ws[:S * (D + 1)].view(S, D + 1)
+        return self._view(0, (self.shape[0], self.shape[3] + 1))
 
 
 class _ElboT0(Function):
@@ -90,7 +121,7 @@ class _ElboT0(Function):
                 for t in (log_mean, log_logvar, prior_log_mean, prior_log_logvar, z, u_mean, u_tril_vec, x, y, eps_theta,
                           eps_f)]
         S = 1 if map_est else eps_theta.shape[0]
-        prog = T0Program(*T0Program.shape_of(S, z, x, eps_f), z.device, map_est)   # fresh workspace per graph node
+        prog = T0Program(*T0Program.shape_of(S, z, x, eps_f.shape[1]), z.device, map_est)   # fresh workspace per graph node
         scal = prog.forward(*args)
         ctx.prog = prog
         ctx.map_est = map_est

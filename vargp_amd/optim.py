@@ -16,19 +16,31 @@ from ._lib import check, lib, ptr, require_device, stream_ptr
 class Yogi(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-2, betas=(0.9, 0.999), eps=1e-3, initial_accumulator=1e-6):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, initial_accumulator=initial_accumulator))
+        # True: somebody else advances the device-side step count before step() (ElboTrainer lets the ELBO
+        # program's first kernel do it), so step() launches nothing but the update kernel
+        self.external_step = False
+
+    def step_counter(self, device):
+        """The device-side step count of the (single) parameter group."""
+        group = self.param_groups[0]
+        if 'step' not in group:
+            group['step'] = torch.zeros(1, dtype=torch.float32, device=device)
+        return group['step']
 
     @torch.no_grad()
     def step(self):
         """One fused launch for all parameter tensors of a group (<= 8).  The step count lives on the
-        device (bias corrections are computed inside the kernel, which also advances the count), so the
-        whole step can sit inside a captured hipGraph."""
+        device (bias corrections are computed inside the kernel), so the whole step can sit inside a
+        captured hipGraph."""
         for group in self.param_groups:
             b1, b2 = group['betas']
             ps = [p for p in group['params'] if p.grad is not None]
             if not ps:
                 continue
             if 'step' not in group:
-                group['step'] = torch.zeros(2, dtype=torch.float32, device=ps[0].device)   # {t, ticket word}
+                group['step'] = torch.zeros(1, dtype=torch.float32, device=ps[0].device)
+            if not self.external_step:
+                group['step'].add_(1.0)
             for p in ps:
                 require_device(p, p.grad)
                 st = self.state[p]
@@ -43,6 +55,6 @@ class Yogi(torch.optim.Optimizer):
                 sizes = (ctypes.c_int64 * k)(*[p.numel() for p in chunk])
                 check(lib().vargp_yogi_step_multi(k, arr(chunk), arr(grads), arr([self.state[p]['exp_avg'] for p in chunk]),
                                                   arr([self.state[p]['exp_avg_sq'] for p in chunk]), sizes,
-                                                  group['lr'], b1, b2, group['eps'], ptr(group['step']),
-                                                  2 if i + 8 >= len(ps) else 1, stream_ptr()),
+                                                  group['lr'], b1, b2, group['eps'], ptr(group['step']), 0,
+                                                  stream_ptr()),
                       'vargp_yogi_step_multi')

@@ -22,7 +22,7 @@ class ElboTrainer:
     replaced by any `loss_fn(x, y) -> (kl_hypers, kl_u, nll)` over an explicit `params` list."""
 
     def __init__(self, gp=None, lr=1e-2, beta=1.0, n_total=None, group=None, noise_seed=1234, optimizer=None,
-                 params=None, loss_fn=None):
+                 params=None, loss_fn=None, native_noise=True):
         self.gp = gp
         self.loss_fn = loss_fn if loss_fn is not None else gp.loss
         self.beta = float(beta)
@@ -51,6 +51,16 @@ class ElboTrainer:
         self._t0 = (gp is not None and loss_fn is None and params is None and hasattr(gp, 'draw_t0_noise')
                     and not gp.prev_params and gp.fused_first_task)
         self._prog, self._seeds, self._own_grads = None, {}, None
+        # with our Yogi (one parameter group) the program's first kernel also advances the optimiser's step count
+        self._bump = None
+        # native noise: the program draws eps_theta / eps_f itself (Philox keyed by noise_seed, device-side step
+        # counter): no randn launches, and ranks see slices of one global draw by construction
+        self.native_noise = bool(native_noise) and self._t0
+        self.noise_seed = int(noise_seed)
+        self._rng_counter = torch.zeros(1, dtype=torch.int32, device=dev) if self.native_noise else None
+        if self._t0 and isinstance(self.optim, Yogi) and len(self.optim.param_groups) == 1:
+            self.optim.external_step = True
+            self._bump = self.optim.step_counter(dev)
 
     # -- hipGraph capture of the step --------------------------------------------------------------
     def capture(self, x, y, warmup=3):
@@ -123,16 +133,23 @@ class ElboTrainer:
         from .fused import T0Program
         gp, kern = self.gp, self.gp.kernel
         x, y = x.contiguous(), y.contiguous()
-        eps_theta, eps_f = gp.draw_t0_noise(x)
-        shape = T0Program.shape_of(eps_f.shape[0], gp.z, x, eps_f)
+        S = 1 if kern.map_est else gp.n_v
+        if self.native_noise and not noise._injected:
+            eps_theta = eps_f = None
+        else:
+            eps_theta, eps_f = gp.draw_t0_noise(x)
+            eps_theta, eps_f = None if eps_theta is None else eps_theta.contiguous(), eps_f.contiguous()
+        shape = T0Program.shape_of(S, gp.z, x, gp.likelihood.n_f)
         if self._prog is None or self._prog.shape != shape:
             self._prog = T0Program(*shape, x.device, kern.map_est)
+            if self.native_noise:
+                self._prog.set_rng(self.noise_seed, self._rng_counter, self.rank * S)
         key = (scale, w)
         if key not in self._seeds:
             self._seeds[key] = torch.tensor([self.beta * w, w, scale * w], dtype=torch.float32, device=x.device)
         scal = self._prog.forward(kern.log_mean.detach(), kern.log_logvar.detach(), kern.prior_log_mean,
                                   kern.prior_log_logvar, gp.z.detach(), gp.u_mean.detach(), gp.u_tril_vec.detach(), x, y,
-                                  None if eps_theta is None else eps_theta.contiguous(), eps_f.contiguous())
+                                  eps_theta, eps_f, bump=self._bump)
         self._prog.backward(self._seeds[key], kern.log_mean.grad, kern.log_logvar.grad, gp.z.grad, gp.u_mean.grad,
                             gp.u_tril_vec.grad)
         return scal
