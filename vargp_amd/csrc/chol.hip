@@ -5,7 +5,7 @@
 //   yields L and T = L^-1 together (see chol_inv_small_kernel).
 // n > 100: blocked right-looking on 96-wide panels; the diagonal blocks use the LDS kernel, the
 //   panel solves and trailing updates are MFMA GEMMs (gemm.hip).
-// Backward (any n) is five GEMMs (see vargp_chol_inv_bwd).
+// Backward (any n) is four GEMMs (see chol_inv_bwd_impl).
 #include "common.h"
 #ifndef VARGP_CHOL_ABL
 #define VARGP_CHOL_ABL 0   // timing ablations of chol_inv_small2_kernel (wrong results): 1 no FMAs, 2 no pivot-row reads,
@@ -420,14 +420,14 @@ __global__ void tril_combine_kernel(const float* __restrict__ gL, const float* _
   out[e] = v;
 }
 
-// out_ij = 0.5 * P[max(i,j)][min(i,j)]   ( = (Phi(P) + Phi(P)^T) / 2 )
-__global__ void phi_sym_kernel(const float* __restrict__ Pm, float* __restrict__ out, int n, int64_t total) {
+// out_ij = half * P[max(i,j)][min(i,j)]   ( half = 0.5: (Phi(P) + Phi(P)^T) / 2 )
+__global__ void phi_sym_kernel(const float* __restrict__ Pm, float* __restrict__ out, int n, int64_t total, float half) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= total) return;
   const int64_t b = e / ((int64_t)n * n), r = e % ((int64_t)n * n);
   const int i = r / n, j = r % n;
   const int hi = i > j ? i : j, lo = i > j ? j : i;
-  out[e] = 0.5f * Pm[b * n * n + (int64_t)hi * n + lo];
+  out[e] = half * Pm[b * n * n + (int64_t)hi * n + lo];
 }
 
 // square batched GEMM helper on dense [nbatch, n, n] buffers (or sub-blocks with explicit ld)
@@ -524,30 +524,49 @@ int vargp::chol_inv_fwd_impl(const float* A, float eps, float* L, float* T, floa
 
 extern "C" int vargp_chol_inv_bwd(const float* L, const float* T, const float* gL, const float* gT, float* gA,
                                   int nbatch, int n, void* ws, size_t ws_bytes, vargp_stream_t stream) {
+  return vargp::chol_inv_bwd_impl(L, T, gL, gT, gA, nbatch, n, ws, ws_bytes, false, as_stream(stream));
+}
+
+// With T = L^-1 (dT = -T dL T) the total gradient on L is  gL_tot = tril(gL) - tril(Y),  Y = T^T gT T^T, and
+//   gA = T^T S T,   S = (Phi(P) + Phi(P)^T) / 2,   P = L^T gL_tot,   Phi = lower triangle with halved diagonal.
+// Only the lower triangle of P is used, and there  L^T tril(Y) = L^T Y - L^T triu_strict(Y)  agrees with
+// L^T Y = (T L)^T gT T^T = gT T^T  (upper x strictly-upper is strictly upper).  So
+//   P = L^T tril(gL) - gT T^T :   four GEMMs in all (gT T^T, L^T gL, T^T S, (.) T) instead of five.
+// gl_lower: gL is already lower-triangular with stored zeros above the diagonal (skips the masking pass).
+int vargp::chol_inv_bwd_impl(const float* L, const float* T, const float* gL, const float* gT, float* gA, int nbatch,
+                             int n, void* ws, size_t ws_bytes, bool gl_lower, hipStream_t st) {
   VARGP_REQUIRE(L && T && gA && ws, "chol_inv_bwd: null pointer");
   VARGP_REQUIRE(ws_bytes >= vargp_chol_workspace_bytes(nbatch, n, 1), "chol_inv_bwd: workspace too small");
-  hipStream_t st = as_stream(stream);
   const int64_t nn = (int64_t)n * n, total = nn * nbatch;
   float* w1 = reinterpret_cast<float*>(ws);
   float* w2 = w1 + total;
   int rc;
-  const float* G2 = nullptr;
-  if (gT) {
-    // d<gT, T> = -<T^T gT T^T, dL>
-    rc = sq_gemm(T, n, nn, 1, 2, gT, n, nn, 0, 0, w1, n, nn, nullptr, 1.f, 0.f, n, n, n, 0, nbatch, st);  // T^T gT
+  if (gT) {   // w1 = gT T^T
+    rc = sq_gemm(gT, n, nn, 0, 0, T, n, nn, 1, 2, w1, n, nn, nullptr, 1.f, 0.f, n, n, n, 0, nbatch, st);
     if (rc) return rc;
-    rc = sq_gemm(w1, n, nn, 0, 0, T, n, nn, 1, 2, w2, n, nn, nullptr, 1.f, 0.f, n, n, n, 0, nbatch, st);  // . T^T
-    if (rc) return rc;
-    G2 = w2;
   }
-  hipLaunchKernelGGL(tril_combine_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, gL, G2, gA, n, total);
-  // P = L^T gL_tot ; Psym = (Phi(P) + Phi(P)^T)/2 ; gA = T^T Psym T
-  rc = sq_gemm(L, n, nn, 1, 2, gA, n, nn, 0, 1, w1, n, nn, nullptr, 1.f, 0.f, n, n, n, 0, nbatch, st);
+  const float* P = w1;
+  if (gL) {
+    const float* gLl = gL;
+    if (!gl_lower) {
+      hipLaunchKernelGGL(tril_combine_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, gL, (const float*)nullptr, gA, n,
+                         total);
+      gLl = gA;
+    }
+    // w2 = L^T tril(gL) - w1
+    rc = sq_gemm(L, n, nn, 1, 2, gLl, n, nn, 0, 1, w2, n, nn, gT ? w1 : nullptr, 1.f, -1.f, n, n, n, 0, nbatch, st);
+    if (rc) return rc;
+    P = w2;
+  } else {
+    VARGP_REQUIRE(gT, "chol_inv_bwd: neither gL nor gT given");
+  }
+  // S = sign * (Phi(P) + Phi(P)^T) / 2  (sign = -1 when P is the bare gT T^T), then gA = T^T S T
+  float* Sm = (P == w1) ? w2 : w1;
+  hipLaunchKernelGGL(phi_sym_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, P, Sm, n, total, gL ? 0.5f : -0.5f);
+  float* tmp = (Sm == w1) ? w2 : w1;
+  rc = sq_gemm(T, n, nn, 1, 2, Sm, n, nn, 0, 0, tmp, n, nn, nullptr, 1.f, 0.f, n, n, n, 0, nbatch, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(phi_sym_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w1, w2, n, total);
-  rc = sq_gemm(T, n, nn, 1, 2, w2, n, nn, 0, 0, w1, n, nn, nullptr, 1.f, 0.f, n, n, n, 0, nbatch, st);
-  if (rc) return rc;
-  rc = sq_gemm(w1, n, nn, 0, 0, T, n, nn, 0, 1, gA, n, nn, nullptr, 1.f, 0.f, n, n, n, 0, nbatch, st);
+  rc = sq_gemm(tmp, n, nn, 0, 0, T, n, nn, 0, 1, gA, n, nn, nullptr, 1.f, 0.f, n, n, n, 0, nbatch, st);
   if (rc) return rc;
   return check_launch("chol_inv_bwd");
 }

@@ -92,6 +92,9 @@ int rbf_direct_launch(const float* X, const float* Y, const float* w, const floa
 int chol_inv_fwd_impl(const float* A, float eps, float* L, float* T, float* logdet, int32_t* info, int nbatch, int n,
                       void* ws, size_t ws_bytes, bool zero_info, hipStream_t st);
 
+int chol_inv_bwd_impl(const float* L, const float* T, const float* gL, const float* gT, float* gA, int nbatch, int n,
+                      void* ws, size_t ws_bytes, bool gl_lower, hipStream_t st);
+
 // Optional per-kernel timing with hipEvents on the launch stream (vargp_prof_* in the C ABI).
 // Disabled (one branch) unless vargp_prof_enable(1); skipped while the stream is being captured.
 struct ProfScope {

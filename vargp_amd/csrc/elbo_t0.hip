@@ -807,7 +807,8 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
     hipLaunchKernelGGL(t0_unpack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, o.gRK, g_u_mean, o.gLL + SC * MM, S, C,
                        M, LD, total);
   }
-  rc = vargp_chol_inv_bwd(o.LL, o.TT, o.gLL, o.gTT, o.gKS, SC + C, M, o.chol, o.chol_bytes, stream);
+  // gLL is lower-triangular by construction (diagonal for the K_uu factors, the L_S block of gRK for the S_u ones)
+  rc = chol_inv_bwd_impl(o.LL, o.TT, o.gLL, o.gTT, o.gKS, SC + C, M, o.chol, o.chol_bytes, true, st);
   if (rc) return rc;
   {
     const int64_t total = (int64_t)C * MM;
