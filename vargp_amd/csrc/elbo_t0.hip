@@ -360,26 +360,57 @@ __global__ __launch_bounds__(256) void t0_softmax_kernel(const float* __restrict
 // ---------------------------------------------------------------------------------------------------------------
 // backward kernels
 // ---------------------------------------------------------------------------------------------------------------
-// KL backward into the small columns of gQP and the diagonal of gLz, plus the backward's zero-fills.
-//   gQP[:, 0] = ga + g a ; gQP[:, 1..3] = 0 ; gQP[:, 4+M .. 4+2M) = g tril(G2) ; pad columns = 0   (g = seed_kl / S)
-//   gLz = diag(g / Lz_ii) ; gT of the S_u factors = 0 ; trailing blocks zero the r / c / gtheta accumulators.
-// (the G block of gQP is written by a GEMM, the P block by t0_pdiag_bwd_kernel)
-__global__ __launch_bounds__(256) void t0_kl_bwd_kernel(const float* __restrict__ QP, const float* __restrict__ Lz,
-                                                        const float* __restrict__ ga, const float* __restrict__ seeds,
-                                                        float* __restrict__ gQP, float* __restrict__ gLz,
-                                                        float* __restrict__ gTtail, float* __restrict__ zero_begin,
-                                                        int64_t zero_count, int S, int C, int M, int NR, int LD, int nkx,
-                                                        int nkl) {
-  if ((int)blockIdx.x >= nkl) {
-    const int nz = gridDim.x - nkl;
-    for (int64_t i = (int64_t)((int)blockIdx.x - nkl) * 256 + threadIdx.x; i < zero_count; i += (int64_t)nz * 256)
-      zero_begin[i] = 0.f;
+// First backward launch, three roles by block index.
+//   blocks < npd (one per row (b, m) of P): predictive-moment backward (gp_utils.py:178-186): gP into the P block of
+//       gQP, gW, the row reduction ga = sum_col P gmu and with it gQP[:, 0] = ga + g a; row 0 of each b also reduces
+//       gkd.  gscale (nullable) = seed multiplying the stored unscaled softmax gradients.
+//   next nkl blocks: KL backward into the remaining small columns of gQP and the diagonal of gLz:
+//       gQP[:, 1..3] = 0 ; gQP[:, 4+M .. 4+2M) = g tril(G2) ; pad columns = 0 ; gLz = diag(g / Lz_ii) ;
+//       gT of the S_u factors = 0                                                          (g = seed_kl / S)
+//   rest: zero-fill of the r / c / gtheta accumulators of the kernel-matrix backward.
+// (the G block of gQP is written by a GEMM afterwards)
+__global__ __launch_bounds__(256) void t0_bwd_head_kernel(const float* __restrict__ QP, const float* __restrict__ W,
+                                                          const float* __restrict__ gmu, const float* __restrict__ gvar,
+                                                          const float* __restrict__ gscale, const float* __restrict__ Lz,
+                                                          const float* __restrict__ seeds, float* __restrict__ gQP,
+                                                          float* __restrict__ gW, float* __restrict__ gkd,
+                                                          float* __restrict__ gLz, float* __restrict__ gTtail,
+                                                          float* __restrict__ zero_begin, int64_t zero_count, int S, int C,
+                                                          int M, int B, int NR, int LD, int npd, int nkx, int nkl) {
+  __shared__ float red[4];
+  const float g = seeds[1] / (float)S;
+  if ((int)blockIdx.x < npd) {
+    const int m = (int)blockIdx.x % M;
+    const int64_t b = blockIdx.x / M;
+    const int64_t offp = (b * M + m) * LD + NR, offw = (b * M + m) * B;
+    const float am = QP[(b * M + m) * LD];
+    const float gs = gscale ? gscale[0] : 1.f;
+    float acc = 0.f, accv = 0.f;
+    for (int col = threadIdx.x; col < B; col += 256) {
+      const float gm = gs * gmu[b * B + col], gv = gs * gvar[b * B + col];
+      const float pv = QP[offp + col], wv = W[offw + col];
+      gQP[offp + col] = am * gm - 2.f * pv * gv;
+      gW[offw + col] = 2.f * wv * gv;
+      acc = fmaf(pv, gm, acc);
+      accv += gv;
+    }
+    const float t = block_sum<256>(acc, red);
+    if (threadIdx.x == 0) gQP[(b * M + m) * LD] = t + g * am;
+    if (m == 0) {
+      const float tv = block_sum<256>(accv, red);
+      if (threadIdx.x == 0) gkd[b] = tv;
+    }
     return;
   }
-  const int64_t b = blockIdx.x / nkx;
+  const int id = (int)blockIdx.x - npd;
+  if (id >= nkl) {
+    const int nz = gridDim.x - npd - nkl;
+    for (int64_t i = (int64_t)(id - nkl) * 256 + threadIdx.x; i < zero_count; i += (int64_t)nz * 256) zero_begin[i] = 0.f;
+    return;
+  }
+  const int64_t b = id / nkx;
   const int s = b / C, c = b % C;
-  const int i0 = ((int)blockIdx.x % nkx) * kKlRows, i1 = min(M, i0 + kKlRows);
-  const float g = seeds[1] / (float)S;
+  const int i0 = (id % nkx) * kKlRows, i1 = min(M, i0 + kKlRows);
   const float* q = QP + b * M * LD;
   float* gq = gQP + b * M * LD;
   for (int e0 = threadIdx.x; e0 < (i1 - i0) * M; e0 += 256) {
@@ -390,39 +421,8 @@ __global__ __launch_bounds__(256) void t0_kl_bwd_kernel(const float* __restrict_
     if (s == 0) gTtail[(int64_t)c * M * M + e] = 0.f;
   }
   for (int i = i0 + threadIdx.x; i < i1; i += 256) {
-    gq[(int64_t)i * LD] = ga[b * M + i] + g * q[(int64_t)i * LD];
     gq[(int64_t)i * LD + 1] = 0.f; gq[(int64_t)i * LD + 2] = 0.f; gq[(int64_t)i * LD + 3] = 0.f;
     for (int col = 4 + 2 * M; col < NR; ++col) gq[(int64_t)i * LD + col] = 0.f;
-  }
-}
-
-// grid (M, S*C): one block per row; gP (into gQP), gW elementwise, ga row reduction; block m == 0 also reduces gkd.
-// gscale (nullable): seed multiplying the stored unscaled softmax gradients.
-__global__ __launch_bounds__(256) void t0_pdiag_bwd_kernel(const float* __restrict__ QP, const float* __restrict__ W,
-                                                           const float* __restrict__ gmu, const float* __restrict__ gvar,
-                                                           const float* __restrict__ gscale, float* __restrict__ gQP,
-                                                           float* __restrict__ gW, float* __restrict__ ga,
-                                                           float* __restrict__ gkd, int M, int B, int NR, int LD) {
-  __shared__ float red[4];
-  const int m = blockIdx.x;
-  const int64_t b = blockIdx.y;
-  const int64_t offp = (b * M + m) * LD + NR, offw = (b * M + m) * B;
-  const float am = QP[(b * M + m) * LD];
-  const float gs = gscale ? gscale[0] : 1.f;
-  float acc = 0.f, accv = 0.f;
-  for (int col = threadIdx.x; col < B; col += 256) {
-    const float gm = gs * gmu[b * B + col], gv = gs * gvar[b * B + col];
-    const float pv = QP[offp + col], wv = W[offw + col];
-    gQP[offp + col] = am * gm - 2.f * pv * gv;
-    gW[offw + col] = 2.f * wv * gv;
-    acc = fmaf(pv, gm, acc);
-    accv += gv;
-  }
-  const float t = block_sum<256>(acc, red);
-  if (threadIdx.x == 0) ga[b * M + m] = t;
-  if (m == 0) {
-    const float tv = block_sum<256>(accv, red);
-    if (threadIdx.x == 0) gkd[b] = tv;
   }
 }
 
@@ -440,12 +440,13 @@ __global__ void t0_unpack_kernel(const float* __restrict__ gRK, float* __restric
 }
 
 // gradient of the packed Cholesky vector of q(u):  gLu = sum_s gRK[.., Lu block] - seed_kl diag(1/Lu_ii) + 2 gS_u Lu,
-// through vec2tril (softplus on the diagonal).  One thread per (c, i, k <= i).
-__global__ void t0_gvec_kernel(const float* __restrict__ vec, const float* __restrict__ Lu, const float* __restrict__ gSu,
-                               const float* __restrict__ gRK, const float* __restrict__ seeds, float* __restrict__ gvec,
-                               int S, int C, int M, int LD, int64_t total) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= total) return;
+// through vec2tril (softplus on the diagonal).  One thread per (c, i, k <= i).  (A role of t0_w_kernel.)
+__device__ __forceinline__ void t0_gvec_role(int blk, const float* __restrict__ vec, const float* __restrict__ Lu,
+                                             const float* __restrict__ gSu, const float* __restrict__ gRK,
+                                             const float* __restrict__ seeds, float* __restrict__ gvec, int S, int C,
+                                             int M, int LD) {
+  const int64_t e = (int64_t)blk * 256 + threadIdx.x;
+  if (e >= (int64_t)C * M * M) return;
   const int k = e % M, i = (e / M) % M;
   const int64_t c = e / ((int64_t)M * M);
   if (k > i) return;
@@ -472,14 +473,21 @@ __global__ void t0_gvec_kernel(const float* __restrict__ vec, const float* __res
 // W = gK o K for both kernel matrices (see rbf.hip for the algebra).
 //   blocks < nuf : K_uf, in place on the K_uf block of gRK (row stride LD); row sums r_uf, column sums c_uf (atomics),
 //                  2 sum W into gtheta[s, D]
-//   blocks >= nuf: K_uu, one wave per row: Wuu = W + W^T, r_uu = its row sums, sum Wuu (= 2 sum W) into gtheta[s, D]
+//   next nuu     : K_uu, one wave per row: Wuu = W + W^T, r_uu = its row sums, sum Wuu (= 2 sum W) into gtheta[s, D]
+//   rest         : the packed-Cholesky-vector gradient (t0_gvec_role), which only shares the launch
 __global__ __launch_bounds__(256) void t0_w_kernel(const float* __restrict__ RK, float* __restrict__ gRK,
                                                    const float* __restrict__ Kuu, const float* __restrict__ gKuu,
                                                    float* __restrict__ Wuu, float* __restrict__ r_uu,
                                                    float* __restrict__ r_uf, float* __restrict__ c_uf,
                                                    float* __restrict__ gtheta, int S, int C, int M, int B, int D, int NR,
-                                                   int LD, int gx, int gy, int nuf) {
+                                                   int LD, int gx, int gy, int nuf, int nuu, const float* __restrict__ vec,
+                                                   const float* __restrict__ Lu, const float* __restrict__ seeds,
+                                                   float* __restrict__ gvec) {
   __shared__ float red[4];
+  if ((int)blockIdx.x >= nuf + nuu) {
+    t0_gvec_role((int)blockIdx.x - nuf - nuu, vec, Lu, gKuu + (int64_t)S * C * M * M, gRK, seeds, gvec, S, C, M, LD);
+    return;
+  }
   const int lane = threadIdx.x & 63;
   if ((int)blockIdx.x < nuf) {
     const int id = blockIdx.x;
@@ -774,14 +782,13 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
     rc = vargp_softmax_nll_bwd(o.mu, o.var, eps_f, d->y, seeds + 2, o.gmu, o.gvar, S, F, C, B, stream);
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(t0_pdiag_bwd_kernel, dim3(M, SC), dim3(256), 0, st, o.QP, o.W, o.gmu, o.gvar,
-                     fused_softmax ? seeds + 2 : nullptr, o.gQP, o.gW, o.ga, o.gkd, M, B, NR, LD);
   {
-    const int nkx = cdiv(M, kKlRows), nkl = nkx * SC;
+    const int npd = M * SC, nkx = cdiv(M, kKlRows), nkl = nkx * SC;
     const int64_t zc = o.r_uu - o.r_uf;
     const int nz = (int)std::min<int64_t>(64, cdiv(zc, 1024));
-    hipLaunchKernelGGL(t0_kl_bwd_kernel, dim3(nkl + nz), dim3(256), 0, st, o.QP, o.LL, o.ga, seeds, o.gQP, o.gLL,
-                       o.gTT + SC * MM, o.r_uf, zc, S, C, M, NR, LD, nkx, nkl);
+    hipLaunchKernelGGL(t0_bwd_head_kernel, dim3(npd + nkl + nz), dim3(256), 0, st, o.QP, o.W, o.gmu, o.gvar,
+                       fused_softmax ? seeds + 2 : nullptr, o.LL, seeds, o.gQP, o.gW, o.gkd, o.gLL, o.gTT + SC * MM, o.r_uf,
+                       zc, S, C, M, B, NR, LD, npd, nkx, nkl);
   }
   {  // W = G^T P:  gG = P gW^T (G block of gQP),  gP += G gW
     GemmParams p = flat_gemm(o.QP + NR, LD, MLD, o.gW, B, MB, o.gQP + 4, LD, MLD, M, M, B);
@@ -810,18 +817,14 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
   // gLL is lower-triangular by construction (diagonal for the K_uu factors, the L_S block of gRK for the S_u ones)
   rc = chol_inv_bwd_impl(o.LL, o.TT, o.gLL, o.gTT, o.gKS, SC + C, M, o.chol, o.chol_bytes, true, st);
   if (rc) return rc;
-  {
-    const int64_t total = (int64_t)C * MM;
-    hipLaunchKernelGGL(t0_gvec_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, d->u_tril_vec, o.Lu, o.gKS + SC * MM,
-                       o.gRK, seeds, g_u_tril_vec, S, C, M, LD, total);
-  }
   // kernel matrices -> z, theta
   const int64_t zrows = (int64_t)C * M;
   {
     const int gx = cdiv(B, 256), gy = cdiv(zrows, kWRows), nuf = gx * gy * S;
     const int nuu = SC * cdiv(M, kUuRows);
-    hipLaunchKernelGGL(t0_w_kernel, dim3(nuf + nuu), dim3(256), 0, st, o.RK, o.gRK, o.KS, o.gKS, o.Wuu, o.r_uu, o.r_uf,
-                       o.c_uf, o.gtheta, S, C, M, B, D, NR, LD, gx, gy, nuf);
+    const int ngv = cdiv((int64_t)C * MM, 256);      // + the gradient of the packed Cholesky vector of q(u)
+    hipLaunchKernelGGL(t0_w_kernel, dim3(nuf + nuu + ngv), dim3(256), 0, st, o.RK, o.gRK, o.KS, o.gKS, o.Wuu, o.r_uu, o.r_uf,
+                       o.c_uf, o.gtheta, S, C, M, B, D, NR, LD, gx, gy, nuf, nuu, d->u_tril_vec, o.Lu, seeds, g_u_tril_vec);
   }
   {
     GemmParams p0{}, p1{};
