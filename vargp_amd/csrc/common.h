@@ -83,6 +83,9 @@ int launch_gemm(const GemmParams& p, int transA, int transB, int nbatch, bool rb
                 const char* tag = "bgemm");
 int launch_gemm_pair(const GemmParams& p0, int nbatch0, const GemmParams& p1, int nbatch1, int transA, int transB,
                      bool rbf, hipStream_t st, const char* tag0, const char* tag1);
+bool chol_rbf_gemm_applicable(int n, const GemmParams& p);
+int launch_chol_rbf_gemm(const float* A, float eps, float* L, float* T, int32_t* info, int nchol, int n,
+                         const GemmParams& p, int nbatch, hipStream_t st);
 // number of K splits launch_gemm will use for an RBF product of this shape (1 = fused epilogue, no partials)
 int rbf_splitk(int M, int N, int K, int nbatch);
 

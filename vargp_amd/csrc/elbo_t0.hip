@@ -696,6 +696,7 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
     hipLaunchKernelGGL(t0_prologue_kernel, dim3(grid), dim3(256), 0, st, a);
   }
   // kernel matrices: K_uu -> KS[:SC], K_uf -> the trailing block of RK
+  bool merged = false;
   if (D <= kRbfDirectD) {
     rc = rbf_direct_launch(d->z, nullptr, o.w, o.g2, o.KS, M, S, C, M, M, D, o.Dp, 0, st);
     if (rc) return rc;
@@ -724,12 +725,24 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
     p1.kscale = o.w; p1.ks_ld = o.Dp; p1.g2 = o.g2;
     p1.na = o.na; p1.sNa[0] = zrows;
     p1.nbv = o.nb; p1.sNb[0] = B;
-    rc = launch_gemm_pair(p0, SC, p1, S, 0, 1, true, st, "rbf_kuu_gemm", "rbf_kuf_gemm");
-    if (rc) return rc;
+    if (chol_rbf_gemm_applicable(M, p1)) {
+      // K_uu first, then ONE launch in which SC + C workgroups factorise (K_uu + eps I, S_u + eps I) while the rest of
+      // the chip builds K_uf, which nothing needs before the factors are done
+      rc = launch_gemm(p0, 0, 1, SC, true, st, "rbf_kuu_gemm");
+      if (rc) return rc;
+      rc = launch_chol_rbf_gemm(o.KS, d->jitter, o.LL, o.TT, d->info, SC + C, M, p1, S, st);
+      if (rc) return rc;
+      merged = true;
+    } else {
+      rc = launch_gemm_pair(p0, SC, p1, S, 0, 1, true, st, "rbf_kuu_gemm", "rbf_kuf_gemm");
+      if (rc) return rc;
+    }
   }
   // both factorisations (K_uu + eps I for every (s, c); S_u + eps I for every c) in one batch
-  rc = chol_inv_fwd_impl(o.KS, d->jitter, o.LL, o.TT, nullptr, d->info, SC + C, M, o.chol, o.chol_bytes, false, st);
-  if (rc) return rc;
+  if (!merged) {
+    rc = chol_inv_fwd_impl(o.KS, d->jitter, o.LL, o.TT, nullptr, d->info, SC + C, M, o.chol, o.chol_bytes, false, st);
+    if (rc) return rc;
+  }
   {
     const int64_t total = (int64_t)SC * M * NR;
     hipLaunchKernelGGL(t0_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, d->u_mean, o.LL + SC * MM, o.Lu, o.RK, C,

@@ -15,6 +15,7 @@
 // On gfx950 the f32 MFMA and the VALU/LDS/SALU issue of a SIMD do not overlap (measured: a slab costs its MFMA
 // cycles PLUS the issue cycles of everything else), so the kernel is written to minimise non-MFMA instructions.
 #include "common.h"
+#include "chol_small2.h"
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
@@ -548,6 +549,26 @@ int rbf_splitk(int M, int N, int K, int nbatch) {
   return force >= 2 ? 2 : 1;      // the workspace holds at most two partials
 }
 
+// One launch, two independent roles: workgroups [0, nchol) factorise one small matrix each (chol2_body: the K_uu + eps I
+// and S_u + eps I factorisations of the ELBO, a latency-bound chain of n pivots on nchol CUs), the others are tiles of an
+// RBF kernel-matrix GEMM (K_uf) that does not depend on the factorisations.  Both need 256 threads.  Launched
+// separately the GEMM would wait for the factorisation kernel, which leaves five sixths of the chip idle.
+struct CholArgs {
+  const float* A; int lda; int64_t sA; float eps;
+  float* L; int ldl; int64_t sL;
+  float* T; int ldt; int64_t sT;
+  int32_t* info; int n; int nchol;
+};
+template <int KCH>
+__global__ __launch_bounds__(256) void chol_rbf_gemm_kernel(const CholArgs c, const GemmParams p, const int tiles) {
+  if ((int)blockIdx.x < c.nchol) {
+    chol2_body<KCH>(blockIdx.x, c.A, c.lda, c.sA, c.eps, c.L, c.ldl, c.sL, c.T, c.ldt, c.sT, nullptr, c.info, 0, c.n, 0);
+    return;
+  }
+  const int id = (int)blockIdx.x - c.nchol;
+  gemm_body<64, 64, 64, true, true, true, true>(p, id % tiles, id / tiles, 0);
+}
+
 static bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 static bool gemm_vec_ok(const GemmParams& p) {
   bool vec = aligned16(p.A) && aligned16(p.B) && (p.lda % 4 == 0) && (p.ldb % 4 == 0);
@@ -575,6 +596,23 @@ int launch_gemm_pair(const GemmParams& p0, int nbatch0, const GemmParams& p1, in
   if (rbf) hipLaunchKernelGGL((gemm_pair_kernel<64, 64, 64, true, true, true, true>), dim3(total), dim3(256), 0, st, pp);
   else hipLaunchKernelGGL((gemm_pair_kernel<64, 64, 64, true, false, true, false>), dim3(total), dim3(256), 0, st, pp);
   return check_launch("gemm_pair");
+}
+
+// factorisations (n in (50, 100], dense n x n matrices) + one RBF GEMM in one launch; false if the shapes do not
+// qualify (the caller then launches them separately)
+bool chol_rbf_gemm_applicable(int n, const GemmParams& p) { return n > 50 && n <= 100 && gemm_vec_ok(p); }
+int launch_chol_rbf_gemm(const float* A, float eps, float* L, float* T, int32_t* info, int nchol, int n,
+                         const GemmParams& p, int nbatch, hipStream_t st) {
+  ProfScope prof("chol_rbf_gemm", st);
+  const int64_t nn = (int64_t)n * n;
+  CholArgs c{A, n, nn, eps, L, n, nn, T, n, nn, info, n, nchol};
+  GemmParams q = p;
+  q.splitk = 1;
+  const int tiles = cdiv(p.M, 64) * cdiv(p.N, 64);
+  const int total = nchol + tiles * nbatch;
+  if (n <= 65) hipLaunchKernelGGL((chol_rbf_gemm_kernel<13>), dim3(total), dim3(256), 0, st, c, q, tiles);
+  else hipLaunchKernelGGL((chol_rbf_gemm_kernel<20>), dim3(total), dim3(256), 0, st, c, q, tiles);
+  return check_launch("chol_rbf_gemm");
 }
 
 // last launch per tag, kept for vargp_prof_replay (measurement only)
