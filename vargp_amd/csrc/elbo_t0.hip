@@ -19,6 +19,7 @@
 
 namespace vargp {
 
+constexpr int kKuuSplit = 4;   // K-splits of the K_uu distance GEMM (few workgroups, long K loop: split to use the chip)
 constexpr int kKlRows = 8;     // rows of one (s, c) block per KL workgroup
 constexpr int kWRows = 8;      // rows per workgroup of the W = gK o K pass (K_uf role)
 constexpr int kUuRows = 16;    // rows per workgroup of the same pass, K_uu role
@@ -69,6 +70,7 @@ struct T0Ws {
   float *gmu, *gvar;               // accumulators zeroed by the forward prologue (softmax gradient, unscaled)
   float *r_uf, *c_uf, *gtheta;     // accumulators zeroed by the first backward kernel
   float *r_uu, *gW, *ga, *gkd, *gQP, *gLL, *gTT, *gRK, *gKS, *Wuu, *Puu, *Puf;
+  float* kpart;                    // split-K partial inner products of K_uu (forward only: aliases gRK)
   void* chol;
   size_t chol_bytes;
   int NR, LD;
@@ -97,6 +99,7 @@ static T0Ws carve_t0(void* ws, int S, int C, int M, int D, int B, int F) {
   o.gQP = take(SC * M * o.LD); o.gLL = take((SC + C) * MM); o.gTT = take((SC + C) * MM);
   o.gRK = take(SC * M * o.LD); o.gKS = take((SC + C) * MM); o.Wuu = take(SC * MM);
   o.Puu = take(SC * M * D); o.Puf = take(SC * M * D);
+  o.kpart = o.gRK;                 // kKuuSplit * SC * M * M <= SC * M * LD floats is checked where it is used
   const size_t cb = vargp_chol_workspace_bytes((int)(SC + C), M, 0), cbb = vargp_chol_workspace_bytes((int)(SC + C), M, 1);
   o.chol_bytes = cb > cbb ? cb : cbb;
   o.chol = p;
@@ -728,8 +731,19 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
     if (chol_rbf_gemm_applicable(M, p1)) {
       // K_uu first, then ONE launch in which SC + C workgroups factorise (K_uu + eps I, S_u + eps I) while the rest of
       // the chip builds K_uf, which nothing needs before the factors are done
-      rc = launch_gemm(p0, 0, 1, SC, true, st, "rbf_kuu_gemm");
-      if (rc) return rc;
+      if (D >= 256 && (int64_t)kKuuSplit * M <= LD) {
+        // 4 SC workgroups with D/64 slabs each would leave half the chip idle for the length of that K loop: split K,
+        // partial inner products to scratch, distance/exp epilogue in a second pass
+        GemmParams ps = p0;
+        ps.splitk = kKuuSplit; ps.sSplit = SC * MM; ps.C = o.kpart;
+        rc = launch_gemm(ps, 0, 1, SC, true, st, "rbf_kuu_gemm");
+        if (rc) return rc;
+        rc = rbf_combine_self_launch(o.kpart, kKuuSplit, o.na, o.g2, o.KS, S, C, M, st);
+        if (rc) return rc;
+      } else {
+        rc = launch_gemm(p0, 0, 1, SC, true, st, "rbf_kuu_gemm");
+        if (rc) return rc;
+      }
       rc = launch_chol_rbf_gemm(o.KS, d->jitter, o.LL, o.TT, d->info, SC + C, M, p1, S, st);
       if (rc) return rc;
       merged = true;
