@@ -126,7 +126,7 @@ int main(int argc, char** argv) {
         vargp_chol_inv_fwd(A, 1e-4f, L, T, nullptr, info, nb, n, nullptr, 0, nullptr);
         hipDeviceSynchronize();
         reinterpret_cast<void (*)(unsigned long long*)>(f)(st);
-        printf("   cycles per pivot (wave 0): loop %.0f  publish %.0f  barrier %.0f  lds-reads %.0f  fma %.0f\n",
+        printf("   cycles per pivot (wave 0): loop %.0f  look-ahead %.0f  barrier %.0f  readlanes %.0f  update %.0f\n",
                st[0] / (double)n, st[1] / (double)n, st[2] / (double)n, st[3] / (double)n, st[4] / (double)n);
       }
     }

@@ -55,6 +55,35 @@ __global__ void k_lds(double* out, uint64_t* cyc, int iters) {
   if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+// all 64 lanes read the SAME address (full broadcast), 25 values + 50 FMAs per iteration: the column-per-wave step
+__global__ void k_lds_same(double* out, uint64_t* cyc, int iters) {
+  __shared__ double buf[256];
+  buf[threadIdx.x & 255] = threadIdx.x * 1e-3;
+  __syncthreads();
+  double a[25], b[25];
+#pragma unroll
+  for (int k = 0; k < 25; ++k) { a[k] = threadIdx.x + k; b[k] = threadIdx.x * 0.5 + k; }
+  const double ma = 1e-3 * threadIdx.x, mb = -2e-3 * threadIdx.x;
+  const int w = threadIdx.x >> 6;
+  const uint64_t t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+    const double* p = buf + ((it & 1) * 128) + w;
+    double pv[25];
+#pragma unroll
+    for (int k = 0; k < 25; ++k) pv[k] = p[4 * k];
+    __builtin_amdgcn_sched_group_barrier(0x100, 25, 0);
+#pragma unroll
+    for (int k = 0; k < 25; ++k) { a[k] = fma(ma, pv[k], a[k]); b[k] = fma(mb, pv[k], b[k]); }
+    asm volatile("" ::: "memory");
+  }
+  const uint64_t t1 = __builtin_amdgcn_s_memtime();
+  double s = 0;
+#pragma unroll
+  for (int k = 0; k < 25; ++k) s += a[k] + b[k];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
 __global__ void k_bar(double* out, uint64_t* cyc, int iters) {
   __shared__ double buf[2][8];
   double s = 0;
@@ -121,6 +150,9 @@ int main() {
   for (int rep = 0; rep < 2; ++rep) k_bcast<<<30, 256>>>(out, cyc, iters);
   hipMemcpy(h, cyc, 8 * 30, hipMemcpyDeviceToHost);
   printf("bcast step (25 x [2 readlane + 2 fma_f64]), 256 threads: %.1f ticks per step\n", (double)h[0] / iters);
+  for (int rep = 0; rep < 2; ++rep) k_lds_same<<<30, 256>>>(out, cyc, iters);
+  hipMemcpy(h, cyc, 8 * 30, hipMemcpyDeviceToHost);
+  printf("same-address step (25 broadcast ds_read_b64 + 50 fma_f64), 256 threads: %.1f ticks per step\n", (double)h[0] / iters);
   // wall-clock calibration of the tick
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipEventRecord(e0); k_fma<<<30, 256>>>(out, cyc, 20000, 0.999); hipEventRecord(e1); hipEventSynchronize(e1);

@@ -1,13 +1,14 @@
 // Batched Cholesky (+ jitter) with explicit inverse factor T = L^-1 and log-determinant
 // (reference: gp_utils.cholesky, var_gp/gp_utils.py:5-11, plus every triangular_solve against it).
 //
-// n <= 100: one workgroup per matrix; fp64 in-place Gauss-Jordan on the packed triangle held in registers
-//   yields L and T = L^-1 together (see chol_inv_small_kernel).
+// n <= 100: one workgroup per matrix, the matrix in registers (fp64), forward elimination on [A | I] yields L and
+//   T = L^-1 together.  n <= 50: rows across threads, pivot row through LDS (chol_inv_small_kernel, below);
+//   50 < n <= 100: columns across waves, rows across lanes, pivot row by v_readlane (chol_small3.h).
 // n > 100: blocked right-looking on 96-wide panels; the diagonal blocks use the LDS kernel, the
 //   panel solves and trailing updates are MFMA GEMMs (gemm.hip).
 // Backward (any n) is four GEMMs (see chol_inv_bwd_impl).
 #include "common.h"
-#ifdef VARGP_CHOL_STAMPS   // per-phase cycle accounting of chol_inv_small2_kernel (wave 0 of block 0), tuning builds only
+#ifdef VARGP_CHOL_STAMPS   // per-phase cycle accounting of chol3_body (wave 0 of block 0), tuning builds only
 __device__ unsigned long long g_chol_stamps[8];
 extern "C" void vargp_debug_chol_stamps(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chol_stamps), 64); }
 #define STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc_[i] += t_ - last_; last_ = t_; } while (0)
@@ -17,10 +18,13 @@ extern "C" void vargp_debug_chol_stamps(unsigned long long* out) { (void)hipMemc
 #include <math.h>
 #include <type_traits>
 #include <stdlib.h>
-#include "chol_small2.h"
+#include "chol_small3.h"
 
 namespace vargp {
 
+constexpr int kCholP = 5;        // threads per matrix row of chol_inv_small_kernel
+// Packed lower-triangular index.
+__device__ __forceinline__ int pk(int i, int j) { return i * (i + 1) / 2 + j; }
 constexpr int kSmallMax = 100;  // largest n the register-resident kernel takes (packed triangle <= 512*10)
 constexpr int kNbSmall = 96;    // panel width of the blocked algorithm (multiple of 32, <= kSmallMax)
 
@@ -168,39 +172,38 @@ __global__ __launch_bounds__(512) void chol_inv_small_kernel(const float* __rest
   }
 }
 
-// stand-alone launch of chol2_body (chol_small2.h): two rows per thread, one matrix per workgroup
-template <int K>
-__global__ __launch_bounds__(256) void chol_inv_small2_kernel(const float* __restrict__ A, int lda, int64_t strideA,
+// stand-alone launch of chol3_body (chol_small3.h): columns across waves, rows across lanes
+template <int KC, int SETS>
+__global__ __launch_bounds__(256) void chol_inv_small3_kernel(const float* __restrict__ A, int lda, int64_t strideA,
                                                               float eps, float* __restrict__ L, int ldl,
                                                               int64_t strideL, float* __restrict__ T, int ldt,
                                                               int64_t strideT, float* __restrict__ logdet,
                                                               int32_t* __restrict__ info, int info_base, int n,
                                                               int logdet_accumulate) {
-  chol2_body<K>(blockIdx.x, A, lda, strideA, eps, L, ldl, strideL, T, ldt, strideT, logdet, info, info_base, n,
-                logdet_accumulate);
+  chol3_body<KC, SETS>(blockIdx.x, A, lda, strideA, eps, L, ldl, strideL, T, ldt, strideT, logdet, info, info_base, n,
+                       logdet_accumulate);
 }
 
 static int launch_small(const float* A, int lda, int64_t sA, float eps, float* L, int ldl, int64_t sL, float* T,
                         int ldt, int64_t sT, float* logdet, int32_t* info, int info_base, int nbatch, int n,
                         int ld_acc, hipStream_t st) {
   ProfScope prof("chol_inv_small", st);
-  static const bool rows1 = getenv("VARGP_CHOL_ROWS") && atoi(getenv("VARGP_CHOL_ROWS")) == 1;   // tuning aid
   const int nt = (int)round_up((int64_t)n * kCholP, 64);
 #define VARGP_CHOL_LAUNCH(K)                                                                                     \
   hipLaunchKernelGGL((chol_inv_small_kernel<double, K>), dim3(nbatch), dim3(nt), 0, st, A, lda, sA, eps, L, ldl, sL, \
                      T, ldt, sT, logdet, info, info_base, n, ld_acc)
+#define VARGP_CHOL3_LAUNCH(KC, SETS)                                                                                   \
+  hipLaunchKernelGGL((chol_inv_small3_kernel<KC, SETS>), dim3(nbatch), dim3(256), 0, st, A, lda, sA, eps, L, ldl, sL, T, \
+                     ldt, sT, logdet, info, info_base, n, ld_acc)
+  // measured (batch 30, MI355X): rows-across-threads kernel 10 / 22 us at n = 20 / 40; columns-across-waves kernel
+  // 48 / 65 us at n = 64 / 100
   if (n <= 20) VARGP_CHOL_LAUNCH(4);
   else if (n <= 40) VARGP_CHOL_LAUNCH(8);
-  else if (n <= 50) VARGP_CHOL_LAUNCH(13);
-  else if (rows1 && n <= 65) VARGP_CHOL_LAUNCH(13);
-  else if (rows1) VARGP_CHOL_LAUNCH(20);
-  else if (n <= 65)
-    hipLaunchKernelGGL((chol_inv_small2_kernel<13>), dim3(nbatch), dim3(256), 0, st, A, lda, sA, eps, L, ldl, sL, T, ldt,
-                       sT, logdet, info, info_base, n, ld_acc);
-  else   // n <= 100
-    hipLaunchKernelGGL((chol_inv_small2_kernel<20>), dim3(nbatch), dim3(256), 0, st, A, lda, sA, eps, L, ldl, sL, T, ldt,
-                       sT, logdet, info, info_base, n, ld_acc);
+  else if (n <= 50) VARGP_CHOL_LAUNCH(10);
+  else if (n <= 64) VARGP_CHOL3_LAUNCH(16, 1);
+  else VARGP_CHOL3_LAUNCH(25, 2);   // n <= 100
 #undef VARGP_CHOL_LAUNCH
+#undef VARGP_CHOL3_LAUNCH
   return check_launch("chol_inv_small");
 }
 

@@ -15,7 +15,7 @@
 // On gfx950 the f32 MFMA and the VALU/LDS/SALU issue of a SIMD do not overlap (measured: a slab costs its MFMA
 // cycles PLUS the issue cycles of everything else), so the kernel is written to minimise non-MFMA instructions.
 #include "common.h"
-#include "chol_small2.h"
+#include "chol_small3.h"
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
@@ -549,7 +549,7 @@ int rbf_splitk(int M, int N, int K, int nbatch) {
   return force >= 2 ? 2 : 1;      // the workspace holds at most two partials
 }
 
-// One launch, two independent roles: workgroups [0, nchol) factorise one small matrix each (chol2_body: the K_uu + eps I
+// One launch, two independent roles: workgroups [0, nchol) factorise one small matrix each (chol3_body: the K_uu + eps I
 // and S_u + eps I factorisations of the ELBO, a latency-bound chain of n pivots on nchol CUs), the others are tiles of an
 // RBF kernel-matrix GEMM (K_uf) that does not depend on the factorisations.  Both need 256 threads.  Launched
 // separately the GEMM would wait for the factorisation kernel, which leaves five sixths of the chip idle.
@@ -559,10 +559,11 @@ struct CholArgs {
   float* T; int ldt; int64_t sT;
   int32_t* info; int n; int nchol;
 };
-template <int KCH>
+template <int KC, int SETS>
 __global__ __launch_bounds__(256) void chol_rbf_gemm_kernel(const CholArgs c, const GemmParams p, const int tiles) {
   if ((int)blockIdx.x < c.nchol) {
-    chol2_body<KCH>(blockIdx.x, c.A, c.lda, c.sA, c.eps, c.L, c.ldl, c.sL, c.T, c.ldt, c.sT, nullptr, c.info, 0, c.n, 0);
+    chol3_body<KC, SETS>(blockIdx.x, c.A, c.lda, c.sA, c.eps, c.L, c.ldl, c.sL, c.T, c.ldt, c.sT, nullptr, c.info, 0, c.n,
+                         0);
     return;
   }
   const int id = (int)blockIdx.x - c.nchol;
@@ -610,8 +611,8 @@ int launch_chol_rbf_gemm(const float* A, float eps, float* L, float* T, int32_t*
   q.splitk = 1;
   const int tiles = cdiv(p.M, 64) * cdiv(p.N, 64);
   const int total = nchol + tiles * nbatch;
-  if (n <= 65) hipLaunchKernelGGL((chol_rbf_gemm_kernel<13>), dim3(total), dim3(256), 0, st, c, q, tiles);
-  else hipLaunchKernelGGL((chol_rbf_gemm_kernel<20>), dim3(total), dim3(256), 0, st, c, q, tiles);
+  if (n <= 64) hipLaunchKernelGGL((chol_rbf_gemm_kernel<16, 1>), dim3(total), dim3(256), 0, st, c, q, tiles);
+  else hipLaunchKernelGGL((chol_rbf_gemm_kernel<25, 2>), dim3(total), dim3(256), 0, st, c, q, tiles);
   return check_launch("chol_rbf_gemm");
 }
 
