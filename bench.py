@@ -96,11 +96,12 @@ def stress(args, device):
     print(json.dumps(res))
 
 
-def measured_traffic():
-    """HBM bytes of one K_uf launch from the committed rocprofv3 PMC passes (profiles/README.md); None if absent."""
+def measured_traffic(tag):
+    """HBM bytes of one launch of the kernel tagged `tag`, from the committed rocprofv3 PMC passes
+    (profiles/README.md); None if absent."""
     try:
         with open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')) as f:
-            return json.load(f)['traffic_bytes']
+            return json.load(f)[tag]['traffic_bytes']
     except Exception:
         return None
 
@@ -222,22 +223,34 @@ def main():
         out = run()
     sync()
     dt = time.perf_counter() - t0
-    # Dominant kernel: hipEvents cannot bracket a node of a replayed graph, and an event pair around a single launch
-    # also times the dispatch gap (+10 us here).  The K_uf distance GEMM of the step (same shapes, buffers held
-    # below) is therefore re-launched back to back between ONE pair of events right after the timed region.
+    # Dominant kernels: hipEvents cannot bracket a node of a replayed graph, and an event pair around a single launch
+    # also times the dispatch gap (+10 us here).  So one more (eager) step is run with launch recording on, and the
+    # recorded launches -- same kernels, same shapes, the trainer's live buffers -- are re-launched back to back between
+    # ONE pair of events (vargp_prof_remember / vargp_prof_replay).
+    #   first task: "chol_rbf_gemm" = the longest launch of the step (K_uu / S_u factorisations + the K_uf distance GEMM
+    #   in one launch); "rbf_kuu_bwd_gemm" = the heaviest pure-MFMA launch (both W.Y products of the kernel backward).
+    #   later tasks (composed path): "rbf_kuf_gemm" = the K_uf distance GEMM of compute_pf_diag.
     _lib.prof_enable(False)
     _lib.prof_read('')
-    with torch.no_grad():
-        theta = gp.kernel.sample_hypers(S)
-        z_all = torch.cat([p['z'] for p in gp.prev_params] + [gp.z], dim=-2) if gp.prev_params else gp.z
-        S_, (C_, Mt_, D_) = theta.shape[0], z_all.shape
-        Kbuf = torch.empty(S_, C_, Mt_, x.shape[0], device=device)
-        ws = torch.empty(_lib.lib().vargp_rbf_workspace_bytes(S_, C_, Mt_, x.shape[0], D_, 0) // 4 + 1, device=device)
-        _lib.check(_lib.lib().vargp_rbf_gram_fwd(_lib.ptr(theta.contiguous()), _lib.ptr(z_all.contiguous()), _lib.ptr(x),
-                                                 _lib.ptr(Kbuf), S_, C_, Mt_, x.shape[0], D_, 1, _lib.ptr(ws), ws.numel() * 4,
-                                                 _lib.stream_ptr()), 'vargp_rbf_gram_fwd')
-        kern_us = _lib.prof_replay_kuf(100)
-        kern_n = 100
+    _lib.prof_remember(True)
+    trainer.step(x, y)
+    sync()
+    _lib.prof_remember(False)
+    kern_n = 100
+    kernels = {}
+    flops_kuf = 2.0 * S * C * M * (N_PREV + 1) * B * D
+    candidates = [('chol_rbf_gemm', flops_kuf, 'chol_rbf_gemm_kernel (K_uu/S_u factorisations, fp64, latency-bound, sharing '
+                   'one launch with the K_uf = rbf(z, x) distance GEMM; flops counted: the GEMM)'),
+                  ('rbf_kuu_bwd_gemm', 2.0 * S * C * M * D * (B + M), 'gemm_pair_kernel (W.Y products of the kernel-matrix '
+                   'backward: [C*M x B] x [B x D] per sample and [M x M] x [M x D] per (sample, class))'),
+                  ('rbf_kuf_gemm', flops_kuf, 'gemm_kernel<RBF> (K_uf = rbf(z, x))')]
+    for tag, fl, desc in candidates:
+        try:
+            kernels[tag] = (_lib.prof_replay(tag, kern_n), fl, desc)
+        except _lib.VargpHipError:
+            pass
+    primary = 'chol_rbf_gemm' if 'chol_rbf_gemm' in kernels else 'rbf_kuf_gemm'
+    kern_us, dominant_flops, dominant_desc = kernels[primary]
     kern_ms = kern_us * kern_n * 1e-3
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -260,11 +273,17 @@ def main():
                                else 'eager'),
                    elbo_rtol_vs_cpu=rtol, finite=bool(finite), cholesky_failures=errs,
                    final_loss=dict(kl_hypers=out[0].item(), kl_u=out[1].item(), nll=out[2].item()),
-                   roofline=dict(bound='mfma', kernel='gemm_kernel<RBF> (K_uf = rbf(z, x), vargp_rbf_gram_fwd)',
+                   roofline=dict(bound='mfma', kernel=dominant_desc,
                                  achieved=achieved, peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
                                  frac=(achieved / MFMA_F32_PEAK_TFLOPS) if achieved else None,
                                  launches=kern_n, avg_us=avg_s * 1e6,
-                                 traffic=measured_traffic() if args.workload == 'smnist' else None))
+                                 traffic=measured_traffic(primary) if args.workload == 'smnist' else None))
+        if 'rbf_kuu_bwd_gemm' in kernels and primary != 'rbf_kuu_bwd_gemm':
+            us2, fl2, desc2 = kernels['rbf_kuu_bwd_gemm']
+            res['roofline_gemm'] = dict(bound='mfma', kernel=desc2, achieved=fl2 / (us2 * 1e-6) / 1e12,
+                                        peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
+                                        frac=fl2 / (us2 * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, launches=kern_n, avg_us=us2,
+                                        traffic=measured_traffic('rbf_kuu_bwd_gemm') if args.workload == 'smnist' else None)
         if world == 1 and not args.no_cpu_baseline and args.workload == 'smnist':
             res['cpu_baseline'] = cpu_baseline(p0, x, y)
         print(json.dumps(res))

@@ -236,9 +236,15 @@ int vargp_hyper_kl_bwd(const float* mean, const float* logvar, const float* prio
  */
 int vargp_prof_enable(int on);
 int vargp_prof_read(const char* tag, double* total_ms, int64_t* launches);
-/* Re-launch the most recent K_uf distance GEMM `iters` times back to back between one pair of hipEvents on
- * `stream` and return the average per-launch time in microseconds (its buffers must still be alive). */
-int vargp_prof_replay_kuf(int iters, double* avg_us, vargp_stream_t stream);
+/* Launch replay, for timing one kernel of a step that otherwise runs inside a captured graph (hipEvents cannot
+ * bracket a graph node, and an event pair around a single launch also times the dispatch gap):
+ * vargp_prof_remember(1) makes the tagged launches ("rbf_kuf_gemm", "rbf_kuu_gemm", "rbf_kuu_bwd_gemm" = the pair
+ * launch of the two W.Y products, "chol_rbf_gemm" = factorisations + K_uf GEMM, "bgemm", ...) keep a copy of their
+ * arguments; vargp_prof_replay re-launches the most recent one with that tag `iters` times back to back between ONE
+ * pair of hipEvents on `stream` and returns the average time per launch in microseconds.  The buffers of the
+ * remembered launch must still be alive.  Synchronises. */
+int vargp_prof_remember(int on);
+int vargp_prof_replay(const char* tag, int iters, double* avg_us, vargp_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -76,7 +76,8 @@ _SIGNATURES = {
     'vargp_elbo_t0_bwd': (c_int, [POINTER(ElboT0Desc)] + [_P] * 7),
     'vargp_prof_enable': (c_int, [c_int]),
     'vargp_prof_read': (c_int, [c_char_p, POINTER(ctypes.c_double), POINTER(c_int64)]),
-    'vargp_prof_replay_kuf': (c_int, [c_int, POINTER(ctypes.c_double), _P]),
+    'vargp_prof_remember': (c_int, [c_int]),
+    'vargp_prof_replay': (c_int, [c_char_p, c_int, POINTER(ctypes.c_double), _P]),
     'vargp_yogi_step': (c_int, [_P, _P, _P, _P, c_int64] + [c_float] * 6 + [_P, _P]),
 }
 EXPORTS = sorted(_SIGNATURES)
@@ -140,8 +141,13 @@ def prof_read(tag):
     return ms.value, n.value
 
 
-def prof_replay_kuf(iters=50):
-    """Average time (us) of the most recent K_uf distance GEMM re-launched back to back (see vargp_hip.h)."""
+def prof_remember(on=True):
+    """While on, tagged launches keep a copy of their arguments for prof_replay (see vargp_hip.h)."""
+    lib().vargp_prof_remember(int(on))
+
+
+def prof_replay(tag, iters=50):
+    """Average time (us) of the most recent launch tagged `tag`, re-launched back to back (see vargp_hip.h)."""
     us = ctypes.c_double(0.0)
-    check(lib().vargp_prof_replay_kuf(int(iters), ctypes.byref(us), stream_ptr()), 'vargp_prof_replay_kuf')
+    check(lib().vargp_prof_replay(tag.encode(), int(iters), ctypes.byref(us), stream_ptr()), 'vargp_prof_replay')
     return us.value

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <functional>
 #include "../../include/vargp_hip.h"
 
 namespace vargp {
@@ -99,6 +100,11 @@ int chol_inv_fwd_impl(const float* A, float eps, float* L, float* T, float* logd
 
 int chol_inv_bwd_impl(const float* L, const float* T, const float* gL, const float* gT, float* gA, int nbatch, int n,
                       void* ws, size_t ws_bytes, bool gl_lower, hipStream_t st);
+
+// Launch replay (vargp_prof_remember / vargp_prof_replay): while remembering, tagged launch sites store a closure that
+// repeats the launch.
+bool prof_remembering();
+void prof_remember(const char* tag, std::function<void(hipStream_t)> relaunch);
 
 // Optional per-kernel timing with hipEvents on the launch stream (vargp_prof_* in the C ABI).
 // Disabled (one branch) unless vargp_prof_enable(1); skipped while the stream is being captured.

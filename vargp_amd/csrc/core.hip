@@ -143,6 +143,45 @@ extern "C" int vargp_yogi_step(float* p, const float* g, float* m, float* v, int
   return check_launch("yogi_step");
 }
 
+static bool g_remember = false;
+static std::vector<std::pair<std::string, std::function<void(hipStream_t)>>> g_replays;
+bool vargp::prof_remembering() { return g_remember; }
+void vargp::prof_remember(const char* tag, std::function<void(hipStream_t)> relaunch) {
+  for (auto& r : g_replays)
+    if (r.first == tag) { r.second = std::move(relaunch); return; }
+  g_replays.emplace_back(tag, std::move(relaunch));
+}
+extern "C" int vargp_prof_remember(int on) {
+  g_remember = on != 0;
+  if (!g_remember) return VARGP_OK;
+  g_replays.clear();
+  return VARGP_OK;
+}
+extern "C" int vargp_prof_replay(const char* tag, int iters, double* avg_us, vargp_stream_t stream) {
+  VARGP_REQUIRE(tag && iters > 0 && avg_us, "prof_replay: bad arguments");
+  const std::function<void(hipStream_t)>* fn = nullptr;
+  for (auto& r : g_replays)
+    if (r.first == tag) fn = &r.second;
+  VARGP_REQUIRE(fn, "prof_replay: no remembered launch tagged '%s'", tag);
+  const bool was = g_remember;
+  g_remember = false;                       // the replays themselves are not remembered
+  hipStream_t st = as_stream(stream);
+  hipEvent_t a, b;
+  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return VARGP_ELAUNCH;
+  for (int i = 0; i < 3; ++i) (*fn)(st);
+  (void)hipEventRecord(a, st);
+  for (int i = 0; i < iters; ++i) (*fn)(st);
+  (void)hipEventRecord(b, st);
+  (void)hipEventSynchronize(b);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, a, b);
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  *avg_us = 1e3 * ms / iters;
+  g_remember = was;
+  return check_launch("prof_replay");
+}
+
 extern "C" int vargp_prof_enable(int on) {
   g_prof_on = on != 0;
   return VARGP_OK;

@@ -586,6 +586,12 @@ int launch_gemm_pair(const GemmParams& p0, int nbatch0, const GemmParams& p1, in
     if (rc) return rc;
     return launch_gemm(p1, transA, transB, nbatch1, rbf, st, tag1);
   }
+  if (prof_remembering() && strcmp(tag0, "replay") != 0) {
+    const GemmParams c0 = p0, c1 = p1;
+    prof_remember(tag0, [c0, c1, nbatch0, nbatch1, transA, transB, rbf](hipStream_t s) {
+      launch_gemm_pair(c0, nbatch0, c1, nbatch1, transA, transB, rbf, s, "replay", "replay");
+    });
+  }
   ProfScope prof("gemm_pair", st);
   GemmPair pp;
   pp.p[0] = p0; pp.p[1] = p1;
@@ -601,9 +607,21 @@ int launch_gemm_pair(const GemmParams& p0, int nbatch0, const GemmParams& p1, in
 
 // factorisations (n in (50, 100], dense n x n matrices) + one RBF GEMM in one launch; false if the shapes do not
 // qualify (the caller then launches them separately)
+static int launch_chol_rbf_gemm_impl(const float* A, float eps, float* L, float* T, int32_t* info, int nchol, int n,
+                                     const GemmParams& p, int nbatch, hipStream_t st);
 bool chol_rbf_gemm_applicable(int n, const GemmParams& p) { return n > 50 && n <= 100 && gemm_vec_ok(p); }
 int launch_chol_rbf_gemm(const float* A, float eps, float* L, float* T, int32_t* info, int nchol, int n,
                          const GemmParams& p, int nbatch, hipStream_t st) {
+  if (prof_remembering()) {
+    const GemmParams pc = p;
+    prof_remember("chol_rbf_gemm", [=](hipStream_t s) {
+      launch_chol_rbf_gemm_impl(A, eps, L, T, info, nchol, n, pc, nbatch, s);
+    });
+  }
+  return launch_chol_rbf_gemm_impl(A, eps, L, T, info, nchol, n, p, nbatch, st);
+}
+static int launch_chol_rbf_gemm_impl(const float* A, float eps, float* L, float* T, int32_t* info, int nchol, int n,
+                                     const GemmParams& p, int nbatch, hipStream_t st) {
   ProfScope prof("chol_rbf_gemm", st);
   const int64_t nn = (int64_t)n * n;
   CholArgs c{A, n, nn, eps, L, n, nn, T, n, nn, info, n, nchol};
@@ -617,12 +635,13 @@ int launch_chol_rbf_gemm(const float* A, float eps, float* L, float* T, int32_t*
 }
 
 // last launch per tag, kept for vargp_prof_replay (measurement only)
-struct SavedGemm { GemmParams p; int transA, transB, nbatch; bool rbf; bool valid; };
-static SavedGemm g_saved_kuf{};
 
 int launch_gemm(const GemmParams& p, int transA, int transB, int nbatch, bool rbf, hipStream_t st, const char* tag) {
   if (p.M <= 0 || p.N <= 0 || nbatch <= 0) return VARGP_OK;
-  if (tag[0] == 'r' && strcmp(tag, "rbf_kuf_gemm") == 0) g_saved_kuf = SavedGemm{p, transA, transB, nbatch, rbf, true};
+  if (prof_remembering() && strcmp(tag, "replay") != 0) {
+    const GemmParams pc = p;
+    prof_remember(tag, [pc, transA, transB, nbatch, rbf](hipStream_t s) { launch_gemm(pc, transA, transB, nbatch, rbf, s, "replay"); });
+  }
   static const int nofast = [] { const char* e = getenv("VARGP_GEMM_NOFAST"); return e ? atoi(e) : 0; }();   // tuning aid
   const_cast<GemmParams&>(p).nofast = nofast;
   ProfScope prof(tag, st);
@@ -642,28 +661,6 @@ int launch_gemm(const GemmParams& p, int transA, int transB, int nbatch, bool rb
 }
 
 }  // namespace vargp
-
-// Re-launch the most recent K_uf distance GEMM (tag "rbf_kuf_gemm") `iters` times back to back between ONE pair of
-// hipEvents and return the average kernel time: per-launch event pairs include the dispatch gap, this does not.
-// The buffers of that launch must still be alive (bench.py holds them).  Synchronises.
-extern "C" int vargp_prof_replay_kuf(int iters, double* avg_us, vargp_stream_t stream) {
-  using namespace vargp;
-  VARGP_REQUIRE(g_saved_kuf.valid && iters > 0 && avg_us, "prof_replay_kuf: nothing recorded");
-  hipStream_t st = as_stream(stream);
-  hipEvent_t a, b;
-  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return VARGP_ELAUNCH;
-  for (int i = 0; i < 3; ++i) launch_gemm(g_saved_kuf.p, g_saved_kuf.transA, g_saved_kuf.transB, g_saved_kuf.nbatch, g_saved_kuf.rbf, st, "replay");
-  (void)hipEventRecord(a, st);
-  for (int i = 0; i < iters; ++i) launch_gemm(g_saved_kuf.p, g_saved_kuf.transA, g_saved_kuf.transB, g_saved_kuf.nbatch, g_saved_kuf.rbf, st, "replay");
-  (void)hipEventRecord(b, st);
-  (void)hipEventSynchronize(b);
-  float ms = 0.f;
-  (void)hipEventElapsedTime(&ms, a, b);
-  (void)hipEventDestroy(a);
-  (void)hipEventDestroy(b);
-  *avg_us = 1e3 * ms / iters;
-  return check_launch("prof_replay_kuf");
-}
 
 extern "C" int vargp_bgemm(const vargp_gemm_desc* d, vargp_stream_t stream) {
   using namespace vargp;
