@@ -488,9 +488,22 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int tile_id
   }
 }
 
+// Workgroup -> tile map that keeps each XCD on a compact set of tiles.  Workgroups go to the 8 XCDs round-robin by
+// linear id, and each XCD has its own L2: with the plain map the 8 column-tiles that share an A panel land on 8
+// different L2s and every panel is fetched 8 times (measured: 98 MB fetched by the backward pair GEMM against 12 MB of
+// operands).  Here XCD x works through the contiguous range [x T/8, (x+1) T/8) of the (batch, tile_m, tile_n) order
+// instead, so the tiles of one A panel meet in one L2.  A speed heuristic only: nothing depends on the placement.
+__device__ __forceinline__ int xcd_remap(int lin, int total) {
+  constexpr int kXcd = 8;
+  const int q = total / kXcd, r = total % kXcd;
+  const int xcd = lin % kXcd, idx = lin / kXcd;
+  return xcd * q + (xcd < r ? xcd : r) + idx;
+}
+
 template <int BM, int BN, int BK, bool AKC, bool BKC, bool VEC, bool RBF>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
-  gemm_body<BM, BN, BK, AKC, BKC, VEC, RBF>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+  const int id = xcd_remap((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
+  gemm_body<BM, BN, BK, AKC, BKC, VEC, RBF>(p, id % (int)gridDim.x, id / (int)gridDim.x, blockIdx.z);
 }
 
 // Two independent problems of the same kernel flavour in ONE launch (1-D grid: the workgroups of problem 0, then
@@ -498,8 +511,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 struct GemmPair { GemmParams p[2]; int nwg0; int tiles[2]; };
 template <int BM, int BN, int BK, bool AKC, bool BKC, bool VEC, bool RBF>
 __global__ __launch_bounds__(256) void gemm_pair_kernel(const GemmPair pp) {
+  // XCD-compact tile ranges within each problem (not across both: the two problems have different K, and a split
+  // across both would hand whole XCDs only short or only long workgroups)
   const int which = (int)blockIdx.x >= pp.nwg0 ? 1 : 0;       // wave-uniform
-  const int id = (int)blockIdx.x - (which ? pp.nwg0 : 0);
+  const int id = which ? xcd_remap((int)blockIdx.x - pp.nwg0, (int)gridDim.x - pp.nwg0) : xcd_remap((int)blockIdx.x, pp.nwg0);
   const int tiles = pp.tiles[which];
   if (which == 0) gemm_body<BM, BN, BK, AKC, BKC, VEC, RBF>(pp.p[0], id % tiles, id / tiles, 0);
   else gemm_body<BM, BN, BK, AKC, BKC, VEC, RBF>(pp.p[1], id % tiles, id / tiles, 0);
@@ -566,7 +581,7 @@ __global__ __launch_bounds__(256) void chol_rbf_gemm_kernel(const CholArgs c, co
                          0);
     return;
   }
-  const int id = (int)blockIdx.x - c.nchol;
+  const int id = xcd_remap((int)blockIdx.x - c.nchol, (int)gridDim.x - c.nchol);
   gemm_body<64, 64, 64, true, true, true, true>(p, id % tiles, id / tiles, 0);
 }
 
