@@ -332,7 +332,7 @@ int vargp::chol_inv_fwd_impl(const float* A, float eps, float* L, float* T, floa
 
 extern "C" int vargp_chol_inv_bwd(const float* L, const float* T, const float* gL, const float* gT, float* gA,
                                   int nbatch, int n, void* ws, size_t ws_bytes, vargp_stream_t stream) {
-  return vargp::chol_inv_bwd_impl(L, T, gL, gT, gA, nbatch, n, ws, ws_bytes, false, as_stream(stream));
+  return vargp::chol_inv_bwd_impl(L, T, gL, gT, gA, nbatch, n, ws, ws_bytes, false, as_stream(stream), false);
 }
 
 // With T = L^-1 (dT = -T dL T) the total gradient on L is  gL_tot = tril(gL) - tril(Y),  Y = T^T gT T^T, and
@@ -341,16 +341,34 @@ extern "C" int vargp_chol_inv_bwd(const float* L, const float* T, const float* g
 // L^T Y = (T L)^T gT T^T = gT T^T  (upper x strictly-upper is strictly upper).  So
 //   P = L^T tril(gL) - gT T^T :   four GEMMs in all (gT T^T, L^T gL, T^T S, (.) T) instead of five.
 // gl_lower: gL is already lower-triangular with stored zeros above the diagonal (skips the masking pass).
+// First product of the backward, w1 = gT T^T, optionally sharing its launch with an unrelated product `other` of the
+// caller (transposition flags oA / oB, batch onb) that is ready at the same time.
+int vargp::chol_inv_bwd_first(const float* T, const float* gT, int nbatch, int n, void* ws, size_t ws_bytes,
+                              const GemmParams* other, int oA, int oB, int onb, hipStream_t st) {
+  VARGP_REQUIRE(T && gT && ws && ws_bytes >= vargp_chol_workspace_bytes(nbatch, n, 1), "chol_inv_bwd_first: bad arguments");
+  const int64_t nn = (int64_t)n * n;
+  float* w1 = reinterpret_cast<float*>(ws);
+  GemmParams p{};
+  p.A = gT; p.B = T; p.C = w1;
+  p.M = n; p.N = n; p.K = n; p.lda = n; p.ldb = n; p.ldc = n; p.ldd = n;
+  p.nb1 = 1; p.nb2 = 1;
+  p.sA[0] = nn; p.sB[0] = nn; p.sC[0] = nn; p.sD[0] = nn;
+  p.alpha = 1.f;
+  p.triB = 2;
+  if (other) return launch_gemm_pair2(p, 0, 1, nbatch, *other, oA, oB, onb, st, "chol_bwd1_pair");
+  return launch_gemm(p, 0, 1, nbatch, false, st);
+}
+
 int vargp::chol_inv_bwd_impl(const float* L, const float* T, const float* gL, const float* gT, float* gA, int nbatch,
-                             int n, void* ws, size_t ws_bytes, bool gl_lower, hipStream_t st) {
+                             int n, void* ws, size_t ws_bytes, bool gl_lower, hipStream_t st, bool first_done) {
   VARGP_REQUIRE(L && T && gA && ws, "chol_inv_bwd: null pointer");
   VARGP_REQUIRE(ws_bytes >= vargp_chol_workspace_bytes(nbatch, n, 1), "chol_inv_bwd: workspace too small");
   const int64_t nn = (int64_t)n * n, total = nn * nbatch;
   float* w1 = reinterpret_cast<float*>(ws);
   float* w2 = w1 + total;
   int rc;
-  if (gT) {   // w1 = gT T^T
-    rc = sq_gemm(gT, n, nn, 0, 0, T, n, nn, 1, 2, w1, n, nn, nullptr, 1.f, 0.f, n, n, n, 0, nbatch, st);
+  if (gT && !first_done) {   // w1 = gT T^T  (first_done: the caller ran chol_inv_bwd_first already)
+    rc = chol_inv_bwd_first(T, gT, nbatch, n, ws, ws_bytes, nullptr, 0, 0, 0, st);
     if (rc) return rc;
   }
   const float* P = w1;

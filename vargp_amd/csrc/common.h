@@ -84,6 +84,8 @@ int launch_gemm(const GemmParams& p, int transA, int transB, int nbatch, bool rb
                 const char* tag = "bgemm");
 int launch_gemm_pair(const GemmParams& p0, int nbatch0, const GemmParams& p1, int nbatch1, int transA, int transB,
                      bool rbf, hipStream_t st, const char* tag0, const char* tag1);
+int launch_gemm_pair2(const GemmParams& p0, int tA0, int tB0, int nbatch0, const GemmParams& p1, int tA1, int tB1,
+                      int nbatch1, hipStream_t st, const char* tag);
 bool chol_rbf_gemm_applicable(int n, const GemmParams& p);
 int launch_chol_rbf_gemm(const float* A, float eps, float* L, float* T, int32_t* info, int nchol, int n,
                          const GemmParams& p, int nbatch, hipStream_t st);
@@ -98,8 +100,10 @@ int rbf_combine_self_launch(const float* part, int nsplit, const float* na, cons
 int chol_inv_fwd_impl(const float* A, float eps, float* L, float* T, float* logdet, int32_t* info, int nbatch, int n,
                       void* ws, size_t ws_bytes, bool zero_info, hipStream_t st);
 
+int chol_inv_bwd_first(const float* T, const float* gT, int nbatch, int n, void* ws, size_t ws_bytes,
+                       const GemmParams* other, int oA, int oB, int onb, hipStream_t st);
 int chol_inv_bwd_impl(const float* L, const float* T, const float* gL, const float* gT, float* gA, int nbatch, int n,
-                      void* ws, size_t ws_bytes, bool gl_lower, hipStream_t st);
+                      void* ws, size_t ws_bytes, bool gl_lower, hipStream_t st, bool first_done);
 
 // Launch replay (vargp_prof_remember / vargp_prof_replay): while remembering, tagged launch sites store a closure that
 // repeats the launch.

@@ -817,32 +817,31 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
                        fused_softmax ? seeds + 2 : nullptr, o.LL, seeds, o.gQP, o.gW, o.gkd, o.gLL, o.gTT + SC * MM, o.r_uf,
                        zc, S, C, M, B, NR, LD, npd, nkx, nkl);
   }
-  {  // W = G^T P:  gG = P gW^T (G block of gQP),  gP += G gW
+  {  // W = G^T P:  gG = P gW^T (G block of gQP),  gP += G gW   -- independent of each other: one launch
     GemmParams p = flat_gemm(o.QP + NR, LD, MLD, o.gW, B, MB, o.gQP + 4, LD, MLD, M, M, B);
-    rc = launch_gemm(p, 0, 1, SC, false, st, "t0_gg_gemm");
-    if (rc) return rc;
     GemmParams q = flat_gemm(o.QP + 4, LD, MLD, o.gW, B, MB, o.gQP + NR, LD, MLD, M, B, M);
     q.triA = 1; q.D = o.gQP + NR; q.beta = 1.f;
-    rc = launch_gemm(q, 0, 0, SC, false, st, "t0_gp_gemm");
+    rc = launch_gemm_pair2(p, 0, 1, SC, q, 0, 0, SC, st, "t0_gg_gp_gemm");
     if (rc) return rc;
   }
-  {  // QP = T RK:  gT = tril(gQP RK^T),  gRK = T^T gQP
+  {  // QP = T RK:  gT = tril(gQP RK^T)
     GemmParams p = flat_gemm(o.gQP, LD, MLD, o.RK, LD, MLD, o.gTT, M, MM, M, M, NR + B);
     p.triC = 1;
     rc = launch_gemm(p, 0, 1, SC, false, st, "t0_gt_gemm");
     if (rc) return rc;
-    GemmParams q = flat_gemm(o.TT, M, MM, o.gQP, LD, MLD, o.gRK, LD, MLD, M, NR + B, M);
-    q.triA = 2;
-    rc = launch_gemm(q, 1, 0, SC, false, st, "t0_grk_gemm");
-    if (rc) return rc;
   }
+  // gRK = T^T gQP shares a launch with the first product of the Cholesky backward (w1 = gT T^T), which only needs gT
+  GemmParams grk = flat_gemm(o.TT, M, MM, o.gQP, LD, MLD, o.gRK, LD, MLD, M, NR + B, M);
+  grk.triA = 2;
+  rc = chol_inv_bwd_first(o.TT, o.gTT, SC + C, M, o.chol, o.chol_bytes, &grk, 1, 0, SC, st);
+  if (rc) return rc;
   {
     const int64_t total = (int64_t)C * M * (M + 1);
     hipLaunchKernelGGL(t0_unpack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, o.gRK, g_u_mean, o.gLL + SC * MM, S, C,
                        M, LD, total);
   }
   // gLL is lower-triangular by construction (diagonal for the K_uu factors, the L_S block of gRK for the S_u ones)
-  rc = chol_inv_bwd_impl(o.LL, o.TT, o.gLL, o.gTT, o.gKS, SC + C, M, o.chol, o.chol_bytes, true, st);
+  rc = chol_inv_bwd_impl(o.LL, o.TT, o.gLL, o.gTT, o.gKS, SC + C, M, o.chol, o.chol_bytes, true, st, true);
   if (rc) return rc;
   // kernel matrices -> z, theta
   const int64_t zrows = (int64_t)C * M;

@@ -245,15 +245,22 @@ __device__ __forceinline__ void store_piece(float* __restrict__ lds, const float
   }
 }
 
+// floats of LDS gemm_body needs (two stages); the kernel owns the array so that several bodies can share one
+template <int BM, int BN, int BK, bool AKC, bool BKC>
+constexpr int gemm_lds_floats() {
+  return 2 * (((LdsLayout<AKC, BM, BK>::kSize + 3) & ~3) + ((LdsLayout<BKC, BN, BK>::kSize + 3) & ~3));
+}
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
 template <int BM, int BN, int BK, bool AKC, bool BKC, bool VEC, bool RBF>
-__device__ __forceinline__ void gemm_body(const GemmParams& p, const int tile_id, const int batch_id, const int split_id) {
+__device__ __forceinline__ void gemm_body(const GemmParams& p, const int tile_id, const int batch_id, const int split_id,
+                                          float* __restrict__ lds) {
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   using LA = LdsLayout<AKC, BM, BK>;
   using LB = LdsLayout<BKC, BN, BK>;
   // two LDS stages: slab s is consumed from stage s&1 while slab s+1 is written to the other one,
   // so one barrier per slab is enough and the staging writes overlap the MFMAs
   constexpr int kStage = ((LA::kSize + 3) & ~3) + ((LB::kSize + 3) & ~3);
-  __shared__ __attribute__((aligned(16))) float lds[2 * kStage];
 
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tm = tile_id / tiles_n, tn = tile_id % tiles_n;
@@ -502,8 +509,9 @@ __device__ __forceinline__ int xcd_remap(int lin, int total) {
 
 template <int BM, int BN, int BK, bool AKC, bool BKC, bool VEC, bool RBF>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
+  __shared__ __attribute__((aligned(16))) float lds[gemm_lds_floats<BM, BN, BK, AKC, BKC>()];
   const int id = xcd_remap((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
-  gemm_body<BM, BN, BK, AKC, BKC, VEC, RBF>(p, id % (int)gridDim.x, id / (int)gridDim.x, blockIdx.z);
+  gemm_body<BM, BN, BK, AKC, BKC, VEC, RBF>(p, id % (int)gridDim.x, id / (int)gridDim.x, blockIdx.z, lds);
 }
 
 // Two independent problems of the same kernel flavour in ONE launch (1-D grid: the workgroups of problem 0, then
@@ -516,8 +524,21 @@ __global__ __launch_bounds__(256) void gemm_pair_kernel(const GemmPair pp) {
   const int which = (int)blockIdx.x >= pp.nwg0 ? 1 : 0;       // wave-uniform
   const int id = which ? xcd_remap((int)blockIdx.x - pp.nwg0, (int)gridDim.x - pp.nwg0) : xcd_remap((int)blockIdx.x, pp.nwg0);
   const int tiles = pp.tiles[which];
-  if (which == 0) gemm_body<BM, BN, BK, AKC, BKC, VEC, RBF>(pp.p[0], id % tiles, id / tiles, 0);
-  else gemm_body<BM, BN, BK, AKC, BKC, VEC, RBF>(pp.p[1], id % tiles, id / tiles, 0);
+  __shared__ __attribute__((aligned(16))) float lds[gemm_lds_floats<BM, BN, BK, AKC, BKC>()];
+  if (which == 0) gemm_body<BM, BN, BK, AKC, BKC, VEC, RBF>(pp.p[0], id % tiles, id / tiles, 0, lds);
+  else gemm_body<BM, BN, BK, AKC, BKC, VEC, RBF>(pp.p[1], id % tiles, id / tiles, 0, lds);
+}
+
+// Same idea for two plain products with DIFFERENT operand layouts (e.g. gG = P gW^T next to gP += G gW): both layout
+// instances live in one kernel, the workgroup picks by problem.
+template <bool A0, bool B0, bool A1, bool B1>
+__global__ __launch_bounds__(256) void gemm_pair2_kernel(const GemmPair pp) {
+  const int which = (int)blockIdx.x >= pp.nwg0 ? 1 : 0;       // wave-uniform
+  const int id = which ? xcd_remap((int)blockIdx.x - pp.nwg0, (int)gridDim.x - pp.nwg0) : xcd_remap((int)blockIdx.x, pp.nwg0);
+  const int tiles = pp.tiles[which];
+  __shared__ __attribute__((aligned(16))) float lds[cmax(gemm_lds_floats<64, 64, 64, A0, B0>(), gemm_lds_floats<64, 64, 64, A1, B1>())];
+  if (which == 0) gemm_body<64, 64, 64, A0, B0, true, false>(pp.p[0], id % tiles, id / tiles, 0, lds);
+  else gemm_body<64, 64, 64, A1, B1, true, false>(pp.p[1], id % tiles, id / tiles, 0, lds);
 }
 
 template <int BM, int BN, int BK, bool VEC, bool RBF>
@@ -581,8 +602,9 @@ __global__ __launch_bounds__(256) void chol_rbf_gemm_kernel(const CholArgs c, co
                          0);
     return;
   }
+  __shared__ __attribute__((aligned(16))) float lds[gemm_lds_floats<64, 64, 64, true, true>()];
   const int id = xcd_remap((int)blockIdx.x - c.nchol, (int)gridDim.x - c.nchol);
-  gemm_body<64, 64, 64, true, true, true, true>(p, id % tiles, id / tiles, 0);
+  gemm_body<64, 64, 64, true, true, true, true>(p, id % tiles, id / tiles, 0, lds);
 }
 
 static bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -647,6 +669,34 @@ static int launch_chol_rbf_gemm_impl(const float* A, float eps, float* L, float*
   if (n <= 64) hipLaunchKernelGGL((chol_rbf_gemm_kernel<16, 1>), dim3(total), dim3(256), 0, st, c, q, tiles);
   else hipLaunchKernelGGL((chol_rbf_gemm_kernel<25, 2>), dim3(total), dim3(256), 0, st, c, q, tiles);
   return check_launch("chol_rbf_gemm");
+}
+
+// two plain products with their own transposition flags in one launch; the layout pairs the ELBO program uses are
+// instantiated, anything else (or unaligned operands) falls back to two launches
+int launch_gemm_pair2(const GemmParams& p0, int tA0, int tB0, int nbatch0, const GemmParams& p1, int tA1, int tB1,
+                      int nbatch1, hipStream_t st, const char* tag) {
+  const bool a0 = tA0 == 0, b0 = tB0 == 1, a1 = tA1 == 0, b1 = tB1 == 1;   // operand K-contiguous?
+  const bool nt_nn = a0 && b0 && a1 && !b1, nt_tn = a0 && b0 && !a1 && !b1;
+  if (!(gemm_vec_ok(p0) && gemm_vec_ok(p1) && (nt_nn || nt_tn))) {
+    int rc = launch_gemm(p0, tA0, tB0, nbatch0, false, st, tag);
+    if (rc) return rc;
+    return launch_gemm(p1, tA1, tB1, nbatch1, false, st, tag);
+  }
+  if (prof_remembering() && strcmp(tag, "replay") != 0) {
+    const GemmParams c0 = p0, c1 = p1;
+    prof_remember(tag, [=](hipStream_t s) { launch_gemm_pair2(c0, tA0, tB0, nbatch0, c1, tA1, tB1, nbatch1, s, "replay"); });
+  }
+  ProfScope prof(tag, st);
+  GemmPair pp;
+  pp.p[0] = p0; pp.p[1] = p1;
+  pp.p[0].splitk = pp.p[1].splitk = 1;
+  pp.tiles[0] = cdiv(p0.M, 64) * cdiv(p0.N, 64);
+  pp.tiles[1] = cdiv(p1.M, 64) * cdiv(p1.N, 64);
+  pp.nwg0 = pp.tiles[0] * nbatch0;
+  const int total = pp.nwg0 + pp.tiles[1] * nbatch1;
+  if (nt_nn) hipLaunchKernelGGL((gemm_pair2_kernel<true, true, true, false>), dim3(total), dim3(256), 0, st, pp);
+  else hipLaunchKernelGGL((gemm_pair2_kernel<true, true, false, false>), dim3(total), dim3(256), 0, st, pp);
+  return check_launch("gemm_pair2");
 }
 
 // last launch per tag, kept for vargp_prof_replay (measurement only)
