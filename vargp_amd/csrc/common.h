@@ -74,8 +74,9 @@ struct GemmParams {
   int64_t sNa[3], sNb[3];
   int same_xy;
   int nofast;   // tuning aid: force the guarded (non-pipelined) slab loop
-  // split-K: blockIdx.z = split index; each split covers a BK-aligned share of [0, K) and writes its partial
-  // product (plain epilogue, alpha only) to C + split * sSplit; a second kernel combines the partials
+  // split-K: each split covers a BK-aligned share of [0, K).  RBF products write their partial inner products to
+  // C + split * sSplit and a second kernel applies the epilogue; plain products (sSplit = 0) accumulate into a
+  // pre-zeroed C with float atomics (no D)
   int splitk;
   int64_t sSplit;
 };

@@ -369,7 +369,8 @@ __global__ __launch_bounds__(256) void t0_softmax_kernel(const float* __restrict
 //       gkd.  gscale (nullable) = seed multiplying the stored unscaled softmax gradients.
 //   next nkl blocks: KL backward into the remaining small columns of gQP and the diagonal of gLz:
 //       gQP[:, 1..3] = 0 ; gQP[:, 4+M .. 4+2M) = g tril(G2) ; pad columns = 0 ; gLz = diag(g / Lz_ii) ;
-//       gT of the S_u factors = 0                                                          (g = seed_kl / S)
+//       gT of the S_u factors = 0 ; the G block of gQP and gT of the K_uu factors = 0 (accumulated by K-split GEMMs)
+//                                                                                           (g = seed_kl / S)
 //   rest: zero-fill of the r / c / gtheta accumulators of the kernel-matrix backward.
 // (the G block of gQP is written by a GEMM afterwards)
 __global__ __launch_bounds__(256) void t0_bwd_head_kernel(const float* __restrict__ QP, const float* __restrict__ W,
@@ -377,8 +378,8 @@ __global__ __launch_bounds__(256) void t0_bwd_head_kernel(const float* __restric
                                                           const float* __restrict__ gscale, const float* __restrict__ Lz,
                                                           const float* __restrict__ seeds, float* __restrict__ gQP,
                                                           float* __restrict__ gW, float* __restrict__ gkd,
-                                                          float* __restrict__ gLz, float* __restrict__ gTtail,
-                                                          float* __restrict__ zero_begin, int64_t zero_count, int S, int C,
+                                                          float* __restrict__ gLz, float* __restrict__ gThead,
+                                                          float* __restrict__ gTtail, float* __restrict__ zero_begin, int64_t zero_count, int S, int C,
                                                           int M, int B, int NR, int LD, int npd, int nkx, int nkl) {
   __shared__ float red[4];
   const float g = seeds[1] / (float)S;
@@ -420,6 +421,8 @@ __global__ __launch_bounds__(256) void t0_bwd_head_kernel(const float* __restric
     const int i = i0 + e0 / M, j = e0 % M;
     const int e = i * M + j;
     gq[(int64_t)i * LD + 4 + M + j] = (j <= i) ? g * q[(int64_t)i * LD + 4 + M + j] : 0.f;
+    gq[(int64_t)i * LD + 4 + j] = 0.f;               // G block and gT: accumulated by K-split GEMMs (float atomics)
+    gThead[b * M * M + e] = 0.f;
     gLz[b * M * M + e] = (i == j) ? g / Lz[b * M * M + e] : 0.f;
     if (s == 0) gTtail[(int64_t)c * M * M + e] = 0.f;
   }
@@ -646,6 +649,9 @@ static int check_desc(const vargp_elbo_t0_desc* d, const char* who) {
   return VARGP_OK;
 }
 
+// K-splits for the products with few output tiles and a long K: about 3 slabs of 64 per workgroup
+static int ksplit(int K) { const int s = K / 192; return s < 1 ? 1 : (s > 8 ? 8 : s); }
+
 static GemmParams flat_gemm(const float* A, int lda, int64_t sA, const float* B, int ldb, int64_t sB, float* C, int ldc,
                             int64_t sC, int M, int N, int K) {
   GemmParams p{};
@@ -814,11 +820,12 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
     const int64_t zc = o.r_uu - o.r_uf;
     const int nz = (int)std::min<int64_t>(64, cdiv(zc, 1024));
     hipLaunchKernelGGL(t0_bwd_head_kernel, dim3(npd + nkl + nz), dim3(256), 0, st, o.QP, o.W, o.gmu, o.gvar,
-                       fused_softmax ? seeds + 2 : nullptr, o.LL, seeds, o.gQP, o.gW, o.gkd, o.gLL, o.gTT + SC * MM, o.r_uf,
+                       fused_softmax ? seeds + 2 : nullptr, o.LL, seeds, o.gQP, o.gW, o.gkd, o.gLL, o.gTT, o.gTT + SC * MM, o.r_uf,
                        zc, S, C, M, B, NR, LD, npd, nkx, nkl);
   }
   {  // W = G^T P:  gG = P gW^T (G block of gQP),  gP += G gW   -- independent of each other: one launch
     GemmParams p = flat_gemm(o.QP + NR, LD, MLD, o.gW, B, MB, o.gQP + 4, LD, MLD, M, M, B);
+    p.splitk = ksplit(B);     // 4 SC tiles with a B-long K loop: split K so that the chip is busy (atomic accumulation)
     GemmParams q = flat_gemm(o.QP + 4, LD, MLD, o.gW, B, MB, o.gQP + NR, LD, MLD, M, B, M);
     q.triA = 1; q.D = o.gQP + NR; q.beta = 1.f;
     rc = launch_gemm_pair2(p, 0, 1, SC, q, 0, 0, SC, st, "t0_gg_gp_gemm");
@@ -827,6 +834,8 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
   {  // QP = T RK:  gT = tril(gQP RK^T)
     GemmParams p = flat_gemm(o.gQP, LD, MLD, o.RK, LD, MLD, o.gTT, M, MM, M, M, NR + B);
     p.triC = 1;
+    p.splitk = ksplit(NR + B);
+    p.sSplit = 0;
     rc = launch_gemm(p, 0, 1, SC, false, st, "t0_gt_gemm");
     if (rc) return rc;
   }

@@ -487,6 +487,10 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int tile_id
             v = p.alpha * acc[a][c][r];
             if (D) v += p.beta * D[(int64_t)row * p.ldd + col];
             if (p.triC == 1 && col > row) v = 0.f;
+            if (p.splitk > 1) {               // K split without a scratch buffer: partial sums meet in C (pre-zeroed)
+              if (v != 0.f) atomicAdd(&C[(int64_t)row * p.ldc + col], v);
+              continue;
+            }
           }
           C[(int64_t)row * p.ldc + col] = v;
         }
@@ -516,7 +520,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 
 // Two independent problems of the same kernel flavour in ONE launch (1-D grid: the workgroups of problem 0, then
 // those of problem 1).  Mid-size problems that cannot fill the chip alone (K_uu: 120 workgroups, K_uf: 384) share it.
-struct GemmPair { GemmParams p[2]; int nwg0; int tiles[2]; };
+struct GemmPair { GemmParams p[2]; int nwg0; int tiles[2]; int per_split[2]; };   // per_split = tiles * nbatch
 template <int BM, int BN, int BK, bool AKC, bool BKC, bool VEC, bool RBF>
 __global__ __launch_bounds__(256) void gemm_pair_kernel(const GemmPair pp) {
   // XCD-compact tile ranges within each problem (not across both: the two problems have different K, and a split
@@ -537,8 +541,9 @@ __global__ __launch_bounds__(256) void gemm_pair2_kernel(const GemmPair pp) {
   const int id = which ? xcd_remap((int)blockIdx.x - pp.nwg0, (int)gridDim.x - pp.nwg0) : xcd_remap((int)blockIdx.x, pp.nwg0);
   const int tiles = pp.tiles[which];
   __shared__ __attribute__((aligned(16))) float lds[cmax(gemm_lds_floats<64, 64, 64, A0, B0>(), gemm_lds_floats<64, 64, 64, A1, B1>())];
-  if (which == 0) gemm_body<64, 64, 64, A0, B0, true, false>(pp.p[0], id % tiles, id / tiles, 0, lds);
-  else gemm_body<64, 64, 64, A1, B1, true, false>(pp.p[1], id % tiles, id / tiles, 0, lds);
+  const int split = id / pp.per_split[which], rem = id % pp.per_split[which];   // K-split outermost
+  if (which == 0) gemm_body<64, 64, 64, A0, B0, true, false>(pp.p[0], rem % tiles, rem / tiles, split, lds);
+  else gemm_body<64, 64, 64, A1, B1, true, false>(pp.p[1], rem % tiles, rem / tiles, split, lds);
 }
 
 template <int BM, int BN, int BK, bool VEC, bool RBF>
@@ -689,11 +694,16 @@ int launch_gemm_pair2(const GemmParams& p0, int tA0, int tB0, int nbatch0, const
   ProfScope prof(tag, st);
   GemmPair pp;
   pp.p[0] = p0; pp.p[1] = p1;
-  pp.p[0].splitk = pp.p[1].splitk = 1;
+  for (int i = 0; i < 2; ++i) {   // splitk > 1: atomic accumulation into a pre-zeroed C (no D, no scratch)
+    if (pp.p[i].splitk < 1) pp.p[i].splitk = 1;
+    pp.p[i].sSplit = 0;
+  }
   pp.tiles[0] = cdiv(p0.M, 64) * cdiv(p0.N, 64);
   pp.tiles[1] = cdiv(p1.M, 64) * cdiv(p1.N, 64);
-  pp.nwg0 = pp.tiles[0] * nbatch0;
-  const int total = pp.nwg0 + pp.tiles[1] * nbatch1;
+  pp.per_split[0] = pp.tiles[0] * nbatch0;
+  pp.per_split[1] = pp.tiles[1] * nbatch1;
+  pp.nwg0 = pp.per_split[0] * pp.p[0].splitk;
+  const int total = pp.nwg0 + pp.per_split[1] * pp.p[1].splitk;
   if (nt_nn) hipLaunchKernelGGL((gemm_pair2_kernel<true, true, true, false>), dim3(total), dim3(256), 0, st, pp);
   else hipLaunchKernelGGL((gemm_pair2_kernel<true, true, false, false>), dim3(total), dim3(256), 0, st, pp);
   return check_launch("gemm_pair2");
