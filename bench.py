@@ -243,13 +243,15 @@ def main():
                    'one launch with the K_uf = rbf(z, x) distance GEMM; flops counted: the GEMM)'),
                   ('rbf_kuu_bwd_gemm', 2.0 * S * C * M * D * (B + M), 'gemm_pair_kernel (W.Y products of the kernel-matrix '
                    'backward: [C*M x B] x [B x D] per sample and [M x M] x [M x D] per (sample, class))'),
-                  ('rbf_kuf_gemm', flops_kuf, 'gemm_kernel<RBF> (K_uf = rbf(z, x))')]
+                  ('rbf_kuf_gemm', flops_kuf, 'gemm_kernel<RBF> (K_uf = rbf(z, x))'),
+                  ('rbf_kuu_gemm', 2.0 * S * C * M * D * (B + M), 'gemm_pair_kernel<RBF> (K_uu = rbf(z, z) and K_uf = rbf(z, x) '
+                   'in one launch)')]
     for tag, fl, desc in candidates:
         try:
             kernels[tag] = (_lib.prof_replay(tag, kern_n), fl, desc)
         except _lib.VargpHipError:
             pass
-    primary = 'chol_rbf_gemm' if 'chol_rbf_gemm' in kernels else 'rbf_kuf_gemm'
+    primary = next(t for t in ('chol_rbf_gemm', 'rbf_kuf_gemm', 'rbf_kuu_gemm') if t in kernels)
     kern_us, dominant_flops, dominant_desc = kernels[primary]
     kern_ms = kern_us * kern_n * 1e-3
     if world > 1:

@@ -180,8 +180,9 @@ __global__ __launch_bounds__(256) void chol_inv_small3_kernel(const float* __res
                                                               int64_t strideT, float* __restrict__ logdet,
                                                               int32_t* __restrict__ info, int info_base, int n,
                                                               int logdet_accumulate) {
+  __shared__ float stage[chol3_stage_floats<KC>()];
   chol3_body<KC, SETS>(blockIdx.x, A, lda, strideA, eps, L, ldl, strideL, T, ldt, strideT, logdet, info, info_base, n,
-                       logdet_accumulate);
+                       logdet_accumulate, stage);
 }
 
 static int launch_small(const float* A, int lda, int64_t sA, float eps, float* L, int ldl, int64_t sL, float* T,

@@ -144,19 +144,22 @@ __device__ __forceinline__ void chol3_steps(const Chol3Ctx& cx, double (&va)[KC]
   }
 }
 
+template <int KC> constexpr int chol3_stage_floats() { return 4 * KC * (4 * KC + 1); }
+
 // One matrix (index b of the batch).  n <= 64: SETS = 1 (rows = lanes); n <= 128 and n <= 4 KC: SETS = 2.
 template <int KC, int SETS>
 __device__ __forceinline__ void chol3_body(const int64_t b, const float* __restrict__ A, int lda, int64_t strideA, float eps,
                                            float* __restrict__ L, int ldl, int64_t strideL, float* __restrict__ T, int ldt,
                                            int64_t strideT, float* __restrict__ logdet, int32_t* __restrict__ info,
-                                           int info_base, int n, int logdet_accumulate) {
+                                           int info_base, int n, int logdet_accumulate, float* __restrict__ stage) {
+  // `stage` = chol3_stage_floats<KC>() floats of LDS owned by the kernel (the matrix on its way in, L and T on their
+  // way out), so that a kernel with other roles can hand over LDS it has anyway
   constexpr int NP = 4 * KC + 4;
   __shared__ double mcol[2][128];
   __shared__ double dpiv[2];
   __shared__ double sd[NP], sq[NP];
   __shared__ float red[4];
   constexpr int LS = 4 * KC + 1;               // odd row stride: lanes (= rows) hit distinct banks
-  __shared__ float stage[4 * KC * LS];         // the matrix on its way in, L and T on their way out
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int ra = lane, rb = lane + 64;       // set a: rows 0..63, set b: rows 64..n-1

@@ -74,6 +74,7 @@ struct GemmParams {
   int64_t sNa[3], sNb[3];
   int same_xy;
   int nofast;   // tuning aid: force the guarded (non-pipelined) slab loop
+  int xcd_remap;   // set by launch_gemm: XCD-compact workgroup -> tile map (small grids)
   // split-K: each split covers a BK-aligned share of [0, K).  RBF products write their partial inner products to
   // C + split * sSplit and a second kernel applies the epilogue; plain products (sSplit = 0) accumulate into a
   // pre-zeroed C with float atomics (no D)

@@ -514,7 +514,8 @@ __device__ __forceinline__ int xcd_remap(int lin, int total) {
 template <int BM, int BN, int BK, bool AKC, bool BKC, bool VEC, bool RBF>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   __shared__ __attribute__((aligned(16))) float lds[gemm_lds_floats<BM, BN, BK, AKC, BKC>()];
-  const int id = xcd_remap((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
+  const int lin = (int)(blockIdx.y * gridDim.x + blockIdx.x), total = (int)(gridDim.x * gridDim.y);
+  const int id = p.xcd_remap ? xcd_remap(lin, total) : lin;
   gemm_body<BM, BN, BK, AKC, BKC, VEC, RBF>(p, id % (int)gridDim.x, id / (int)gridDim.x, blockIdx.z, lds);
 }
 
@@ -602,12 +603,13 @@ struct CholArgs {
 };
 template <int KC, int SETS>
 __global__ __launch_bounds__(256) void chol_rbf_gemm_kernel(const CholArgs c, const GemmParams p, const int tiles) {
+  // one LDS array for both roles (the factorisation stages its matrix through 40 KB of it): 2 workgroups per CU
+  __shared__ __attribute__((aligned(16))) float lds[cmax(gemm_lds_floats<64, 64, 64, true, true>(), chol3_stage_floats<KC>())];
   if ((int)blockIdx.x < c.nchol) {
     chol3_body<KC, SETS>(blockIdx.x, c.A, c.lda, c.sA, c.eps, c.L, c.ldl, c.sL, c.T, c.ldt, c.sT, nullptr, c.info, 0, c.n,
-                         0);
+                         0, lds);
     return;
   }
-  __shared__ __attribute__((aligned(16))) float lds[gemm_lds_floats<64, 64, 64, true, true>()];
   const int id = xcd_remap((int)blockIdx.x - c.nchol, (int)gridDim.x - c.nchol);
   gemm_body<64, 64, 64, true, true, true, true>(p, id % tiles, id / tiles, 0, lds);
 }
@@ -671,8 +673,13 @@ static int launch_chol_rbf_gemm_impl(const float* A, float eps, float* L, float*
   q.splitk = 1;
   const int tiles = cdiv(p.M, 64) * cdiv(p.N, 64);
   const int total = nchol + tiles * nbatch;
-  if (n <= 64) hipLaunchKernelGGL((chol_rbf_gemm_kernel<16, 1>), dim3(total), dim3(256), 0, st, c, q, tiles);
-  else hipLaunchKernelGGL((chol_rbf_gemm_kernel<25, 2>), dim3(total), dim3(256), 0, st, c, q, tiles);
+  // The kernel needs 68 KB of LDS, so two workgroups fit a CU.  While the GEMM is small enough to finish under the
+  // factorisations anyway (the BASELINE shapes), reserving unused dynamic LDS keeps every factorising CU to itself --
+  // a co-resident GEMM workgroup competes for its issue slots and stretches the pivot chain (68 -> 77 us measured);
+  // with many samples the GEMM dominates and wants both slots (S = 64: 950 -> 676 us).
+  const unsigned pad = tiles * nbatch <= 1024 ? 24u * 1024u : 0u;
+  if (n <= 64) hipLaunchKernelGGL((chol_rbf_gemm_kernel<16, 1>), dim3(total), dim3(256), pad, st, c, q, tiles);
+  else hipLaunchKernelGGL((chol_rbf_gemm_kernel<25, 2>), dim3(total), dim3(256), pad, st, c, q, tiles);
   return check_launch("chol_rbf_gemm");
 }
 
@@ -721,6 +728,13 @@ int launch_gemm(const GemmParams& p, int transA, int transB, int nbatch, bool rb
   const_cast<GemmParams&>(p).nofast = nofast;
   ProfScope prof(tag, st);
   VARGP_REQUIRE(nbatch <= 65535, "bgemm: batch %d exceeds 65535", nbatch);
+  {
+    // XCD-compact tile ranges pay while one XCD's share of the operands fits its 4 MB L2; on big grids (the
+    // M = 2048 predictive sweep: 25 MB of B per XCD) the plain map, which spreads neighbours over the XCDs, is faster
+    static const int xcd_force = [] { const char* e = getenv("VARGP_GEMM_XCD"); return e ? atoi(e) : -1; }();   // tuning aid
+    const int64_t wgs = (int64_t)cdiv(p.M, 64) * cdiv(p.N, 64) * nbatch;
+    const_cast<GemmParams&>(p).xcd_remap = xcd_force >= 0 ? xcd_force : (wgs <= 4096 ? 1 : 0);
+  }
   bool vec = aligned16(p.A) && aligned16(p.B) && (p.lda % 4 == 0) && (p.ldb % 4 == 0);
   for (int i = 0; i < 3; ++i) vec = vec && (p.sA[i] % 4 == 0) && (p.sB[i] % 4 == 0);
   const int64_t t128 = (int64_t)cdiv(p.M, 128) * cdiv(p.N, 128) * nbatch;
