@@ -34,7 +34,7 @@ KERNELS = {
 def one(pattern):
     files = glob.glob(os.path.join(ROOT, 'gpurun_out', pattern))
     assert files, pattern
-    return sorted(files)[-1]
+    return max(files, key=os.path.getmtime)
 
 
 def stats_rows(path):
@@ -80,8 +80,13 @@ def main():
     lines = []
     tot = 0.0
     nlaunch = 0.0
+    # bench.py re-launches three recorded kernels 3 + 100 times each for its live timing: not part of a step
+    replayed = ('void vargp::chol_rbf_gemm_kernel', 'void vargp::gemm_pair_kernel<64, 64, 64, true, false, true, false>',
+                'void vargp::gemm_kernel<64, 64, 64, true, true, true, true>')
     for r in rows:
         calls, avg = int(r['Calls']), float(r['AverageNs']) / 1e3
+        if r['Name'].startswith(replayed):
+            calls -= 103
         if calls < steps // 2:
             continue
         per = calls / steps
@@ -91,8 +96,8 @@ def main():
             lines.append(f"| `{r['Name'][:76]}` | {per:.1f} | {avg:.1f} | {calls * avg / steps:.1f} |")
     with open(os.path.join(OUT, f'{tag}_top_kernels.md'), 'w') as g:
         g.write('| kernel | launches/step | avg µs | µs/step |\n|---|---|---|---|\n' + '\n'.join(lines) + '\n\n')
-        g.write(f'Sum of kernel time: {tot:.0f} µs per step over {nlaunch:.0f} launches '
-                f'(includes the 100 replays per kernel of the bench\'s live timing, spread over {steps} steps).\n')
+        g.write(f'Sum of kernel time: {tot:.0f} µs per step over {nlaunch:.0f} launches (eager run, {steps} steps; the 103 '
+                f're-launches per timed kernel of bench.py\'s live measurement are subtracted).\n')
     print(json.dumps(traffic, indent=1))
     print(open(os.path.join(OUT, f'{tag}_top_kernels.md')).read())
 
