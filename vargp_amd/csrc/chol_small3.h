@@ -3,24 +3,27 @@
 // K_uu next to the K_uf kernel-matrix GEMM).
 //
 // Algorithm: forward elimination on [A | I] held in place in registers (fp64), which yields L = chol(A) and
-// T = L^-1 from one sweep: slot (i, e) holds the Schur-complement entry A_ie until column e has been eliminated (step
-// e), afterwards entry (i, e) of the unit-lower inverse.  The Schur complement stays symmetric, so at step j ROW j of the
-// register file is the whole pivot vector (inverse row j for e < j, 1 in place of the pivot d_j, column j of A for
-// e > j) and a step is   v_i <- v_i + m_i * p   for every row i > j,   m_i = -A_ij / d_j.
+// T = L^-1 from one sweep: entry (i, e) holds the Schur-complement entry A_ie until column e has been eliminated (step
+// e), afterwards entry (i, e) of the unit-lower inverse.  A step is   v_i <- v_i + m_i * p   for every row i > j, with
+// p = row j (the Schur complement stays symmetric, so row j is the pivot vector: inverse row j for e < j, the pivot
+// d_j at e = j, column j of A for e > j) and m_i = -A_ij / d_j.  Rows i <= j are finished; row j's frozen tail
+// (e > j) IS column j of the unscaled factor (L_ej = A_je / sqrt(d_j)), so L needs no storage of its own.
 //
-// Mapping (what makes a step cheap): COLUMNS across waves, ROWS across lanes.
-//   wave w owns the columns e = 4k + w (k < KC); lane l holds row l (set a) and row l + 64 (set b).
-//   * the pivot-row entries a wave needs are then the same for all its lanes and sit in the registers of ONE of its
-//     own lanes: v_readlane hands them to the FMAs as scalar operands -- no LDS traffic for the pivot row at all (a
-//     rows-across-waves mapping moves 20-25 fp64 values per lane per step through LDS and is bound by that);
-//   * the multipliers m_i need column j, which lives in one wave (j % 4): that wave computes them (pivot by v_readlane,
-//     reciprocal by rcp + Newton) and hands them to the others through LDS, two values per lane.  It does so one step
-//     AHEAD: in step j the next pivot column is updated first and its wave prepares step j + 1 while the others are
-//     still in the bulk of the update, so the one barrier per pivot rarely waits.
-//   All pivot steps are instantiated at compile time (template recursion): every register index, the set holding the
-//   pivot row and its lane are static, and the finished rows of set a drop out of the update once j >= 64.
-// At the end  L_ie = A_ie(at step e) / sqrt(d_e)  (parked in fp32 registers when column e is eliminated),
-// T_ie = v_ie / sqrt(d_i),  T_ii = 1 / sqrt(d_i).
+// Mapping (what makes a step cheap): ROWS across waves and register slots, COLUMNS across lanes.
+//   wave w holds the rows i = 4k + w in slot k (k < KC); lane l holds column l (set a) and column l + 64 (set b).
+//   * a finished row is a register slot, and which slots are finished at step j is known at compile time (all pivot
+//     steps are instantiated by template recursion): they drop out of the update -- half the work of a mapping that
+//     puts rows on lanes, where finished rows still ride along in every instruction;
+//   * the pivot row p is one slot of one wave: that wave writes it to LDS together with the scaled copy q = -p / d_j
+//     (one value per lane and set each) and everybody reads q back the same way;
+//   * the multiplier of row i is -A_ij / d_j, and A_ij = p_i by symmetry: the update is  v_ie <- v_ie + p_i q_e  with
+//     p_i read from the published row as a same-address LDS broadcast (two rows per ds_read2_b64) -- per live row
+//     half an LDS instruction and one FMA per column set, nothing else;
+//   * the inverse entry (i, j) restarts as 0 + m_i * 1.  Instead of a select in every slot, the pivot is published as
+//     1 + d_j: A_ij + p_i q_j = p_i - p_i (1 + d_j) / d_j = m_i, up to eps * d_j relative, in fp64;
+//   * look-ahead: the wave holding row j + 1 updates that slot first in step j and publishes it at once (pivot by
+//     v_readlane, reciprocal by rcp + Newton), so the one barrier per pivot rarely waits.
+// 1/d_j by v_rcp_f64 + two Newton steps; matrix I/O staged through LDS (coalesced global access, transposition for L).
 #pragma once
 #include "common.h"
 #include <math.h>
@@ -46,7 +49,7 @@ __device__ __forceinline__ double fast_rcp(double d) {
   return x;
 }
 
-// value of `v` in lane `lane` (wave-uniform index) broadcast to the whole wave
+// value of `v` in lane `lane` (compile-time or wave-uniform index) broadcast to the whole wave
 __device__ __forceinline__ double lane_bcast(double v, int lane) {
   const unsigned long long u = __double_as_longlong(v);
   const unsigned lo = __builtin_amdgcn_readlane((int)(u & 0xffffffffu), lane);
@@ -55,98 +58,90 @@ __device__ __forceinline__ double lane_bcast(double v, int lane) {
 }
 
 struct Chol3Ctx {
-  double* mcol;   // [2][128]  multipliers of set a (0..63) and set b (64..127), double-buffered by step parity
-  double* dpiv;   // [2]       pivot d_j (<= 0 or NaN: not positive-definite)
+  double* prow;   // [2][128]  pivot row p (columns 0..127; the pivot itself stored as 1 + d), double-buffered by parity
+  double* qrow;   // [2][128]  q = -p / d, same layout
+  double* dpiv;   // [2]       the pivot d (<= 0 or NaN: not positive-definite)
   double* sd;     // [n]       all pivots, for the final scaling
   int n, lane, w;
 };
 
-// What the wave holding column J does before step J can start: pivot d_J (from the lane holding row J), its
-// reciprocal, the multipliers m_i = -A_iJ / d_J of all rows below (to LDS), and it parks column J of A (the unscaled
-// column of L) before the slot is reused for the inverse.
+// Row J (slot J / 4 of wave J % 4) to LDS, final once step J - 1 has updated it: p, the scaled copy q = -p / d_J and
+// d_J.  Column J counts as 1 + d_J in both, so that the update below leaves m_i = -p_i / d_J in entry (i, J):
+// A_iJ + p_i q_J = p_i - p_i (1 + d) / d = -p_i / d   (A_iJ = p_i by symmetry, to rounding).
 template <int KC, int SETS, int J>
-__device__ __forceinline__ void chol3_prepare(const Chol3Ctx& cx, double (&va)[KC], double (&vb)[KC], float (&la)[KC],
-                                              float (&lb)[KC]) {
-  constexpr int kj = J / 4;
-  constexpr bool second = J >= 64;                          // row J lives in set b (rows 64..)
+__device__ __forceinline__ void chol3_publish(const Chol3Ctx& cx, const double (&va)[KC], const double (&vb)[KC]) {
+  constexpr bool second = J >= 64;
   constexpr int jl = second ? J - 64 : J;
-  double* mcol = cx.mcol + (J & 1) * 128;
-  const double d = lane_bcast(second ? vb[kj] : va[kj], jl);
-  if (cx.lane == 0) { cx.dpiv[J & 1] = d; cx.sd[J] = d; }
-  const double di = fast_rcp(d);
-  if constexpr (!second) {                                  // rows of set a below the pivot exist only while J < 63
-    la[kj] = (float)va[kj];
-    mcol[cx.lane] = (cx.lane > J && cx.lane < cx.n) ? -va[kj] * di : 0.0;
-  }
+  double* prow = cx.prow + (J & 1) * 128;
+  double* qrow = cx.qrow + (J & 1) * 128;
+  double pa = va[J / 4], pb = vb[J / 4];
+  const double d = lane_bcast(second ? pb : pa, jl);
+  const double ndi = -fast_rcp(d);
+  if constexpr (second) { if (cx.lane == jl) pb = 1.0 + d; } else { if (cx.lane == jl) pa = 1.0 + d; }
+  prow[cx.lane] = pa;
+  qrow[cx.lane] = pa * ndi;
   if constexpr (SETS == 2) {
-    lb[kj] = (float)vb[kj];
-    const int rb = cx.lane + 64;
-    mcol[64 + cx.lane] = (rb > J && rb < cx.n) ? -vb[kj] * di : 0.0;
+    prow[64 + cx.lane] = pb;
+    qrow[64 + cx.lane] = pb * ndi;
   }
+  if (cx.lane == 0) { cx.dpiv[J & 1] = d; cx.sd[J] = d; }
 }
 
 template <int KC, int SETS, int J>
-__device__ __forceinline__ void chol3_steps(const Chol3Ctx& cx, double (&va)[KC], double (&vb)[KC], float (&la)[KC],
-                                            float (&lb)[KC], int& fail VARGP_STAMP_PARAMS) {
+__device__ __forceinline__ void chol3_steps(const Chol3Ctx& cx, double (&va)[KC], double (&vb)[KC],
+                                            int& fail VARGP_STAMP_PARAMS) {
   if constexpr (J < 4 * KC && J < 64 * SETS) {
-    constexpr int kj = J / 4, wj = J % 4;
-    constexpr int k1 = (J + 1) / 4, w1 = (J + 1) % 4;        // slot / wave of the next pivot column
-    constexpr bool second = J >= 64;                         // the pivot row lives in set b
-    constexpr int jl = second ? J - 64 : J;                  // its lane
+    constexpr int kj = J / 4, wj = J % 4;                    // slot / wave of the pivot row
+    constexpr int k1 = (J + 1) / 4, w1 = (J + 1) % 4;        // ... of the next one
+    constexpr bool has_next = k1 < KC && J + 1 < 64 * SETS;
     if (J >= cx.n || fail) return;                           // uniform
     const int lane = cx.lane, w = cx.w;
-    const bool owner = w == wj;                              // uniform: this wave holds column J
     STAMP(0);
-    __syncthreads();                                         // multipliers and pivot of step J are in LDS
+    __syncthreads();                                         // row J is in LDS
     STAMP(2);
-    const double* mcol = cx.mcol + (J & 1) * 128;
+    // every LDS read of the step up front: the pivot, this lane's columns of q, and -- same address in every lane --
+    // the entries p_i of the rows i = 4k + w this wave still updates (p_i = A_iJ by symmetry: the multiplier of row i)
     const double d = cx.dpiv[J & 1];
-    double ma = 0.0, mb = 0.0;
-    if constexpr (!second) ma = mcol[lane];                  // J >= 64: every row of set a is above the pivot
-    if constexpr (SETS == 2) mb = mcol[64 + lane];
-    // this wave's columns of the pivot row come straight out of the registers of the lane that holds row J
-    // (v_readlane -> scalar operands of the FMAs); the pivot itself counts as 1
-    double pv[KC];
+    const double* qrow = cx.qrow + (J & 1) * 128;
+    const double* pw = cx.prow + (J & 1) * 128 + w;
+    const double qa = qrow[lane];
+    double qb = 0.0;
+    if constexpr (SETS == 2) qb = qrow[64 + lane];
+    double pr[KC];
 #pragma unroll
-    for (int k = 0; k < KC; ++k) pv[k] = lane_bcast(second ? vb[k] : va[k], jl);
-    if (owner) pv[kj] = 1.0;
+    for (int k = kj; k < KC; ++k) pr[k] = pw[4 * k];
+    __builtin_amdgcn_sched_group_barrier(0x100, (KC - kj + 1) / 2 + 3, 0);   // DS reads first
     if (!(d > 0.0)) { fail = J + 1; return; }                // uniform
+    // rows i = 4k + w > J only: slots below kj are finished for every wave, slot kj for the waves w <= wj
+    if (w <= wj) pr[kj] = 0.0;
     STAMP(3);
-    // slot (i, J) itself restarts as an inverse entry, 0 + m * 1, in the rows below the pivot
-#define VARGP_CHOL3_UPDATE(k)                                                                          \
-    do {                                                                                                 \
-      if constexpr (!second) {                                                                           \
-        const double ta = fma(ma, pv[k], va[k]);                                                         \
-        va[k] = ((k) == kj && owner && lane > J) ? ma : ta;                                              \
-      }                                                                                                  \
-      if constexpr (SETS == 2) {                                                                         \
-        const double tb = fma(mb, pv[k], vb[k]);                                                         \
-        vb[k] = ((k) == kj && owner && lane + 64 > J) ? mb : tb;                                         \
-      }                                                                                                  \
+#define VARGP_CHOL3_UPDATE(k)                                                \
+    do {                                                                       \
+      va[k] = fma(pr[k], qa, va[k]);                                           \
+      if constexpr (SETS == 2) vb[k] = fma(pr[k], qb, vb[k]);                  \
     } while (0)
-    // look-ahead: the next pivot column first, so that its wave can prepare step J + 1 (pivot, reciprocal, multipliers)
-    // while everybody else is still in the bulk of this update; the barrier of step J + 1 then finds them ready
-    if constexpr (k1 < KC) VARGP_CHOL3_UPDATE(k1);
-    if constexpr (J + 1 < 4 * KC && J + 1 < 64 * SETS) {
-      if (w == w1 && J + 1 < cx.n) chol3_prepare<KC, SETS, J + 1>(cx, va, vb, la, lb);
+    // look-ahead: the next pivot row first, published at once
+    if constexpr (has_next) {
+      VARGP_CHOL3_UPDATE(k1);
+      if (w == w1 && J + 1 < cx.n) chol3_publish<KC, SETS, J + 1>(cx, va, vb);
     }
     STAMP(1);
 #pragma unroll
-    for (int k = 0; k < KC; ++k) {
-      if (k != k1) VARGP_CHOL3_UPDATE(k);
+    for (int k = kj; k < KC; ++k) {
+      if (!(has_next && k == k1)) VARGP_CHOL3_UPDATE(k);
     }
 #undef VARGP_CHOL3_UPDATE
 #ifdef VARGP_CHOL_STAMPS
-    asm volatile("" ::"v"(va[0]), "v"(vb[KC - 1]));
+    asm volatile("" ::"v"(va[KC - 1]), "v"(vb[KC - 1]));
     STAMP(4);
 #endif
-    chol3_steps<KC, SETS, J + 1>(cx, va, vb, la, lb, fail VARGP_STAMP_ARGS);
+    chol3_steps<KC, SETS, J + 1>(cx, va, vb, fail VARGP_STAMP_ARGS);
   }
 }
 
 template <int KC> constexpr int chol3_stage_floats() { return 4 * KC * (4 * KC + 1); }
 
-// One matrix (index b of the batch).  n <= 64: SETS = 1 (rows = lanes); n <= 128 and n <= 4 KC: SETS = 2.
+// One matrix (index b of the batch).  n <= 64: SETS = 1 (columns = lanes); n <= 128 and n <= 4 KC: SETS = 2.
 template <int KC, int SETS>
 __device__ __forceinline__ void chol3_body(const int64_t b, const float* __restrict__ A, int lda, int64_t strideA, float eps,
                                            float* __restrict__ L, int ldl, int64_t strideL, float* __restrict__ T, int ldt,
@@ -155,51 +150,54 @@ __device__ __forceinline__ void chol3_body(const int64_t b, const float* __restr
   // `stage` = chol3_stage_floats<KC>() floats of LDS owned by the kernel (the matrix on its way in, L and T on their
   // way out), so that a kernel with other roles can hand over LDS it has anyway
   constexpr int NP = 4 * KC + 4;
-  __shared__ double mcol[2][128];
+  __shared__ double prow[2][128], qrow[2][128];
   __shared__ double dpiv[2];
   __shared__ double sd[NP], sq[NP];
   __shared__ float red[4];
-  constexpr int LS = 4 * KC + 1;               // odd row stride: lanes (= rows) hit distinct banks
+  constexpr int LS = 4 * KC + 1;               // odd row stride: column-wise access hits distinct banks too
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int ra = lane, rb = lane + 64;       // set a: rows 0..63, set b: rows 64..n-1
-  const bool minea = ra < n, mineb = SETS == 2 && rb < n;
+  const int ca = lane, cb = lane + 64;       // set a: columns 0..63, set b: columns 64..n-1
+  const bool minea = ca < n, mineb = SETS == 2 && cb < n;
   A += b * strideA;
   L += b * strideL;
   if (T) T += b * strideT;
 
-  // the matrix comes in through LDS: coalesced global reads, then every lane picks the entries of its rows (a lane
-  // owns whole rows, so reading them straight from global memory would touch one cache line per lane and entry)
-  for (int e = tid; e < n * n; e += 256) {
-    const int i = e / n, j = e - i * n;
-    stage[i * LS + j] = A[(int64_t)i * lda + j];
+  // the matrix comes in through LDS: coalesced global reads, then every thread picks its entries (rows 4k + w)
+  const int di = 256 / n, dj = 256 - di * n;   // element e -> e + 256 without a division per element
+  {
+    int i = tid / n, j = tid - i * n;
+    for (int e = tid; e < n * n; e += 256) {
+      stage[i * LS + j] = A[(int64_t)i * lda + j];
+      i += di; j += dj;
+      if (j >= n) { j -= n; ++i; }
+    }
   }
   __syncthreads();
   double va[KC], vb[KC];
-  float la[KC], lb[KC];
 #pragma unroll
   for (int k = 0; k < KC; ++k) {
-    const int e = 4 * k + w;
-    va[k] = 0.0; vb[k] = 0.0; la[k] = 0.f; lb[k] = 0.f;
-    if (e < n) {   // only the lower triangle of the input is trusted: mirror it
+    const int i = 4 * k + w;
+    va[k] = 0.0; vb[k] = 0.0;
+    if (i < n) {   // only the lower triangle of the input is trusted: mirror it
       if (minea) {
-        const int hi = ra > e ? ra : e, lo = ra > e ? e : ra;
-        va[k] = (double)stage[hi * LS + lo] + (e == ra ? (double)eps : 0.0);
+        const int hi = i > ca ? i : ca, lo = i > ca ? ca : i;
+        va[k] = (double)stage[hi * LS + lo] + (i == ca ? (double)eps : 0.0);
       }
       if (mineb) {
-        const int hi = rb > e ? rb : e, lo = rb > e ? e : rb;
-        vb[k] = (double)stage[hi * LS + lo] + (e == rb ? (double)eps : 0.0);
+        const int hi = i > cb ? i : cb, lo = i > cb ? cb : i;
+        vb[k] = (double)stage[hi * LS + lo] + (i == cb ? (double)eps : 0.0);
       }
     }
   }
 
   int fail = 0;
-  const Chol3Ctx cx{&mcol[0][0], dpiv, sd, n, lane, w};
-  if (w == 0) chol3_prepare<KC, SETS, 0>(cx, va, vb, la, lb);     // step 0 has no predecessor to prepare it
+  const Chol3Ctx cx{&prow[0][0], &qrow[0][0], dpiv, sd, n, lane, w};
+  if (w == 0) chol3_publish<KC, SETS, 0>(cx, va, vb);      // row 0 has no predecessor to publish it
 #ifdef VARGP_CHOL_STAMPS
   unsigned long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
 #endif
-  chol3_steps<KC, SETS, 0>(cx, va, vb, la, lb, fail VARGP_STAMP_ARGS);
+  chol3_steps<KC, SETS, 0>(cx, va, vb, fail VARGP_STAMP_ARGS);
   __syncthreads();
 #ifdef VARGP_CHOL_STAMPS
   if (tid == 0 && b == 0) for (int i = 0; i < 8; ++i) g_chol_stamps[i] = acc_[i];
@@ -221,33 +219,41 @@ __device__ __forceinline__ void chol3_body(const int64_t b, const float* __restr
     sd[tid] = 1.0 / s;
   }
   __syncthreads();
-  // L, then T: entries to LDS by their owners, coalesced rows out
+  // Entry (i, e) of the register file: e < i -> T_ie sqrt(d_i); e == i -> d_i; e > i -> L_ei sqrt(d_i).
+  // L (transposed on the way through LDS), then T: entries to LDS by their owners, coalesced rows out.
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     float* out = pass == 0 ? L : T;
     const int ldo = pass == 0 ? ldl : ldt;
     if (out == nullptr) continue;                           // uniform
 #pragma unroll
-    for (int half = 0; half < SETS; ++half) {
-      const int r = half ? rb : ra;
-      if (half ? mineb : minea) {
-        const double si = sq[r], isi = sd[r];
+    for (int k = 0; k < KC; ++k) {
+      const int i = 4 * k + w;
+      if (i < n) {
+        const double si = sq[i], isi = sd[i];
 #pragma unroll
-        for (int k = 0; k < KC; ++k) {
-          const int e = 4 * k + w;
-          if (e < n) {
-            float v = 0.f;
-            if (e < r) v = pass == 0 ? (float)((double)(half ? lb[k] : la[k]) * sd[e]) : (float)((half ? vb[k] : va[k]) * isi);
-            else if (e == r) v = pass == 0 ? (float)si : (float)isi;
-            stage[r * LS + e] = v;
+        for (int half = 0; half < SETS; ++half) {
+          const int e = half ? cb : ca;
+          if (half ? mineb : minea) {
+            const double v = half ? vb[k] : va[k];
+            if (pass == 0) {          // L: lower entry (e, i) from the frozen tail of row i, zero at (i, e)
+              if (e > i) { stage[e * LS + i] = (float)(v * isi); stage[i * LS + e] = 0.f; }
+              else if (e == i) stage[i * LS + i] = (float)si;
+            } else {                  // T: lower entry (i, e), zero above
+              stage[i * LS + e] = e < i ? (float)(v * isi) : (e == i ? (float)isi : 0.f);
+            }
           }
         }
       }
     }
     __syncthreads();
-    for (int e = tid; e < n * n; e += 256) {
-      const int i = e / n, j = e - i * n;
-      out[(int64_t)i * ldo + j] = stage[i * LS + j];
+    {
+      int i = tid / n, j = tid - i * n;
+      for (int e = tid; e < n * n; e += 256) {
+        out[(int64_t)i * ldo + j] = stage[i * LS + j];
+        i += di; j += dj;
+        if (j >= n) { j -= n; ++i; }
+      }
     }
     __syncthreads();
   }
