@@ -220,42 +220,51 @@ __device__ __forceinline__ void chol3_body(const int64_t b, const float* __restr
   }
   __syncthreads();
   // Entry (i, e) of the register file: e < i -> T_ie sqrt(d_i); e == i -> d_i; e > i -> L_ei sqrt(d_i).
-  // L (transposed on the way through LDS), then T: entries to LDS by their owners, coalesced rows out.
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    float* out = pass == 0 ? L : T;
-    const int ldo = pass == 0 ? ldl : ldt;
-    if (out == nullptr) continue;                           // uniform
+  // T first: its rows lie across the lanes, so the stores are coalesced as they are.
+  if (T) {
 #pragma unroll
     for (int k = 0; k < KC; ++k) {
       const int i = 4 * k + w;
       if (i < n) {
-        const double si = sq[i], isi = sd[i];
+        const double isi = sd[i];
+        if (minea) T[(int64_t)i * ldt + ca] = ca < i ? (float)(va[k] * isi) : (ca == i ? (float)isi : 0.f);
+        if (mineb) T[(int64_t)i * ldt + cb] = cb < i ? (float)(vb[k] * isi) : (cb == i ? (float)isi : 0.f);
+      }
+    }
+  }
+  // L is the transpose of the row tails: through LDS (lower entry (e, i) from the tail of row i, zero at (i, e)),
+  // then coalesced rows out
 #pragma unroll
-        for (int half = 0; half < SETS; ++half) {
-          const int e = half ? cb : ca;
-          if (half ? mineb : minea) {
-            const double v = half ? vb[k] : va[k];
-            if (pass == 0) {          // L: lower entry (e, i) from the frozen tail of row i, zero at (i, e)
-              if (e > i) { stage[e * LS + i] = (float)(v * isi); stage[i * LS + e] = 0.f; }
-              else if (e == i) stage[i * LS + i] = (float)si;
-            } else {                  // T: lower entry (i, e), zero above
-              stage[i * LS + e] = e < i ? (float)(v * isi) : (e == i ? (float)isi : 0.f);
-            }
-          }
+  for (int k = 0; k < KC; ++k) {
+    const int i = 4 * k + w;
+    if (i < n) {
+      const double si = sq[i], isi = sd[i];
+#pragma unroll
+      for (int half = 0; half < SETS; ++half) {
+        const int e = half ? cb : ca;
+        if (half ? mineb : minea) {
+          const double v = half ? vb[k] : va[k];
+          if (e > i) { stage[e * LS + i] = (float)(v * isi); stage[i * LS + e] = 0.f; }
+          else if (e == i) stage[i * LS + i] = (float)si;
         }
       }
     }
-    __syncthreads();
-    {
-      int i = tid / n, j = tid - i * n;
-      for (int e = tid; e < n * n; e += 256) {
-        out[(int64_t)i * ldo + j] = stage[i * LS + j];
-        i += di; j += dj;
-        if (j >= n) { j -= n; ++i; }
-      }
+  }
+  __syncthreads();
+  if ((n & 3) == 0 && (ldl & 3) == 0 && (reinterpret_cast<uintptr_t>(L) & 15) == 0) {
+    const int n4 = n >> 2;
+    for (int q = tid; q < n * n4; q += 256) {
+      const int i = q / n4, j = (q - i * n4) << 2;
+      const float* sp = stage + i * LS + j;
+      *reinterpret_cast<float4*>(L + (int64_t)i * ldl + j) = make_float4(sp[0], sp[1], sp[2], sp[3]);
     }
-    __syncthreads();
+  } else {
+    int i = tid / n, j = tid - i * n;
+    for (int e = tid; e < n * n; e += 256) {
+      L[(int64_t)i * ldl + j] = stage[i * LS + j];
+      i += di; j += dj;
+      if (j >= n) { j -= n; ++i; }
+    }
   }
   if (logdet) {   // sum_j log L_jj
     float acc = 0.f;
