@@ -372,7 +372,7 @@ int vargp::chol_inv_bwd_impl(const float* L, const float* T, const float* gL, co
     rc = chol_inv_bwd_first(T, gT, nbatch, n, ws, ws_bytes, nullptr, 0, 0, 0, st);
     if (rc) return rc;
   }
-  const float* P = w1;
+  float* Sm = nullptr;
   if (gL) {
     const float* gLl = gL;
     if (!gl_lower) {
@@ -380,16 +380,24 @@ int vargp::chol_inv_bwd_impl(const float* L, const float* T, const float* gL, co
                          total);
       gLl = gA;
     }
-    // w2 = L^T tril(gL) - w1
-    rc = sq_gemm(L, n, nn, 1, 2, gLl, n, nn, 0, 1, w2, n, nn, gT ? w1 : nullptr, 1.f, -1.f, n, n, n, 0, nbatch, st);
+    // S = (Phi(P) + Phi(P)^T) / 2 with P = L^T tril(gL) - w1, written symmetrically by the GEMM's epilogue from the
+    // lower triangle of 0.5 P (tiles above the diagonal are not computed)
+    GemmParams p{};
+    p.A = L; p.B = gLl; p.C = w2; p.D = gT ? w1 : nullptr;
+    p.M = n; p.N = n; p.K = n; p.lda = n; p.ldb = n; p.ldc = n; p.ldd = n;
+    p.nb1 = 1; p.nb2 = 1;
+    p.sA[0] = nn; p.sB[0] = nn; p.sC[0] = nn; p.sD[0] = nn;
+    p.alpha = 0.5f; p.beta = gT ? -0.5f : 0.f;
+    p.triA = 2; p.triB = 1; p.triC = 2; p.symout = 1;
+    rc = launch_gemm(p, 1, 0, nbatch, false, st);
     if (rc) return rc;
-    P = w2;
+    Sm = w2;
   } else {
     VARGP_REQUIRE(gT, "chol_inv_bwd: neither gL nor gT given");
+    // only gT: S = -(Phi(w1) + Phi(w1)^T) / 2
+    Sm = w2;
+    hipLaunchKernelGGL(phi_sym_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w1, Sm, n, total, -0.5f);
   }
-  // S = sign * (Phi(P) + Phi(P)^T) / 2  (sign = -1 when P is the bare gT T^T), then gA = T^T S T
-  float* Sm = (P == w1) ? w2 : w1;
-  hipLaunchKernelGGL(phi_sym_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, P, Sm, n, total, gL ? 0.5f : -0.5f);
   float* tmp = (Sm == w1) ? w2 : w1;
   rc = sq_gemm(T, n, nn, 1, 2, Sm, n, nn, 0, 0, tmp, n, nn, nullptr, 1.f, 0.f, n, n, n, 0, nbatch, st);
   if (rc) return rc;

@@ -146,7 +146,8 @@ template <int KC, int SETS>
 __device__ __forceinline__ void chol3_body(const int64_t b, const float* __restrict__ A, int lda, int64_t strideA, float eps,
                                            float* __restrict__ L, int ldl, int64_t strideL, float* __restrict__ T, int ldt,
                                            int64_t strideT, float* __restrict__ logdet, int32_t* __restrict__ info,
-                                           int info_base, int n, int logdet_accumulate, float* __restrict__ stage) {
+                                           int info_base, int n, int logdet_accumulate, float* __restrict__ stage,
+                                           const CholExtra* extra = nullptr) {
   // `stage` = chol3_stage_floats<KC>() floats of LDS owned by the kernel (the matrix on its way in, L and T on their
   // way out), so that a kernel with other roles can hand over LDS it has anyway
   constexpr int NP = 4 * KC + 4;
@@ -251,17 +252,30 @@ __device__ __forceinline__ void chol3_body(const int64_t b, const float* __restr
     }
   }
   __syncthreads();
-  if ((n & 3) == 0 && (ldl & 3) == 0 && (reinterpret_cast<uintptr_t>(L) & 15) == 0) {
+  // optional extra destination(s) for L (CholExtra, common.h)
+  float* xb = nullptr;
+  int ldx = 0, ncopy = 0;
+  int64_t sxc = 0;
+  if (extra && b >= extra->first) {
+    xb = extra->base + (b - extra->first) * extra->stride_b;
+    ldx = extra->ld; ncopy = extra->ncopy; sxc = extra->stride_copy;
+  }
+  if ((n & 3) == 0 && (ldl & 3) == 0 && (reinterpret_cast<uintptr_t>(L) & 15) == 0 &&
+      (!xb || ((ldx & 3) == 0 && (sxc & 3) == 0 && (reinterpret_cast<uintptr_t>(xb) & 15) == 0))) {
     const int n4 = n >> 2;
     for (int q = tid; q < n * n4; q += 256) {
       const int i = q / n4, j = (q - i * n4) << 2;
       const float* sp = stage + i * LS + j;
-      *reinterpret_cast<float4*>(L + (int64_t)i * ldl + j) = make_float4(sp[0], sp[1], sp[2], sp[3]);
+      const float4 v4 = make_float4(sp[0], sp[1], sp[2], sp[3]);
+      *reinterpret_cast<float4*>(L + (int64_t)i * ldl + j) = v4;
+      for (int c = 0; c < ncopy; ++c) *reinterpret_cast<float4*>(xb + c * sxc + (int64_t)i * ldx + j) = v4;
     }
   } else {
     int i = tid / n, j = tid - i * n;
     for (int e = tid; e < n * n; e += 256) {
-      L[(int64_t)i * ldl + j] = stage[i * LS + j];
+      const float v = stage[i * LS + j];
+      L[(int64_t)i * ldl + j] = v;
+      for (int c = 0; c < ncopy; ++c) xb[c * sxc + (int64_t)i * ldx + j] = v;
       i += di; j += dj;
       if (j >= n) { j -= n; ++i; }
     }

@@ -75,6 +75,7 @@ struct GemmParams {
   int same_xy;
   int nofast;   // tuning aid: force the guarded (non-pipelined) slab loop
   int xcd_remap;   // set by launch_gemm: XCD-compact workgroup -> tile map (small grids)
+  int symout;      // plain products: write C_ij = C_ji = value for j <= i, nothing from above the diagonal (use with triC = 2)
   // split-K: each split covers a BK-aligned share of [0, K).  RBF products write their partial inner products to
   // C + split * sSplit and a second kernel applies the epilogue; plain products (sSplit = 0) accumulate into a
   // pre-zeroed C with float atomics (no D)
@@ -89,8 +90,11 @@ int launch_gemm_pair(const GemmParams& p0, int nbatch0, const GemmParams& p1, in
 int launch_gemm_pair2(const GemmParams& p0, int tA0, int tB0, int nbatch0, const GemmParams& p1, int tA1, int tB1,
                       int nbatch1, hipStream_t st, const char* tag);
 bool chol_rbf_gemm_applicable(int n, const GemmParams& p);
+// Extra destination for the factors L of the batch entries b >= first: ncopy copies, entry (b - first) of copy c at
+// base + (b - first) * stride_b + c * stride_copy, row stride ld (the ELBO program wants L_S inside its RK operand).
+struct CholExtra { float* base; int first; int ld; int64_t stride_b, stride_copy; int ncopy; };
 int launch_chol_rbf_gemm(const float* A, float eps, float* L, float* T, int32_t* info, int nchol, int n,
-                         const GemmParams& p, int nbatch, hipStream_t st);
+                         const GemmParams& p, int nbatch, hipStream_t st, const CholExtra* extra = nullptr);
 // number of K splits launch_gemm will use for an RBF product of this shape (1 = fused epilogue, no partials)
 int rbf_splitk(int M, int N, int K, int nbatch);
 

@@ -114,6 +114,10 @@ static T0Ws carve_t0(void* ws, int S, int C, int M, int D, int B, int F) {
 struct ProArgs {
   const float *mean, *logvar, *pmean, *plogvar, *eps_theta, *vec;
   float *theta, *w, *g2, *kd, *Lu, *Su, *scalars, *zero_begin, *bump;
+  // when the factorisation writes L_S into RK itself, the prologue writes the other small columns (no pack launch)
+  float* RK;
+  const float* u_mean;
+  int NR, LD;
   int32_t* info;
   int64_t zero_count, Dp;
   int S, C, M, D, ninfo, map_est, nzero_blocks;
@@ -219,7 +223,19 @@ __global__ __launch_bounds__(256) void t0_prologue_kernel(const ProArgs a) {
   const float dl = softplus_t0(rl[lo]);
   const float acc = fmaf(hi == lo ? dl : rh[lo], dl, (acc0 + acc1) + (acc2 + acc3));
   a.Su[e] = acc;
-  a.Lu[e] = j < i ? v[(int64_t)i * (i + 1) / 2 + j] : (j == i ? dl : 0.f);
+  const float lu = j < i ? v[(int64_t)i * (i + 1) / 2 + j] : (j == i ? dl : 0.f);
+  a.Lu[e] = lu;
+  if (a.RK) {   // RK[s, c, i, :] = [ m | 0 0 0 | (L_S: by the factorisation) | Lu | 0.. ]
+    for (int s = 0; s < a.S; ++s) {
+      float* r = a.RK + (((int64_t)s * a.C + c) * M + i) * a.LD;
+      r[4 + M + j] = lu;
+      if (j == 0) {
+        r[0] = a.u_mean[c * M + i];
+        r[1] = 0.f; r[2] = 0.f; r[3] = 0.f;
+        for (int col = 4 + 2 * M; col < a.NR; ++col) r[col] = 0.f;
+      }
+    }
+  }
 }
 
 // weighted squared row norms of the inducing points (na) and of the minibatch (nb), one wave per row; grid (rows/4, S)
@@ -683,9 +699,13 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
   const bool native = d->eps_f == nullptr;
   const float* eps_f = native ? o.eps_f : d->eps_f;
 
+  // the merged factorisation + K_uf launch also writes L_S into RK; then the prologue writes RK's other small columns
+  const bool merge_chol = D > kRbfDirectD && M > 50 && M <= 100 && (D % 4) == 0 && (LD % 4) == 0 &&
+                          ((reinterpret_cast<uintptr_t>(d->z) | reinterpret_cast<uintptr_t>(d->x)) & 15) == 0;
   {
     ProfScope prof("t0_prologue", st);
     ProArgs a{};
+    if (merge_chol) { a.RK = o.RK; a.u_mean = d->u_mean; a.NR = NR; a.LD = LD; }
     a.mean = d->log_mean; a.logvar = d->log_logvar; a.pmean = d->prior_log_mean; a.plogvar = d->prior_log_logvar;
     a.eps_theta = d->eps_theta; a.vec = d->u_tril_vec;
     a.theta = o.theta; a.w = o.w; a.g2 = o.g2; a.kd = o.kd; a.Lu = o.Lu; a.Su = o.KS + SC * MM; a.scalars = d->scalars;
@@ -734,7 +754,7 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
     p1.kscale = o.w; p1.ks_ld = o.Dp; p1.g2 = o.g2;
     p1.na = o.na; p1.sNa[0] = zrows;
     p1.nbv = o.nb; p1.sNb[0] = B;
-    if (chol_rbf_gemm_applicable(M, p1)) {
+    if (merge_chol && chol_rbf_gemm_applicable(M, p1)) {
       // K_uu first, then ONE launch in which SC + C workgroups factorise (K_uu + eps I, S_u + eps I) while the rest of
       // the chip builds K_uf, which nothing needs before the factors are done
       if (D >= 256 && (int64_t)kKuuSplit * M <= LD) {
@@ -750,7 +770,8 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
         rc = launch_gemm(p0, 0, 1, SC, true, st, "rbf_kuu_gemm");
         if (rc) return rc;
       }
-      rc = launch_chol_rbf_gemm(o.KS, d->jitter, o.LL, o.TT, d->info, SC + C, M, p1, S, st);
+      const CholExtra lx{o.RK + 4, SC, LD, MLD, (int64_t)C * MLD, S};      // L_S[c] -> RK[s, c, :, 4:4+M] for every s
+      rc = launch_chol_rbf_gemm(o.KS, d->jitter, o.LL, o.TT, d->info, SC + C, M, p1, S, st, &lx);
       if (rc) return rc;
       merged = true;
     } else {
@@ -763,7 +784,8 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
     rc = chol_inv_fwd_impl(o.KS, d->jitter, o.LL, o.TT, nullptr, d->info, SC + C, M, o.chol, o.chol_bytes, false, st);
     if (rc) return rc;
   }
-  {
+  if (!merged) {
+    VARGP_REQUIRE(!merge_chol, "elbo_t0_fwd: merged launch expected but not applicable");
     const int64_t total = (int64_t)SC * M * NR;
     hipLaunchKernelGGL(t0_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, d->u_mean, o.LL + SC * MM, o.Lu, o.RK, C,
                        M, NR, LD, total);

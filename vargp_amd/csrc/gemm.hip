@@ -487,6 +487,13 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int tile_id
             v = p.alpha * acc[a][c][r];
             if (D) v += p.beta * D[(int64_t)row * p.ldd + col];
             if (p.triC == 1 && col > row) v = 0.f;
+            if (p.symout) {                   // symmetric result from its lower triangle
+              if (col <= row) {
+                C[(int64_t)row * p.ldc + col] = v;
+                if (col < row) C[(int64_t)col * p.ldc + row] = v;
+              }
+              continue;
+            }
             if (p.splitk > 1) {               // K split without a scratch buffer: partial sums meet in C (pre-zeroed)
               if (v != 0.f) atomicAdd(&C[(int64_t)row * p.ldc + col], v);
               continue;
@@ -600,6 +607,7 @@ struct CholArgs {
   float* L; int ldl; int64_t sL;
   float* T; int ldt; int64_t sT;
   int32_t* info; int n; int nchol;
+  CholExtra extra;   // base == nullptr: none
 };
 template <int KC, int SETS>
 __global__ __launch_bounds__(256) void chol_rbf_gemm_kernel(const CholArgs c, const GemmParams p, const int tiles) {
@@ -607,7 +615,7 @@ __global__ __launch_bounds__(256) void chol_rbf_gemm_kernel(const CholArgs c, co
   __shared__ __attribute__((aligned(16))) float lds[cmax(gemm_lds_floats<64, 64, 64, true, true>(), chol3_stage_floats<KC>())];
   if ((int)blockIdx.x < c.nchol) {
     chol3_body<KC, SETS>(blockIdx.x, c.A, c.lda, c.sA, c.eps, c.L, c.ldl, c.sL, c.T, c.ldt, c.sT, nullptr, c.info, 0, c.n,
-                         0, lds);
+                         0, lds, c.extra.base ? &c.extra : nullptr);
     return;
   }
   const int id = xcd_remap((int)blockIdx.x - c.nchol, (int)gridDim.x - c.nchol);
@@ -652,23 +660,24 @@ int launch_gemm_pair(const GemmParams& p0, int nbatch0, const GemmParams& p1, in
 // factorisations (n in (50, 100], dense n x n matrices) + one RBF GEMM in one launch; false if the shapes do not
 // qualify (the caller then launches them separately)
 static int launch_chol_rbf_gemm_impl(const float* A, float eps, float* L, float* T, int32_t* info, int nchol, int n,
-                                     const GemmParams& p, int nbatch, hipStream_t st);
+                                     const GemmParams& p, int nbatch, hipStream_t st, const CholExtra& extra);
 bool chol_rbf_gemm_applicable(int n, const GemmParams& p) { return n > 50 && n <= 100 && gemm_vec_ok(p); }
 int launch_chol_rbf_gemm(const float* A, float eps, float* L, float* T, int32_t* info, int nchol, int n,
-                         const GemmParams& p, int nbatch, hipStream_t st) {
+                         const GemmParams& p, int nbatch, hipStream_t st, const CholExtra* extra) {
+  const CholExtra ex = extra ? *extra : CholExtra{};
   if (prof_remembering()) {
     const GemmParams pc = p;
     prof_remember("chol_rbf_gemm", [=](hipStream_t s) {
-      launch_chol_rbf_gemm_impl(A, eps, L, T, info, nchol, n, pc, nbatch, s);
+      launch_chol_rbf_gemm_impl(A, eps, L, T, info, nchol, n, pc, nbatch, s, ex);
     });
   }
-  return launch_chol_rbf_gemm_impl(A, eps, L, T, info, nchol, n, p, nbatch, st);
+  return launch_chol_rbf_gemm_impl(A, eps, L, T, info, nchol, n, p, nbatch, st, ex);
 }
 static int launch_chol_rbf_gemm_impl(const float* A, float eps, float* L, float* T, int32_t* info, int nchol, int n,
-                                     const GemmParams& p, int nbatch, hipStream_t st) {
+                                     const GemmParams& p, int nbatch, hipStream_t st, const CholExtra& extra) {
   ProfScope prof("chol_rbf_gemm", st);
   const int64_t nn = (int64_t)n * n;
-  CholArgs c{A, n, nn, eps, L, n, nn, T, n, nn, info, n, nchol};
+  CholArgs c{A, n, nn, eps, L, n, nn, T, n, nn, info, n, nchol, extra};
   GemmParams q = p;
   q.splitk = 1;
   const int tiles = cdiv(p.M, 64) * cdiv(p.N, 64);
