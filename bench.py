@@ -34,6 +34,8 @@ DOMINANT_TAG = 'rbf_kuf'       # the K_uf distance GEMM incl. its split-K combin
 WORKLOADS = {
     'smnist': dict(S=3, M=100, n_prev=0, desc='Split-MNIST task-0 ELBO step (BASELINE config 1)'),
     'smnist_s64': dict(S=64, M=100, n_prev=0, desc='Split-MNIST task-0, 64 hyper-samples on ONE GPU (BASELINE config 3 unsharded)'),
+    'smnist_t1': dict(S=3, M=100, n_prev=1, desc='Split-MNIST task 1 (Mt=200), M=100, S=3 (composed per-op path)'),
+    'smnist_t4': dict(S=3, M=100, n_prev=4, desc='Split-MNIST task 4 (Mt=500), M=100, S=3 (composed per-op path)'),
     'pmnist_t0': dict(S=10, M=200, n_prev=0, desc='Permuted-MNIST task 0, M=200, S=10 (BASELINE config 2)'),
     'pmnist_t1': dict(S=10, M=200, n_prev=1, desc='Permuted-MNIST task 1 (Mt=400), M=200, S=10'),
     'pmnist_t4': dict(S=10, M=200, n_prev=4, desc='Permuted-MNIST task 4 (Mt=1000), M=200, S=10'),
