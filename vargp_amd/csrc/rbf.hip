@@ -102,6 +102,32 @@ __global__ __launch_bounds__(256) void rbf_norm_kernel(const float* __restrict__
   if (lane == 0) nrm[(int64_t)s * rows + row] = acc;
 }
 
+// prep + both norm passes in one launch: nrm_x[s][row] = sum_d w_sd x[row][d]^2 (likewise y), w_sd = exp(-2 theta_sd)
+// evaluated on the fly; the blocks with blockIdx.x == 0 also store w (zero-padded to Dp) and g2 = exp(2 theta_sD) for the
+// GEMM that follows.  One wave per row; grid (ceil((xrows + yrows) / 4), S).
+__global__ __launch_bounds__(256) void rbf_prep_norm_kernel(const float* __restrict__ theta, const float* __restrict__ x,
+                                                            const float* __restrict__ y, float* __restrict__ w,
+                                                            float* __restrict__ g2, float* __restrict__ na,
+                                                            float* __restrict__ nb, int64_t xrows, int64_t yrows, int D,
+                                                            int64_t Dp) {
+  const int s = blockIdx.y, lane = threadIdx.x & 63;
+  const float* th = theta + (int64_t)s * (D + 1);
+  if (blockIdx.x == 0) {
+    for (int d = threadIdx.x; d < Dp; d += 256) w[s * Dp + d] = d < D ? expf(-2.f * th[d]) : 0.f;
+    if (threadIdx.x == 0) g2[s] = expf(2.f * th[D]);
+  }
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= xrows + yrows) return;
+  const bool isx = row < xrows;
+  const float* xr = isx ? x + row * D : y + (row - xrows) * D;
+  float acc = 0.f;
+  for (int d = lane; d < D; d += 64) { const float v = xr[d]; acc = fmaf(v * v, expf(-2.f * th[d]), acc); }
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    if (isx) na[(int64_t)s * xrows + row] = acc; else nb[(int64_t)s * yrows + (row - xrows)] = acc;
+  }
+}
+
 // W = gK o K with its row sums r, column sums c and total (dlog gamma = 2 sum W) in one pass.
 // grid (ceil(N/256), ceil(Mb/32), nb): a thread owns one column of a 32-row strip; r and c are
 // accumulated with float atomics (pre-zeroed by the caller), the total with one atomic per block.
@@ -151,7 +177,7 @@ __global__ void rbf_add_kernel(float* __restrict__ r, const float* __restrict__ 
 // block = 64 d-columns x 4 row lanes, RPB rows per block.
 constexpr int RPB = 32;
 __global__ __launch_bounds__(256) void rbf_final_kernel(const float* __restrict__ x, const float* __restrict__ R,
-                                                        const float* __restrict__ P, const float* __restrict__ w,
+                                                        const float* __restrict__ P, const float* __restrict__ theta,
                                                         float* __restrict__ g, float* __restrict__ gtheta,
                                                         int64_t rows, int D, int64_t Dp, int S, float kappa,
                                                         int accumulate) {
@@ -168,7 +194,7 @@ __global__ __launch_bounds__(256) void rbf_final_kernel(const float* __restrict_
     ga[j] = 0.f;
   }
   for (int s = 0; s < S; ++s) {
-    const float wv = dok ? w[s * Dp + d] : 0.f;
+    const float wv = dok ? expf(-2.f * theta[(int64_t)s * (D + 1) + d]) : 0.f;   // 1/sigma_d^2
     float th = 0.f;
 #pragma unroll
     for (int j = 0; j < RPB / 4; ++j) {
@@ -235,14 +261,13 @@ extern "C" int vargp_rbf_gram_fwd(const float* theta, const float* X, const floa
   VARGP_REQUIRE(ws_bytes >= vargp_rbf_workspace_bytes(S, C, M, N, D, 0), "rbf_gram_fwd: workspace too small");
   hipStream_t st = as_stream(stream);
   RbfWs o = carve(ws, S, C, M, N, D, false);
-  hipLaunchKernelGGL(rbf_prep_kernel, dim3(S), dim3(256), 0, st, theta, o.w, o.g2, D, o.Dp);
   if (D <= kDirectD) {
+    hipLaunchKernelGGL(rbf_prep_kernel, dim3(S), dim3(256), 0, st, theta, o.w, o.g2, D, o.Dp);
     return rbf_direct_launch(X, Y, o.w, o.g2, K, N, S, C, M, N, D, o.Dp, y_shared, st);
   }
   const int64_t xrows = (int64_t)C * M, yrows = y_shared ? N : (int64_t)C * N;
-  hipLaunchKernelGGL(rbf_norm_kernel, dim3(cdiv(xrows, 4), S), dim3(256), 0, st, X, o.w, o.na, xrows, D, o.Dp);
-  if (!self)
-    hipLaunchKernelGGL(rbf_norm_kernel, dim3(cdiv(yrows, 4), S), dim3(256), 0, st, Y, o.w, o.nb, yrows, D, o.Dp);
+  hipLaunchKernelGGL(rbf_prep_norm_kernel, dim3(cdiv(xrows + (self ? 0 : yrows), 4), S), dim3(256), 0, st, theta, X, Y, o.w,
+                     o.g2, o.na, o.nb, xrows, self ? (int64_t)0 : yrows, D, o.Dp);
   // shared Y: the classes' inducing points are just more rows of one [C*M, D] x [D, N] product
   const int Cb = y_shared ? 1 : C, Mb = y_shared ? C * M : M;
   GemmParams p{};
@@ -293,7 +318,6 @@ extern "C" int vargp_rbf_gram_bwd(const float* theta, const float* X, const floa
   const int nb = S * Cb;
 
   if (!accumulate) zero_async(gtheta, sizeof(float) * (size_t)S * (D + 1), st);
-  hipLaunchKernelGGL(rbf_prep_kernel, dim3(S), dim3(256), 0, st, theta, o.w, o.g2, D, o.Dp);
   const int64_t nrows = (int64_t)S * xrows;
   float* Wfirst = self ? o.W2 : o.Wm;  // self: raw W goes to W2, W + W^T to Wm
   zero_async(o.r, sizeof(float) * (size_t)(o.P - o.r), st);   // r and c are adjacent
@@ -315,7 +339,7 @@ extern "C" int vargp_rbf_gram_bwd(const float* theta, const float* X, const floa
   int rc = launch_gemm(p, 0, 0, nb, false, st, self ? "rbf_kuu_bwd_gemm" : "rbf_kuf_bwd_gemm");
   if (rc) return rc;
   const dim3 gx(cdiv(D, 64), cdiv(xrows, RPB));
-  hipLaunchKernelGGL(rbf_final_kernel, gx, dim3(256), 0, st, X, o.r, o.P, o.w, gX, gtheta, xrows, D, o.Dp, S,
+  hipLaunchKernelGGL(rbf_final_kernel, gx, dim3(256), 0, st, X, o.r, o.P, theta, gX, gtheta, xrows, D, o.Dp, S,
                      self ? 1.f : 2.f, accumulate);
   if (!self) {
     const float* Qp = nullptr;
@@ -333,7 +357,7 @@ extern "C" int vargp_rbf_gram_bwd(const float* theta, const float* X, const floa
       Qp = o.Q;
     }
     const dim3 gy(cdiv(D, 64), cdiv(yrows, RPB));
-    hipLaunchKernelGGL(rbf_final_kernel, gy, dim3(256), 0, st, Y, o.c, Qp, o.w, gY, gtheta, yrows, D, o.Dp, S, 0.f,
+    hipLaunchKernelGGL(rbf_final_kernel, gy, dim3(256), 0, st, Y, o.c, Qp, theta, gY, gtheta, yrows, D, o.Dp, S, 0.f,
                        accumulate);
   }
   return check_launch("rbf_gram_bwd");
