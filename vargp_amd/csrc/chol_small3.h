@@ -164,30 +164,44 @@ __device__ __forceinline__ void chol3_body(const int64_t b, const float* __restr
   L += b * strideL;
   if (T) T += b * strideT;
 
-  // the matrix comes in through LDS: coalesced global reads, then every thread picks its entries (rows 4k + w)
   const int di = 256 / n, dj = 256 - di * n;   // element e -> e + 256 without a division per element
-  {
-    int i = tid / n, j = tid - i * n;
-    for (int e = tid; e < n * n; e += 256) {
-      stage[i * LS + j] = A[(int64_t)i * lda + j];
-      i += di; j += dj;
-      if (j >= n) { j -= n; ++i; }
-    }
-  }
-  __syncthreads();
   double va[KC], vb[KC];
+  if (extra && extra->symmetric_input) {
+    // both triangles valid: row i lies across the lanes, coalesced as it is
 #pragma unroll
-  for (int k = 0; k < KC; ++k) {
-    const int i = 4 * k + w;
-    va[k] = 0.0; vb[k] = 0.0;
-    if (i < n) {   // only the lower triangle of the input is trusted: mirror it
-      if (minea) {
-        const int hi = i > ca ? i : ca, lo = i > ca ? ca : i;
-        va[k] = (double)stage[hi * LS + lo] + (i == ca ? (double)eps : 0.0);
+    for (int k = 0; k < KC; ++k) {
+      const int i = 4 * k + w;
+      va[k] = 0.0; vb[k] = 0.0;
+      if (i < n) {
+        if (minea) va[k] = (double)A[(int64_t)i * lda + ca] + (i == ca ? (double)eps : 0.0);
+        if (mineb) vb[k] = (double)A[(int64_t)i * lda + cb] + (i == cb ? (double)eps : 0.0);
       }
-      if (mineb) {
-        const int hi = i > cb ? i : cb, lo = i > cb ? cb : i;
-        vb[k] = (double)stage[hi * LS + lo] + (i == cb ? (double)eps : 0.0);
+    }
+  } else {
+    // only the lower triangle is trusted: the matrix comes in through LDS (coalesced global reads), then every
+    // thread picks its entries (rows 4k + w) mirrored
+    {
+      int i = tid / n, j = tid - i * n;
+      for (int e = tid; e < n * n; e += 256) {
+        stage[i * LS + j] = A[(int64_t)i * lda + j];
+        i += di; j += dj;
+        if (j >= n) { j -= n; ++i; }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+      const int i = 4 * k + w;
+      va[k] = 0.0; vb[k] = 0.0;
+      if (i < n) {
+        if (minea) {
+          const int hi = i > ca ? i : ca, lo = i > ca ? ca : i;
+          va[k] = (double)stage[hi * LS + lo] + (i == ca ? (double)eps : 0.0);
+        }
+        if (mineb) {
+          const int hi = i > cb ? i : cb, lo = i > cb ? cb : i;
+          vb[k] = (double)stage[hi * LS + lo] + (i == cb ? (double)eps : 0.0);
+        }
       }
     }
   }
@@ -232,6 +246,19 @@ __device__ __forceinline__ void chol3_body(const int64_t b, const float* __restr
         if (mineb) T[(int64_t)i * ldt + cb] = cb < i ? (float)(vb[k] * isi) : (cb == i ? (float)isi : 0.f);
       }
     }
+  }
+  if (extra && extra->diag_only_before_first && b < extra->first) {
+    // only diag(L) is wanted: rows straight from registers, zeros off the diagonal
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+      const int i = 4 * k + w;
+      if (i < n) {
+        const float si = (float)sq[i];
+        if (minea) L[(int64_t)i * ldl + ca] = ca == i ? si : 0.f;
+        if (mineb) L[(int64_t)i * ldl + cb] = cb == i ? si : 0.f;
+      }
+    }
+    return;   // (no logdet in this mode: the merged launch never asks for it)
   }
   // L is the transpose of the row tails: through LDS (lower entry (e, i) from the tail of row i, zero at (i, e)),
   // then coalesced rows out

@@ -92,7 +92,12 @@ int launch_gemm_pair2(const GemmParams& p0, int tA0, int tB0, int nbatch0, const
 bool chol_rbf_gemm_applicable(int n, const GemmParams& p);
 // Extra destination for the factors L of the batch entries b >= first: ncopy copies, entry (b - first) of copy c at
 // base + (b - first) * stride_b + c * stride_copy, row stride ld (the ELBO program wants L_S inside its RK operand).
-struct CholExtra { float* base; int first; int ld; int64_t stride_b, stride_copy; int ncopy; };
+// symmetric_input: both triangles of every input matrix are valid (coalesced direct load instead of the mirrored one).
+// diag_only_before_first: for the batch entries b < first only the diagonal of L is wanted (the rest is written as 0).
+struct CholExtra {
+  float* base; int first; int ld; int64_t stride_b, stride_copy; int ncopy;
+  int symmetric_input, diag_only_before_first;
+};
 int launch_chol_rbf_gemm(const float* A, float eps, float* L, float* T, int32_t* info, int nchol, int n,
                          const GemmParams& p, int nbatch, hipStream_t st, const CholExtra* extra = nullptr);
 // number of K splits launch_gemm will use for an RBF product of this shape (1 = fused epilogue, no partials)

@@ -770,7 +770,9 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
         rc = launch_gemm(p0, 0, 1, SC, true, st, "rbf_kuu_gemm");
         if (rc) return rc;
       }
-      const CholExtra lx{o.RK + 4, SC, LD, MLD, (int64_t)C * MLD, S};      // L_S[c] -> RK[s, c, :, 4:4+M] for every s
+      // L_S[c] -> RK[s, c, :, 4:4+M] for every s; K_uu and S_u arrive with both triangles; of the K_uu factors only
+      // the diagonal of L is ever used (log-determinant, and L^T diag(.) in the backward), everything else goes through T
+      const CholExtra lx{o.RK + 4, SC, LD, MLD, (int64_t)C * MLD, S, 1, 1};
       rc = launch_chol_rbf_gemm(o.KS, d->jitter, o.LL, o.TT, d->info, SC + C, M, p1, S, st, &lx);
       if (rc) return rc;
       merged = true;
