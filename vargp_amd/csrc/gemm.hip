@@ -609,17 +609,17 @@ struct CholArgs {
   int32_t* info; int n; int nchol;
   CholExtra extra;   // base == nullptr: none
 };
-template <int KC, int SETS>
+template <int KC, int SETS, int BM, int BK>
 __global__ __launch_bounds__(256) void chol_rbf_gemm_kernel(const CholArgs c, const GemmParams p, const int tiles) {
   // one LDS array for both roles (the factorisation stages its matrix through 40 KB of it): 2 workgroups per CU
-  __shared__ __attribute__((aligned(16))) float lds[cmax(gemm_lds_floats<64, 64, 64, true, true>(), chol3_stage_floats<KC>())];
+  __shared__ __attribute__((aligned(16))) float lds[cmax(gemm_lds_floats<BM, 64, BK, true, true>(), chol3_stage_floats<KC>())];
   if ((int)blockIdx.x < c.nchol) {
     chol3_body<KC, SETS>(blockIdx.x, c.A, c.lda, c.sA, c.eps, c.L, c.ldl, c.sL, c.T, c.ldt, c.sT, nullptr, c.info, 0, c.n,
                          0, lds, c.extra.base ? &c.extra : nullptr);
     return;
   }
   const int id = xcd_remap((int)blockIdx.x - c.nchol, (int)gridDim.x - c.nchol);
-  gemm_body<64, 64, 64, true, true, true, true>(p, id % tiles, id / tiles, 0, lds);
+  gemm_body<BM, 64, BK, true, true, true, true>(p, id % tiles, id / tiles, 0, lds);
 }
 
 static bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -680,15 +680,26 @@ static int launch_chol_rbf_gemm_impl(const float* A, float eps, float* L, float*
   CholArgs c{A, n, nn, eps, L, n, nn, T, n, nn, info, n, nchol, extra};
   GemmParams q = p;
   q.splitk = 1;
-  const int tiles = cdiv(p.M, 64) * cdiv(p.N, 64);
+  // GEMM tile: 64x64x64 normally; 128x64x32 when that lets the GEMM finish in ONE round on the CUs the
+  // factorisations leave free (the BASELINE shape: 384 tiles on 216 CUs would need two rounds, 192 need one)
+  static const int tile_force = [] { const char* e = getenv("VARGP_MERGED_TILE"); return e ? atoi(e) : 0; }();   // tuning aid
+  const int t64 = cdiv(p.M, 64) * cdiv(p.N, 64), t128 = cdiv(p.M, 128) * cdiv(p.N, 64);
+  const int free_cus = 256 - nchol;
+  const bool big = tile_force ? tile_force == 2 : (t64 * nbatch > free_cus && t128 * nbatch <= free_cus);
+  const int tiles = big ? t128 : t64;
   const int total = nchol + tiles * nbatch;
   // The kernel needs 68 KB of LDS, so two workgroups fit a CU.  While the GEMM is small enough to finish under the
   // factorisations anyway (the BASELINE shapes), reserving unused dynamic LDS keeps every factorising CU to itself --
   // a co-resident GEMM workgroup competes for its issue slots and stretches the pivot chain (68 -> 77 us measured);
   // with many samples the GEMM dominates and wants both slots (S = 64: 950 -> 676 us).
-  const unsigned pad = tiles * nbatch <= 1024 ? 24u * 1024u : 0u;
-  if (n <= 64) hipLaunchKernelGGL((chol_rbf_gemm_kernel<16, 1>), dim3(total), dim3(256), pad, st, c, q, tiles);
-  else hipLaunchKernelGGL((chol_rbf_gemm_kernel<25, 2>), dim3(total), dim3(256), pad, st, c, q, tiles);
+  const unsigned pad = tiles * nbatch <= 1024 ? (big ? 40u : 24u) * 1024u : 0u;
+#define VARGP_MERGED(KC, SETS)                                                                                        \
+  do {                                                                                                                  \
+    if (big) hipLaunchKernelGGL((chol_rbf_gemm_kernel<KC, SETS, 128, 32>), dim3(total), dim3(256), pad, st, c, q, tiles); \
+    else hipLaunchKernelGGL((chol_rbf_gemm_kernel<KC, SETS, 64, 64>), dim3(total), dim3(256), pad, st, c, q, tiles);    \
+  } while (0)
+  if (n <= 64) VARGP_MERGED(16, 1); else VARGP_MERGED(25, 2);
+#undef VARGP_MERGED
   return check_launch("chol_rbf_gemm");
 }
 
