@@ -19,7 +19,10 @@ def _problem(S, F_, C, M, D, B, seed, kind='gauss'):
 # (S, F, C, M, D, B): odd M (padded small-column block), B not a multiple of 4 (padded row stride, scalar GEMM
 # loads), C > 16 (generic softmax kernels), D <= 32 (direct distance form), M > 100 (blocked Cholesky)
 SHAPES = [(2, 3, 3, 33, 40, 50), (3, 2, 4, 20, 64, 37), (2, 2, 18, 12, 36, 24), (2, 3, 2, 20, 2, 64),
-          (1, 2, 2, 130, 48, 40)]
+          (1, 2, 2, 130, 48, 40),
+          # tiny / degenerate: one class, one hyper-sample, one likelihood sample, 3 inducing points, 2 data points;
+          # M = 64 and M = 65 (the two register-slot layouts of the factorisation kernel), M = 100 with B % 4 != 0
+          (1, 1, 1, 3, 33, 2), (2, 2, 2, 64, 40, 33), (2, 2, 2, 65, 40, 32), (1, 2, 2, 100, 36, 50), (1, 2, 3, 51, 36, 8)]
 
 
 @pytest.mark.parametrize('shape', SHAPES, ids=[str(s) for s in SHAPES])
