@@ -69,7 +69,7 @@ struct T0Ws {
   float *theta, *eps_theta, *eps_f, *w, *g2, *kd, *na, *nb, *Lu, *KS, *LL, *TT, *RK, *QP, *W, *mu, *var;
   float *gmu, *gvar;               // accumulators zeroed by the forward prologue (softmax gradient, unscaled)
   float *r_uf, *c_uf, *gtheta;     // accumulators zeroed by the first backward kernel
-  float *r_uu, *gW, *ga, *gkd, *gQP, *gLL, *gTT, *gRK, *gKS, *Wuu, *Puu, *Puf;
+  float *r_uu, *gW, *gkd, *gQP, *gLL, *gTT, *gRK, *gKS, *Wuu, *Puu, *Puf;
   float* kpart;                    // split-K partial inner products of K_uu (forward only: aliases gRK)
   void* chol;
   size_t chol_bytes;
@@ -95,7 +95,7 @@ static T0Ws carve_t0(void* ws, int S, int C, int M, int D, int B, int F) {
   o.mu = take(SC * B); o.var = take(SC * B);
   o.gmu = take(SC * B); o.gvar = take(SC * B);                                    // adjacent: one zero range
   o.r_uf = take(SC * M); o.c_uf = take((int64_t)S * B); o.gtheta = take(S * D1);  // adjacent: one zero range
-  o.r_uu = take(SC * M); o.gW = take(SC * M * B); o.ga = take(SC * M); o.gkd = take(SC);
+  o.r_uu = take(SC * M); o.gW = take(SC * M * B); o.gkd = take(SC);
   o.gQP = take(SC * M * o.LD); o.gLL = take((SC + C) * MM); o.gTT = take((SC + C) * MM);
   o.gRK = take(SC * M * o.LD); o.gKS = take((SC + C) * MM); o.Wuu = take(SC * MM);
   o.Puu = take(SC * M * D); o.Puf = take(SC * M * D);

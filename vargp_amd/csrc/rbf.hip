@@ -88,20 +88,6 @@ __global__ __launch_bounds__(256) void rbf_combine_kernel(const float* __restric
   K[e] = (same_xy && m == col) ? g2[s] : g2[s] * expf(-0.5f * d2);
 }
 
-// nrm[s][row] = sum_d w[s][d] x[row][d]^2 ; one wave per row, grid (ceil(rows/4), S)
-__global__ __launch_bounds__(256) void rbf_norm_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                       float* __restrict__ nrm, int64_t rows, int D, int64_t Dp) {
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int s = blockIdx.y, lane = threadIdx.x & 63;
-  if (row >= rows) return;
-  const float* xr = x + row * D;
-  const float* ws = w + s * Dp;
-  float acc = 0.f;
-  for (int d = lane; d < D; d += 64) { const float v = xr[d]; acc = fmaf(v * v, ws[d], acc); }
-  acc = wave_sum(acc);
-  if (lane == 0) nrm[(int64_t)s * rows + row] = acc;
-}
-
 // prep + both norm passes in one launch: nrm_x[s][row] = sum_d w_sd x[row][d]^2 (likewise y), w_sd = exp(-2 theta_sd)
 // evaluated on the fly; the blocks with blockIdx.x == 0 also store w (zero-padded to Dp) and g2 = exp(2 theta_sD) for the
 // GEMM that follows.  One wave per row; grid (ceil((xrows + yrows) / 4), S).
