@@ -757,14 +757,15 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
     if (merge_chol && chol_rbf_gemm_applicable(M, p1)) {
       // K_uu first, then ONE launch in which SC + C workgroups factorise (K_uu + eps I, S_u + eps I) while the rest of
       // the chip builds K_uf, which nothing needs before the factors are done
-      if (D >= 256 && (int64_t)kKuuSplit * M <= LD) {
+      static const int ksp = [] { const char* e = getenv("VARGP_KUU_SPLIT"); return e ? atoi(e) : kKuuSplit; }();   // tuning aid
+      if (D >= 256 && (int64_t)ksp * M <= LD && ksp > 1) {
         // 4 SC workgroups with D/64 slabs each would leave half the chip idle for the length of that K loop: split K,
         // partial inner products to scratch, distance/exp epilogue in a second pass
         GemmParams ps = p0;
-        ps.splitk = kKuuSplit; ps.sSplit = SC * MM; ps.C = o.kpart;
+        ps.splitk = ksp; ps.sSplit = SC * MM; ps.C = o.kpart;
         rc = launch_gemm(ps, 0, 1, SC, true, st, "rbf_kuu_gemm");
         if (rc) return rc;
-        rc = rbf_combine_self_launch(o.kpart, kKuuSplit, o.na, o.g2, o.KS, S, C, M, st);
+        rc = rbf_combine_self_launch(o.kpart, ksp, o.na, o.g2, o.KS, S, C, M, st);
         if (rc) return rc;
       } else {
         rc = launch_gemm(p0, 0, 1, SC, true, st, "rbf_kuu_gemm");
