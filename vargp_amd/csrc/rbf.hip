@@ -13,7 +13,7 @@
 namespace vargp {
 
 struct RbfWs {
-  float *w, *g2, *na, *nb, *part, *Wm, *W2, *r, *c, *P, *Q;
+  float *w, *g2, *na, *nb, *part, *Wm, *r, *c, *P, *Q;
   int64_t Dp;
   size_t bytes;
 };
@@ -31,7 +31,6 @@ static RbfWs carve(void* ws, int S, int C, int M, int N, int D, bool backward) {
     o.part = take((int64_t)2 * S * C * M * N);      // split-K partial products (at most 2 splits)
   } else {
     o.Wm = take((int64_t)S * C * M * N);
-    o.W2 = take((int64_t)S * C * M * N);
     o.r = take((int64_t)S * C * M);
     o.c = take((int64_t)S * C * N);
     o.P = take((int64_t)S * C * M * D);
@@ -143,18 +142,32 @@ __global__ __launch_bounds__(256) void rbf_w_kernel(const float* __restrict__ K,
   if (threadIdx.x == 0) atomicAdd(&gtheta[(b / Cb) * (D + 1) + D], 2.f * tot);
 }
 
-// square case (Y = X): W <- W + W^T (out of place into Ws), r <- r + c.  grid (ceil(M*M/256), nb)
-__global__ __launch_bounds__(256) void rbf_w_sym_kernel(const float* __restrict__ W, float* __restrict__ Ws, int M) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  const int64_t b = blockIdx.y;
-  if (e >= M * M) return;
-  const int i = e / M, j = e % M;
-  const float* w = W + b * M * M;
-  Ws[b * M * M + e] = w[e] + w[(int64_t)j * M + i];
-}
-__global__ void rbf_add_kernel(float* __restrict__ r, const float* __restrict__ c, int64_t n) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) r[i] += c[i];
+// Square case (Y = X) in one pass: Ws = W + W^T with W = gK o K, r = its row sums (= row + column sums of W), and
+// sum Ws (= 2 sum W) into gtheta[s, D].  kSelfRows consecutive rows of one matrix per block, a wave takes every 4th.
+constexpr int kSelfRows = 16;
+__global__ __launch_bounds__(256) void rbf_w_self_kernel(const float* __restrict__ K, const float* __restrict__ gK,
+                                                         float* __restrict__ Ws, float* __restrict__ r,
+                                                         float* __restrict__ gtheta, int M, int Cb, int D, int nchunk) {
+  __shared__ float red[4];
+  const int lane = threadIdx.x & 63;
+  const int64_t b = blockIdx.x / nchunk;
+  const int i0 = ((int)blockIdx.x % nchunk) * kSelfRows, i1 = min(M, i0 + kSelfRows);
+  const float* Kb = K + b * M * M;
+  const float* gKb = gK + b * M * M;
+  float tot = 0.f;
+  for (int i = i0 + (threadIdx.x >> 6); i < i1; i += 4) {
+    float acc = 0.f;
+    for (int j = lane; j < M; j += 64) {
+      const float v = Kb[(int64_t)i * M + j] * gKb[(int64_t)i * M + j] + Kb[(int64_t)j * M + i] * gKb[(int64_t)j * M + i];
+      Ws[b * M * M + (int64_t)i * M + j] = v;
+      acc += v;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) r[b * M + i] = acc;
+    tot += acc;
+  }
+  const float t = block_sum<256>(lane == 0 ? tot : 0.f, red);   // every lane of a wave holds the wave's total
+  if (threadIdx.x == 0) atomicAdd(&gtheta[(b / Cb) * (D + 1) + D], t);
 }
 
 // Finalise one side.  rows = points of this side (flattened over classes), S samples.
@@ -304,14 +317,13 @@ extern "C" int vargp_rbf_gram_bwd(const float* theta, const float* X, const floa
   const int nb = S * Cb;
 
   if (!accumulate) zero_async(gtheta, sizeof(float) * (size_t)S * (D + 1), st);
-  const int64_t nrows = (int64_t)S * xrows;
-  float* Wfirst = self ? o.W2 : o.Wm;  // self: raw W goes to W2, W + W^T to Wm
-  zero_async(o.r, sizeof(float) * (size_t)(o.P - o.r), st);   // r and c are adjacent
-  hipLaunchKernelGGL(rbf_w_kernel, dim3(cdiv(N, 256), cdiv(Mb, WROWS), nb), dim3(256), 0, st, K, gK, Wfirst, o.r, o.c,
-                     gtheta, Mb, N, Cb, D);
   if (self) {
-    hipLaunchKernelGGL(rbf_w_sym_kernel, dim3(cdiv((int64_t)M * M, 256), nb), dim3(256), 0, st, Wfirst, o.Wm, M);
-    hipLaunchKernelGGL(rbf_add_kernel, dim3(cdiv(nrows, 256)), dim3(256), 0, st, o.r, o.c, nrows);
+    const int nchunk = cdiv(M, kSelfRows);
+    hipLaunchKernelGGL(rbf_w_self_kernel, dim3(nb * nchunk), dim3(256), 0, st, K, gK, o.Wm, o.r, gtheta, M, Cb, D, nchunk);
+  } else {
+    zero_async(o.r, sizeof(float) * (size_t)(o.P - o.r), st);   // r and c are adjacent
+    hipLaunchKernelGGL(rbf_w_kernel, dim3(cdiv(N, 256), cdiv(Mb, WROWS), nb), dim3(256), 0, st, K, gK, o.Wm, o.r, o.c,
+                       gtheta, Mb, N, Cb, D);
   }
   // P = W . Y   ([Mb, N] x [N, D]) per (s, class-batch)
   GemmParams p{};
