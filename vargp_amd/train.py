@@ -79,7 +79,9 @@ class ElboTrainer:
                 self.step(self._sx, self._sy)
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        if noise._shard is not None:
+        if noise._shard is not None and not (self._t0 and self.native_noise):
+            # the composed (t > 0) path draws its noise from the shared torch generator inside the captured region;
+            # the first-task program has its own counter-based generator and needs no generator bookkeeping per replay
             self.graph.register_generator_state(noise._shard[2])
         if self.world == 1:
             with torch.cuda.graph(self.graph):
