@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void yogi_multi_kernel(YogiPack pk, int ntenso
 
 using namespace vargp;
 
-extern "C" int vargp_version(void) { return 100; }
+extern "C" int vargp_version(void) { return 110; }   // 110: native first-task program, launch replay, 4-GEMM Cholesky backward
 extern "C" const char* vargp_last_error(void) { return g_err; }
 
 extern "C" int vargp_sum_outer(const float* in, float* out, int64_t outer, int64_t inner, vargp_stream_t stream) {
