@@ -106,8 +106,6 @@ int rbf_splitk(int M, int N, int K, int nbatch);
 constexpr int kRbfDirectD = 32;   // D <= this: kernel matrices from the direct (no-cancellation) distance form
 int rbf_direct_launch(const float* X, const float* Y, const float* w, const float* g2, float* K, int64_t ldk, int S,
                       int C, int M, int N, int D, int64_t Dp, int y_shared, hipStream_t st);
-int rbf_combine_self_launch(const float* part, int nsplit, const float* na, const float* g2, float* K, int S, int C, int M,
-                            hipStream_t st);
 int chol_inv_fwd_impl(const float* A, float eps, float* L, float* T, float* logdet, int32_t* info, int nbatch, int n,
                       void* ws, size_t ws_bytes, bool zero_info, hipStream_t st);
 

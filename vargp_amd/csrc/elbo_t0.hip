@@ -257,6 +257,46 @@ __global__ __launch_bounds__(256) void t0_norm_kernel(const float* __restrict__ 
   }
 }
 
+// Epilogue of the K-split K_uu product and the row norms in one launch (they do not depend on each other: the norms
+// the K_uu distances need are the diagonal of the weighted Gram matrix G = sum of the partial products itself).
+//   blocks < ncomb: K_uu[s,c,i,j] = g2 exp(-(G_ii + G_jj - 2 G_ij) / 2), exactly g2 on the diagonal; one thread per entry
+//   rest          : na, nb of t0_norm_kernel (for the K_uf epilogue), one wave per row and hyper-sample
+__global__ __launch_bounds__(256) void t0_combine_norm_kernel(const float* __restrict__ part, int nsplit, int64_t sSplit,
+                                                              const float* __restrict__ g2, float* __restrict__ Kuu, int C,
+                                                              int M, int64_t total, int ncomb, const float* __restrict__ z,
+                                                              const float* __restrict__ x, const float* __restrict__ w,
+                                                              float* __restrict__ na, float* __restrict__ nb,
+                                                              int64_t zrows, int64_t xrows, int D, int64_t Dp, int nrow4) {
+  if ((int)blockIdx.x < ncomb) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int j = e % M, i = (e / M) % M;
+    const int64_t b = e / ((int64_t)M * M);        // s * C + c
+    const int64_t base = b * M * M;
+    float gij = 0.f, gii = 0.f, gjj = 0.f;
+    for (int k = 0; k < nsplit; ++k) {
+      const float* pk = part + k * sSplit + base;
+      gij += pk[(int64_t)i * M + j]; gii += pk[(int64_t)i * M + i]; gjj += pk[(int64_t)j * M + j];
+    }
+    const float gam = g2[b / C];
+    Kuu[e] = i == j ? gam : gam * expf(-0.5f * (gii + gjj - 2.f * gij));
+    return;
+  }
+  const int id = (int)blockIdx.x - ncomb;
+  const int64_t row = (int64_t)(id % nrow4) * 4 + (threadIdx.x >> 6);
+  const int s = id / nrow4, lane = threadIdx.x & 63;
+  if (row >= zrows + xrows) return;
+  const bool isz = row < zrows;
+  const float* xr = isz ? z + row * D : x + (row - zrows) * D;
+  const float* ws = w + s * Dp;
+  float acc = 0.f;
+  for (int d = lane; d < D; d += 64) { const float v = xr[d]; acc = fmaf(v * v, ws[d], acc); }
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    if (isz) na[(int64_t)s * zrows + row] = acc; else nb[(int64_t)s * xrows + (row - zrows)] = acc;
+  }
+}
+
 // RK[s,c,i, 0:NR] = [ m_ci | 0 0 0 | LS_c[i,:] | Lu_c[i,:] | 0.. ]  for every s (the K_uf block is written by the GEMM)
 __global__ void t0_pack_kernel(const float* __restrict__ m, const float* __restrict__ LS, const float* __restrict__ Lu,
                                float* __restrict__ RK, int C, int M, int NR, int LD, int64_t total) {
@@ -733,8 +773,12 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
     if (rc) return rc;
   } else {
     const int64_t zrows = (int64_t)C * M;
-    hipLaunchKernelGGL(t0_norm_kernel, dim3(cdiv(zrows + B, 4), S), dim3(256), 0, st, d->z, d->x, o.w, o.na, o.nb, zrows,
-                       (int64_t)B, D, o.Dp);
+    static const int ksp = [] { const char* e = getenv("VARGP_KUU_SPLIT"); return e ? atoi(e) : kKuuSplit; }();   // tuning aid
+    // merged factorisation launch + K-split K_uu product: the norms ride in the K_uu epilogue launch
+    const bool split_kuu = merge_chol && D >= 256 && (int64_t)ksp * M <= LD && ksp > 1;
+    if (!split_kuu)
+      hipLaunchKernelGGL(t0_norm_kernel, dim3(cdiv(zrows + B, 4), S), dim3(256), 0, st, d->z, d->x, o.w, o.na, o.nb, zrows,
+                         (int64_t)B, D, o.Dp);
     GemmParams p0{}, p1{};
     p0.A = d->z; p0.B = d->z; p0.C = o.KS;
     p0.M = M; p0.N = M; p0.K = D; p0.lda = D; p0.ldb = D; p0.ldc = M;
@@ -757,16 +801,17 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
     if (merge_chol && chol_rbf_gemm_applicable(M, p1)) {
       // K_uu first, then ONE launch in which SC + C workgroups factorise (K_uu + eps I, S_u + eps I) while the rest of
       // the chip builds K_uf, which nothing needs before the factors are done
-      static const int ksp = [] { const char* e = getenv("VARGP_KUU_SPLIT"); return e ? atoi(e) : kKuuSplit; }();   // tuning aid
-      if (D >= 256 && (int64_t)ksp * M <= LD && ksp > 1) {
+      if (split_kuu) {
         // 4 SC workgroups with D/64 slabs each would leave half the chip idle for the length of that K loop: split K,
-        // partial inner products to scratch, distance/exp epilogue in a second pass
+        // partial inner products to scratch, distance/exp epilogue (+ the row norms) in a second launch
         GemmParams ps = p0;
         ps.splitk = ksp; ps.sSplit = SC * MM; ps.C = o.kpart;
         rc = launch_gemm(ps, 0, 1, SC, true, st, "rbf_kuu_gemm");
         if (rc) return rc;
-        rc = rbf_combine_self_launch(o.kpart, ksp, o.na, o.g2, o.KS, S, C, M, st);
-        if (rc) return rc;
+        const int64_t total = SC * MM;
+        const int ncomb = cdiv(total, 256), nrow4 = cdiv(zrows + B, 4);
+        hipLaunchKernelGGL(t0_combine_norm_kernel, dim3(ncomb + nrow4 * S), dim3(256), 0, st, o.kpart, ksp, SC * MM, o.g2,
+                           o.KS, C, M, total, ncomb, d->z, d->x, o.w, o.na, o.nb, zrows, (int64_t)B, D, o.Dp, nrow4);
       } else {
         rc = launch_gemm(p0, 0, 1, SC, true, st, "rbf_kuu_gemm");
         if (rc) return rc;

@@ -225,15 +225,6 @@ __global__ __launch_bounds__(256) void rbf_final_kernel(const float* __restrict_
   }
 }
 
-// epilogue pass over split-K partial inner products of a self (X = Y) kernel matrix batch [S][C][M][M]
-int rbf_combine_self_launch(const float* part, int nsplit, const float* na, const float* g2, float* K, int S, int C, int M,
-                            hipStream_t st) {
-  const int64_t total = (int64_t)S * C * M * M;
-  hipLaunchKernelGGL(rbf_combine_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, part, nsplit, total, na, na, g2, K,
-                     (int64_t)C * M, M, (int64_t)C * M, (int64_t)M, M, 1, total);
-  return check_launch("rbf_combine");
-}
-
 int rbf_direct_launch(const float* X, const float* Y, const float* w, const float* g2, float* K, int64_t ldk, int S,
                       int C, int M, int N, int D, int64_t Dp, int y_shared, hipStream_t st) {
   const int64_t total = (int64_t)S * C * M * N;
