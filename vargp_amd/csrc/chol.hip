@@ -26,7 +26,7 @@ constexpr int kCholP = 5;        // threads per matrix row of chol_inv_small_ker
 // Packed lower-triangular index.
 __device__ __forceinline__ int pk(int i, int j) { return i * (i + 1) / 2 + j; }
 constexpr int kSmallMax = 100;  // largest n the register-resident kernel takes (packed triangle <= 512*10)
-constexpr int kNbSmall = 96;    // panel width of the blocked algorithm (multiple of 32, <= kSmallMax)
+constexpr int kNbSmall = 100;   // panel width of the blocked algorithm (multiple of 4, <= kSmallMax): 2 panels at n = 200
 
 template <typename F> __device__ __forceinline__ F rcp_of(F d);
 template <> __device__ __forceinline__ double rcp_of<double>(double d) { return fast_rcp(d); }
