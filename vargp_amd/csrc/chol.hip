@@ -26,7 +26,12 @@ constexpr int kCholP = 5;        // threads per matrix row of chol_inv_small_ker
 // Packed lower-triangular index.
 __device__ __forceinline__ int pk(int i, int j) { return i * (i + 1) / 2 + j; }
 constexpr int kSmallMax = 100;  // largest n the register-resident kernel takes (packed triangle <= 512*10)
-constexpr int kNbSmall = 100;   // panel width of the blocked algorithm (multiple of 4, <= kSmallMax): 2 panels at n = 200
+constexpr int kNbMax = 100;     // widest panel of the blocked algorithm (multiple of 4, <= kSmallMax)
+// panel width: 100 (two panels at n = 200, four at 400) unless VARGP_CHOL_PANEL says otherwise (tuning aid)
+static int panel_width() {
+  static const int v = [] { const char* e = getenv("VARGP_CHOL_PANEL"); const int x = e ? atoi(e) : kNbMax; return (x >= 32 && x <= kNbMax && x % 4 == 0) ? x : kNbMax; }();
+  return v;
+}
 
 template <typename F> __device__ __forceinline__ F rcp_of(F d);
 template <> __device__ __forceinline__ double rcp_of<double>(double d) { return fast_rcp(d); }
@@ -261,7 +266,7 @@ extern "C" size_t vargp_chol_workspace_bytes(int nbatch, int n, int backward) {
   const size_t nn = (size_t)nbatch * n * n * sizeof(float);
   if (backward) return 2 * nn + 256;
   if (n <= kSmallMax) return 256;
-  return nn + (size_t)nbatch * n * kNbSmall * sizeof(float) + 256;
+  return nn + (size_t)nbatch * n * kNbMax * sizeof(float) + 256;
 }
 
 extern "C" int vargp_chol_inv_fwd(const float* A, float eps, float* L, float* T, float* logdet, int32_t* info,
@@ -282,6 +287,7 @@ int vargp::chol_inv_fwd_impl(const float* A, float eps, float* L, float* T, floa
   VARGP_REQUIRE(ws && ws_bytes >= vargp_chol_workspace_bytes(nbatch, n, 0), "chol_inv_fwd: workspace too small");
   float* W = reinterpret_cast<float*>(ws);
   float* tmp = W + (int64_t)nbatch * nn;
+  const int kNbSmall = panel_width();
   const int64_t stmp = (int64_t)n * kNbSmall;
   hipLaunchKernelGGL(copy_jitter_kernel, dim3(cdiv(nn, 256), nbatch), dim3(256), 0, st, A, W, n, eps);
   zero_async(L, sizeof(float) * nbatch * nn, st);
