@@ -105,18 +105,29 @@ __global__ __launch_bounds__(256) void yogi_multi_kernel(YogiPack pk, int ntenso
   float* __restrict__ v = pk.v[t];
   const float tt = step[0] + (step_mode ? 1.f : 0.f);
   const float bias1 = 1.f - powf(b1, tt), sb2 = sqrtf(1.f - powf(b2, tt));
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int64_t i = (int64_t)blk * kYogiPerBlock + u * 256 + threadIdx.x;
-    if (i < n) {
-      const float gi = g[i], g2 = gi * gi;
-      const float mi = b1 * m[i] + (1.f - b1) * gi;
-      float vi = v[i];
-      const float df = vi - g2;
-      vi -= (1.f - b2) * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * g2;
-      m[i] = mi;
-      v[i] = vi;
-      p[i] -= (lr / bias1) * mi / (sqrtf(vi) / sb2 + eps);
+  auto upd = [&](float& pi, float gi, float& mi, float& vi) {
+    const float g2 = gi * gi;
+    mi = b1 * mi + (1.f - b1) * gi;
+    const float df = vi - g2;
+    vi -= (1.f - b2) * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * g2;
+    pi -= (lr / bias1) * mi / (sqrtf(vi) / sb2 + eps);
+  };
+  const int64_t i0 = (int64_t)blk * kYogiPerBlock + 4 * threadIdx.x;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                         reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+  if (aligned && i0 + 4 <= n) {           // 16 bytes per lane and array: one load / store instruction each
+    float4 p4 = *reinterpret_cast<const float4*>(p + i0), m4 = *reinterpret_cast<const float4*>(m + i0);
+    float4 v4 = *reinterpret_cast<const float4*>(v + i0);
+    const float4 g4 = *reinterpret_cast<const float4*>(g + i0);
+    upd(p4.x, g4.x, m4.x, v4.x); upd(p4.y, g4.y, m4.y, v4.y); upd(p4.z, g4.z, m4.z, v4.z); upd(p4.w, g4.w, m4.w, v4.w);
+    *reinterpret_cast<float4*>(p + i0) = p4;
+    *reinterpret_cast<float4*>(m + i0) = m4;
+    *reinterpret_cast<float4*>(v + i0) = v4;
+  } else {
+    for (int64_t i = i0; i < i0 + 4 && i < n; ++i) {
+      float pi = p[i], mi = m[i], vi = v[i];
+      upd(pi, g[i], mi, vi);
+      p[i] = pi; m[i] = mi; v[i] = vi;
     }
   }
 }
