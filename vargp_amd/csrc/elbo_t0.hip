@@ -546,13 +546,17 @@ __global__ __launch_bounds__(256) void t0_w_kernel(const float* __restrict__ RK,
                                                    const float* __restrict__ Lu, const float* __restrict__ seeds,
                                                    float* __restrict__ gvec) {
   __shared__ float red[4];
-  if ((int)blockIdx.x >= nuf + nuu) {
-    t0_gvec_role((int)blockIdx.x - nuf - nuu, vec, Lu, gKuu + (int64_t)S * C * M * M, gRK, seeds, gvec, S, C, M, LD);
+  // block order: the packed-vector gradient first (long per-thread loops: started early they finish under the rest),
+  // then K_uu, then K_uf
+  const int ngv = (int)gridDim.x - nuf - nuu;
+  if ((int)blockIdx.x < ngv) {
+    t0_gvec_role((int)blockIdx.x, vec, Lu, gKuu + (int64_t)S * C * M * M, gRK, seeds, gvec, S, C, M, LD);
     return;
   }
+  const int bid = (int)blockIdx.x - ngv;
   const int lane = threadIdx.x & 63;
-  if ((int)blockIdx.x < nuf) {
-    const int id = blockIdx.x;
+  if (bid >= nuu) {
+    const int id = bid - nuu;
     const int col = (id % gx) * 256 + threadIdx.x;
     const int CM = C * M;
     const int row0 = ((id / gx) % gy) * kWRows;
@@ -575,7 +579,7 @@ __global__ __launch_bounds__(256) void t0_w_kernel(const float* __restrict__ RK,
   }
   // K_uu role: kUuRows consecutive rows of one (s, c) matrix per block, a wave takes every 4th of them
   const int nchunk = (M + kUuRows - 1) / kUuRows;
-  const int id = (int)blockIdx.x - nuf;
+  const int id = bid;
   const int64_t b = id / nchunk;
   const int i0 = (id % nchunk) * kUuRows, i1 = min(M, i0 + kUuRows);
   const float* K = Kuu + b * M * M;
