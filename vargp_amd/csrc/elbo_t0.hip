@@ -709,8 +709,12 @@ static int check_desc(const vargp_elbo_t0_desc* d, const char* who) {
   return VARGP_OK;
 }
 
-// K-splits for the products with few output tiles and a long K: about 3 slabs of 64 per workgroup
-static int ksplit(int K) { const int s = K / 192; return s < 1 ? 1 : (s > 8 ? 8 : s); }
+// K-splits for the products with few output tiles and a long K: about 4 slabs of 64 per workgroup (measured best)
+static int ksplit(int K) {
+  static const int per = [] { const char* e = getenv("VARGP_KSPLIT_PER"); return e ? atoi(e) : 256; }();   // tuning aid
+  const int s = K / per;
+  return s < 1 ? 1 : (s > 8 ? 8 : s);
+}
 
 static GemmParams flat_gemm(const float* A, int lda, int64_t sA, const float* B, int ldb, int64_t sB, float* C, int ldc,
                             int64_t sC, int M, int N, int K) {
