@@ -10,7 +10,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libvargp_hip.so')
+LIB_PATH = os.environ.get('VARGP_HIP_LIB') or os.path.join(_HERE, 'libvargp_hip.so')   # env: tuning builds only
 
 
 class GemmDesc(Structure):

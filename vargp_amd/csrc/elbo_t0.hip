@@ -20,10 +20,22 @@
 namespace vargp {
 
 constexpr int kKuuSplit = 4;   // K-splits of the K_uu distance GEMM (few workgroups, long K loop: split to use the chip)
-constexpr int kKlRows = 8;     // rows of one (s, c) block per KL workgroup
-constexpr int kWRows = 8;      // rows per workgroup of the W = gK o K pass (K_uf role)
-constexpr int kUuRows = 16;    // rows per workgroup of the same pass, K_uu role
-constexpr int kFinRows = 32;   // rows per workgroup of the RBF finalisation
+#ifndef VARGP_KL_ROWS
+#define VARGP_KL_ROWS 8
+#endif
+#ifndef VARGP_W_ROWS
+#define VARGP_W_ROWS 8
+#endif
+#ifndef VARGP_UU_ROWS
+#define VARGP_UU_ROWS 16
+#endif
+#ifndef VARGP_FIN_ROWS
+#define VARGP_FIN_ROWS 32
+#endif
+constexpr int kKlRows = VARGP_KL_ROWS;     // rows of one (s, c) block per KL workgroup
+constexpr int kWRows = VARGP_W_ROWS;      // rows per workgroup of the W = gK o K pass (K_uf role)
+constexpr int kUuRows = VARGP_UU_ROWS;    // rows per workgroup of the same pass, K_uu role
+constexpr int kFinRows = VARGP_FIN_ROWS;   // rows per workgroup of the RBF finalisation
 
 __device__ __forceinline__ float softplus_t0(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 __device__ __forceinline__ float sigmoid_t0(float x) { return 1.f / (1.f + expf(-x)); }
