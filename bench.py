@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Workload at N=1: BASELINE config 1 — Split-MNIST task 0 shape, S=3 hyper-samples, F=10, C=10, M=100,
+Workload at N=1: BASELINE config 2 (BASELINE.json configs[1]) — Split-MNIST task 0 shape, S=3 hyper-samples, F=10, C=10, M=100,
 D=784, B=512, synthetic data resident in HBM.  One step = zero_grad + VARGP.loss + combine + backward
 + (N>1: one RCCL all-reduce) + Yogi step, exactly as experiments/vargp.py:29-37 does it.
 N>1 is sample-parallel WEAK scaling: every rank evaluates its own 3 of the 3N hyper-samples, so the
@@ -32,11 +32,11 @@ DOMINANT_TAG = 'rbf_kuf'       # the K_uf distance GEMM incl. its split-K combin
 
 # Secondary workloads (not the driver's default line): other BASELINE configs, same step definition.
 WORKLOADS = {
-    'smnist': dict(S=3, M=100, n_prev=0, desc='Split-MNIST task-0 ELBO step (BASELINE config 1)'),
-    'smnist_s64': dict(S=64, M=100, n_prev=0, desc='Split-MNIST task-0, 64 hyper-samples on ONE GPU (BASELINE config 3 unsharded)'),
+    'smnist': dict(S=3, M=100, n_prev=0, desc='BASELINE config 2 (Split-MNIST t=0): S3 F10 C10 M100 D784 B512 ELBO step'),
+    'smnist_s64': dict(S=64, M=100, n_prev=0, desc='BASELINE config 4 (Split-MNIST t=0, 64 hyper-samples x 10 classes), samples split over the ranks'),
     'smnist_t1': dict(S=3, M=100, n_prev=1, desc='Split-MNIST task 1 (Mt=200), M=100, S=3 (composed per-op path)'),
     'smnist_t4': dict(S=3, M=100, n_prev=4, desc='Split-MNIST task 4 (Mt=500), M=100, S=3 (composed per-op path)'),
-    'pmnist_t0': dict(S=10, M=200, n_prev=0, desc='Permuted-MNIST task 0, M=200, S=10 (BASELINE config 2)'),
+    'pmnist_t0': dict(S=10, M=200, n_prev=0, desc='BASELINE config 3 (Permuted-MNIST), task 0: M=200, S=10'),
     'pmnist_t1': dict(S=10, M=200, n_prev=1, desc='Permuted-MNIST task 1 (Mt=400), M=200, S=10'),
     'pmnist_t4': dict(S=10, M=200, n_prev=4, desc='Permuted-MNIST task 4 (Mt=1000), M=200, S=10'),
 }
@@ -64,7 +64,7 @@ def make_model(device, seed=0):
 
 
 def stress(args, device):
-    """BASELINE config 4: N=1e6, D=784, M=2048, C=10, S=1 predictive sweep, K_uf tiled over N in HBM."""
+    """BASELINE config 5: N=1e6, D=784, M=2048, C=10, S=1 predictive sweep, K_uf tiled over N in HBM."""
     from vargp_amd import _lib
     from vargp_amd.kernels import RBFKernel
     from vargp_amd.likelihoods import MulticlassSoftmax
@@ -90,7 +90,7 @@ def stress(args, device):
     res = dict(metric='predictive points/sec (stress)', value=n / dt, unit='points/s', n_gpus=1, steps=1, warmup=1,
                ms_per_step=1e3 * dt, higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32',
                data='synthetic', finite=bool(torch.isfinite(probs).all().item()),
-               config=dict(workload='BASELINE config 4: predictive sweep N=%d D=784 M=2048 C=10 S=1, tile %d' % (n, tile)),
+               config=dict(workload='BASELINE config 5: predictive sweep N=%d D=784 M=2048 C=10 S=1, tile %d' % (n, tile)),
                roofline=dict(bound='mfma', kernel='gemm_kernel<RBF> K_uf tile [10*2048 x 784] x [784 x 8192]',
                              achieved=flops / avg_s / 1e12 if kern_n else None, peak=MFMA_F32_PEAK_TFLOPS,
                              unit='TFLOP/s', frac=flops / avg_s / 1e12 / MFMA_F32_PEAK_TFLOPS if kern_n else None,

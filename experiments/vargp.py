@@ -48,12 +48,15 @@ class JsonlLogger:
 
 def train(task_id, train_set, val_set, test_set, ep_var_mean=True, map_est_hypers=False, dkl=False,
           epochs=1, M=20, n_f=10, n_var_samples=3, batch_size=512, lr=1e-2, beta=1.0,
-          eval_interval=10, patience=20, prev_params=None, logger=None, device=None, graph=False):
+          eval_interval=10, patience=20, prev_params=None, logger=None, device=None, graph=False, seed=None):
     gp = VARGP.create_clf(train_set, M=M, n_f=n_f, n_var_samples=n_var_samples, prev_params=prev_params,
                           ep_var_mean=ep_var_mean, map_est_hypers=map_est_hypers, dkl=dkl).to(device)
     stopper = EarlyStopper(patience=patience)
     N = len(train_set)
-    trainer = ElboTrainer(gp, lr=lr, beta=beta, n_total=N)          # Yogi, as the reference (:23)
+    # the program's counter-based noise generator is keyed by the run's seed (the reference draws from the torch global
+    # generator that set_seeds controls, train_utils.py:13-19): replicates with different seeds see different noise
+    noise_seed = (int(seed) if seed is not None else torch.initial_seed()) * 1000003 + task_id
+    trainer = ElboTrainer(gp, lr=lr, beta=beta, n_total=N, noise_seed=noise_seed & 0x7FFFFFFFFFFFFFFF)   # Yogi (:23)
     loader = DataLoader(train_set, batch_size=batch_size, shuffle=True)
     captured_for = None
 
@@ -67,6 +70,11 @@ def train(task_id, train_set, val_set, test_set, ep_var_mean=True, map_est_hyper
                 kl_hypers, kl_u, lik = trainer.step_graph(x, y)
             else:
                 kl_hypers, kl_u, lik = trainer.step(x, y)
+        if graph and vargp_amd.linalg_error_count():
+            # 'defer' mode never syncs inside a step: failed factorisations are NaN-filled and flagged on the device.
+            # The reference raises at once (torch.cholesky, gp_utils.py:10); here the check runs once per epoch.
+            raise torch.linalg.LinAlgError(f'task {task_id}, epoch {e + 1}: a Cholesky factorisation met a matrix that is '
+                                           'not positive-definite')
 
         if (e + 1) % eval_interval == 0:
             acc_summary = {
@@ -117,7 +125,7 @@ def toy(args):
         sd = train(t, toy_train, toy_val, toy_test, epochs=args.epochs, M=args.M, lr=args.lr, beta=args.beta,
                    batch_size=args.batch_size, ep_var_mean=args.ep_var_mean, map_est_hypers=args.map_est_hypers,
                    dkl=args.dkl, prev_params=prev_params, logger=logger, device=device, patience=-1,
-                   eval_interval=args.eval_interval, graph=args.graph)
+                   eval_interval=args.eval_interval, graph=args.graph, seed=args.seed)
         prev_params.append(sd)
     logger.close()
 
@@ -141,7 +149,7 @@ def split_mnist(args):
         sd = train(t, mnist_train, mnist_val, mnist_test, epochs=args.epochs, M=args.M, lr=args.lr, beta=args.beta,
                    batch_size=args.batch_size, ep_var_mean=args.ep_var_mean, map_est_hypers=args.map_est_hypers,
                    dkl=args.dkl, prev_params=prev_params, logger=logger, device=device,
-                   eval_interval=args.eval_interval, graph=args.graph)
+                   eval_interval=args.eval_interval, graph=args.graph, seed=args.seed)
         prev_params.append(sd)
     logger.close()
 
@@ -168,7 +176,7 @@ def permuted_mnist(args):
         sd = train(t, mnist_train, ConcatDataset(mnist_val), ConcatDataset(mnist_test), epochs=args.epochs, M=args.M,
                    lr=args.lr, beta=args.beta, batch_size=args.batch_size, ep_var_mean=args.ep_var_mean,
                    map_est_hypers=args.map_est_hypers, dkl=args.dkl, prev_params=prev_params, logger=logger,
-                   device=device, eval_interval=args.eval_interval, graph=args.graph)
+                   device=device, eval_interval=args.eval_interval, graph=args.graph, seed=args.seed)
         prev_params.append(sd)
     logger.close()
 

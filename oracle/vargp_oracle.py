@@ -311,7 +311,8 @@ def hash_normal(shape, seed):
 
 def make_problem(S, F_, C, M, D, B, n_prev=0, seed=0, kind='gauss', dtype=torch.float32, n_v=None):
     """Synthetic problem of the named shape.  kind='gauss': x ~ N(0, 0.25/D) so that
-    K_uf is O(1); kind='mnist': 19 %-dense U[0,1] pixels.  Inducing points are data-like rows.
+    K_uf is O(1); kind='mnist': 19 %-dense U[0,1] pixels; kind='toy': clustered 2-D normals (ill-conditioned at t>0);
+    kind='wtoy': well-separated 2-D grid points.  Inducing points are data-like rows.
     Returns (params, prev, x, y, noise)."""
     n_v = S if n_v is None else n_v
 
@@ -325,16 +326,29 @@ def make_problem(S, F_, C, M, D, B, n_prev=0, seed=0, kind='gauss', dtype=torch.
     x = data(B, seed + 1).to(dtype)
     y = (torch.arange(B) % C).to(torch.int64)
 
-    def task_params(sd):
+    zgrid = None
+    if kind == 'wtoy':
+        # well-separated 2-D toy (SURVEY §8c caveat 5): per class, the inducing points of ALL tasks are distinct
+        # cells of a jittered grid (spacing 0.7 = 1.4 lengthscales at the initial lengthscale 0.5), so that K_uu
+        # stays well-conditioned as the tasks accumulate; the minibatch is uniform over the same box
+        assert D == 2
+        n_all = (n_prev + 1) * M
+        side = int(math.ceil(math.sqrt(n_all)))
+        order = torch.argsort(hash_uniform((C, side * side), seed + 41), dim=-1)[:, :n_all]      # (C, n_all) cells
+        cells = torch.stack([order // side, order % side], dim=-1).to(torch.float64)
+        zgrid = 0.7 * (cells - 0.5 * (side - 1)) + 0.1 * (hash_uniform((C, n_all, 2), seed + 43) - 0.5)
+        x = (0.7 * side * (hash_uniform((B, 2), seed + 1) - 0.5)).to(dtype)
+
+    def task_params(sd, t=None):
         return dict(
-            z=data(C * M, sd).reshape(C, M, D).to(dtype),
+            z=(zgrid[:, t * M:(t + 1) * M] if zgrid is not None else data(C * M, sd).reshape(C, M, D)).to(dtype),
             u_mean=(0.5 * hash_normal((C, M, 1), sd + 3)).to(dtype),
             u_tril_vec=(mat2trilvec(torch.eye(M, dtype=torch.float64).expand(C, M, M))
                         + 0.05 * hash_normal((C, M * (M + 1) // 2), sd + 5)).to(dtype),
         )
 
-    prev = [task_params(seed + 1000 * (t + 1)) for t in range(n_prev)]
-    params = task_params(seed + 11)
+    prev = [task_params(seed + 1000 * (t + 1), t) for t in range(n_prev)]
+    params = task_params(seed + 11, n_prev)
     log_init = math.log(0.5) + 0.05 * hash_normal((D + 1,), seed + 13)
     params.update(
         log_mean=log_init.to(dtype),

@@ -11,10 +11,12 @@ from helpers import (load_case, rel_l2, to_dev, rtol_for, RTOL_SCALAR, ATOL_PRED
 pytestmark = pytest.mark.gpu
 
 
-def _run(name, ep_var_mean=True):
+def _run(name, ep_var_mean=None):
     from vargp_amd import noise
     from gpu_common import build_gp, grads_of, DEV
     g, params, prev, x, y, nz = load_case(name)
+    if ep_var_mean is None:      # the *_nomean fixtures were produced with ep_var_mean=False
+        ep_var_mean = bool(int(g['ep_var_mean'])) if 'ep_var_mean' in g.files else True
     S, F_ = int(g['meta'][0]), int(g['meta'][1])
     gp = build_gp(params, prev, S, F_, ep_var_mean)
     xd, yd = x.to(DEV), y.to(DEV)
@@ -29,8 +31,12 @@ def _run(name, ep_var_mean=True):
     return g, (params, prev, x, y, nz), sc, grads_of(gp), pmu.cpu(), pvar.cpu(), probs.cpu()
 
 
-@pytest.mark.parametrize('name', ['toy_t0', 'toy_t1', 'toy_t2', 'smnist_small_t0', 'smnist_small_t1'])
+@pytest.mark.parametrize('name', ['toy_t0', 'toy_t1', 'toy_t2', 'smnist_small_t0', 'smnist_small_t1',
+                                  'wtoy_t1', 'wtoy_t2', 'wtoy_t1_nomean', 'wtoy_t2_nomean'])
 def test_loss_grads_predict_vs_reference_golden(name):
+    """toy_t1 / toy_t2 are the ill-conditioned clustered cases (tolerance exception, helpers.py); wtoy_* are the
+    well-separated toy at t = 1, 2 held to the north-star 1e-4, *_nomean with ep_var_mean=False (the u_<t sample and the
+    gp_cond mean enter the KL, reference vargp.py:137-152)."""
     g, (params, prev, x, y, nz), sc, grads, pmu, pvar, probs = _run(name)
     for k in ['kl_hypers', 'kl_u', 'nll', 'total']:
         np.testing.assert_allclose(sc[k], float(g[k]), rtol=rtol_for(name), err_msg=k)

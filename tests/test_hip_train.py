@@ -73,14 +73,7 @@ def test_graph_step_equals_eager_step():
             tr = ElboTrainer(gp, lr=1e-3, beta=10.0, n_total=12000)
             with noise.inject(**to_dev(nz, DEV)):
                 if mode == 'graph':
-                    snap = copy.deepcopy(gp.state_dict())
-                    tr.capture(xd, yd, warmup=2)
-                    gp.load_state_dict(snap)            # undo the warm-up / capture steps
-                    for grp in tr.optim.param_groups:
-                        grp['step'].zero_()
-                    for st in tr.optim.state.values():
-                        st['exp_avg'].fill_(1e-6)
-                        st['exp_avg_sq'].fill_(1e-6)
+                    tr.capture(xd, yd, warmup=2)        # capture() restores parameters / optimiser state / noise stream
                     for _ in range(3):
                         out = tr.step_graph()
                 else:
@@ -122,5 +115,50 @@ def test_graph_replays_stay_finite(C, M, B, D):
             torch.cuda.synchronize()
             assert all(torch.isfinite(o).item() for o in out)
             assert all(bool(torch.isfinite(p.grad).all()) for p in gp.parameters())
+    finally:
+        ops.set_cholesky_error_mode('raise')
+
+
+def test_graph_survives_ragged_eager_step_and_capture_keeps_state():
+    """A captured step, then the ragged last minibatch of an epoch through the eager step (another shape, hence another
+    program), then allocations that would reuse a freed workspace, then replays again: the trajectory must equal the
+    all-eager one.  (The captured graph holds raw pointers into its program: programs are kept per shape.)  Also:
+    capture() itself leaves parameters, optimiser state and the noise stream untouched."""
+    from vargp_amd import ops
+    from vargp_amd.kernels import RBFKernel
+    from vargp_amd.likelihoods import MulticlassSoftmax
+    from vargp_amd.synthetic import mnist_like
+    from vargp_amd.train import ElboTrainer
+    from vargp_amd.vargp import VARGP
+    C, M, B, D, Br = 4, 24, 96, 40, 56
+    ops.set_cholesky_error_mode('defer')
+    try:
+        xall, yall = mnist_like(2048, D, C, kind='gauss', seed=1)
+        x, y = xall[:B].to(DEV), yall[:B].to(DEV)
+        xr, yr = xall[B:B + Br].to(DEV), yall[B:B + Br].to(DEV)
+        res = []
+        for mode in ('eager', 'graph'):
+            torch.manual_seed(0)
+            z = torch.stack([xall[yall == c][:M] for c in range(C)])
+            gp = VARGP(z, RBFKernel(D), MulticlassSoftmax(n_f=5), n_var_samples=2).to(DEV)
+            tr = ElboTrainer(gp, lr=3e-3, beta=2.0, n_total=2048, noise_seed=11)
+            if mode == 'graph':
+                before = {k: v.detach().clone() for k, v in gp.state_dict().items()}
+                tr.capture(x, y)
+                for k, v in gp.state_dict().items():
+                    assert torch.equal(v, before[k]), k
+            full = (lambda: tr.step_graph(x, y)) if mode == 'graph' else (lambda: tr.step(x, y))
+            outs = []
+            for epoch in range(2):
+                outs.append([o.item() for o in full()])
+                outs.append([o.item() for o in full()])
+                outs.append([o.item() for o in tr.step(xr, yr)])          # ragged batch: eager, different shape
+                junk = [torch.full((1 << 20,), float('nan'), device=DEV) for _ in range(8)]   # would land in freed blocks
+                del junk
+            torch.cuda.synchronize()
+            res.append((outs, {k: v.detach().cpu().clone() for k, v in gp.state_dict().items()}))
+        np.testing.assert_allclose(np.array(res[1][0]), np.array(res[0][0]), rtol=1e-5)
+        for k in res[0][1]:
+            assert rel_l2(res[1][1][k], res[0][1][k]) < 1e-5, k
     finally:
         ops.set_cholesky_error_mode('raise')

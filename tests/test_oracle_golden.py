@@ -8,7 +8,8 @@ from oracle import vargp_oracle as orc
 from helpers import (load_case, rel_l2, RTOL_SCALAR, ATOL_PRED, RTOL_PRED, ATOL_PROBS, REL_L2_GRAD,
                      GRAD_KEYS, GOLDEN)
 
-E2E = ['toy_t0', 'toy_t1', 'toy_t2', 'smnist_small_t0', 'smnist_small_t1']
+E2E = ['toy_t0', 'toy_t1', 'toy_t2', 'smnist_small_t0', 'smnist_small_t1', 'wtoy_t1', 'wtoy_t2', 'wtoy_t1_nomean',
+       'wtoy_t2_nomean']
 
 
 @pytest.fixture(scope='module')
@@ -63,7 +64,9 @@ def test_likelihood(ops):
 @pytest.mark.parametrize('name', E2E)
 def test_e2e_loss_grads_predict(name):
     g, params, prev, x, y, noise = load_case(name)
-    sc, grads = orc.elbo_step(params, prev, x, y, noise, beta=float(g['beta']), n_total=float(g['n_total']))
+    epm = bool(int(g['ep_var_mean'])) if 'ep_var_mean' in g.files else True     # False pins the u_<t / gp_cond branch
+    sc, grads = orc.elbo_step(params, prev, x, y, noise, beta=float(g['beta']), n_total=float(g['n_total']),
+                              ep_var_mean=epm)
     for k in ['kl_hypers', 'kl_u', 'nll', 'total']:
         np.testing.assert_allclose(sc[k].item(), float(g[k]), rtol=RTOL_SCALAR, err_msg=k)
     for k in GRAD_KEYS:
@@ -74,9 +77,11 @@ def test_e2e_loss_grads_predict(name):
     np.testing.assert_allclose(orc.predict(params, prev, x, noise).numpy(), g['probs'], atol=ATOL_PROBS)
 
 
-def test_e2e_full_size_cfg2():
-    """Cfg2 (S3 F10 C10 M100 D784 B512): inputs regenerated from the seed, outputs from the reference."""
-    g, params, prev, x, y, noise = load_case('smnist_full_t0')
+@pytest.mark.parametrize('name', ['smnist_full_t0', 'pmnist_full_t0', 'pmnist_red_t1', 'pmnist_red_t2', 'smnist_s64_t0'])
+def test_e2e_full_size(name):
+    """Outputs-only fixtures (inputs regenerated from the seed, outputs from the reference): Cfg2 (S3 F10 C10 M100 D784
+    B512), Cfg3 task 0 at full size (S10 M200) and tasks 1, 2 (Mt = 400, 600) at reduced D/B, Cfg4's S = 64 unsharded."""
+    g, params, prev, x, y, noise = load_case(name)
     sc, grads = orc.elbo_step(params, prev, x, y, noise, beta=float(g['beta']), n_total=float(g['n_total']))
     for k in ['kl_hypers', 'kl_u', 'nll', 'total']:
         np.testing.assert_allclose(sc[k].item(), float(g[k]), rtol=RTOL_SCALAR, err_msg=k)

@@ -9,6 +9,7 @@ training loop can run.  Same attributes and methods as the reference classes: `.
 """
 import gzip
 import os
+import warnings
 import struct
 
 import torch
@@ -81,6 +82,9 @@ def load_mnist(root, train=True, synthetic=None, n_synth=None, seed=0):
         return _read_idx(pi).reshape(-1, 784).float() / 255., _read_idx(pl).long()
     if synthetic is False:
         raise FileNotFoundError(f'MNIST IDX files not found under {root} (no network to download them)')
+    if synthetic is None:
+        warnings.warn(f'MNIST IDX files not found under {root}: using the MNIST-shaped SYNTHETIC surrogate; accuracies '
+                      'logged by this run are not MNIST accuracies (pass --synthetic to silence this)', stacklevel=2)
     n = n_synth or (60000 if train else 10000)
     x, y = mnist_like(n, 784, 10, kind='mnist_classes', seed=seed + (0 if train else 1))
     return x, y

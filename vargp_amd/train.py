@@ -50,7 +50,9 @@ class ElboTrainer:
         # straight into the optimiser's buffers
         self._t0 = (gp is not None and loss_fn is None and params is None and hasattr(gp, 'draw_t0_noise')
                     and not gp.prev_params and gp.fused_first_task)
-        self._prog, self._seeds, self._own_grads = None, {}, None
+        # one program (descriptor + workspace) PER SHAPE, never freed: a captured hipGraph holds raw pointers into the
+        # program it was captured with, and the ragged last minibatch of an epoch runs eagerly through another shape
+        self._progs, self._prog, self._seeds, self._own_grads = {}, None, {}, None
         # with our Yogi (one parameter group) the program's first kernel also advances the optimiser's step count
         self._bump = None
         # native noise: the program draws eps_theta / eps_f itself (Philox keyed by noise_seed, device-side step
@@ -72,12 +74,16 @@ class ElboTrainer:
         from . import ops
         assert ops._chol_mode == 'defer', "set_cholesky_error_mode('defer') before capturing"
         self._sx, self._sy = x.clone(), y.clone()
+        # the warm-up steps are real steps: snapshot parameters, optimiser state and the noise stream, restore afterwards,
+        # so that the graph-mode trajectory equals the eager one (no extra updates on the first minibatch)
+        snap = self._snapshot_state()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
                 self.step(self._sx, self._sy)
         torch.cuda.current_stream().wait_stream(side)
+        self._restore_state(snap)
         self.graph = torch.cuda.CUDAGraph()
         if noise._shard is not None and not (self._t0 and self.native_noise):
             # the composed (t > 0) path draws its noise from the shared torch generator inside the captured region;
@@ -93,6 +99,45 @@ class ElboTrainer:
             with torch.cuda.graph(self.graph_opt, pool=self.graph.pool()):
                 self.optim.step()
         return self
+
+    def _snapshot_state(self):
+        snap = dict(params=[p.detach().clone() for p in self.params], rng=None, gen=None, opt=[])
+        if self._rng_counter is not None:
+            snap['rng'] = self._rng_counter.clone()
+        if noise._shard is not None:
+            snap['gen'] = noise._shard[2].get_state()
+        for grp in self.optim.param_groups:
+            snap['opt'].append({k: v.clone() for k, v in grp.items() if torch.is_tensor(v)})
+        snap['state'] = {id(p): {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+                         for p, st in self.optim.state.items()}
+        return snap
+
+    def _restore_state(self, snap):
+        with torch.no_grad():
+            for p, v in zip(self.params, snap['params']):
+                p.copy_(v)
+            if snap['rng'] is not None:
+                self._rng_counter.copy_(snap['rng'])
+            if snap['gen'] is not None:
+                noise._shard[2].set_state(snap['gen'])
+            for grp, saved in zip(self.optim.param_groups, snap['opt']):
+                for k, v in saved.items():
+                    grp[k].copy_(v)                                   # in place: the kernels hold these pointers
+                if 'step' in grp and torch.is_tensor(grp['step']) and 'step' not in saved:
+                    grp['step'].zero_()                               # created by the warm-up
+            for p, st in self.optim.state.items():
+                old = snap['state'].get(id(p))
+                for k, v in st.items():
+                    if not torch.is_tensor(v):
+                        continue
+                    if old is not None and k in old:
+                        v.copy_(old[k])
+                    else:                                             # moment buffers created by the warm-up
+                        v.fill_(self.optim.defaults.get('initial_accumulator', 0.0))
+                if old is not None:
+                    for k, v in old.items():
+                        if not torch.is_tensor(v):
+                            st[k] = v
 
     def step_graph(self, x=None, y=None):
         """Replay the captured step (optionally on a new minibatch of the captured shape)."""
@@ -143,9 +188,11 @@ class ElboTrainer:
             eps_theta, eps_f = None if eps_theta is None else eps_theta.contiguous(), eps_f.contiguous()
         shape = T0Program.shape_of(S, gp.z, x, gp.likelihood.n_f)
         if self._prog is None or self._prog.shape != shape:
-            self._prog = T0Program(*shape, x.device, kern.map_est)
-            if self.native_noise:
-                self._prog.set_rng(self.noise_seed, self._rng_counter, self.rank * S)
+            if shape not in self._progs:
+                self._progs[shape] = T0Program(*shape, x.device, kern.map_est)
+                if self.native_noise:
+                    self._progs[shape].set_rng(self.noise_seed, self._rng_counter, self.rank * S)
+            self._prog = self._progs[shape]
         key = (scale, w)
         if key not in self._seeds:
             self._seeds[key] = torch.tensor([self.beta * w, w, scale * w], dtype=torch.float32, device=x.device)
