@@ -63,8 +63,11 @@ def test_chol_inv_large_fwd_bwd(n, nb):
     L64 = torch.linalg.cholesky(A64 + 1e-4 * torch.eye(n, dtype=torch.float64))
     T64 = torch.linalg.solve_triangular(L64, torch.eye(n, dtype=torch.float64).expand(nb, n, n), upper=False)
     ((L64 * gL.double()).sum() + (T64 * gT.double()).sum()).backward()
-    assert rel_l2(L.detach().cpu(), L64.detach()) < 2e-6
-    assert rel_l2(T.detach().cpu(), T64.detach()) < 2e-5
+    # bar: no worse than twice what fp32 LAPACK (the reference's torch.cholesky / triangular_solve) reaches on this matrix
+    L32 = torch.linalg.cholesky(A + 1e-4 * torch.eye(n))
+    T32 = torch.linalg.solve_triangular(L32, torch.eye(n).expand(nb, n, n), upper=False)
+    assert rel_l2(L.detach().cpu(), L64.detach()) < 2.0 * rel_l2(L32, L64.detach()) + 1e-6
+    assert rel_l2(T.detach().cpu(), T64.detach()) < 2.0 * rel_l2(T32, T64.detach()) + 1e-6
     eye_err = (T.detach().cpu().double() @ L.detach().cpu().double() - torch.eye(n, dtype=torch.float64)).abs().max().item()
     assert eye_err < 1e-4, eye_err
     g64 = 0.5 * (A64.grad + A64.grad.mT)                           # the op returns the symmetric gradient
