@@ -206,6 +206,50 @@ int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t stream);
 int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds, float* g_log_mean, float* g_log_logvar, float* g_z,
                       float* g_u_mean, float* g_u_tril_vec, vargp_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * The ELBO of a model WITH previous tasks as one native program (vargp_amd/csrc/elbo_tn.hip); nblk = 1 is a first-task
+ * model of any M.  Replaces VARGP.compute_q / compute_pf_diag / forward / loss for ep_var_mean = True
+ * (var_gp/vargp.py:35-194: the linear_joint chain gp_utils.py:101-147 over the earlier tasks, linear_marginal_diag
+ * gp_utils.py:150-191, the conditional prior gp_cond gp_utils.py:68-98 + MVN KL vargp.py:146-190, RBFKernel kernels.py:24-77,
+ * MulticlassSoftmax.loss likelihoods.py:13-45) and its autograd backward.  The chain is evaluated in its block form: ONE
+ * kernel matrix over all Mt = nblk * M inducing points, ONE factorisation L = chol(K + eps I) with T = L^-1 (every
+ * factor of the chain is a leading block of L), block-diagonal small products with T_ii, three Mt x Mt x B GEMMs
+ * (tests/block_algorithm.py pins the identities against the chain in fp64).
+ *
+ * Caller-maintained packed operands (the program writes only the CURRENT task's part, on every fwd):
+ *   z_all  (C, Mt, D):        rows [i*M, (i+1)*M) of class c = inducing points of task i; the last M rows are scratch
+ *   rk_all (C, nblk, M, NR):  NR = 4 + M rounded up to 4;  row j of block i = [ u_mean_i[j] | 0 0 0 | Lu_i[j, :] | 0.. ],
+ *                             Lu_i = vec2tril(u_tril_vec_i) (gp_utils.py:22-49); the last block is scratch
+ * Other shapes as vargp_elbo_t0_desc.  y == NULL: predictive moments only (no likelihood / KL; eps_theta must be given
+ * unless map_est) -- VARGP.forward / predict.  vargp_elbo_tn_moments returns where fwd left mu, var (S, C, B).
+ * info[0 .. S*C): Cholesky status of K(z_<=t) + eps I per (s, c).
+ */
+typedef struct vargp_elbo_tn_desc {
+  int32_t S, C, M, D, B, F, nblk;
+  int32_t map_est;
+  float jitter;
+  const float *log_mean, *log_logvar, *prior_log_mean, *prior_log_logvar;
+  const float *z, *u_mean, *u_tril_vec; /* current task */
+  float* z_all;
+  float* rk_all;
+  const float* x;
+  const int64_t* y;
+  const float *eps_theta, *eps_f;
+  float* scalars;
+  int32_t* info;
+  void* ws;
+  size_t ws_bytes;
+  float* bump;
+  uint64_t rng_seed;
+  uint32_t* rng_counter;
+  int32_t rng_sample_offset;
+} vargp_elbo_tn_desc;
+size_t vargp_elbo_tn_workspace_bytes(int S, int C, int M, int D, int B, int F, int nblk);
+int vargp_elbo_tn_fwd(const vargp_elbo_tn_desc* d, vargp_stream_t stream);
+int vargp_elbo_tn_bwd(const vargp_elbo_tn_desc* d, const float* seeds, float* g_log_mean, float* g_log_logvar, float* g_z,
+                      float* g_u_mean, float* g_u_tril_vec, vargp_stream_t stream);
+int vargp_elbo_tn_moments(const vargp_elbo_tn_desc* d, float** mu, float** var);
+
 /* Same update for up to 8 tensors in one launch.  `step` (device float) = the step count t.
  * step_mode 0: use t as is.  1: use t + 1 (the caller advances the stored count elsewhere, e.g. through the `bump`
  * pointer of vargp_elbo_t0_desc, so that the optimiser needs no "t += 1" launch of its own). */

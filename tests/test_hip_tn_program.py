@@ -1,0 +1,170 @@
+"""GPU: the native block-structured ELBO program for models with previous tasks (vargp_elbo_tn_fwd / _bwd,
+csrc/elbo_tn.hip) against the fp64 oracle (which follows the reference's linear_joint chain), against the composed
+per-op path (the reference's op-by-op structure on the same HIP kernels), as a first-task program (nblk = 1) against
+the first-task program, in its forward-only (predict) mode, and driven directly by the trainer."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vargp_oracle as orc
+from helpers import rel_l2, to_dev, RTOL_SCALAR, REL_L2_GRAD, ATOL_PROBS, ATOL_PRED, RTOL_PRED
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _d(o):
+    return {k: v.double() for k, v in o.items()}
+
+
+# (S, F, C, M, D, B, n_prev): M % 4 != 0 (unaligned diagonal blocks), B % 4 != 0, C > 16 (generic softmax kernels),
+# D <= 32 (direct distance form), Mt <= 100 (register-resident factorisation) and Mt > 100 (blocked), one to four
+# earlier tasks, tiny / degenerate sizes
+SHAPES = [(2, 3, 3, 12, 40, 48, 1), (2, 3, 3, 33, 40, 50, 2), (3, 2, 4, 20, 64, 37, 1), (2, 2, 18, 12, 36, 24, 2),
+          (2, 3, 2, 20, 2, 64, 3), (1, 2, 2, 60, 48, 40, 4), (1, 1, 1, 3, 33, 2, 1), (2, 2, 2, 100, 36, 52, 1),
+          (2, 2, 3, 50, 24, 32, 1)]
+
+
+@pytest.mark.parametrize('shape', SHAPES, ids=[str(s) for s in SHAPES])
+def test_program_matches_fp64_oracle(shape):
+    from vargp_amd import noise
+    from gpu_common import build_gp, grads_of
+    S, F_, C, M, D, B, n_prev = shape
+    kind = 'wtoy' if D == 2 else 'gauss'
+    params, prev, x, y, nz = orc.make_problem(S, F_, C, M, D, B, n_prev=n_prev, seed=41, kind=kind)
+    gp = build_gp(params, prev, S, F_)
+    assert gp._tn_applicable()
+    with noise.inject(**to_dev(nz, DEV)):
+        kl_h, kl_u, nll = gp.loss(x.to(DEV), y.to(DEV))
+        (2.0 * kl_h + kl_u + 7.0 * nll).backward()
+        with torch.no_grad():
+            pmu, pvar = gp(x.to(DEV))
+            probs = gp.predict(x.to(DEV))
+    sc, og = orc.elbo_step(_d(params), [_d(p) for p in prev], x.double(), y, _d(nz), beta=2.0, n_total=7 * B)
+    for k, v in [('kl_hypers', kl_h), ('kl_u', kl_u), ('nll', nll)]:
+        np.testing.assert_allclose(v.item(), sc[k].item(), rtol=RTOL_SCALAR, err_msg=k)
+    for k, g in grads_of(gp).items():
+        assert rel_l2(g.cpu(), og[k]) < REL_L2_GRAD, k
+    m64, v64, _ = orc.forward(_d(params), [_d(p) for p in prev], x.double(), _d(nz))
+    np.testing.assert_allclose(pmu.cpu().numpy(), m64.numpy(), rtol=RTOL_PRED, atol=ATOL_PRED)
+    np.testing.assert_allclose(pvar.cpu().numpy(), v64.numpy(), rtol=RTOL_PRED, atol=ATOL_PRED)
+    np.testing.assert_allclose(probs.cpu().numpy(), orc.predict(_d(params), [_d(p) for p in prev], x.double(), _d(nz)).numpy(),
+                               atol=ATOL_PROBS)
+
+
+@pytest.mark.parametrize('name', ['wtoy_t2', 'smnist_small_t1', 'pmnist_red_t1'])
+def test_program_equals_composed_path(name):
+    """Same inputs through the program and through the reference-shaped composition of per-op kernels
+    (compute_q's linear_joint chain, linear_marginal_diag, the conditional prior + MVN KL)."""
+    from vargp_amd import noise
+    from gpu_common import build_gp, grads_of
+    from helpers import load_case, GRAD_KEYS
+    g, params, prev, x, y, nz = load_case(name)
+    S, F_ = int(g['meta'][0]), int(g['meta'][1])
+    res = []
+    for fused in (True, False):
+        gp = build_gp(params, prev, S, F_)
+        gp.fused_tasks = fused
+        with noise.inject(**to_dev(nz, DEV)):
+            kl_h, kl_u, nll = gp.loss(x.to(DEV), y.to(DEV))
+            (float(g['beta']) * kl_h + kl_u + (float(g['n_total']) / x.shape[0]) * nll).backward()
+            with torch.no_grad():
+                probs = gp.predict(x.to(DEV))
+        res.append(((kl_h.item(), kl_u.item(), nll.item()), {k: v.cpu() for k, v in grads_of(gp).items()}, probs.cpu()))
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=2e-5)
+    for k in GRAD_KEYS:
+        assert rel_l2(res[0][1][k], res[1][1][k]) < 2e-4, k
+    np.testing.assert_allclose(res[0][2].numpy(), res[1][2].numpy(), atol=2e-5)
+
+
+@pytest.mark.parametrize('shape', [(2, 3, 3, 40, 48, 64), (2, 2, 2, 200, 64, 96)])
+def test_program_single_block_equals_first_task_program(shape):
+    """nblk = 1: the same program is a first-task ELBO for any M; against the first-task program (csrc/elbo_t0.hip)."""
+    from vargp_amd import fused
+    from gpu_common import build_gp
+    S, F_, C, M, D, B = shape
+    params, prev, x, y, nz = orc.make_problem(S, F_, C, M, D, B, n_prev=0, seed=43, kind='gauss')
+    gp = build_gp(params, prev, S, F_)
+    k = gp.kernel
+    xd, yd = x.to(DEV), y.to(DEV)
+    et, ef = nz['eps_theta'].to(DEV), nz['eps_f'].to(DEV)
+    seeds = torch.tensor([2.0, 1.0, 5.0], device=DEV)
+    args = (k.log_mean.detach(), k.log_logvar.detach(), k.prior_log_mean, k.prior_log_logvar, gp.z.detach(),
+            gp.u_mean.detach(), gp.u_tril_vec.detach())
+    out = []
+    for which in ('t0', 'tn'):
+        grads = [torch.empty_like(t) for t in (k.log_mean, k.log_logvar, gp.z, gp.u_mean, gp.u_tril_vec)]
+        if which == 't0':
+            prog = fused.T0Program(S, C, M, D, B, F_, DEV)
+            sc = prog.forward(*args, xd, yd, et, ef).clone()
+        else:
+            prog = fused.TnProgram(S, C, M, D, B, F_, 1, DEV)
+            sc = prog.forward(*args, *gp._tn_operands(), xd, yd, et, ef).clone()
+        prog.backward(seeds, *grads)
+        out.append((sc.cpu(), [t.cpu() for t in grads]))
+    np.testing.assert_allclose(out[1][0].numpy(), out[0][0].numpy(), rtol=2e-5)
+    for a, b, name in zip(out[1][1], out[0][1], ['log_mean', 'log_logvar', 'z', 'u_mean', 'u_tril_vec']):
+        assert rel_l2(a, b) < 2e-4, name
+
+
+def test_trainer_direct_program_equals_autograd_route_t1():
+    """ElboTrainer drives TnProgram directly; the same steps through gp.loss -> autograd -> Yogi give the same parameters.
+    Also: hipGraph replay of the step == eager."""
+    from vargp_amd import noise, ops
+    from vargp_amd.optim import Yogi
+    from vargp_amd.train import ElboTrainer
+    from gpu_common import build_gp
+    S, F_, C, M, D, B = 2, 3, 4, 24, 48, 64
+    params, prev, x, y, nz = orc.make_problem(S, F_, C, M, D, B, n_prev=2, seed=8, kind='gauss')
+    xd, yd = x.to(DEV), y.to(DEV)
+    beta, n_total = 1.5, 10 * B
+    gp_a, gp_b = build_gp(params, prev, S, F_), build_gp(params, prev, S, F_)
+    tr = ElboTrainer(gp_a, lr=3e-3, beta=beta, n_total=n_total)
+    assert tr._tn
+    opt = Yogi([p for p in gp_b.parameters() if p.requires_grad], lr=3e-3)
+    for it in range(3):
+        nzd = {k: (v + 0.1 * it).to(DEV) for k, v in nz.items()}
+        with noise.inject(**nzd):
+            out_a = [float(v) for v in tr.step(xd, yd)]
+            for p in gp_b.parameters():
+                p.grad = None
+            kl_h, kl_u, nll = gp_b.loss(xd, yd)
+            (beta * kl_h + kl_u + (n_total / B) * nll).backward()
+            opt.step()
+        np.testing.assert_allclose(out_a, [kl_h.item(), kl_u.item(), nll.item()], rtol=1e-5)
+    for (k, pa), (_, pb) in zip(gp_a.named_parameters(), gp_b.named_parameters()):
+        assert rel_l2(pa.detach().cpu(), pb.detach().cpu()) < 1e-5, k
+
+    # graph replay == eager (native noise: same seed, same counter)
+    ops.set_cholesky_error_mode('defer')
+    try:
+        res = []
+        for mode in ('eager', 'graph'):
+            gp = build_gp(params, prev, S, F_)
+            tr = ElboTrainer(gp, lr=3e-3, beta=beta, n_total=n_total, noise_seed=3)
+            if mode == 'graph':
+                tr.capture(xd, yd)
+            for _ in range(3):
+                out = tr.step_graph(xd, yd) if mode == 'graph' else tr.step(xd, yd)
+            torch.cuda.synchronize()
+            res.append(([o.item() for o in out], {k: v.detach().cpu().clone() for k, v in gp.state_dict().items()}))
+        np.testing.assert_allclose(res[1][0], res[0][0], rtol=1e-5)
+        for k in res[0][1]:
+            assert rel_l2(res[1][1][k], res[0][1][k]) < 1e-5, k
+        assert ops.linalg_error_count() == 0
+    finally:
+        ops.set_cholesky_error_mode('raise')
+
+
+def test_program_non_pd_is_flagged():
+    """Duplicate inducing points across tasks with zero jitter would break the factorisation; with the reference's jitter
+    the matrix stays PD.  A NaN input must be flagged (info != 0) and NaN-poison the result, not crash."""
+    from vargp_amd import ops
+    from gpu_common import build_gp
+    S, F_, C, M, D, B = 1, 2, 2, 16, 8, 16
+    params, prev, x, y, nz = orc.make_problem(S, F_, C, M, D, B, n_prev=1, seed=9, kind='gauss')
+    params['z'][0, 0, 0] = float('nan')
+    gp = build_gp(params, prev, S, F_)
+    ops.set_cholesky_error_mode('raise')
+    with pytest.raises(torch.linalg.LinAlgError):
+        gp.loss(x.to(DEV), y.to(DEV))

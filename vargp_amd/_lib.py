@@ -41,6 +41,22 @@ class ElboT0Desc(Structure):
     ]
 
 
+class ElboTnDesc(Structure):
+    _fields_ = [
+        ('S', c_int32), ('C', c_int32), ('M', c_int32), ('D', c_int32), ('B', c_int32), ('F', c_int32), ('nblk', c_int32),
+        ('map_est', c_int32), ('jitter', c_float),
+        ('log_mean', c_void_p), ('log_logvar', c_void_p), ('prior_log_mean', c_void_p), ('prior_log_logvar', c_void_p),
+        ('z', c_void_p), ('u_mean', c_void_p), ('u_tril_vec', c_void_p),
+        ('z_all', c_void_p), ('rk_all', c_void_p),
+        ('x', c_void_p), ('y', c_void_p),
+        ('eps_theta', c_void_p), ('eps_f', c_void_p),
+        ('scalars', c_void_p), ('info', c_void_p),
+        ('ws', c_void_p), ('ws_bytes', c_size_t),
+        ('bump', c_void_p),
+        ('rng_seed', ctypes.c_uint64), ('rng_counter', c_void_p), ('rng_sample_offset', c_int32),
+    ]
+
+
 _P = c_void_p
 _SIGNATURES = {
     'vargp_version': (c_int, []),
@@ -74,6 +90,10 @@ _SIGNATURES = {
     'vargp_elbo_t0_workspace_bytes': (c_size_t, [c_int] * 6),
     'vargp_elbo_t0_fwd': (c_int, [POINTER(ElboT0Desc), _P]),
     'vargp_elbo_t0_bwd': (c_int, [POINTER(ElboT0Desc)] + [_P] * 7),
+    'vargp_elbo_tn_workspace_bytes': (c_size_t, [c_int] * 7),
+    'vargp_elbo_tn_fwd': (c_int, [POINTER(ElboTnDesc), _P]),
+    'vargp_elbo_tn_bwd': (c_int, [POINTER(ElboTnDesc)] + [_P] * 7),
+    'vargp_elbo_tn_moments': (c_int, [POINTER(ElboTnDesc), POINTER(c_void_p), POINTER(c_void_p)]),
     'vargp_prof_enable': (c_int, [c_int]),
     'vargp_prof_read': (c_int, [c_char_p, POINTER(ctypes.c_double), POINTER(c_int64)]),
     'vargp_prof_remember': (c_int, [c_int]),

@@ -1,0 +1,599 @@
+// The ELBO of a model WITH previous tasks (t > 0; also any first-task model, nblk = 1) as ONE native program:
+// vargp_elbo_tn_fwd / vargp_elbo_tn_bwd (reference: VARGP.compute_q / compute_pf_diag / forward / loss,
+// var_gp/vargp.py:35-194; linear_joint / linear_marginal_diag / gp_cond, var_gp/gp_utils.py:68-191).
+//
+// The reference folds the earlier tasks into q(u_<=t | theta) with a chain of linear_joint calls (one Cholesky, four
+// triangular solves and three GEMMs per earlier task, on joint covariances that grow to Mt x Mt), then factorises
+// K_uu + eps I and S_<=t + eps I again for the predictive moments, then the conditional prior for the KL.  All of it
+// is a function of ONE kernel matrix.  With K' = K(z_<=t, z_<=t) + eps I, L = chol(K'), T = L^-1 and blocks of size M in
+// task order (tests/block_algorithm.py pins every identity against the oracle in fp64):
+//   * every Lz of the chain is a leading block of L, and A_i = K_{i,<i} (K_{<i,<i} + eps I)^-1 = L_{i,<i} T_{<i,<i};
+//   * joint mean mu_<=t = L a with a = [T_ii m_i]_i, joint covariance S_<=t = (L H)(L H)^T with H = blockdiag(T_ii Lu_i);
+//   * predictive moments: P = T K_uf, V2 = T^T P, W = H^T P (block-diagonal):
+//         mu_b = sum_m P a,   var_b = gamma^2 - |P_b|^2 + |W_b|^2 + eps |V2_b|^2
+//     (the eps term is the jitter of chol(S_<=t + eps I), gp_utils.py:182);
+//   * p(u_t | u_<t) has covariance + jitter = L_tt L_tt^T (last diagonal block), so
+//         KL[s,c] = sum log diag L_tt - sum log diag Lu_t + 0.5 (|H_t|_F^2 + |a_t|^2 - M)        (ep_var_mean = True).
+// So a step is: two kernel-matrix GEMMs, ONE blocked factorisation of size Mt, four GEMMs, two reductions -- and the
+// backward is GEMMs as well (the Cholesky adjoint needs no L at all: gL is diagonal here).
+// Gradients reach theta (through both kernel matrices), the current z (last M rows of each class), u_mean, u_tril_vec.
+#include "common.h"
+#include "elbo_shared.h"
+
+namespace vargp {
+
+struct TnWs {
+  float *theta, *eps_theta, *eps_f;          // first, in this order (vargp_amd/fused.py exposes them as views)
+  float *g2, *kd, *mu, *var, *gmu, *gvar;    // gmu, gvar adjacent: one zero range (accumulated by the softmax kernel)
+  float *Kall, *Kuf, *LL, *TT, *QPs, *P, *V2, *W;
+  float *gQPs, *gP, *gT, *gKuf, *gK, *gRKt, *gkd, *gtheta, *gz_all;
+  void *chol, *rbf;
+  size_t chol_bytes, rbf_bytes;
+  int NRs, Mt;
+  size_t bytes;
+};
+
+static TnWs carve_tn(void* ws, int S, int C, int M, int D, int B, int F, int nblk) {
+  TnWs o{};
+  o.Mt = M * nblk;
+  o.NRs = (int)round_up(4 + M, 4);
+  const int64_t SC = (int64_t)S * C, Mt = o.Mt, D1 = D + 1;
+  float* p = reinterpret_cast<float*>(ws);
+  auto take = [&](int64_t n) { float* q = p; p += round_up(n, 64); return q; };
+  o.theta = take(S * D1); o.eps_theta = take(S * D1); o.eps_f = take((int64_t)S * F * C * B);
+  o.g2 = take(S); o.kd = take(SC);
+  o.mu = take(SC * B); o.var = take(SC * B);
+  o.gmu = take(SC * B); o.gvar = take(SC * B);
+  o.Kall = take(SC * Mt * Mt); o.Kuf = take(SC * Mt * B);
+  o.LL = take(SC * Mt * Mt); o.TT = take(SC * Mt * Mt);
+  o.QPs = take(SC * Mt * o.NRs);
+  o.P = take(SC * Mt * B); o.V2 = take(SC * Mt * B); o.W = take(SC * Mt * B);
+  o.gQPs = take(SC * Mt * o.NRs); o.gP = take(SC * Mt * B);
+  o.gT = take(SC * Mt * Mt); o.gKuf = take(SC * Mt * B); o.gK = take(SC * Mt * Mt);
+  o.gRKt = take(SC * M * o.NRs); o.gkd = take(SC); o.gtheta = take(S * D1);
+  o.gz_all = take((int64_t)C * Mt * D);
+  const size_t cf = vargp_chol_workspace_bytes((int)SC, o.Mt, 0), cb = vargp_chol_workspace_bytes((int)SC, o.Mt, 1);
+  o.chol_bytes = cf > cb ? cf : cb;
+  o.chol = p;
+  p += round_up((int64_t)(o.chol_bytes + 3) / 4, 64);
+  size_t rb = 0;
+  for (int bw = 0; bw < 2; ++bw) {
+    rb = std::max(rb, vargp_rbf_workspace_bytes(S, C, o.Mt, o.Mt, D, bw));
+    rb = std::max(rb, vargp_rbf_workspace_bytes(S, C, o.Mt, B, D, bw));
+  }
+  o.rbf_bytes = rb;
+  o.rbf = p;
+  p += round_up((int64_t)(rb + 3) / 4, 64);
+  o.bytes = (size_t)((char*)p - (char*)ws);
+  return o;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward kernels
+// ---------------------------------------------------------------------------------------------------------------
+struct TnProArgs {
+  const float *mean, *logvar, *pmean, *plogvar, *eps_theta, *vec, *u_mean, *z;
+  float *theta, *g2, *kd, *scalars, *zero_begin, *bump, *rk_last, *z_all;
+  int32_t* info;
+  int64_t zero_count;
+  int S, C, M, D, Mt, NRs, nblk, ninfo, map_est, nzero_blocks, npack_blocks;
+  int native, nrng_blocks;
+  uint64_t seed;
+  const uint32_t* rng_counter;
+  int64_t g0_theta, g0_f, n_f;
+  float *eps_theta_out, *eps_f_out;
+};
+
+// Multi-role prologue, role by block index:
+//   block 0            kl_hypers (kernels.py:70-77) -> scalars[0]; scalars[1..2] = 0; info = 0; *bump += 1
+//   blocks 1..S        theta_s = mean + eps_s exp(logvar/2) (kernels.py:62-68), gamma_s^2 (kernels.py:58-60)
+//   next nzero_blocks  zero-fill of the softmax-gradient accumulators
+//   next nrng_blocks   (native noise only) the likelihood noise
+//   next npack_blocks  the current task's block of the packed operand rk_all: [u_mean | 0 0 0 | Lu = vec2tril(vec) | 0..]
+//                      (gp_utils.py:22-49: softplus on the diagonal)
+//   rest               the current inducing points into the last M rows of every class of z_all
+__global__ __launch_bounds__(256) void tn_prologue_kernel(const TnProArgs a) {
+  __shared__ float red[4];
+  const int blk = blockIdx.x, tid = threadIdx.x;
+  const int D1 = a.D + 1;
+  if (blk == 0) {
+    float acc = 0.f;
+    if (!a.map_est)
+      for (int d = tid; d < D1; d += 256) {
+        const float dv = a.logvar[d] - a.plogvar[d], dm = a.mean[d] - a.pmean[d];
+        acc += 0.5f * (expf(dv) + dm * dm * expf(-a.plogvar[d]) - 1.f - dv);
+      }
+    const float t = block_sum<256>(acc, red);
+    if (tid == 0) {
+      a.scalars[0] = t; a.scalars[1] = 0.f; a.scalars[2] = 0.f;
+      if (a.bump) a.bump[0] += 1.f;
+    }
+    for (int i = tid; i < a.ninfo; i += 256) a.info[i] = 0;
+    return;
+  }
+  if (blk <= a.S) {
+    const int s = blk - 1;
+    for (int d = tid; d < D1; d += 256) {
+      float t;
+      if (a.map_est) {
+        t = a.mean[d];
+      } else {
+        float e;
+        if (a.native) {
+          e = normal1(a.seed, kStreamTheta, (uint64_t)(a.g0_theta + (int64_t)s * D1 + d), a.rng_counter[0]);
+          a.eps_theta_out[s * D1 + d] = e;
+        } else {
+          e = a.eps_theta[s * D1 + d];
+        }
+        t = a.mean[d] + e * expf(0.5f * a.logvar[d]);
+      }
+      a.theta[s * D1 + d] = t;
+      if (d == a.D) {
+        const float g = expf(2.f * t);
+        a.g2[s] = g;
+        for (int c = 0; c < a.C; ++c) a.kd[s * a.C + c] = g;
+      }
+    }
+    return;
+  }
+  int id = blk - 1 - a.S;
+  if (id < a.nzero_blocks) {
+    for (int64_t i = (int64_t)id * 256 + tid; i < a.zero_count; i += (int64_t)a.nzero_blocks * 256) a.zero_begin[i] = 0.f;
+    return;
+  }
+  id -= a.nzero_blocks;
+  if (id < a.nrng_blocks) {
+    const uint32_t step = a.rng_counter[0];
+    const int64_t gfirst = a.g0_f >> 2, glast = (a.g0_f + a.n_f + 3) >> 2;
+    for (int64_t G = gfirst + (int64_t)id * 256 + tid; G < glast; G += (int64_t)a.nrng_blocks * 256) {
+      float v[4];
+      normal4(a.seed, kStreamF, (uint64_t)G, step, v);
+#pragma unroll
+      for (int l = 0; l < 4; ++l) {
+        const int64_t i = 4 * G + l - a.g0_f;
+        if (i >= 0 && i < a.n_f) a.eps_f_out[i] = v[l];
+      }
+    }
+    return;
+  }
+  id -= a.nrng_blocks;
+  const int M = a.M;
+  if (id < a.npack_blocks) {
+    const int64_t e = (int64_t)id * 256 + tid;          // (c, i, col) of the last block, col < NRs
+    if (e >= (int64_t)a.C * M * a.NRs) return;
+    const int col = e % a.NRs, i = (e / a.NRs) % M;
+    const int64_t c = e / ((int64_t)a.NRs * M);
+    float v = 0.f;
+    if (col == 0) v = a.u_mean[c * M + i];
+    else if (col >= 4 && col < 4 + M) {
+      const int j = col - 4;
+      if (j <= i) {
+        const float x = a.vec[c * ((int64_t)M * (M + 1) / 2) + (int64_t)i * (i + 1) / 2 + j];
+        v = j == i ? softplus_t0(x) : x;
+      }
+    }
+    a.rk_last[(c * a.nblk * M + i) * a.NRs + col] = v;      // rk_last = rk_all + (nblk - 1) * M * NRs; class stride nblk*M*NRs
+    return;
+  }
+  id -= a.npack_blocks;
+  const int64_t e = (int64_t)id * 256 + tid;              // (c, i, d) of the current inducing points
+  if (e >= (int64_t)a.C * M * a.D) return;
+  const int d = e % a.D, i = (e / a.D) % M;
+  const int64_t c = e / ((int64_t)a.D * M);
+  a.z_all[(c * a.Mt + (a.Mt - M) + i) * a.D + d] = a.z[e];
+}
+
+// Two roles.  Blocks < npd: predictive mean / variance, 64 minibatch columns x 4 row lanes over all Mt rows:
+//   mu = sum_m P a,  var = kd - sum P^2 + sum W^2 + eps sum V2^2     (a = column 0 of QPs, one value per row of P).
+// Blocks >= npd: the KL of q(u_t | u_<t) against p(u_t | u_<t) (vargp.py:182-190) from the last block of QPs:
+//   kl[s,c] = sum log diag L_tt - sum log diag Lu_t + 0.5 (|H_t|_F^2 + |a_t|^2 - M),  kl_u = (1/S) sum kl[s,c]  (atomic)
+constexpr int kTnKlRows = 8;
+__global__ __launch_bounds__(256) void tn_pdiag_kl_kernel(const float* __restrict__ P, const float* __restrict__ W,
+                                                          const float* __restrict__ V2, const float* __restrict__ QPs,
+                                                          const float* __restrict__ kd, const float* __restrict__ L,
+                                                          const float* __restrict__ rk_all, float* __restrict__ mu,
+                                                          float* __restrict__ var, float* __restrict__ kl_u, float eps,
+                                                          int S, int C, int M, int Mt, int nblk, int B, int NRs, int nbx,
+                                                          int npd, int nkx, uint32_t* rng_counter) {
+  __shared__ float red[4][4][64];
+  if (rng_counter && blockIdx.x == 0 && threadIdx.x == 0) rng_counter[0] += 1u;   // this step's noise has been drawn
+  if ((int)blockIdx.x < npd) {
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int col = ((int)blockIdx.x % nbx) * 64 + cx;
+    const int64_t b = blockIdx.x / nbx;
+    float m0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+    if (col < B) {
+      const float* p = P + b * Mt * B + col;
+      const float* w = W + b * Mt * B + col;
+      const float* v = V2 + b * Mt * B + col;
+      const float* q = QPs + b * Mt * NRs;
+#pragma unroll 4
+      for (int m = ry; m < Mt; m += 4) {
+        const float pv = p[(int64_t)m * B], wv = w[(int64_t)m * B], vv = v[(int64_t)m * B];
+        m0 = fmaf(pv, q[(int64_t)m * NRs], m0);
+        d1 = fmaf(pv, pv, d1);
+        d2 = fmaf(wv, wv, d2);
+        d3 = fmaf(vv, vv, d3);
+      }
+    }
+    red[0][ry][cx] = m0; red[1][ry][cx] = d1; red[2][ry][cx] = d2; red[3][ry][cx] = d3;
+    __syncthreads();
+    if (ry == 0 && col < B) {
+      m0 = red[0][0][cx] + red[0][1][cx] + red[0][2][cx] + red[0][3][cx];
+      d1 = red[1][0][cx] + red[1][1][cx] + red[1][2][cx] + red[1][3][cx];
+      d2 = red[2][0][cx] + red[2][1][cx] + red[2][2][cx] + red[2][3][cx];
+      d3 = red[3][0][cx] + red[3][1][cx] + red[3][2][cx] + red[3][3][cx];
+      mu[b * B + col] = m0;
+      var[b * B + col] = kd[b] - d1 + d2 + eps * d3;
+    }
+    return;
+  }
+  if (!kl_u) return;
+  const int id = (int)blockIdx.x - npd;
+  const int64_t b = id / nkx;          // s * C + c
+  const int c = b % C;
+  const int i0 = (id % nkx) * kTnKlRows, i1 = min(M, i0 + kTnKlRows);
+  const int r0 = Mt - M;               // first row of the current task's block
+  const float* q = QPs + (b * Mt + r0) * NRs;
+  const float* rk = rk_all + ((int64_t)c * nblk + (nblk - 1)) * M * NRs;
+  float acc = 0.f;
+  for (int e = threadIdx.x; e < (i1 - i0) * M; e += 256) {
+    const int i = i0 + e / M, j = e % M;
+    if (j <= i) { const float v = q[(int64_t)i * NRs + 4 + j]; acc = fmaf(v, v, acc); }
+  }
+  for (int i = i0 + threadIdx.x; i < i1; i += 256) {
+    const float a = q[(int64_t)i * NRs];
+    acc = fmaf(a, a, acc);
+    acc += 2.f * (logf(L[(b * Mt + r0 + i) * Mt + r0 + i]) - logf(rk[(int64_t)i * NRs + 4 + i])) - 1.f;
+  }
+  const float t = block_sum<256>(acc, &red[0][0][0]);
+  if (threadIdx.x == 0) atomicAdd(kl_u, 0.5f * t / (float)S);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward kernels
+// ---------------------------------------------------------------------------------------------------------------
+// First backward launch, two roles by block index.
+//   blocks < npd (one per row (b, m), m < Mt): gP = a gmu - 2 P gvar; W <- gW = 2 W gvar and V2 <- gV2 = 2 eps V2 gvar
+//       IN PLACE; ga = sum_col P gmu (+ g a on the current task's block: KL) -> column 0 of gQPs; row 0 of each b also
+//       reduces gkd = sum_col gvar.  gscale (nullable) = seed multiplying the stored unscaled softmax gradients.
+//   rest: the other columns of gQPs: 1..3 and the padding = 0; the H columns = g tril(H_t) on the current task's block
+//       (KL), 0 elsewhere (the product P gW^T is accumulated on top by a GEMM).                       (g = seed_kl / S)
+__global__ __launch_bounds__(256) void tn_bwd_head_kernel(const float* __restrict__ P, float* __restrict__ W,
+                                                          float* __restrict__ V2, const float* __restrict__ QPs,
+                                                          const float* __restrict__ gmu, const float* __restrict__ gvar,
+                                                          const float* __restrict__ gscale, const float* __restrict__ seeds,
+                                                          float* __restrict__ gP, float* __restrict__ gQPs,
+                                                          float* __restrict__ gkd, float eps, int S, int M, int Mt, int B,
+                                                          int NRs, int npd) {
+  __shared__ float red[4];
+  const float g = seeds[1] / (float)S;
+  if ((int)blockIdx.x < npd) {
+    const int m = (int)blockIdx.x % Mt;
+    const int64_t b = blockIdx.x / Mt;
+    const int64_t off = (b * Mt + m) * B;
+    const float am = QPs[(b * Mt + m) * NRs];
+    const float gs = gscale ? gscale[0] : 1.f;
+    float acc = 0.f, accv = 0.f;
+    for (int col = threadIdx.x; col < B; col += 256) {
+      const float gm = gs * gmu[b * B + col], gv = gs * gvar[b * B + col];
+      const float pv = P[off + col];
+      gP[off + col] = am * gm - 2.f * pv * gv;
+      W[off + col] = 2.f * W[off + col] * gv;
+      V2[off + col] = 2.f * eps * V2[off + col] * gv;
+      acc = fmaf(pv, gm, acc);
+      accv += gv;
+    }
+    const float t = block_sum<256>(acc, red);
+    if (threadIdx.x == 0) gQPs[(b * Mt + m) * NRs] = t + (m >= Mt - M ? g * am : 0.f);
+    if (m == 0) {
+      const float tv = block_sum<256>(accv, red);
+      if (threadIdx.x == 0) gkd[b] = tv;
+    }
+    return;
+  }
+  const int64_t e = (int64_t)((int)blockIdx.x - npd) * 256 + threadIdx.x;       // (row, col >= 1) of gQPs
+  const int cols = NRs - 1;
+  const int64_t row = e / cols;
+  const int col = 1 + (int)(e % cols);
+  if (row >= (int64_t)npd) return;             // npd = number of rows of gQPs
+  const int m = row % Mt;
+  float v = 0.f;
+  if (m >= Mt - M && col >= 4 && col < 4 + M) {
+    const int i = m - (Mt - M), j = col - 4;
+    if (j <= i) v = g * QPs[row * NRs + col];
+  }
+  gQPs[row * NRs + col] = v;
+}
+
+// Smat_jj += g / 2 on the current task's block (the diagonal gL = g / L_jj of the log-determinant, see the backward),
+// and, sharing the launch, nothing else.  One thread per (b, i).
+__global__ void tn_diag_kernel(float* __restrict__ Smat, const float* __restrict__ seeds, int S, int M, int Mt, int64_t total) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int i = e % M;
+  const int64_t b = e / M;
+  const int j = Mt - M + i;
+  Smat[(b * Mt + j) * Mt + j] += 0.5f * seeds[1] / (float)S;
+}
+
+// Parameter gradients of the current task from gRKt[s,c] = T_tt^T [ga_t | . | gH_t]:
+//   g_u_mean[c,i] = sum_s gRKt[s,c,i,0]
+//   gLu[c,i,k]    = sum_s gRKt[s,c,i,4+k]  (k <= i)  - seed_kl / Lu_ii on the diagonal, through vec2tril (softplus')
+// and, in the remaining blocks, the gradient of the current inducing points = the last M rows of every class of gz_all.
+__global__ __launch_bounds__(256) void tn_unpack_kernel(const float* __restrict__ gRKt, const float* __restrict__ vec,
+                                                        const float* __restrict__ rk_last, const float* __restrict__ seeds,
+                                                        const float* __restrict__ gz_all, float* __restrict__ g_u_mean,
+                                                        float* __restrict__ gvec, float* __restrict__ g_z, int S, int C, int M,
+                                                        int Mt, int D, int NRs, int nblk, int nun) {
+  if ((int)blockIdx.x < nun) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;     // (c, i, jj), jj = 0: mean, jj = 1 + k: Lu_ik
+    if (e >= (int64_t)C * M * (M + 1)) return;
+    const int jj = e % (M + 1), i = (e / (M + 1)) % M;
+    const int64_t c = e / ((int64_t)(M + 1) * M);
+    const int k = jj - 1;
+    if (k > i) return;
+    const int col = jj == 0 ? 0 : 3 + jj;
+    float acc = 0.f;
+    for (int s = 0; s < S; ++s) acc += gRKt[(((int64_t)s * C + c) * M + i) * NRs + col];
+    if (jj == 0) { g_u_mean[c * M + i] = acc; return; }
+    const int64_t idx = c * ((int64_t)M * (M + 1) / 2) + (int64_t)i * (i + 1) / 2 + k;
+    if (i == k) {
+      acc -= seeds[1] / rk_last[(c * nblk * M + i) * NRs + 4 + i];
+      const float x = vec[idx];
+      acc *= (x > 20.f) ? 1.f : sigmoid_t0(x);
+    }
+    gvec[idx] = acc;
+    return;
+  }
+  const int64_t e = (int64_t)((int)blockIdx.x - nun) * 256 + threadIdx.x;
+  if (e >= (int64_t)C * M * D) return;
+  const int d = e % D, i = (e / D) % M;
+  const int64_t c = e / ((int64_t)D * M);
+  g_z[e] = gz_all[(c * Mt + (Mt - M) + i) * D + d];
+}
+
+static int check_tn(const vargp_elbo_tn_desc* d, const char* who) {
+  VARGP_REQUIRE(d, "%s: null descriptor", who);
+  VARGP_REQUIRE(d->S > 0 && d->C > 0 && d->M > 0 && d->D > 0 && d->B > 0 && d->F > 0 && d->nblk > 0, "%s: bad dims", who);
+  VARGP_REQUIRE(d->log_mean && d->z && d->u_mean && d->u_tril_vec && d->z_all && d->rk_all && d->x && d->scalars && d->info &&
+                    d->ws, "%s: null pointer", who);
+  const bool native = d->eps_f == nullptr && d->y != nullptr;
+  VARGP_REQUIRE(!native || (d->rng_counter && d->eps_theta == nullptr && d->rng_sample_offset >= 0),
+                "%s: native noise needs rng_counter, eps_theta == eps_f == NULL and a sample offset >= 0", who);
+  VARGP_REQUIRE(d->map_est ? d->S == 1
+                           : (d->log_logvar && d->prior_log_mean && d->prior_log_logvar && (native || d->eps_theta)),
+                "%s: hyper-parameter arguments inconsistent with map_est", who);
+  VARGP_REQUIRE(d->ws_bytes >= vargp_elbo_tn_workspace_bytes(d->S, d->C, d->M, d->D, d->B, d->F, d->nblk),
+                "%s: workspace too small", who);
+  return VARGP_OK;
+}
+
+// batched product over (s, c, block): strides of the three batch dims given per operand
+static GemmParams blk_gemm(const float* A, int lda, const int64_t (&sA)[3], const float* B, int ldb, const int64_t (&sB)[3],
+                           float* C, int ldc, const int64_t (&sC)[3], int M, int N, int K, int nC, int nblk) {
+  GemmParams p{};
+  p.A = A; p.B = B; p.C = C; p.D = nullptr;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldd = ldc;
+  p.nb1 = nC; p.nb2 = nblk;
+  for (int i = 0; i < 3; ++i) { p.sA[i] = sA[i]; p.sB[i] = sB[i]; p.sC[i] = sC[i]; p.sD[i] = sC[i]; }
+  p.alpha = 1.f; p.beta = 0.f;
+  return p;
+}
+
+}  // namespace vargp
+
+using namespace vargp;
+
+extern "C" size_t vargp_elbo_tn_workspace_bytes(int S, int C, int M, int D, int B, int F, int nblk) {
+  return carve_tn(nullptr, S, C, M, D, B, F, nblk).bytes + 256;
+}
+
+extern "C" int vargp_elbo_tn_moments(const vargp_elbo_tn_desc* d, float** mu, float** var) {
+  VARGP_REQUIRE(d && d->ws && mu && var, "elbo_tn_moments: null pointer");
+  const TnWs o = carve_tn(d->ws, d->S, d->C, d->M, d->D, d->B, d->F, d->nblk);
+  *mu = o.mu; *var = o.var;
+  return VARGP_OK;
+}
+
+extern "C" int vargp_elbo_tn_fwd(const vargp_elbo_tn_desc* d, vargp_stream_t stream) {
+  int rc = check_tn(d, "elbo_tn_fwd");
+  if (rc) return rc;
+  hipStream_t st = as_stream(stream);
+  const int S = d->S, C = d->C, M = d->M, D = d->D, B = d->B, F = d->F, nblk = d->nblk, SC = S * C;
+  const TnWs o = carve_tn(d->ws, S, C, M, D, B, F, nblk);
+  const int Mt = o.Mt, NRs = o.NRs;
+  const int64_t MtMt = (int64_t)Mt * Mt, MtB = (int64_t)Mt * B, MtN = (int64_t)Mt * NRs;
+  const bool lik = d->y != nullptr;                 // y == NULL: predictive moments only (no likelihood, no KL)
+  const bool native = lik && d->eps_f == nullptr;
+  const bool fused_softmax = C <= 16;
+  const float* eps_f = native ? o.eps_f : d->eps_f;
+  {
+    ProfScope prof("tn_prologue", st);
+    TnProArgs a{};
+    a.mean = d->log_mean; a.logvar = d->log_logvar; a.pmean = d->prior_log_mean; a.plogvar = d->prior_log_logvar;
+    a.eps_theta = d->eps_theta; a.vec = d->u_tril_vec; a.u_mean = d->u_mean; a.z = d->z;
+    a.theta = o.theta; a.g2 = o.g2; a.kd = o.kd; a.scalars = d->scalars; a.bump = d->bump;
+    a.rk_last = d->rk_all + (int64_t)(nblk - 1) * M * NRs; a.z_all = d->z_all;
+    a.info = d->info; a.ninfo = SC;
+    a.zero_begin = o.gmu; a.zero_count = o.Kall - o.gmu;
+    a.S = S; a.C = C; a.M = M; a.D = D; a.Mt = Mt; a.NRs = NRs; a.nblk = nblk; a.map_est = d->map_est;
+    a.nzero_blocks = (int)std::min<int64_t>(64, cdiv(a.zero_count, 1024));
+    if (native) {
+      const int64_t per_sample_f = (int64_t)F * C * B;
+      a.native = 1; a.seed = d->rng_seed; a.rng_counter = d->rng_counter;
+      a.g0_theta = (int64_t)d->rng_sample_offset * (D + 1); a.g0_f = (int64_t)d->rng_sample_offset * per_sample_f;
+      a.n_f = S * per_sample_f;
+      a.eps_theta_out = o.eps_theta; a.eps_f_out = o.eps_f;
+      a.nrng_blocks = (int)std::min<int64_t>(512, cdiv(a.n_f + 7, 1024));
+    }
+    a.npack_blocks = cdiv((int64_t)C * M * NRs, 256);
+    const int grid = 1 + S + a.nzero_blocks + a.nrng_blocks + a.npack_blocks + cdiv((int64_t)C * M * D, 256);
+    hipLaunchKernelGGL(tn_prologue_kernel, dim3(grid), dim3(256), 0, st, a);
+  }
+  // kernel matrices over ALL inducing points (earlier tasks + current): K_all (S,C,Mt,Mt), K_uf (S,C,Mt,B)
+  rc = vargp_rbf_gram_fwd(o.theta, d->z_all, nullptr, o.Kall, S, C, Mt, Mt, D, 0, o.rbf, o.rbf_bytes, stream);
+  if (rc) return rc;
+  rc = vargp_rbf_gram_fwd(o.theta, d->z_all, d->x, o.Kuf, S, C, Mt, B, D, 1, o.rbf, o.rbf_bytes, stream);
+  if (rc) return rc;
+  // L = chol(K_all + eps I), T = L^-1: every factor of the reference's chain is a leading block of these
+  rc = chol_inv_fwd_impl(o.Kall, d->jitter, o.LL, o.TT, nullptr, d->info, SC, Mt, o.chol, o.chol_bytes, false, st);
+  if (rc) return rc;
+  {  // [a_i | . | H_i] = T_ii [m_i | 0 | Lu_i] for every (s, c, block i)
+    const int64_t sA[3] = {C * MtMt, MtMt, (int64_t)M * Mt + M}, sB[3] = {0, (int64_t)nblk * M * NRs, (int64_t)M * NRs},
+                  sC[3] = {C * MtN, MtN, (int64_t)M * NRs};
+    GemmParams p = blk_gemm(o.TT, Mt, sA, d->rk_all, NRs, sB, o.QPs, NRs, sC, M, NRs, M, C, nblk);
+    p.triA = 1;
+    rc = launch_gemm(p, 0, 0, SC * nblk, false, st, "tn_small_gemm");
+    if (rc) return rc;
+  }
+  {  // P = T K_uf
+    GemmParams p = flat_gemm(o.TT, Mt, MtMt, o.Kuf, B, MtB, o.P, B, MtB, Mt, B, Mt);
+    p.triA = 1;
+    rc = launch_gemm(p, 0, 0, SC, false, st, "tn_p_gemm");
+    if (rc) return rc;
+  }
+  {  // V2 = T^T P  (= K'^-1 K_uf: the eps term of the variance)
+    GemmParams p = flat_gemm(o.TT, Mt, MtMt, o.P, B, MtB, o.V2, B, MtB, Mt, B, Mt);
+    p.triA = 2;
+    rc = launch_gemm(p, 1, 0, SC, false, st, "tn_v2_gemm");
+    if (rc) return rc;
+  }
+  {  // W_i = H_i^T P_i
+    const int64_t sA[3] = {C * MtN, MtN, (int64_t)M * NRs}, sB[3] = {C * MtB, MtB, (int64_t)M * B};
+    GemmParams p = blk_gemm(o.QPs + 4, NRs, sA, o.P, B, sB, o.W, B, sB, M, B, M, C, nblk);
+    p.triA = 2;
+    rc = launch_gemm(p, 1, 0, SC * nblk, false, st, "tn_w_gemm");
+    if (rc) return rc;
+  }
+  {
+    const int nbx = cdiv(B, 64), npd = nbx * SC, nkx = cdiv(M, kTnKlRows);
+    hipLaunchKernelGGL(tn_pdiag_kl_kernel, dim3(npd + (lik ? nkx * SC : 0)), dim3(256), 0, st, o.P, o.W, o.V2, o.QPs, o.kd,
+                       o.LL, d->rk_all, o.mu, o.var, lik ? d->scalars + 1 : nullptr, d->jitter, S, C, M, Mt, nblk, B, NRs,
+                       nbx, npd, nkx, native ? d->rng_counter : nullptr);
+  }
+  if (lik) {
+    if (fused_softmax) {
+      const int64_t total = (int64_t)S * F * B;
+      hipLaunchKernelGGL(t0_softmax_kernel<16>, dim3(cdiv(total, 256)), dim3(256), 0, st, o.mu, o.var, eps_f, d->y,
+                         d->scalars + 2, o.gmu, o.gvar, S, F, C, B);
+    } else {
+      rc = vargp_softmax_nll_fwd(o.mu, o.var, eps_f, d->y, d->scalars + 2, S, F, C, B, stream);
+      if (rc) return rc;
+    }
+  }
+  return check_launch("elbo_tn_fwd");
+}
+
+extern "C" int vargp_elbo_tn_bwd(const vargp_elbo_tn_desc* d, const float* seeds, float* g_log_mean, float* g_log_logvar,
+                                 float* g_z, float* g_u_mean, float* g_u_tril_vec, vargp_stream_t stream) {
+  int rc = check_tn(d, "elbo_tn_bwd");
+  if (rc) return rc;
+  VARGP_REQUIRE(seeds && g_log_mean && g_log_logvar && g_z && g_u_mean && g_u_tril_vec && d->y, "elbo_tn_bwd: null pointer");
+  hipStream_t st = as_stream(stream);
+  const int S = d->S, C = d->C, M = d->M, D = d->D, B = d->B, F = d->F, nblk = d->nblk, SC = S * C;
+  const TnWs o = carve_tn(d->ws, S, C, M, D, B, F, nblk);
+  const int Mt = o.Mt, NRs = o.NRs;
+  const int64_t MtMt = (int64_t)Mt * Mt, MtB = (int64_t)Mt * B, MtN = (int64_t)Mt * NRs;
+  const bool native = d->eps_f == nullptr;
+  const bool fused_softmax = C <= 16;
+  const float* eps_f = native ? o.eps_f : d->eps_f;
+  const float* eps_theta = native ? o.eps_theta : d->eps_theta;
+
+  if (!fused_softmax) {
+    rc = vargp_softmax_nll_bwd(o.mu, o.var, eps_f, d->y, seeds + 2, o.gmu, o.gvar, S, F, C, B, stream);
+    if (rc) return rc;
+  }
+  {
+    const int npd = SC * Mt;
+    const int nrest = cdiv((int64_t)npd * (NRs - 1), 256);
+    hipLaunchKernelGGL(tn_bwd_head_kernel, dim3(npd + nrest), dim3(256), 0, st, o.P, o.W, o.V2, o.QPs, o.gmu, o.gvar,
+                       fused_softmax ? seeds + 2 : nullptr, seeds, o.gP, o.gQPs, o.gkd, d->jitter, S, M, Mt, B, NRs, npd);
+  }
+  float* gW = o.W;      // in place (tn_bwd_head_kernel)
+  float* gV2 = o.V2;
+  {  // W_i = H_i^T P_i:  gH_i += P_i gW_i^T (K-split, atomic accumulation on top of the KL term),  gP_i += H_i gW_i
+    const int64_t sQ[3] = {C * MtN, MtN, (int64_t)M * NRs}, sP[3] = {C * MtB, MtB, (int64_t)M * B};
+    GemmParams p = blk_gemm(o.P, B, sP, gW, B, sP, o.gQPs + 4, NRs, sQ, M, M, B, C, nblk);
+    p.splitk = ksplit(B);
+    if (p.splitk <= 1) { p.D = o.gQPs + 4; p.ldd = NRs; p.beta = 1.f; for (int i = 0; i < 3; ++i) p.sD[i] = sQ[i]; }
+    GemmParams q = blk_gemm(o.QPs + 4, NRs, sQ, gW, B, sP, o.gP, B, sP, M, B, M, C, nblk);
+    q.triA = 1; q.D = o.gP; q.ldd = B; q.beta = 1.f;
+    rc = launch_gemm_pair2(p, 0, 1, SC * nblk, q, 0, 0, SC * nblk, st, "tn_gh_gp_gemm");
+    if (rc) return rc;
+  }
+  {  // V2 = T^T P:  gP += T gV2
+    GemmParams p = flat_gemm(o.TT, Mt, MtMt, gV2, B, MtB, o.gP, B, MtB, Mt, B, Mt);
+    p.triA = 1; p.D = o.gP; p.beta = 1.f;
+    rc = launch_gemm(p, 0, 0, SC, false, st, "tn_gp_v2_gemm");
+    if (rc) return rc;
+  }
+  {  // gT = tril(gP K_uf^T + P gV2^T)  (P = T K_uf and V2 = T^T P), then the diagonal blocks' share from the small products
+    GemmParams p = flat_gemm(o.gP, B, MtB, o.Kuf, B, MtB, o.gT, Mt, MtMt, Mt, Mt, B);
+    p.triC = 1;
+    rc = launch_gemm(p, 0, 1, SC, false, st, "tn_gt_gemm");
+    if (rc) return rc;
+    GemmParams q = flat_gemm(o.P, B, MtB, gV2, B, MtB, o.gT, Mt, MtMt, Mt, Mt, B);
+    q.triC = 1; q.D = o.gT; q.beta = 1.f;
+    rc = launch_gemm(q, 0, 1, SC, false, st, "tn_gt_gemm");
+    if (rc) return rc;
+    const int64_t sQ[3] = {C * MtN, MtN, (int64_t)M * NRs}, sR[3] = {0, (int64_t)nblk * M * NRs, (int64_t)M * NRs},
+                  sT[3] = {C * MtMt, MtMt, (int64_t)M * Mt + M};
+    GemmParams r = blk_gemm(o.gQPs, NRs, sQ, d->rk_all, NRs, sR, o.gT, Mt, sT, M, M, NRs, C, nblk);
+    r.triC = 1; r.D = o.gT; r.ldd = Mt; r.beta = 1.f;
+    rc = launch_gemm(r, 0, 1, SC * nblk, false, st, "tn_gt_diag_gemm");
+    if (rc) return rc;
+  }
+  {  // gK_uf = T^T gP
+    GemmParams p = flat_gemm(o.TT, Mt, MtMt, o.gP, B, MtB, o.gKuf, B, MtB, Mt, B, Mt);
+    p.triA = 2;
+    rc = launch_gemm(p, 1, 0, SC, false, st, "tn_gkuf_gemm");
+    if (rc) return rc;
+  }
+  {  // parameter gradients of the current task: [g m_t | . | g Lu_t] = T_tt^T [ga_t | . | gH_t]
+    const int64_t off = (int64_t)(Mt - M) * Mt + (Mt - M);
+    GemmParams p = flat_gemm(o.TT + off, Mt, MtMt, o.gQPs + (int64_t)(Mt - M) * NRs, NRs, MtN, o.gRKt, NRs, (int64_t)M * NRs, M,
+                             NRs, M);
+    p.triA = 2;
+    rc = launch_gemm(p, 1, 0, SC, false, st, "tn_grk_gemm");
+    if (rc) return rc;
+  }
+  // Cholesky backward.  Only diag(L_tt) is used forward (log-determinant), so gL = diag(g / L_jj) on the current block:
+  //   P_low = tril(L^T gL - gT T^T) = g I_t - tril(gT T^T)   (the lower triangle of L^T diag(.) is its diagonal)
+  //   Smat  = (Phi(P_low) + Phi(P_low)^T) / 2 = -0.5 sym(tril(gT T^T)) + 0.5 g I_t,     gK = T^T Smat T
+  float* Smat = reinterpret_cast<float*>(o.chol);
+  float* tmp = Smat + SC * MtMt;
+  {
+    GemmParams p = flat_gemm(o.gT, Mt, MtMt, o.TT, Mt, MtMt, Smat, Mt, MtMt, Mt, Mt, Mt);
+    p.alpha = -0.5f; p.triA = 1; p.triB = 2; p.triC = 2; p.symout = 1;
+    rc = launch_gemm(p, 0, 1, SC, false, st, "tn_chol_bwd1");
+    if (rc) return rc;
+    const int64_t total = (int64_t)SC * M;
+    hipLaunchKernelGGL(tn_diag_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, Smat, seeds, S, M, Mt, total);
+    GemmParams q = flat_gemm(o.TT, Mt, MtMt, Smat, Mt, MtMt, tmp, Mt, MtMt, Mt, Mt, Mt);
+    q.triA = 2;
+    rc = launch_gemm(q, 1, 0, SC, false, st, "tn_chol_bwd2");
+    if (rc) return rc;
+    GemmParams r = flat_gemm(tmp, Mt, MtMt, o.TT, Mt, MtMt, o.gK, Mt, MtMt, Mt, Mt, Mt);
+    r.triB = 1;
+    rc = launch_gemm(r, 0, 0, SC, false, st, "tn_chol_bwd3");
+    if (rc) return rc;
+  }
+  // kernel matrices -> theta, z
+  rc = vargp_rbf_gram_bwd(o.theta, d->z_all, nullptr, o.Kall, o.gK, o.gz_all, nullptr, o.gtheta, S, C, Mt, Mt, D, 0, 0, o.rbf,
+                          o.rbf_bytes, stream);
+  if (rc) return rc;
+  rc = vargp_rbf_gram_bwd(o.theta, d->z_all, d->x, o.Kuf, o.gKuf, o.gz_all, nullptr, o.gtheta, S, C, Mt, B, D, 1, 1, o.rbf,
+                          o.rbf_bytes, stream);
+  if (rc) return rc;
+  {
+    const int nun = cdiv((int64_t)C * M * (M + 1), 256);
+    hipLaunchKernelGGL(tn_unpack_kernel, dim3(nun + cdiv((int64_t)C * M * D, 256)), dim3(256), 0, st, o.gRKt, d->u_tril_vec,
+                       d->rk_all + (int64_t)(nblk - 1) * M * NRs, seeds, o.gz_all, g_u_mean, g_u_tril_vec, g_z, S, C, M, Mt, D,
+                       NRs, nblk, nun);
+  }
+  hipLaunchKernelGGL(t0_hyper_bwd_kernel, dim3(cdiv(D + 1, 256)), dim3(256), 0, st, d->log_mean, d->log_logvar,
+                     d->prior_log_mean, d->prior_log_logvar, eps_theta, o.gtheta, o.g2, o.gkd, seeds, g_log_mean,
+                     g_log_logvar, S, C, D + 1, d->map_est);
+  return check_launch("elbo_tn_bwd");
+}

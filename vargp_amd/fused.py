@@ -1,4 +1,7 @@
-"""First-task ELBO through the native program `vargp_elbo_t0_fwd / _bwd` (csrc/elbo_t0.hip).
+"""The ELBO through the native programs: `vargp_elbo_t0_fwd / _bwd` (csrc/elbo_t0.hip, first task) and
+`vargp_elbo_tn_fwd / _bwd` (csrc/elbo_tn.hip, models with previous tasks: `TnProgram`, `elbo_tn`, at the end of this file).
+
+First task:
 
 `VARGP.loss` of a model without previous tasks (reference: var_gp/vargp.py:156-194) is, on this path, two C-ABI
 calls: the forward sequences ~10 kernels (hyper-parameter sampling + KL, both kernel matrices in one GEMM launch,
@@ -17,7 +20,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from . import ops
-from ._lib import ElboT0Desc, check, lib, ptr, require_device, stream_ptr, workspace
+from ._lib import ElboT0Desc, ElboTnDesc, check, lib, ptr, require_device, stream_ptr, workspace
 from .ops import JITTER
 
 
@@ -147,3 +150,148 @@ def elbo_t0(kernel, z, u_mean, u_tril_vec, x, y, eps_theta, eps_f):
     module (variational hyper-parameters and their prior)."""
     return _ElboT0.apply(kernel.log_mean, kernel.log_logvar, z, u_mean, u_tril_vec, x, y, eps_theta, eps_f,
                          kernel.prior_log_mean, kernel.prior_log_logvar, bool(kernel.map_est))
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# models with previous tasks (and any forward-only evaluation): the block-structured program, csrc/elbo_tn.hip
+# ----------------------------------------------------------------------------------------------------------------
+def tn_row_width(M):
+    """Row width NR of the packed operand rk_all: [u_mean | 0 0 0 | Lu (M columns)] rounded up to a multiple of 4."""
+    return (4 + M + 3) // 4 * 4
+
+
+def pack_tn_operands(prev, C, M, D, device):
+    """Caller-maintained operands of the program for a model whose earlier tasks are `prev` (list of dicts with z
+    (C,M,D), u_mean (C,M,1), u_tril (C,M,M), all M equal): z_all (C, Mt, D) and rk_all (C, nblk, M, NR) with the earlier
+    tasks filled in and the last block left for the program (it writes the current task there on every forward)."""
+    nblk = len(prev) + 1
+    NR = tn_row_width(M)
+    z_all = torch.zeros(C, nblk * M, D, dtype=torch.float32, device=device)
+    rk_all = torch.zeros(C, nblk, M, NR, dtype=torch.float32, device=device)
+    for i, p in enumerate(prev):
+        z_all[:, i * M:(i + 1) * M] = p['z']
+        rk_all[:, i, :, 0] = p['u_mean'].reshape(C, M)
+        rk_all[:, i, :, 4:4 + M] = p['u_tril']
+    return z_all, rk_all
+
+
+class TnProgram:
+    """Descriptor + workspace of `vargp_elbo_tn_*` for fixed (S, C, M, D, B, F, nblk).  One `backward` per `forward`;
+    `forward(y=None)` evaluates the predictive moments only."""
+
+    def __init__(self, S, C, M, D, B, F, nblk, device, map_est=False):
+        self.shape = (S, C, M, D, B, F, nblk)
+        self.map_est = bool(map_est)
+        nbytes = lib().vargp_elbo_tn_workspace_bytes(S, C, M, D, B, F, nblk)
+        self.ws = workspace(nbytes, device)
+        self.scalars = torch.empty(3, dtype=torch.float32, device=device)
+        self.info = torch.empty(S * C, dtype=torch.int32, device=device)
+        self.desc = ElboTnDesc(S=S, C=C, M=M, D=D, B=B, F=F, nblk=nblk, map_est=int(self.map_est), jitter=JITTER,
+                               scalars=_p(self.scalars), info=_p(self.info), ws=_p(self.ws),
+                               ws_bytes=self.ws.numel() * 4)
+        self._keep = None
+        self._rng = None
+        self.busy = False          # forward done, backward pending (the workspace carries the intermediates)
+
+    def set_rng(self, seed, counter, sample_offset=0):
+        """Native noise, as T0Program.set_rng."""
+        assert counter.is_cuda and counter.numel() == 1 and counter.element_size() == 4
+        self._rng = (int(seed), counter, int(sample_offset))
+        self.desc.rng_seed, self.desc.rng_counter, self.desc.rng_sample_offset = int(seed), _p(counter), int(sample_offset)
+
+    def _view(self, index, shape):
+        S, C, M, D, B, F_, nblk = self.shape
+        sizes = [S * (D + 1), S * (D + 1), S * F_ * C * B]
+        off = sum((n + 63) // 64 * 64 for n in sizes[:index])
+        return self.ws[off:off + sizes[index]].view(shape)
+
+    def theta(self):
+        return self._view(0, (self.shape[0], self.shape[3] + 1))
+
+    def eps_theta(self):
+        return self._view(1, (self.shape[0], self.shape[3] + 1))
+
+    def eps_f(self):
+        S, C, M, D, B, F_, nblk = self.shape
+        return self._view(2, (S, F_, C, B))
+
+    def moments(self):
+        """(mu, var) (S, C, B) of the last forward: views into the workspace."""
+        S, C, M, D, B, F_, nblk = self.shape
+        pm, pv = ctypes.c_void_p(), ctypes.c_void_p()
+        check(lib().vargp_elbo_tn_moments(ctypes.byref(self.desc), ctypes.byref(pm), ctypes.byref(pv)), 'vargp_elbo_tn_moments')
+        base = self.ws.data_ptr()
+        om, ov = (pm.value - base) // 4, (pv.value - base) // 4
+        return self.ws[om:om + S * C * B].view(S, C, B), self.ws[ov:ov + S * C * B].view(S, C, B)
+
+    def forward(self, log_mean, log_logvar, prior_log_mean, prior_log_logvar, z, u_mean, u_tril_vec, z_all, rk_all, x, y,
+                eps_theta, eps_f, bump=None):
+        """-> scalars (3,) = (kl_hypers, kl_u, nll) (y given) or None (y None: moments only)."""
+        tensors = (log_mean, log_logvar, prior_log_mean, prior_log_logvar, z, u_mean, u_tril_vec, z_all, rk_all, x, y,
+                   eps_theta, eps_f)
+        require_device(*tensors)
+        for t in tensors:
+            if t is not None and not t.is_contiguous():
+                raise ValueError('TnProgram.forward needs contiguous tensors')
+        S, C, M, D, B, F_, nblk = self.shape
+        assert z.shape == (C, M, D) and x.shape == (B, D) and (y is None or y.dtype == torch.int64)
+        assert z_all.shape == (C, nblk * M, D) and rk_all.shape == (C, nblk, M, tn_row_width(M))
+        assert u_mean.numel() == C * M and u_tril_vec.shape == (C, M * (M + 1) // 2) and log_mean.numel() == D + 1
+        if y is not None and eps_f is None:
+            assert self._rng is not None and eps_theta is None, 'native noise: call set_rng() and pass no eps tensors'
+        elif y is not None:
+            assert eps_f.shape == (S, F_, C, B) and (self.map_est or eps_theta.shape == (S, D + 1))
+        d = self.desc
+        d.log_mean, d.log_logvar = _p(log_mean), _p(log_logvar)
+        d.prior_log_mean, d.prior_log_logvar = _p(prior_log_mean), _p(prior_log_logvar)
+        d.z, d.u_mean, d.u_tril_vec, d.x, d.y = _p(z), _p(u_mean), _p(u_tril_vec), _p(x), _p(y)
+        d.z_all, d.rk_all = _p(z_all), _p(rk_all)
+        d.eps_theta, d.eps_f = _p(eps_theta), _p(eps_f)
+        d.bump = _p(bump)
+        self._keep = tensors + (bump,)
+        check(lib().vargp_elbo_tn_fwd(ctypes.byref(d), stream_ptr()), 'vargp_elbo_tn_fwd')
+        ops._note_chol_errors(self.info)
+        return self.scalars if y is not None else None
+
+    def backward(self, seeds, g_log_mean, g_log_logvar, g_z, g_u_mean, g_u_tril_vec):
+        require_device(seeds, g_log_mean, g_log_logvar, g_z, g_u_mean, g_u_tril_vec)
+        assert self._keep is not None, 'TnProgram.backward without a forward'
+        for g in (g_log_mean, g_log_logvar, g_z, g_u_mean, g_u_tril_vec):
+            assert g.is_contiguous() and g.dtype == torch.float32
+        check(lib().vargp_elbo_tn_bwd(ctypes.byref(self.desc), ptr(seeds), ptr(g_log_mean), ptr(g_log_logvar), ptr(g_z),
+                                      ptr(g_u_mean), ptr(g_u_tril_vec), stream_ptr()), 'vargp_elbo_tn_bwd')
+
+
+class _ElboTn(Function):
+    @staticmethod
+    def forward(ctx, log_mean, log_logvar, z, u_mean, u_tril_vec, x, y, eps_theta, eps_f, prior_log_mean,
+                prior_log_logvar, map_est, prog, z_all, rk_all):
+        args = [t.contiguous() if t is not None else None
+                for t in (log_mean, log_logvar, prior_log_mean, prior_log_logvar, z, u_mean, u_tril_vec)]
+        scal = prog.forward(*args, z_all, rk_all, x.contiguous(), y.contiguous(),
+                            None if eps_theta is None else eps_theta.contiguous(), eps_f.contiguous())
+        prog.busy = True
+        ctx.prog = prog
+        ctx.map_est = map_est
+        ctx.shapes = (log_mean.shape, z.shape, u_mean.shape, u_tril_vec.shape)
+        return scal[0].clone(), scal[1].clone(), scal[2].clone()
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_klh, g_klu, g_nll):
+        prog = ctx.prog
+        seeds = torch.stack([g_klh.reshape(()), g_klu.reshape(()), g_nll.reshape(())]).float()
+        sh_mean, sh_z, sh_um, sh_uv = ctx.shapes
+        dev = seeds.device
+        g_mean, g_logvar = torch.empty(sh_mean, device=dev), torch.empty(sh_mean, device=dev)
+        g_z, g_um, g_uv = torch.empty(sh_z, device=dev), torch.empty(sh_um, device=dev), torch.empty(sh_uv, device=dev)
+        prog.backward(seeds, g_mean, g_logvar, g_z, g_um, g_uv)
+        prog.busy = False
+        ctx.prog = None
+        return (g_mean, None if ctx.map_est else g_logvar, g_z, g_um, g_uv) + (None,) * 10
+
+
+def elbo_tn(kernel, z, u_mean, u_tril_vec, x, y, eps_theta, eps_f, prog, z_all, rk_all):
+    """-> (kl_hypers, kl_u, nll) of VARGP.loss for a model with previous tasks (ep_var_mean = True) as ONE autograd node."""
+    return _ElboTn.apply(kernel.log_mean, kernel.log_logvar, z, u_mean, u_tril_vec, x, y, eps_theta, eps_f,
+                         kernel.prior_log_mean, kernel.prior_log_logvar, bool(kernel.map_est), prog, z_all, rk_all)

@@ -46,10 +46,11 @@ class ElboTrainer:
             noise.set_shard(self.rank, self.world, noise_seed, dev)
 
         self.graph = None
-        # first-task models run the native program directly (fused.T0Program): no autograd graph, gradients written
-        # straight into the optimiser's buffers
-        self._t0 = (gp is not None and loss_fn is None and params is None and hasattr(gp, 'draw_t0_noise')
-                    and not gp.prev_params and gp.fused_first_task)
+        # models on a native program (fused.T0Program: first task; fused.TnProgram: later tasks, ep_var_mean=True) drive it
+        # directly: no autograd graph, gradients written straight into the optimiser's buffers
+        is_model = gp is not None and loss_fn is None and params is None and hasattr(gp, 'draw_t0_noise')
+        self._tn = bool(is_model and gp.prev_params and gp.var_mean_mask == 1.0 and gp._tn_applicable())   # csrc/elbo_tn.hip
+        self._t0 = bool(is_model and not gp.prev_params and gp.fused_first_task) or self._tn               # csrc/elbo_t0.hip
         # one program (descriptor + workspace) PER SHAPE, never freed: a captured hipGraph holds raw pointers into the
         # program it was captured with, and the ragged last minibatch of an epoch runs eagerly through another shape
         self._progs, self._prog, self._seeds, self._own_grads = {}, None, {}, None
@@ -177,7 +178,7 @@ class ElboTrainer:
     def _t0_fwd_bwd(self, x, y, scale, w):
         """Native first-task program: scalars (kl_hypers, kl_u, nll) of this rank's samples, and the gradient of
         w * (beta kl_hypers + kl_u + scale nll) written into every p.grad."""
-        from .fused import T0Program
+        from .fused import T0Program, TnProgram
         gp, kern = self.gp, self.gp.kernel
         x, y = x.contiguous(), y.contiguous()
         S = 1 if kern.map_est else gp.n_v
@@ -187,18 +188,21 @@ class ElboTrainer:
             eps_theta, eps_f = gp.draw_t0_noise(x)
             eps_theta, eps_f = None if eps_theta is None else eps_theta.contiguous(), eps_f.contiguous()
         shape = T0Program.shape_of(S, gp.z, x, gp.likelihood.n_f)
+        if self._tn:
+            shape = shape + (len(gp.prev_params) + 1,)
         if self._prog is None or self._prog.shape != shape:
             if shape not in self._progs:
-                self._progs[shape] = T0Program(*shape, x.device, kern.map_est)
+                self._progs[shape] = (TnProgram if self._tn else T0Program)(*shape, x.device, kern.map_est)
                 if self.native_noise:
                     self._progs[shape].set_rng(self.noise_seed, self._rng_counter, self.rank * S)
             self._prog = self._progs[shape]
         key = (scale, w)
         if key not in self._seeds:
             self._seeds[key] = torch.tensor([self.beta * w, w, scale * w], dtype=torch.float32, device=x.device)
+        packed = gp._tn_operands() if self._tn else ()
         scal = self._prog.forward(kern.log_mean.detach(), kern.log_logvar.detach(), kern.prior_log_mean,
-                                  kern.prior_log_logvar, gp.z.detach(), gp.u_mean.detach(), gp.u_tril_vec.detach(), x, y,
-                                  eps_theta, eps_f, bump=self._bump)
+                                  kern.prior_log_logvar, gp.z.detach(), gp.u_mean.detach(), gp.u_tril_vec.detach(), *packed,
+                                  x, y, eps_theta, eps_f, bump=self._bump)
         self._prog.backward(self._seeds[key], kern.log_mean.grad, kern.log_logvar.grad, gp.z.grad, gp.u_mean.grad,
                             gp.u_tril_vec.grad)
         return scal

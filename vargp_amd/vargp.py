@@ -7,7 +7,12 @@ Differences that do not change results:
   * for tasks t > 0 the prior covariance of p(u_t | u_<t, theta) does not depend on the u_<t sample,
     so its Cholesky is computed once per (s, c) instead of n_v times (reference vargp.py:146-155), and
     with ep_var_mean=True (the default) the KL does not depend on the u_<t sample at all,
-    so that sample is not drawn.
+    so that sample is not drawn;
+  * with ep_var_mean=True, `loss` of a model with previous tasks runs as ONE native program in the block-structured
+    form of the linear_joint chain (csrc/elbo_tn.hip, fused.TnProgram): one kernel matrix over all inducing points, one
+    factorisation, GEMMs; `compute_q` / `compute_pf_diag` / `forward(loss_cache=...)` below keep the reference's
+    op-by-op composition (API surface, the ep_var_mean=False ablation, and what the program is tested against);
+    gradient-free `forward` / `predict` use the same program for every model.
 """
 import torch
 import torch.nn as nn
@@ -24,6 +29,8 @@ class VARGP(nn.Module):
         super().__init__()
         self.var_mean_mask = float(ep_var_mean)
         self.fused_first_task = True     # VARGP.loss of a first-task model runs as one fused node (fused.py)
+        self.fused_tasks = True          # ... and of a model with previous tasks as the block-structured program
+        self._tn_ops, self._tn_progs = None, {}
         # frozen earlier tasks: plain dicts, not buffers (same as the reference, vargp.py:17-20);
         # u_tril is materialised lazily on first use because that needs the device the params live on
         self.prev_params = [dict(z=p['z'], u_mean=p['u_mean'], u_tril_vec=p['u_tril_vec'])
@@ -93,9 +100,46 @@ class VARGP(nn.Module):
         Kxx_diag = self.kernel.compute_diag(theta)
         return linear_marginal_diag(mu_leq_t, S_leq_t, Kzz, Kzx, Kxx_diag, cache=cache)
 
+    # -- the block-structured native program (csrc/elbo_tn.hip) ------------------------------------------------------
+    def _tn_applicable(self):
+        return (self.fused_tasks and type(self.kernel) is RBFKernel and self.z.is_cuda
+                and all(p['z'].shape[-2] == self.M for p in self.prev_params))
+
+    def _tn_operands(self):
+        """z_all (C, Mt, D), rk_all (C, nblk, M, NR): earlier tasks packed once, the last block is the program's scratch."""
+        dev = self.z.device
+        if self._tn_ops is None or self._tn_ops[0].device != dev:
+            prev = [self._prev(i) for i in range(len(self.prev_params))]
+            with torch.no_grad():
+                self._tn_ops = fused.pack_tn_operands(prev, self.z.size(0), self.M, self.z.size(-1), dev)
+        return self._tn_ops
+
+    def _tn_program(self, B):
+        S = 1 if self.kernel.map_est else self.n_v
+        shape = (S, self.z.size(0), self.M, self.z.size(-1), B, self.likelihood.n_f, len(self.prev_params) + 1)
+        prog = self._tn_progs.get(shape)
+        if prog is None:
+            prog = self._tn_progs[shape] = fused.TnProgram(*shape, self.z.device, self.kernel.map_est)
+        elif prog.busy:      # a loss() whose backward has not run yet still owns that workspace
+            prog = fused.TnProgram(*shape, self.z.device, self.kernel.map_est)
+        return prog
+
+    def _tn_args(self):
+        k = self.kernel
+        return (k.log_mean.detach(), k.log_logvar.detach(), k.prior_log_mean, k.prior_log_logvar, self.z.detach().contiguous(),
+                self.u_mean.detach().contiguous(), self.u_tril_vec.detach().contiguous(), *self._tn_operands())
+
     def forward(self, x, loss_cache=False):
         """x (B, D) -> pred_mu, pred_var (S, C, B); fills `loss_cache` with the KL ingredients if it is
         a dict  (vargp.py:115-175)."""
+        if not torch.is_grad_enabled() and not isinstance(loss_cache, dict) and self._tn_applicable():
+            # gradient-free evaluation (predict, accuracy sweeps): the native program, predictive moments only
+            kern = self.kernel
+            eps_theta = None if kern.map_est else noise.draw('eps_theta', (self.n_v, kern.log_mean.shape[0]), x.device)
+            prog = self._tn_program(x.size(0))
+            prog.forward(*self._tn_args(), x.contiguous(), None, None if eps_theta is None else eps_theta.contiguous(), None)
+            mu, var = prog.moments()
+            return mu.clone(), var.clone()
         theta = self.kernel.sample_hypers(self.n_v)
 
         if self.prev_params:
@@ -159,6 +203,11 @@ class VARGP(nn.Module):
         if not self.prev_params and self.fused_first_task:
             # first task: the native program (csrc/elbo_t0.hip) as one autograd node
             return fused.elbo_t0(self.kernel, self.z, self.u_mean, self.u_tril_vec, x, y, *self.draw_t0_noise(x))
+        if self.prev_params and self.var_mean_mask == 1.0 and self._tn_applicable():
+            # later tasks: the block-structured program (csrc/elbo_tn.hip) as one autograd node
+            eps_theta, eps_f = self.draw_t0_noise(x)
+            return fused.elbo_tn(self.kernel, self.z, self.u_mean, self.u_tril_vec, x, y, eps_theta, eps_f,
+                                 self._tn_program(x.size(0)), *self._tn_operands())
         loss_cache = dict()
         pred_mu, pred_var = self(x, loss_cache=loss_cache)
         nll = self.likelihood.loss(pred_mu, pred_var, y)
