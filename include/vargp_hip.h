@@ -288,6 +288,9 @@ int vargp_prof_read(const char* tag, double* total_ms, int64_t* launches);
  * pair of hipEvents on `stream` and returns the average time per launch in microseconds.  The buffers of the
  * remembered launch must still be alive.  Synchronises. */
 int vargp_prof_remember(int on);
+/* Tuning aid: force the tile shape of subsequent vargp_bgemm / internal GEMM launches (0 = automatic choice,
+ * 1 = 128x128x16, 2 = 128x64x32, 3 = 64x64x64).  Results do not depend on it beyond summation order. */
+int vargp_tune_gemm_tile(int tile);
 int vargp_prof_replay(const char* tag, int iters, double* avg_us, vargp_stream_t stream);
 
 #ifdef __cplusplus

@@ -109,6 +109,36 @@ int main(int argc, char** argv) {
     us = time_us([&] { gemm(A, B, C, 100, 512, 100, 1, 0, 30, 10000, 51200, 51200, 2, 0); }, iters);
     printf("small G^T.P 100x512x100 b30 (triA up)%8.1f us\n", us);
   }
+  if (which == "tiles") {   // tile-shape sweep on the mid-size batched products of the t > 0 program
+    struct Case { const char* name; int M, N, K, tA, tB, nb, triA; };
+    const Case cases[] = {
+        {"P=T.K      200x512x200  b30 ", 200, 512, 200, 0, 0, 30, 1},  {"sq         200x200x200  b30 ", 200, 200, 200, 0, 0, 30, 0},
+        {"P=T.K      400x512x400  b100", 400, 512, 400, 0, 0, 100, 1}, {"sq         400x400x400  b100", 400, 400, 400, 0, 0, 100, 0},
+        {"gT NT      400x400x512  b100", 400, 400, 512, 0, 1, 100, 0}, {"V2=T^T.P   400x512x400  b100", 400, 512, 400, 1, 0, 100, 2},
+        {"P=T.K      500x512x500  b30 ", 500, 512, 500, 0, 0, 30, 1},  {"P=T.K      600x512x600  b100", 600, 512, 600, 0, 0, 100, 1},
+        {"P=T.K     1000x512x1000 b100", 1000, 512, 1000, 0, 0, 100, 1}, {"sq        1000x1000x1000 b100", 1000, 1000, 1000, 0, 0, 100, 0},
+        {"W.z        400x784x400  b100", 400, 784, 400, 0, 0, 100, 0}, {"W.x       4000x784x512  b10 ", 4000, 784, 512, 0, 0, 10, 0},
+        {"W.x       2000x784x512  b3  ", 2000, 784, 512, 0, 0, 3, 0},  {"W.z        200x784x200  b30 ", 200, 784, 200, 0, 0, 30, 0},
+        {"blk        200x512x200  b200", 200, 512, 200, 0, 0, 200, 1}, {"blk NT     200x200x512  b200", 200, 200, 512, 0, 1, 200, 0},
+        {"blk        100x512x100  b60 ", 100, 512, 100, 0, 0, 60, 1},
+    };
+    float* A = dev_rand((size_t)100 * 1000 * 1000, 1.f, 8);
+    float* B = dev_rand((size_t)100 * 1000 * 1000, 1.f, 9);
+    float* C; CK(hipMalloc(&C, (size_t)100 * 1000 * 1000 * 4));
+    for (const Case& c : cases) {
+      printf("%s", c.name);
+      for (int tile = 1; tile <= 3; ++tile) {
+        vargp_tune_gemm_tile(tile);
+        const long sA = (long)c.M * c.K, sB = (long)c.K * c.N, sC = (long)c.M * c.N;
+        double us = time_us([&] { gemm(A, B, C, c.M, c.N, c.K, c.tA, c.tB, c.nb, sA, sB, sC, c.triA, 0); }, iters);
+        printf("   t%d %8.1f us", tile, us);
+      }
+      vargp_tune_gemm_tile(0);
+      const long sA = (long)c.M * c.K, sB = (long)c.K * c.N, sC = (long)c.M * c.N;
+      double us = time_us([&] { gemm(A, B, C, c.M, c.N, c.K, c.tA, c.tB, c.nb, sA, sB, sC, c.triA, 0); }, iters);
+      printf("   auto %8.1f us\n", us);
+    }
+  }
   if (want("chol")) {
     for (int n : {20, 40, 64, 100}) {
       const int nb = 30;

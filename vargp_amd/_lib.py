@@ -97,6 +97,7 @@ _SIGNATURES = {
     'vargp_prof_enable': (c_int, [c_int]),
     'vargp_prof_read': (c_int, [c_char_p, POINTER(ctypes.c_double), POINTER(c_int64)]),
     'vargp_prof_remember': (c_int, [c_int]),
+    'vargp_tune_gemm_tile': (c_int, [c_int]),
     'vargp_prof_replay': (c_int, [c_char_p, c_int, POINTER(ctypes.c_double), _P]),
     'vargp_yogi_step': (c_int, [_P, _P, _P, _P, c_int64] + [c_float] * 6 + [_P, _P]),
 }

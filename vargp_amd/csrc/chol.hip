@@ -23,6 +23,11 @@ extern "C" void vargp_debug_chol_stamps(unsigned long long* out) { (void)hipMemc
 namespace vargp {
 
 constexpr int kCholP = 5;        // threads per matrix row of chol_inv_small_kernel
+// A co-launched GEMM pays while it is about as long as a diagonal block's pivot chain (~50 us); a much longer one is
+// faster on its own with the big tiles (measured: Permuted-MNIST K_uf, 5040 tiles: 481 us merged vs 394 + 57 separate)
+static bool co_gemm_is_comparable(const GemmParams& p, int nbatch) {
+  return (int64_t)cdiv(p.M, 64) * cdiv(p.N, 64) * nbatch <= 1024;
+}
 // Packed lower-triangular index.
 __device__ __forceinline__ int pk(int i, int j) { return i * (i + 1) / 2 + j; }
 constexpr int kSmallMax = 100;  // largest n the register-resident kernel takes (packed triangle <= 512*10)
@@ -213,13 +218,18 @@ static int launch_small(const float* A, int lda, int64_t sA, float eps, float* L
   return check_launch("chol_inv_small");
 }
 
-// W[b] = lower(A[b]) + eps I  (dense copy incl. upper part, which is never read)
-__global__ void copy_jitter_kernel(const float* __restrict__ A, float* __restrict__ W, int n, float eps) {
+// Prologue of the blocked path in one pass: W[b] = A[b] + eps I (dense copy incl. the upper part, which is never read),
+// L[b] = 0, T[b] = 0 (the panel GEMMs only write below the diagonal blocks; the zeros above them must be real zeros)
+__global__ void chol_prep_kernel(const float* __restrict__ A, float* __restrict__ W, float* __restrict__ L,
+                                 float* __restrict__ T, int n, float eps) {
   const int64_t b = blockIdx.y;
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (int64_t)n * n) return;
   const int i = e / n, j = e % n;
-  W[b * n * n + e] = A[b * n * n + e] + (i == j ? eps : 0.f);
+  const int64_t o = b * n * n + e;
+  W[o] = A[o] + (i == j ? eps : 0.f);
+  L[o] = 0.f;
+  if (T) T[o] = 0.f;
 }
 
 // out = tril(gL) - tril(G2)   (either input may be null)
@@ -274,26 +284,33 @@ extern "C" int vargp_chol_inv_fwd(const float* A, float eps, float* L, float* T,
   return vargp::chol_inv_fwd_impl(A, eps, L, T, logdet, info, nbatch, n, ws, ws_bytes, true, as_stream(stream));
 }
 
-// zero_info = false: the caller has already cleared the status words (the fused ELBO program does it in its prologue)
+// zero_info = false: the caller has already cleared the status words (the fused ELBO program does it in its prologue).
+// co / co_nbatch / co_done: an RBF kernel-matrix GEMM of the caller that does not depend on the factorisation; if the
+// first diagonal block qualifies (50 < width <= 100, T wanted, no logdet) the two share ONE launch (the pivot chain of a
+// diagonal block keeps nbatch of the 256 CUs busy for ~50 us: the GEMM runs on the others) and *co_done is set.
 int vargp::chol_inv_fwd_impl(const float* A, float eps, float* L, float* T, float* logdet, int32_t* info, int nbatch,
-                             int n, void* ws, size_t ws_bytes, bool zero_info, hipStream_t st) {
+                             int n, void* ws, size_t ws_bytes, bool zero_info, hipStream_t st, const GemmParams* co,
+                             int co_nbatch, bool* co_done) {
   VARGP_REQUIRE(A && L, "chol_inv_fwd: null pointer");
   VARGP_REQUIRE(nbatch > 0 && n > 0, "chol_inv_fwd: bad dims");
   const int64_t nn = (int64_t)n * n;
+  if (co_done) *co_done = false;
   if (info && zero_info) zero_async(info, sizeof(int32_t) * nbatch, st);
-  if (n <= kSmallMax)
+  if (n <= kSmallMax) {
+    if (co && T && !logdet && info && chol_rbf_gemm_applicable(n, *co) && co_gemm_is_comparable(*co, co_nbatch)) {
+      if (co_done) *co_done = true;
+      return launch_chol_rbf_gemm_ld(A, n, nn, eps, L, n, nn, T, n, nn, info, nbatch, n, *co, co_nbatch, st);
+    }
     return launch_small(A, n, nn, eps, L, n, nn, T, n, nn, logdet, info, 0, nbatch, n, 0, st);
+  }
 
   VARGP_REQUIRE(ws && ws_bytes >= vargp_chol_workspace_bytes(nbatch, n, 0), "chol_inv_fwd: workspace too small");
   float* W = reinterpret_cast<float*>(ws);
   float* tmp = W + (int64_t)nbatch * nn;
   const int kNbSmall = panel_width();
   const int64_t stmp = (int64_t)n * kNbSmall;
-  hipLaunchKernelGGL(copy_jitter_kernel, dim3(cdiv(nn, 256), nbatch), dim3(256), 0, st, A, W, n, eps);
-  zero_async(L, sizeof(float) * nbatch * nn, st);
-  // the blocked inverse needs the factor even if the caller does not want T: use tmp-free path
   float* Tout = T;
-  if (Tout) zero_async(Tout, sizeof(float) * nbatch * nn, st);
+  hipLaunchKernelGGL(chol_prep_kernel, dim3(cdiv(nn, 256), nbatch), dim3(256), 0, st, A, W, L, Tout, n, eps);
   int rc;
   for (int k0 = 0; k0 < n; k0 += kNbSmall) {
     const int kb = (n - k0 < kNbSmall) ? n - k0 : kNbSmall;
@@ -304,7 +321,12 @@ int vargp::chol_inv_fwd_impl(const float* A, float eps, float* L, float* T, floa
     float* Tkk = Tout ? Tout + dkk : tmp;
     const int ldt = Tout ? n : kb;
     const int64_t sT = Tout ? nn : stmp;
-    rc = launch_small(W + dkk, n, nn, 0.f, L + dkk, n, nn, Tkk, ldt, sT, logdet, info, k0, nbatch, kb, k0 > 0, st);
+    if (k0 == 0 && co && Tout && !logdet && info && chol_rbf_gemm_applicable(kb, *co) && co_gemm_is_comparable(*co, co_nbatch)) {
+      rc = launch_chol_rbf_gemm_ld(W, n, nn, 0.f, L, n, nn, Tkk, ldt, sT, info, nbatch, kb, *co, co_nbatch, st);
+      if (co_done) *co_done = true;
+    } else {
+      rc = launch_small(W + dkk, n, nn, 0.f, L + dkk, n, nn, Tkk, ldt, sT, logdet, info, k0, nbatch, kb, k0 > 0, st);
+    }
     if (rc) return rc;
     if (rem > 0) {
       if (!Tout) {

@@ -106,8 +106,21 @@ int rbf_splitk(int M, int N, int K, int nbatch);
 constexpr int kRbfDirectD = 32;   // D <= this: kernel matrices from the direct (no-cancellation) distance form
 int rbf_direct_launch(const float* X, const float* Y, const float* w, const float* g2, float* K, int64_t ldk, int S,
                       int C, int M, int N, int D, int64_t Dp, int y_shared, hipStream_t st);
+int rbf_gram_fwd_impl(const float* theta, const float* X, const float* Y, float* K, int S, int C, int M, int N, int D,
+                      int y_shared, void* ws, size_t ws_bytes, int sym_out, hipStream_t st);
+int rbf_gram_bwd_impl(const float* theta, const float* X, const float* Y, const float* K, const float* gK, float* gX,
+                      float* gY, float* gtheta, int S, int C, int M, int N, int D, int y_shared, int accumulate, void* ws,
+                      size_t ws_bytes, int sym_gk, hipStream_t st);
 int chol_inv_fwd_impl(const float* A, float eps, float* L, float* T, float* logdet, int32_t* info, int nbatch, int n,
-                      void* ws, size_t ws_bytes, bool zero_info, hipStream_t st);
+                      void* ws, size_t ws_bytes, bool zero_info, hipStream_t st, const GemmParams* co = nullptr,
+                      int co_nbatch = 0, bool* co_done = nullptr);
+// factorisations of nchol matrices (n in (50, 100]) with explicit leading dimensions / batch strides + one RBF GEMM
+int launch_chol_rbf_gemm_ld(const float* A, int lda, int64_t sA, float eps, float* L, int ldl, int64_t sL, float* T, int ldt,
+                            int64_t sT, int32_t* info, int nchol, int n, const GemmParams& p, int nbatch, hipStream_t st);
+// w = exp(-2 theta) (zero-padded to Dp), g2 = exp(2 theta_D) and the weighted squared row norms of x (xrows x D) and of
+// y (yrows x D, may be 0 rows) for every hyper-sample, in one launch
+int rbf_prep_norm_launch(const float* theta, const float* x, int64_t xrows, const float* y, int64_t yrows, float* w,
+                         float* g2, float* na, float* nb, int S, int D, int64_t Dp, hipStream_t st);
 
 int chol_inv_bwd_first(const float* T, const float* gT, int nbatch, int n, void* ws, size_t ws_bytes,
                        const GemmParams* other, int oA, int oB, int onb, hipStream_t st);

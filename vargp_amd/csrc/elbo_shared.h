@@ -140,4 +140,181 @@ static GemmParams flat_gemm(const float* A, int lda, int64_t sA, const float* B,
 }
 
 
+#ifndef VARGP_W_ROWS
+#define VARGP_W_ROWS 8
+#endif
+#ifndef VARGP_UU_ROWS
+#define VARGP_UU_ROWS 16
+#endif
+#ifndef VARGP_FIN_ROWS
+#define VARGP_FIN_ROWS 32
+#endif
+constexpr int kWRows = VARGP_W_ROWS;      // rows per workgroup of the W = gK o K pass (K_uf role)
+constexpr int kUuRows = VARGP_UU_ROWS;    // rows per workgroup of the same pass, K_uu role
+constexpr int kFinRows = VARGP_FIN_ROWS;   // rows per workgroup of the RBF finalisation
+
+// gradient of the packed Cholesky vector of q(u):  gLu = sum_s gRK[.., Lu block] - seed_kl diag(1/Lu_ii) + 2 gS_u Lu,
+// through vec2tril (softplus on the diagonal).  One thread per (c, i, k <= i).  (A role of t0_w_kernel.)
+__device__ __forceinline__ void t0_gvec_role(int blk, const float* __restrict__ vec, const float* __restrict__ Lu,
+                                             const float* __restrict__ gSu, const float* __restrict__ gRK,
+                                             const float* __restrict__ seeds, float* __restrict__ gvec, int S, int C,
+                                             int M, int LD) {
+  const int64_t e = (int64_t)blk * 256 + threadIdx.x;
+  if (e >= (int64_t)C * M * M) return;
+  const int k = e % M, i = (e / M) % M;
+  const int64_t c = e / ((int64_t)M * M);
+  if (k > i) return;
+  const float* gs = gSu + (c * M + i) * M;
+  const float* lu = Lu + c * M * M + k;
+  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+  int j = k & ~3;                       // Lu[j][k] = 0 (stored) for j < k: start at the aligned group containing k
+  for (; j + 4 <= M; j += 4) {
+    acc0 = fmaf(gs[j], lu[(int64_t)j * M], acc0); acc1 = fmaf(gs[j + 1], lu[(int64_t)(j + 1) * M], acc1);
+    acc2 = fmaf(gs[j + 2], lu[(int64_t)(j + 2) * M], acc2); acc3 = fmaf(gs[j + 3], lu[(int64_t)(j + 3) * M], acc3);
+  }
+  for (; j < M; ++j) acc0 = fmaf(gs[j], lu[(int64_t)j * M], acc0);
+  float g = 2.f * ((acc0 + acc1) + (acc2 + acc3));
+  for (int s = 0; s < S; ++s) g += gRK[(((int64_t)s * C + c) * M + i) * LD + 4 + M + k];
+  const int64_t idx = c * ((int64_t)M * (M + 1) / 2) + (int64_t)i * (i + 1) / 2 + k;
+  if (i == k) {
+    g -= seeds[1] / lu[(int64_t)i * M];
+    const float x = vec[idx];
+    g *= (x > 20.f) ? 1.f : sigmoid_t0(x);
+  }
+  gvec[idx] = g;
+}
+
+// W = gK o K for both kernel matrices (see rbf.hip for the algebra).
+//   blocks < nuf : K_uf, in place on the K_uf block of gRK (row stride LD); row sums r_uf, column sums c_uf (atomics),
+//                  2 sum W into gtheta[s, D]
+//   next nuu     : K_uu, one wave per row: Wuu = W + W^T, r_uu = its row sums, sum Wuu (= 2 sum W) into gtheta[s, D]
+//   rest         : the packed-Cholesky-vector gradient (t0_gvec_role), which only shares the launch
+static __global__ __launch_bounds__(256) void t0_w_kernel(const float* __restrict__ RK, float* __restrict__ gRK,
+                                                   const float* __restrict__ Kuu, const float* __restrict__ gKuu,
+                                                   float* __restrict__ Wuu, float* __restrict__ r_uu,
+                                                   float* __restrict__ r_uf, float* __restrict__ c_uf,
+                                                   float* __restrict__ gtheta, int S, int C, int M, int B, int D, int NR,
+                                                   int LD, int gx, int gy, int nuf, int nuu, const float* __restrict__ vec,
+                                                   const float* __restrict__ Lu, const float* __restrict__ seeds,
+                                                   float* __restrict__ gvec, int sym_guu) {
+  __shared__ float red[4];
+  // block order: the packed-vector gradient first (long per-thread loops: started early they finish under the rest),
+  // then K_uu, then K_uf
+  const int ngv = (int)gridDim.x - nuf - nuu;
+  if ((int)blockIdx.x < ngv) {
+    t0_gvec_role((int)blockIdx.x, vec, Lu, gKuu + (int64_t)S * C * M * M, gRK, seeds, gvec, S, C, M, LD);
+    return;
+  }
+  const int bid = (int)blockIdx.x - ngv;
+  const int lane = threadIdx.x & 63;
+  if (bid >= nuu) {
+    const int id = bid - nuu;
+    const int col = (id % gx) * 256 + threadIdx.x;
+    const int CM = C * M;
+    const int row0 = ((id / gx) % gy) * kWRows;
+    const int64_t s = id / (gx * gy);
+    const bool cok = col < B;
+    float csum = 0.f;
+    const int rend = min(kWRows, CM - row0);
+    for (int rr = 0; rr < rend; ++rr) {
+      const int64_t off = (s * CM + row0 + rr) * LD + NR + col;
+      float v = 0.f;
+      if (cok) { v = RK[off] * gRK[off]; gRK[off] = v; }
+      csum += v;
+      const float rs = wave_sum(v);
+      if (lane == 0 && rs != 0.f) atomicAdd(&r_uf[s * CM + row0 + rr], rs);
+    }
+    if (cok) atomicAdd(&c_uf[s * B + col], csum);
+    const float tot = block_sum<256>(csum, red);
+    if (threadIdx.x == 0) atomicAdd(&gtheta[s * (D + 1) + D], 2.f * tot);
+    return;
+  }
+  // K_uu role: kUuRows consecutive rows of one (s, c) matrix per block, a wave takes every 4th of them
+  const int nchunk = (M + kUuRows - 1) / kUuRows;
+  const int id = bid;
+  const int64_t b = id / nchunk;
+  const int i0 = (id % nchunk) * kUuRows, i1 = min(M, i0 + kUuRows);
+  const float* K = Kuu + b * M * M;
+  const float* gK = gKuu + b * M * M;
+  float tot = 0.f;
+  for (int i = i0 + (threadIdx.x >> 6); i < i1; i += 4) {
+    float acc = 0.f;
+    for (int j = lane; j < M; j += 64) {
+      // sym_guu: gK_uu is symmetric (it comes out of the Cholesky backward), so W + W^T = 2 W: no transposed reads
+      const float v = sym_guu ? 2.f * K[(int64_t)i * M + j] * gK[(int64_t)i * M + j]
+                              : K[(int64_t)i * M + j] * gK[(int64_t)i * M + j] + K[(int64_t)j * M + i] * gK[(int64_t)j * M + i];
+      Wuu[b * M * M + (int64_t)i * M + j] = v;
+      acc += v;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) r_uu[b * M + i] = acc;
+    tot += acc;
+  }
+  // every lane of a wave holds the wave's total: count it once
+  const float t = block_sum<256>(lane == 0 ? tot : 0.f, red);
+  if (threadIdx.x == 0) atomicAdd(&gtheta[(b / C) * (D + 1) + D], t);
+}
+
+// RBF finalisation (rbf.hip), both kernel matrices at once.  grid (ceil(D/64), nzy + nxy), 64 d-columns x 4 row lanes.
+//   y-blocks < nzy  (inducing points):  gz[row,d] = -sum_s w_sd ((r_uu + r_uf) z - (P_uu + P_uf))
+//                                       gtheta[s,d] += w_sd sum_row z ((r_uu z - P_uu) + (r_uf z - 2 P_uf))
+//   y-blocks >= nzy (minibatch side):   gtheta[s,d] += w_sd sum_n c_uf x^2
+static __global__ __launch_bounds__(256) void t0_final_kernel(const float* __restrict__ z, const float* __restrict__ x,
+                                                       const float* __restrict__ r_uu, const float* __restrict__ r_uf,
+                                                       const float* __restrict__ c_uf, const float* __restrict__ Puu,
+                                                       const float* __restrict__ Puf, const float* __restrict__ w,
+                                                       float* __restrict__ gz, float* __restrict__ gtheta,
+                                                       int64_t zrows, int64_t xrows, int D, int64_t Dp, int S, int nzy) {
+  __shared__ float red[4][64];
+  constexpr int RJ = kFinRows / 4;
+  const int dx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int d = blockIdx.x * 64 + dx;
+  const bool dok = d < D;
+  const bool zside = (int)blockIdx.y < nzy;
+  const int64_t rows = zside ? zrows : xrows;
+  const int64_t row0 = (int64_t)(zside ? blockIdx.y : blockIdx.y - nzy) * kFinRows;
+  const float* src = zside ? z : x;
+  float xa[RJ], ga[RJ];
+#pragma unroll
+  for (int j = 0; j < RJ; ++j) {
+    const int64_t row = row0 + ry + 4 * j;
+    xa[j] = (dok && row < rows) ? src[row * D + d] : 0.f;
+    ga[j] = 0.f;
+  }
+  for (int s = 0; s < S; ++s) {
+    const float wv = dok ? w[s * Dp + d] : 0.f;
+    float th = 0.f;
+#pragma unroll
+    for (int j = 0; j < RJ; ++j) {
+      const int64_t row = row0 + ry + 4 * j;
+      if (row < rows) {
+        if (zside) {
+          const int64_t sr = (int64_t)s * rows + row;
+          const float p1 = dok ? Puu[sr * D + d] : 0.f, p2 = dok ? Puf[sr * D + d] : 0.f;
+          const float rx1 = r_uu[sr] * xa[j], rx2 = r_uf[sr] * xa[j];
+          ga[j] -= wv * ((rx1 - p1) + (rx2 - p2));
+          th += xa[j] * ((rx1 - p1) + (rx2 - 2.f * p2));
+        } else {
+          th += xa[j] * (c_uf[(int64_t)s * rows + row] * xa[j]);
+        }
+      }
+    }
+    __syncthreads();
+    red[ry][dx] = th;
+    __syncthreads();
+    if (ry == 0 && dok) {
+      const float t = red[0][dx] + red[1][dx] + red[2][dx] + red[3][dx];
+      atomicAdd(&gtheta[(int64_t)s * (D + 1) + d], wv * t);
+    }
+  }
+  if (zside && dok) {
+#pragma unroll
+    for (int j = 0; j < RJ; ++j) {
+      const int64_t row = row0 + ry + 4 * j;
+      if (row < rows) gz[row * D + d] = ga[j];
+    }
+  }
+}
+
+
 }  // namespace vargp

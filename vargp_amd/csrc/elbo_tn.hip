@@ -24,9 +24,12 @@ namespace vargp {
 
 struct TnWs {
   float *theta, *eps_theta, *eps_f;          // first, in this order (vargp_amd/fused.py exposes them as views)
-  float *g2, *kd, *mu, *var, *gmu, *gvar;    // gmu, gvar adjacent: one zero range (accumulated by the softmax kernel)
+  float *g2, *kd, *w, *na, *nb, *mu, *var, *gmu, *gvar;   // gmu, gvar adjacent: one zero range (accumulated by the softmax kernel)
+  int64_t Dp;
   float *Kall, *Kuf, *LL, *TT, *QPs, *P, *V2, *W;
-  float *gQPs, *gP, *gT, *gKuf, *gK, *gRKt, *gkd, *gtheta, *gz_all;
+  float *gQPs, *gP, *gT, *gKuf, *gK, *gRKt, *gkd, *gz_all;
+  float *r_uf, *c_uf, *gtheta;               // adjacent: one zero range (accumulators of the kernel-matrix backward)
+  float *r_uu, *Wuu, *Puu, *Puf;             // Wuu aliases gT (dead once the Cholesky backward has consumed it)
   void *chol, *rbf;
   size_t chol_bytes, rbf_bytes;
   int NRs, Mt;
@@ -41,7 +44,9 @@ static TnWs carve_tn(void* ws, int S, int C, int M, int D, int B, int F, int nbl
   float* p = reinterpret_cast<float*>(ws);
   auto take = [&](int64_t n) { float* q = p; p += round_up(n, 64); return q; };
   o.theta = take(S * D1); o.eps_theta = take(S * D1); o.eps_f = take((int64_t)S * F * C * B);
+  o.Dp = round_up(D, 4);
   o.g2 = take(S); o.kd = take(SC);
+  o.w = take(S * o.Dp); o.na = take(SC * Mt); o.nb = take((int64_t)S * B);
   o.mu = take(SC * B); o.var = take(SC * B);
   o.gmu = take(SC * B); o.gvar = take(SC * B);
   o.Kall = take(SC * Mt * Mt); o.Kuf = take(SC * Mt * B);
@@ -50,20 +55,16 @@ static TnWs carve_tn(void* ws, int S, int C, int M, int D, int B, int F, int nbl
   o.P = take(SC * Mt * B); o.V2 = take(SC * Mt * B); o.W = take(SC * Mt * B);
   o.gQPs = take(SC * Mt * o.NRs); o.gP = take(SC * Mt * B);
   o.gT = take(SC * Mt * Mt); o.gKuf = take(SC * Mt * B); o.gK = take(SC * Mt * Mt);
-  o.gRKt = take(SC * M * o.NRs); o.gkd = take(SC); o.gtheta = take(S * D1);
+  o.gRKt = take(SC * M * o.NRs); o.gkd = take(SC);
   o.gz_all = take((int64_t)C * Mt * D);
+  o.r_uf = take(SC * Mt); o.c_uf = take((int64_t)S * B); o.gtheta = take(S * D1);
+  o.r_uu = take(SC * Mt); o.Wuu = o.gT; o.Puu = take(SC * Mt * D); o.Puf = take(SC * Mt * D);
   const size_t cf = vargp_chol_workspace_bytes((int)SC, o.Mt, 0), cb = vargp_chol_workspace_bytes((int)SC, o.Mt, 1);
   o.chol_bytes = cf > cb ? cf : cb;
   o.chol = p;
   p += round_up((int64_t)(o.chol_bytes + 3) / 4, 64);
-  size_t rb = 0;
-  for (int bw = 0; bw < 2; ++bw) {
-    rb = std::max(rb, vargp_rbf_workspace_bytes(S, C, o.Mt, o.Mt, D, bw));
-    rb = std::max(rb, vargp_rbf_workspace_bytes(S, C, o.Mt, B, D, bw));
-  }
-  o.rbf_bytes = rb;
-  o.rbf = p;
-  p += round_up((int64_t)(rb + 3) / 4, 64);
+  o.rbf_bytes = 0;
+  o.rbf = nullptr;
   o.bytes = (size_t)((char*)p - (char*)ws);
   return o;
 }
@@ -259,15 +260,23 @@ __global__ __launch_bounds__(256) void tn_pdiag_kl_kernel(const float* __restric
 //       reduces gkd = sum_col gvar.  gscale (nullable) = seed multiplying the stored unscaled softmax gradients.
 //   rest: the other columns of gQPs: 1..3 and the padding = 0; the H columns = g tril(H_t) on the current task's block
 //       (KL), 0 elsewhere (the product P gW^T is accumulated on top by a GEMM).                       (g = seed_kl / S)
+//   last: zero-fill of the accumulators of the kernel-matrix backward.
 __global__ __launch_bounds__(256) void tn_bwd_head_kernel(const float* __restrict__ P, float* __restrict__ W,
                                                           float* __restrict__ V2, const float* __restrict__ QPs,
                                                           const float* __restrict__ gmu, const float* __restrict__ gvar,
                                                           const float* __restrict__ gscale, const float* __restrict__ seeds,
                                                           float* __restrict__ gP, float* __restrict__ gQPs,
                                                           float* __restrict__ gkd, float eps, int S, int M, int Mt, int B,
-                                                          int NRs, int npd) {
+                                                          int NRs, int npd, int nrest, float* __restrict__ zero_begin,
+                                                          int64_t zero_count) {
   __shared__ float red[4];
   const float g = seeds[1] / (float)S;
+  if ((int)blockIdx.x >= npd + nrest) {       // zero-fill of the r / c / gtheta accumulators of the kernel-matrix backward
+    const int nz = (int)gridDim.x - npd - nrest;
+    for (int64_t i = (int64_t)((int)blockIdx.x - npd - nrest) * 256 + threadIdx.x; i < zero_count; i += (int64_t)nz * 256)
+      zero_begin[i] = 0.f;
+    return;
+  }
   if ((int)blockIdx.x < npd) {
     const int m = (int)blockIdx.x % Mt;
     const int64_t b = blockIdx.x / Mt;
@@ -432,13 +441,52 @@ extern "C" int vargp_elbo_tn_fwd(const vargp_elbo_tn_desc* d, vargp_stream_t str
     hipLaunchKernelGGL(tn_prologue_kernel, dim3(grid), dim3(256), 0, st, a);
   }
   // kernel matrices over ALL inducing points (earlier tasks + current): K_all (S,C,Mt,Mt), K_uf (S,C,Mt,B)
-  rc = vargp_rbf_gram_fwd(o.theta, d->z_all, nullptr, o.Kall, S, C, Mt, Mt, D, 0, o.rbf, o.rbf_bytes, stream);
+  const int64_t zrows = (int64_t)C * Mt;
+  const bool mfma = D > kRbfDirectD;
+  bool kuf_done = false;
+  GemmParams pf{};       // K_uf = rbf(z_all, x): the classes' inducing points are just more rows of one [C*Mt, D] x [D, B] product
+  rc = rbf_prep_norm_launch(o.theta, d->z_all, zrows, d->x, B, o.w, o.g2, o.na, o.nb, S, D, o.Dp, st);
   if (rc) return rc;
-  rc = vargp_rbf_gram_fwd(o.theta, d->z_all, d->x, o.Kuf, S, C, Mt, B, D, 1, o.rbf, o.rbf_bytes, stream);
+  if (!mfma) {           // small input dimension: direct (cancellation-free) distances
+    rc = rbf_direct_launch(d->z_all, nullptr, o.w, o.g2, o.Kall, Mt, S, C, Mt, Mt, D, o.Dp, 0, st);
+    if (rc) return rc;
+    rc = rbf_direct_launch(d->z_all, d->x, o.w, o.g2, o.Kuf, B, S, C, Mt, B, D, o.Dp, 1, st);
+    if (rc) return rc;
+    kuf_done = true;
+  } else {
+    GemmParams p0{};     // K_all: tiles touching the lower triangle, mirrored (the matrix is symmetric)
+    p0.A = d->z_all; p0.B = d->z_all; p0.C = o.Kall;
+    p0.M = Mt; p0.N = Mt; p0.K = D; p0.lda = D; p0.ldb = D; p0.ldc = Mt;
+    p0.nb1 = C; p0.nb2 = 1;
+    p0.sA[1] = (int64_t)Mt * D; p0.sB[1] = (int64_t)Mt * D;
+    p0.sC[0] = C * MtMt; p0.sC[1] = MtMt;
+    p0.alpha = 1.f;
+    p0.kscale = o.w; p0.ks_ld = o.Dp; p0.g2 = o.g2;
+    p0.na = o.na; p0.sNa[0] = zrows; p0.sNa[1] = Mt;
+    p0.nbv = o.na; p0.sNb[0] = zrows; p0.sNb[1] = Mt;
+    static const int ksym = [] { const char* e = getenv("VARGP_TN_KSYM"); return e ? atoi(e) : 1; }();   // tuning aid
+    p0.same_xy = 1;
+    if (ksym) { p0.triC = 2; p0.symout = 1; }
+    rc = launch_gemm(p0, 0, 1, SC, true, st, "rbf_kuu_gemm");
+    if (rc) return rc;
+    pf.A = d->z_all; pf.B = d->x; pf.C = o.Kuf;
+    pf.M = C * Mt; pf.N = B; pf.K = D; pf.lda = D; pf.ldb = D; pf.ldc = B;
+    pf.nb1 = 1; pf.nb2 = 1;
+    pf.sC[0] = (int64_t)C * MtB;
+    pf.alpha = 1.f;
+    pf.kscale = o.w; pf.ks_ld = o.Dp; pf.g2 = o.g2;
+    pf.na = o.na; pf.sNa[0] = zrows;
+    pf.nbv = o.nb; pf.sNb[0] = B;
+  }
+  // L = chol(K_all + eps I), T = L^-1: every factor of the reference's chain is a leading block of these.  The K_uf
+  // GEMM, which nothing needs before T exists, shares the launch of the first diagonal block's pivot chain.
+  rc = chol_inv_fwd_impl(o.Kall, d->jitter, o.LL, o.TT, nullptr, d->info, SC, Mt, o.chol, o.chol_bytes, false, st,
+                         kuf_done ? nullptr : &pf, S, &kuf_done);
   if (rc) return rc;
-  // L = chol(K_all + eps I), T = L^-1: every factor of the reference's chain is a leading block of these
-  rc = chol_inv_fwd_impl(o.Kall, d->jitter, o.LL, o.TT, nullptr, d->info, SC, Mt, o.chol, o.chol_bytes, false, st);
-  if (rc) return rc;
+  if (!kuf_done) {
+    rc = launch_gemm(pf, 0, 1, S, true, st, "rbf_kuf_gemm");
+    if (rc) return rc;
+  }
   {  // [a_i | . | H_i] = T_ii [m_i | 0 | Lu_i] for every (s, c, block i)
     const int64_t sA[3] = {C * MtMt, MtMt, (int64_t)M * Mt + M}, sB[3] = {0, (int64_t)nblk * M * NRs, (int64_t)M * NRs},
                   sC[3] = {C * MtN, MtN, (int64_t)M * NRs};
@@ -507,8 +555,11 @@ extern "C" int vargp_elbo_tn_bwd(const vargp_elbo_tn_desc* d, const float* seeds
   {
     const int npd = SC * Mt;
     const int nrest = cdiv((int64_t)npd * (NRs - 1), 256);
-    hipLaunchKernelGGL(tn_bwd_head_kernel, dim3(npd + nrest), dim3(256), 0, st, o.P, o.W, o.V2, o.QPs, o.gmu, o.gvar,
-                       fused_softmax ? seeds + 2 : nullptr, seeds, o.gP, o.gQPs, o.gkd, d->jitter, S, M, Mt, B, NRs, npd);
+    const int64_t zc = o.r_uu - o.r_uf;
+    const int nz = (int)std::min<int64_t>(64, cdiv(zc, 1024));
+    hipLaunchKernelGGL(tn_bwd_head_kernel, dim3(npd + nrest + nz), dim3(256), 0, st, o.P, o.W, o.V2, o.QPs, o.gmu, o.gvar,
+                       fused_softmax ? seeds + 2 : nullptr, seeds, o.gP, o.gQPs, o.gkd, d->jitter, S, M, Mt, B, NRs, npd,
+                       nrest, o.r_uf, zc);
   }
   float* gW = o.W;      // in place (tn_bwd_head_kernel)
   float* gV2 = o.V2;
@@ -519,8 +570,18 @@ extern "C" int vargp_elbo_tn_bwd(const vargp_elbo_tn_desc* d, const float* seeds
     if (p.splitk <= 1) { p.D = o.gQPs + 4; p.ldd = NRs; p.beta = 1.f; for (int i = 0; i < 3; ++i) p.sD[i] = sQ[i]; }
     GemmParams q = blk_gemm(o.QPs + 4, NRs, sQ, gW, B, sP, o.gP, B, sP, M, B, M, C, nblk);
     q.triA = 1; q.D = o.gP; q.ldd = B; q.beta = 1.f;
-    rc = launch_gemm_pair2(p, 0, 1, SC * nblk, q, 0, 0, SC * nblk, st, "tn_gh_gp_gemm");
-    if (rc) return rc;
+    const int64_t wgs = (int64_t)SC * nblk * (cdiv(M, 64) * cdiv(M, 64) * std::max(p.splitk, 1) + cdiv(M, 64) * cdiv(B, 64));
+    if (wgs <= 4096) {     // mid-size: one launch for both
+      rc = launch_gemm_pair2(p, 0, 1, SC * nblk, q, 0, 0, SC * nblk, st, "tn_gh_gp_gemm");
+      if (rc) return rc;
+    } else {               // each fills the chip by itself: own launches with the tile shape that suits them
+      p.splitk = 1; p.D = o.gQPs + 4; p.ldd = NRs; p.beta = 1.f;
+      for (int i = 0; i < 3; ++i) p.sD[i] = sQ[i];
+      rc = launch_gemm(p, 0, 1, SC * nblk, false, st, "tn_gh_gemm");
+      if (rc) return rc;
+      rc = launch_gemm(q, 0, 0, SC * nblk, false, st, "tn_gp_gemm");
+      if (rc) return rc;
+    }
   }
   {  // V2 = T^T P:  gP += T gV2
     GemmParams p = flat_gemm(o.TT, Mt, MtMt, gV2, B, MtB, o.gP, B, MtB, Mt, B, Mt);
@@ -579,13 +640,48 @@ extern "C" int vargp_elbo_tn_bwd(const vargp_elbo_tn_desc* d, const float* seeds
     rc = launch_gemm(r, 0, 0, SC, false, st, "tn_chol_bwd3");
     if (rc) return rc;
   }
-  // kernel matrices -> theta, z
-  rc = vargp_rbf_gram_bwd(o.theta, d->z_all, nullptr, o.Kall, o.gK, o.gz_all, nullptr, o.gtheta, S, C, Mt, Mt, D, 0, 0, o.rbf,
-                          o.rbf_bytes, stream);
-  if (rc) return rc;
-  rc = vargp_rbf_gram_bwd(o.theta, d->z_all, d->x, o.Kuf, o.gKuf, o.gz_all, nullptr, o.gtheta, S, C, Mt, B, D, 1, 1, o.rbf,
-                          o.rbf_bytes, stream);
-  if (rc) return rc;
+  // kernel matrices -> theta, z  (the fused passes of the first-task program, elbo_shared.h):
+  //   W = gK o K for both kernel matrices in one launch (K_uf in place on gK_uf; K_all: gK is symmetric, W + W^T = 2 W),
+  //   both W.Y products, one finalisation for the inducing-point and the minibatch side
+  const int64_t zrows = (int64_t)C * Mt;
+  {
+    const int gx = cdiv(B, 256), gy = cdiv(zrows, kWRows), nuf = gx * gy * S;
+    const int nuu = SC * cdiv(Mt, kUuRows);
+    hipLaunchKernelGGL(t0_w_kernel, dim3(nuf + nuu), dim3(256), 0, st, o.Kuf, o.gKuf, o.Kall, o.gK, o.Wuu, o.r_uu, o.r_uf,
+                       o.c_uf, o.gtheta, S, C, Mt, B, D, 0, B, gx, gy, nuf, nuu, (const float*)nullptr, (const float*)nullptr,
+                       seeds, (float*)nullptr, 1);
+  }
+  {
+    GemmParams p0{}, p1{};
+    p0.A = o.Wuu; p0.B = d->z_all; p0.C = o.Puu;
+    p0.M = Mt; p0.N = D; p0.K = Mt; p0.lda = Mt; p0.ldb = D; p0.ldc = D;
+    p0.nb1 = C; p0.nb2 = 1;
+    p0.sA[0] = C * MtMt; p0.sA[1] = MtMt;
+    p0.sB[1] = (int64_t)Mt * D;
+    p0.sC[0] = zrows * D; p0.sC[1] = (int64_t)Mt * D;
+    p0.alpha = 1.f;
+    p1.A = o.gKuf; p1.B = d->x; p1.C = o.Puf;
+    p1.M = C * Mt; p1.N = D; p1.K = B; p1.lda = B; p1.ldb = D; p1.ldc = D;
+    p1.nb1 = 1; p1.nb2 = 1;
+    p1.sA[0] = C * MtB;
+    p1.sC[0] = zrows * D;
+    p1.alpha = 1.f;
+    const int64_t wgs = (int64_t)cdiv(Mt, 64) * cdiv(D, 64) * SC + (int64_t)cdiv(C * Mt, 64) * cdiv(D, 64) * S;
+    if (wgs <= 4096) {     // mid-size: neither fills the chip alone, one launch (64^3 tiles)
+      rc = launch_gemm_pair(p0, SC, p1, S, 0, 0, false, st, "rbf_kuu_bwd_gemm", "rbf_kuf_bwd_gemm");
+      if (rc) return rc;
+    } else {
+      rc = launch_gemm(p0, 0, 0, SC, false, st, "rbf_kuu_bwd_gemm");
+      if (rc) return rc;
+      rc = launch_gemm(p1, 0, 0, S, false, st, "rbf_kuf_bwd_gemm");
+      if (rc) return rc;
+    }
+  }
+  {
+    const int nzy = cdiv(zrows, kFinRows), nxy = cdiv(B, kFinRows);
+    hipLaunchKernelGGL(t0_final_kernel, dim3(cdiv(D, 64), nzy + nxy), dim3(256), 0, st, d->z_all, d->x, o.r_uu, o.r_uf, o.c_uf,
+                       o.Puu, o.Puf, o.w, o.gz_all, o.gtheta, zrows, (int64_t)B, D, o.Dp, S, nzy);
+  }
   {
     const int nun = cdiv((int64_t)C * M * (M + 1), 256);
     hipLaunchKernelGGL(tn_unpack_kernel, dim3(nun + cdiv((int64_t)C * M * D, 256)), dim3(256), 0, st, o.gRKt, d->u_tril_vec,

@@ -263,7 +263,11 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int tile_id
   constexpr int kStage = ((LA::kSize + 3) & ~3) + ((LB::kSize + 3) & ~3);
 
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int tm = tile_id / tiles_n, tn = tile_id % tiles_n;
+  int tm = tile_id / tiles_n, tn = tile_id % tiles_n;
+  // triangular operands clip the K range per tile: hand out the long tiles of a matrix first, so that the launch does not
+  // end on them (workgroups are dispatched in id order)
+  if (p.triA == 1) tm = (p.M + BM - 1) / BM - 1 - tm;
+  if (p.triB == 2) tn = tiles_n - 1 - tn;
   const int m0 = tm * BM, n0 = tn * BN;
   const int b = batch_id;
   const int i2 = b % p.nb2, i1 = (b / p.nb2) % p.nb1, i0 = b / (p.nb2 * p.nb1);
@@ -464,6 +468,49 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int tile_id
     na = p.na + i0 * p.sNa[0] + i1 * p.sNa[1] + i2 * p.sNa[2];
     nbv = p.nbv + i0 * p.sNb[0] + i1 * p.sNb[1] + i2 * p.sNb[2];
   }
+  if (p.symout && p.splitk <= 1) {
+    // Symmetric result from the tiles that touch its lower triangle: C_ij = C_ji = value for j <= i.  The direct store is
+    // coalesced as it stands (lanes run along a row); the mirrored one would scatter 4-byte writes down a column, so each
+    // 32 x 32 accumulator block is transposed through LDS first (a private 32 x 33 patch per wave: conflict-free both
+    // ways) and then stored along rows as well.  (Uniform control flow: every wave of the workgroup runs all blocks.)
+    float* patch = lds + wave * (32 * 33);
+    __syncthreads();                                          // the K loop is done with the LDS stages
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+#pragma unroll
+      for (int c = 0; c < TN; ++c) {
+        const int R0 = m0 + wm0 + 32 * a, C0 = n0 + wn0 + 32 * c;
+        const int col = C0 + li;
+        float nbc = 0.f;
+        if constexpr (RBF) nbc = (col < p.N) ? nbv[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rl = (r & 3) + 8 * (r >> 2) + 4 * lh, row = R0 + rl;
+          float v;
+          if constexpr (RBF) {
+            const float d2 = ((row < p.M) ? na[row] : 0.f) + nbc - 2.f * acc[a][c][r];
+            v = (p.same_xy && row == col) ? g2 : g2 * expf(-0.5f * d2);
+          } else {
+            v = p.alpha * acc[a][c][r];
+            if (D && row < p.M && col < p.N) v += p.beta * D[(int64_t)row * p.ldd + col];
+          }
+          if (row < p.M && col < p.N && col <= row) C[(int64_t)row * p.ldc + col] = v;
+          patch[rl * 33 + li] = v;
+        }
+        __syncthreads();
+        if (C0 < R0 + 32) {                                   // (uniform) the block has entries below the diagonal
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int jl = (r & 3) + 8 * (r >> 2) + 4 * lh;   // mirrored entry: row C0 + jl, column R0 + li
+            const int mrow = C0 + jl, mcol = R0 + li;
+            if (mrow < mcol && mcol < p.M && mrow < p.N) C[(int64_t)mrow * p.ldc + mcol] = patch[li * 33 + jl];
+          }
+        }
+        __syncthreads();
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
 #pragma unroll
@@ -487,13 +534,6 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int tile_id
             v = p.alpha * acc[a][c][r];
             if (D) v += p.beta * D[(int64_t)row * p.ldd + col];
             if (p.triC == 1 && col > row) v = 0.f;
-            if (p.symout) {                   // symmetric result from its lower triangle
-              if (col <= row) {
-                C[(int64_t)row * p.ldc + col] = v;
-                if (col < row) C[(int64_t)col * p.ldc + row] = v;
-              }
-              continue;
-            }
             if (p.splitk > 1) {               // K split without a scratch buffer: partial sums meet in C (pre-zeroed)
               if (v != 0.f) atomicAdd(&C[(int64_t)row * p.ldc + col], v);
               continue;
@@ -703,6 +743,35 @@ static int launch_chol_rbf_gemm_impl(const float* A, float eps, float* L, float*
   return check_launch("chol_rbf_gemm");
 }
 
+int launch_chol_rbf_gemm_ld(const float* A, int lda, int64_t sA, float eps, float* L, int ldl, int64_t sL, float* T, int ldt,
+                            int64_t sT, int32_t* info, int nchol, int n, const GemmParams& p, int nbatch, hipStream_t st) {
+  if (prof_remembering()) {
+    const GemmParams pc = p;
+    prof_remember("chol_rbf_gemm", [=](hipStream_t s) {
+      launch_chol_rbf_gemm_ld(A, lda, sA, eps, L, ldl, sL, T, ldt, sT, info, nchol, n, pc, nbatch, s);
+    });
+  }
+  ProfScope prof("chol_rbf_gemm", st);
+  CholArgs c{A, lda, sA, eps, L, ldl, sL, T, ldt, sT, info, n, nchol, CholExtra{}};
+  GemmParams q = p;
+  q.splitk = 1;
+  const int t64 = cdiv(p.M, 64) * cdiv(p.N, 64), t128 = cdiv(p.M, 128) * cdiv(p.N, 64);
+  const int free_cus = 256 - nchol;
+  const bool big = t64 * nbatch > free_cus && (t128 * nbatch <= free_cus || t64 * nbatch > 1024);
+  const int tiles = big ? t128 : t64;
+  const int total = nchol + tiles * nbatch;
+  // factorising CUs exclusive (see launch_chol_rbf_gemm_impl) only while the GEMM fits one round on the other CUs
+  const unsigned pad = tiles * nbatch <= free_cus ? (big ? 40u : 24u) * 1024u : 0u;
+#define VARGP_MERGED(KC, SETS)                                                                                        \
+  do {                                                                                                                  \
+    if (big) hipLaunchKernelGGL((chol_rbf_gemm_kernel<KC, SETS, 128, 32>), dim3(total), dim3(256), pad, st, c, q, tiles); \
+    else hipLaunchKernelGGL((chol_rbf_gemm_kernel<KC, SETS, 64, 64>), dim3(total), dim3(256), pad, st, c, q, tiles);    \
+  } while (0)
+  if (n <= 64) VARGP_MERGED(16, 1); else VARGP_MERGED(25, 2);
+#undef VARGP_MERGED
+  return check_launch("chol_rbf_gemm");
+}
+
 // two plain products with their own transposition flags in one launch; the layout pairs the ELBO program uses are
 // instantiated, anything else (or unaligned operands) falls back to two launches
 int launch_gemm_pair2(const GemmParams& p0, int tA0, int tB0, int nbatch0, const GemmParams& p1, int tA1, int tB1,
@@ -736,7 +805,7 @@ int launch_gemm_pair2(const GemmParams& p0, int tA0, int tB0, int nbatch0, const
   return check_launch("gemm_pair2");
 }
 
-// last launch per tag, kept for vargp_prof_replay (measurement only)
+static int g_tile_force = 0;   // vargp_tune_gemm_tile (measurement only)
 
 int launch_gemm(const GemmParams& p, int transA, int transB, int nbatch, bool rbf, hipStream_t st, const char* tag) {
   if (p.M <= 0 || p.N <= 0 || nbatch <= 0) return VARGP_OK;
@@ -759,17 +828,30 @@ int launch_gemm(const GemmParams& p, int transA, int transB, int nbatch, bool rb
   for (int i = 0; i < 3; ++i) vec = vec && (p.sA[i] % 4 == 0) && (p.sB[i] % 4 == 0);
   const int64_t t128 = (int64_t)cdiv(p.M, 128) * cdiv(p.N, 128) * nbatch;
   const int64_t t12864 = (int64_t)cdiv(p.M, 128) * cdiv(p.N, 64) * nbatch;
-  static const int force = [] { const char* e = getenv("VARGP_GEMM_TILE"); return e ? atoi(e) : 0; }();   // tuning aid
+  static const int force_env = [] { const char* e = getenv("VARGP_GEMM_TILE"); return e ? atoi(e) : 0; }();   // tuning aid
+  const int force = g_tile_force ? g_tile_force : force_env;
+  // Tile choice, from the sweep `tests/native/bench_kernels tiles` on MI355X (mid-size batched products of the ELBO
+  // programs): 128x64x32 is the robust mid-size shape; 64x64x64 when it pads M less and K ranges are clipped by a
+  // triangular operand (finer clipping, better balance: 400x512x400 b100 140 vs 182/192 us) or when the problem is small
+  // (more workgroups); 128x128x16 only for large square-ish problems (>= 1024 both ways), where it reaches 80-90 % of peak.
+  const bool tri = p.triA != 0 || p.triB != 0;
+  const bool pad64_less = round_up(p.M, 64) < round_up(p.M, 128);
   if (force == 1) dispatch_tile<128, 128, 16>(p, transA, transB, nbatch, rbf, vec, st);
   else if (force == 2) dispatch_tile<128, 64, 32>(p, transA, transB, nbatch, rbf, vec, st);
   else if (force == 3) dispatch_tile<64, 64, 64>(p, transA, transB, nbatch, rbf, vec, st);
-  else if (t128 >= 512) dispatch_tile<128, 128, 16>(p, transA, transB, nbatch, rbf, vec, st);
-  else if (t12864 >= 512 && p.M > 64) dispatch_tile<128, 64, 32>(p, transA, transB, nbatch, rbf, vec, st);
+  else if (t12864 >= 384 && tri && pad64_less) dispatch_tile<64, 64, 64>(p, transA, transB, nbatch, rbf, vec, st);
+  else if (t128 >= 2048 && !tri && p.M >= 1024 && p.N >= 1024) dispatch_tile<128, 128, 16>(p, transA, transB, nbatch, rbf, vec, st);
+  else if (t12864 >= 384 && p.M > 64) dispatch_tile<128, 64, 32>(p, transA, transB, nbatch, rbf, vec, st);
   else dispatch_tile<64, 64, 64>(p, transA, transB, nbatch, rbf, vec, st);
   return check_launch("bgemm");
 }
 
 }  // namespace vargp
+
+extern "C" int vargp_tune_gemm_tile(int tile) {
+  vargp::g_tile_force = (tile >= 0 && tile <= 3) ? tile : 0;
+  return VARGP_OK;
+}
 
 extern "C" int vargp_bgemm(const vargp_gemm_desc* d, vargp_stream_t stream) {
   using namespace vargp;

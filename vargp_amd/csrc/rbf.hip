@@ -147,7 +147,8 @@ __global__ __launch_bounds__(256) void rbf_w_kernel(const float* __restrict__ K,
 constexpr int kSelfRows = 16;
 __global__ __launch_bounds__(256) void rbf_w_self_kernel(const float* __restrict__ K, const float* __restrict__ gK,
                                                          float* __restrict__ Ws, float* __restrict__ r,
-                                                         float* __restrict__ gtheta, int M, int Cb, int D, int nchunk) {
+                                                         float* __restrict__ gtheta, int M, int Cb, int D, int nchunk,
+                                                         int sym) {
   __shared__ float red[4];
   const int lane = threadIdx.x & 63;
   const int64_t b = blockIdx.x / nchunk;
@@ -158,7 +159,9 @@ __global__ __launch_bounds__(256) void rbf_w_self_kernel(const float* __restrict
   for (int i = i0 + (threadIdx.x >> 6); i < i1; i += 4) {
     float acc = 0.f;
     for (int j = lane; j < M; j += 64) {
-      const float v = Kb[(int64_t)i * M + j] * gKb[(int64_t)i * M + j] + Kb[(int64_t)j * M + i] * gKb[(int64_t)j * M + i];
+      // sym: gK is symmetric (K always is), so W = gK o K is too and W + W^T = 2 W: no transposed (uncoalesced) reads
+      const float v = sym ? 2.f * Kb[(int64_t)i * M + j] * gKb[(int64_t)i * M + j]
+                          : Kb[(int64_t)i * M + j] * gKb[(int64_t)i * M + j] + Kb[(int64_t)j * M + i] * gKb[(int64_t)j * M + i];
       Ws[b * M * M + (int64_t)i * M + j] = v;
       acc += v;
     }
@@ -225,6 +228,13 @@ __global__ __launch_bounds__(256) void rbf_final_kernel(const float* __restrict_
   }
 }
 
+int rbf_prep_norm_launch(const float* theta, const float* x, int64_t xrows, const float* y, int64_t yrows, float* w,
+                         float* g2, float* na, float* nb, int S, int D, int64_t Dp, hipStream_t st) {
+  hipLaunchKernelGGL(rbf_prep_norm_kernel, dim3(cdiv(xrows + yrows, 4), S), dim3(256), 0, st, theta, x, y, w, g2, na, nb,
+                     xrows, yrows, D, Dp);
+  return check_launch("rbf_prep_norm");
+}
+
 int rbf_direct_launch(const float* X, const float* Y, const float* w, const float* g2, float* K, int64_t ldk, int S,
                       int C, int M, int N, int D, int64_t Dp, int y_shared, hipStream_t st) {
   const int64_t total = (int64_t)S * C * M * N;
@@ -243,13 +253,18 @@ extern "C" size_t vargp_rbf_workspace_bytes(int S, int C, int M, int N, int D, i
 
 extern "C" int vargp_rbf_gram_fwd(const float* theta, const float* X, const float* Y, float* K, int S, int C, int M,
                                   int N, int D, int y_shared, void* ws, size_t ws_bytes, vargp_stream_t stream) {
+  return vargp::rbf_gram_fwd_impl(theta, X, Y, K, S, C, M, N, D, y_shared, ws, ws_bytes, 0, as_stream(stream));
+}
+
+// sym_out (Y = NULL only): compute the tiles that touch the lower triangle and mirror them (K is symmetric)
+int vargp::rbf_gram_fwd_impl(const float* theta, const float* X, const float* Y, float* K, int S, int C, int M, int N, int D,
+                             int y_shared, void* ws, size_t ws_bytes, int sym_out, hipStream_t st) {
   VARGP_REQUIRE(theta && X && K && ws, "rbf_gram_fwd: null pointer");
   VARGP_REQUIRE(S > 0 && C > 0 && M > 0 && D > 0, "rbf_gram_fwd: bad dims");
   const bool self = (Y == nullptr);
   if (self) { N = M; y_shared = 0; }
   VARGP_REQUIRE(N > 0, "rbf_gram_fwd: bad N");
   VARGP_REQUIRE(ws_bytes >= vargp_rbf_workspace_bytes(S, C, M, N, D, 0), "rbf_gram_fwd: workspace too small");
-  hipStream_t st = as_stream(stream);
   RbfWs o = carve(ws, S, C, M, N, D, false);
   if (D <= kDirectD) {
     hipLaunchKernelGGL(rbf_prep_kernel, dim3(S), dim3(256), 0, st, theta, o.w, o.g2, D, o.Dp);
@@ -272,7 +287,8 @@ extern "C" int vargp_rbf_gram_fwd(const float* theta, const float* X, const floa
   p.na = o.na; p.sNa[0] = xrows; p.sNa[1] = Mb;
   p.nbv = self ? o.na : o.nb; p.sNb[0] = self ? xrows : yrows; p.sNb[1] = (self || !y_shared) ? N : 0;
   p.same_xy = self ? 1 : 0;
-  const int nsplit = rbf_splitk(Mb, N, D, S * Cb);
+  const int nsplit = (self && sym_out) ? 1 : rbf_splitk(Mb, N, D, S * Cb);
+  if (self && sym_out) { p.triC = 2; p.symout = 1; }
   int rc;
   {
     ProfScope whole(self ? "rbf_kuu" : "rbf_kuf", st);    // distance GEMM (+ combine pass if K was split)
@@ -297,11 +313,18 @@ extern "C" int vargp_rbf_gram_fwd(const float* theta, const float* X, const floa
 extern "C" int vargp_rbf_gram_bwd(const float* theta, const float* X, const float* Y, const float* K, const float* gK,
                                   float* gX, float* gY, float* gtheta, int S, int C, int M, int N, int D,
                                   int y_shared, int accumulate, void* ws, size_t ws_bytes, vargp_stream_t stream) {
+  return vargp::rbf_gram_bwd_impl(theta, X, Y, K, gK, gX, gY, gtheta, S, C, M, N, D, y_shared, accumulate, ws, ws_bytes, 0,
+                                  as_stream(stream));
+}
+
+// sym_gk (Y = NULL only): the caller guarantees a symmetric gK (e.g. the output of the Cholesky backward)
+int vargp::rbf_gram_bwd_impl(const float* theta, const float* X, const float* Y, const float* K, const float* gK, float* gX,
+                             float* gY, float* gtheta, int S, int C, int M, int N, int D, int y_shared, int accumulate,
+                             void* ws, size_t ws_bytes, int sym_gk, hipStream_t st) {
   VARGP_REQUIRE(theta && X && K && gK && gtheta && ws, "rbf_gram_bwd: null pointer");
   const bool self = (Y == nullptr);
   if (self) { N = M; y_shared = 0; gY = nullptr; }
   VARGP_REQUIRE(ws_bytes >= vargp_rbf_workspace_bytes(S, C, M, N, D, 1), "rbf_gram_bwd: workspace too small");
-  hipStream_t st = as_stream(stream);
   RbfWs o = carve(ws, S, C, M, N, D, true);
   const int Cb = y_shared ? 1 : C, Mb = y_shared ? C * M : M;
   const int64_t xrows = (int64_t)C * M, yrows = y_shared ? N : (int64_t)C * N;
@@ -310,7 +333,8 @@ extern "C" int vargp_rbf_gram_bwd(const float* theta, const float* X, const floa
   if (!accumulate) zero_async(gtheta, sizeof(float) * (size_t)S * (D + 1), st);
   if (self) {
     const int nchunk = cdiv(M, kSelfRows);
-    hipLaunchKernelGGL(rbf_w_self_kernel, dim3(nb * nchunk), dim3(256), 0, st, K, gK, o.Wm, o.r, gtheta, M, Cb, D, nchunk);
+    hipLaunchKernelGGL(rbf_w_self_kernel, dim3(nb * nchunk), dim3(256), 0, st, K, gK, o.Wm, o.r, gtheta, M, Cb, D, nchunk,
+                       sym_gk);
   } else {
     zero_async(o.r, sizeof(float) * (size_t)(o.P - o.r), st);   // r and c are adjacent
     hipLaunchKernelGGL(rbf_w_kernel, dim3(cdiv(N, 256), cdiv(Mb, WROWS), nb), dim3(256), 0, st, K, gK, o.Wm, o.r, o.c,
