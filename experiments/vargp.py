@@ -10,7 +10,8 @@ Same commands, flags and defaults:
 
 Differences: wandb / tensorboard / fire are optional (a JSONL logger under --log_dir is always written);
 MNIST is read from IDX files under --data_dir if present, else an MNIST-shaped synthetic surrogate is used
-(no network); --graph replays the training step from a captured hipGraph.
+(no network); --graph replays the training step from a captured hipGraph; `toy --retrain` is the counterpart of the
+reference's experiments/vargp_retrain.py (VARGPRetrain).
 """
 import argparse
 import json
@@ -48,9 +49,15 @@ class JsonlLogger:
 
 def train(task_id, train_set, val_set, test_set, ep_var_mean=True, map_est_hypers=False, dkl=False,
           epochs=1, M=20, n_f=10, n_var_samples=3, batch_size=512, lr=1e-2, beta=1.0,
-          eval_interval=10, patience=20, prev_params=None, logger=None, device=None, graph=False, seed=None):
-    gp = VARGP.create_clf(train_set, M=M, n_f=n_f, n_var_samples=n_var_samples, prev_params=prev_params,
-                          ep_var_mean=ep_var_mean, map_est_hypers=map_est_hypers, dkl=dkl).to(device)
+          eval_interval=10, patience=20, prev_params=None, logger=None, device=None, graph=False, seed=None,
+          retrain=False):
+    if retrain:      # the variant of experiments/vargp_retrain.py:14-19 (earlier tasks' inducing parameters re-optimised)
+        from vargp_amd.vargp_retrain import VARGPRetrain
+        gp = VARGPRetrain.create_clf(train_set, M=M, n_f=n_f, n_var_samples=n_var_samples, prev_params=prev_params).to(device)
+        graph = False
+    else:
+        gp = VARGP.create_clf(train_set, M=M, n_f=n_f, n_var_samples=n_var_samples, prev_params=prev_params,
+                              ep_var_mean=ep_var_mean, map_est_hypers=map_est_hypers, dkl=dkl).to(device)
     stopper = EarlyStopper(patience=patience)
     N = len(train_set)
     # the program's counter-based noise generator is keyed by the run's seed (the reference draws from the torch global
@@ -125,7 +132,7 @@ def toy(args):
         sd = train(t, toy_train, toy_val, toy_test, epochs=args.epochs, M=args.M, lr=args.lr, beta=args.beta,
                    batch_size=args.batch_size, ep_var_mean=args.ep_var_mean, map_est_hypers=args.map_est_hypers,
                    dkl=args.dkl, prev_params=prev_params, logger=logger, device=device, patience=-1,
-                   eval_interval=args.eval_interval, graph=args.graph, seed=args.seed)
+                   eval_interval=args.eval_interval, graph=args.graph, seed=args.seed, retrain=args.retrain)
         prev_params.append(sd)
     logger.close()
 
@@ -207,6 +214,10 @@ def main(argv=None):
                         help='force the MNIST-shaped synthetic surrogate (default: only if IDX files are missing)')
         sp.add_argument('--n_synth', type=int, default=None, help='size of the synthetic training set')
         sp.add_argument('--graph', action='store_true', help='replay the training step from a captured hipGraph')
+        if name == 'toy':
+            sp.add_argument('--retrain', action='store_true',
+                            help='VARGPRetrain (reference: experiments/vargp_retrain.py toy): re-optimise the earlier '
+                                 "tasks' inducing parameters")
         if name == 'p-mnist':
             sp.add_argument('--n_tasks', type=int, default=10)
     args = ap.parse_args(argv)

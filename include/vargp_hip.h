@@ -273,6 +273,16 @@ int vargp_hyper_kl_bwd(const float* mean, const float* logvar, const float* prio
                        const float* gkl, float* gmean, float* glogvar, int D1, vargp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Deep-kernel feature map (reference: DeepRBFKernel.phi, var_gp/kernels.py:80-96 = Linear(D,256) - ReLU - Linear(256,256)
+ * - ReLU - Linear(256,64) in front of the RBF kernel).  The three matrix products are vargp_bgemm; these two fuse the
+ * bias and the activation around them:  y[r,c] = act(x[r,c] + bias[c]),  act = ReLU if relu else identity;
+ * backward: gx = gy * (y > 0) (or gy), gbias[c] = sum_r gx[r,c]  (gbias is zeroed by the call).
+ */
+int vargp_bias_act_fwd(const float* x, const float* bias, float* y, int64_t rows, int cols, int relu, vargp_stream_t stream);
+int vargp_bias_act_bwd(const float* y, const float* gy, float* gx, float* gbias, int64_t rows, int cols, int relu,
+                       vargp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Measurement hooks (no reference counterpart): when enabled, the heavy launches are bracketed by
  * hipEvents on their own stream, tagged "rbf_kuf" / "rbf_kuu" (distance GEMM incl. the split-K combine pass),
  * "rbf_kuf_gemm", "rbf_kuu_gemm", "rbf_kuf_bwd_gemm", "rbf_kuu_bwd_gemm", "chol_inv_small", "bgemm".

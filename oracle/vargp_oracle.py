@@ -29,6 +29,34 @@ JITTER = 1e-4  # reference: var_gp/gp_utils.py:5 (eps default)
 
 
 # ----------------------------------------------------------------------------------------------
+# Deep-kernel feature map  (reference: DeepRBFKernel, var_gp/kernels.py:80-96)
+# ----------------------------------------------------------------------------------------------
+_feature_map = None
+
+
+def deep_features(phi, x):
+    """Linear(D,256) - ReLU - Linear(256,256) - ReLU - Linear(256,feat); phi = {'0.weight', '0.bias', '2.*', '4.*'}."""
+    h = F.relu(F.linear(x, phi['0.weight'], phi['0.bias']))
+    h = F.relu(F.linear(h, phi['2.weight'], phi['2.bias']))
+    return F.linear(h, phi['4.weight'], phi['4.bias'])
+
+
+class deep_kernel:
+    """with deep_kernel(phi): every rbf_gram inside acts on phi(.) -- the DeepRBFKernel ablation of VARGP.create_clf."""
+
+    def __init__(self, phi):
+        self.phi = phi
+
+    def __enter__(self):
+        global _feature_map
+        self.old, _feature_map = _feature_map, self.phi
+
+    def __exit__(self, *a):
+        global _feature_map
+        _feature_map = self.old
+
+
+# ----------------------------------------------------------------------------------------------
 # RBF / ARD kernel  (reference: var_gp/kernels.py:24-60)
 # ----------------------------------------------------------------------------------------------
 def rbf_gram(theta, x, y=None, full_gram=False):
@@ -42,6 +70,9 @@ def rbf_gram(theta, x, y=None, full_gram=False):
     full_gram=True reproduces the reference's (wasteful) B x B Gram of y whose diagonal is the
     only part used (kernels.py:51,54); used by the cpu_baseline timing so the work matches.
     """
+    if _feature_map is not None:      # deep kernel (var_gp/kernels.py:80-96): the RBF kernel acts on phi(x), phi(y)
+        x = deep_features(_feature_map, x)
+        y = deep_features(_feature_map, y) if y is not None else None
     S = theta.shape[0]
     lead = x.dim() - 2
     th = theta.reshape(S, *([1] * lead), 1, -1)
@@ -364,3 +395,71 @@ def make_problem(S, F_, C, M, D, B, n_prev=0, seed=0, kind='gauss', dtype=torch.
     if n_prev:
         noise['eps_u'] = hash_normal((n_v, S, C, Mt_prev), seed + 37).to(dtype)
     return params, prev, x, y, noise
+
+
+# ----------------------------------------------------------------------------------------------
+# VARGPRetrain  (reference: var_gp/vargp_retrain.py:119-233) -- the variant that re-optimises the inducing
+# parameters of the earlier tasks and adds an importance-ratio term for the frozen copies
+# ----------------------------------------------------------------------------------------------
+def mvn_logprob(u, mu, L):
+    """log N(u; mu, L L^T), event = last dim  (torch.distributions.MultivariateNormal.log_prob)."""
+    n = u.shape[-1]
+    bshape = torch.broadcast_shapes(u.shape[:-1], mu.shape[:-1], L.shape[:-2])
+    diff = (u - mu).expand(*bshape, n).unsqueeze(-1)
+    sol = torch.linalg.solve_triangular(L.expand(*bshape, n, n), diff, upper=False).squeeze(-1)
+    return -0.5 * sol.pow(2).sum(-1) - L.diagonal(dim1=-2, dim2=-1).log().sum(-1) - 0.5 * n * math.log(2.0 * math.pi)
+
+
+def retrain_loss(params, retrain, frozen, x, y, noise):
+    """(kl_hypers, kl_u, nll) of VARGPRetrain.loss for a model with earlier tasks (vargp_retrain.py:119-233).
+    retrain: the re-optimised copies of the earlier tasks' (z, u_mean, u_tril_vec) [trainable]; frozen: the same
+    quantities as constants (the reference's prev_params); noise: eps_theta, eps_f, eps_u_leq (n_v,S,C,Mt),
+    eps_u_tilde (n_v,n_v,S,C,Mt-M).  The two u draws are `.sample()` in the reference: no gradient flows through them."""
+    theta = sample_hypers(params['log_mean'], params['log_logvar'], noise['eps_theta'])
+    # q(u_<=t | theta) from the re-optimised parameters (:131-133)
+    _, _, mu_leq, S_leq, z_leq, _, _ = compute_q(theta, params, retrain)
+    pmu, pvar, _, _ = compute_pf_diag(theta, x, mu_leq, S_leq, z_leq)
+    nll = softmax_nll(pmu, pvar, y, noise['eps_f'])
+    # p(u_<=t | theta) = N(0, K(z_<=t))  (:137-138), KL(q || p) with both Cholesky factors jittered (:160-161)
+    K_leq = rbf_gram(theta, z_leq)
+    L_q = chol(S_leq)
+    kl = mvn_kl(mu_leq.squeeze(-1), L_q, torch.zeros_like(mu_leq.squeeze(-1)), chol(K_leq)).sum(-1).mean(0)
+    # q(u~_<t | theta), p(u~_<t | theta) from the frozen copies (:141-145)
+    mu_lt, S_lt, _, _, _, _, _ = compute_q(theta, params, frozen)
+    z_lt = torch.cat([p['z'] for p in frozen], dim=-2)
+    K_lt = rbf_gram(theta, z_lt)
+    # u_<=t ~ q (no gradient), u~_<t ~ p(u~_<t | u_<=t) (no gradient)  (:148-158)
+    with torch.no_grad():
+        u_leq = mu_leq.squeeze(-1).unsqueeze(0) + (L_q.unsqueeze(0) @ noise['eps_u_leq'].unsqueeze(-1)).squeeze(-1)
+        Lz = chol(K_leq)
+        Kzx = rbf_gram(theta, z_leq, z_lt)
+        Lz_Kzx = _lsolve(Lz, Kzx)
+        p_mu, p_S = gp_cond(u_leq.unsqueeze(-1), K_lt.unsqueeze(0), Lz.unsqueeze(0), Lz_Kzx.unsqueeze(0))
+        u_tilde = p_mu.squeeze(-1).unsqueeze(0) + (chol(p_S).unsqueeze(0) @ noise['eps_u_tilde'].unsqueeze(-1)).squeeze(-1)
+    # importance ratio  E[log p(u~) - log q(u~)]  (:196-219)
+    lp = mvn_logprob(u_tilde, torch.zeros_like(mu_lt.squeeze(-1)), chol(K_lt))
+    lq = mvn_logprob(u_tilde, mu_lt.squeeze(-1), chol(S_lt))
+    ratio = (lp - lq).sum(-1).mean(-1).mean(-1).mean(-1)
+    kl_h = kl_hypers(params['log_mean'], params['log_logvar'], params['prior_log_mean'], params['prior_log_logvar'])
+    return kl_h, kl + ratio, nll
+
+
+def make_dkl_problem(S, F_, C, M, D, B, n_prev, seed, feat=64):
+    """Inputs of a deep-kernel case: make_problem's data / inducing points scaled to unit variance in the D-dim input
+    space, hyper-parameters of the feat-dim RBF kernel, and deterministic weights of the feature map.
+    Returns (params, prev, x, y, noise, phi)."""
+    params, prev, x, y, noise = make_problem(S, F_, C, M, D, B, n_prev=n_prev, seed=seed, kind='gauss')
+    scale = math.sqrt(D / 0.25)
+    x = x * scale
+    for p in [params] + prev:
+        p['z'] = p['z'] * scale
+    params.update(log_mean=(math.log(0.5) + 0.05 * hash_normal((feat + 1,), seed + 13)).float(),
+                  log_logvar=(-2.0 + 0.1 * hash_normal((feat + 1,), seed + 17)).float(),
+                  prior_log_mean=(0.02 * hash_normal((feat + 1,), seed + 19)).float(),
+                  prior_log_logvar=(0.02 * hash_normal((feat + 1,), seed + 23)).float())
+    noise['eps_theta'] = hash_normal((S, feat + 1), seed + 29).float()
+    phi = {}
+    for li, (o, i) in zip((0, 2, 4), [(256, D), (256, 256), (feat, 256)]):
+        phi[f'{li}.weight'] = (hash_normal((o, i), seed + 61 + li) * (0.6 / math.sqrt(i))).float()
+        phi[f'{li}.bias'] = (0.05 * hash_normal((o,), seed + 71 + li)).float()
+    return params, prev, x, y, noise, phi

@@ -57,3 +57,13 @@ def to_dev(obj, dev):
     if isinstance(obj, list):
         return [to_dev(v, dev) for v in obj]
     return obj.to(dev)
+
+
+def load_retrain_case(name):
+    """-> (g, params, prev, x, y, noise) of a VARGPRetrain fixture (inputs stored)."""
+    g = np.load(os.path.join(GOLDEN, f'{name}.npz'))
+    n_prev = int(g['meta'][6])
+    params = {k: torch.from_numpy(g[f'p_{k}']) for k in PARAM_KEYS}
+    prev = [{k: torch.from_numpy(g[f'prev{i}_{k}']) for k in ['z', 'u_mean', 'u_tril_vec']} for i in range(n_prev)]
+    noise = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('n_')}
+    return g, params, prev, torch.from_numpy(g['x']), torch.from_numpy(g['y']), noise

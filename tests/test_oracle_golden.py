@@ -100,3 +100,56 @@ def test_fp64_matches_fp32():
     sc32, _ = orc.elbo_step(f32(params), [f32(p) for p in prev], x.float(), y, f32(noise))
     for k in sc64:
         np.testing.assert_allclose(sc32[k].item(), sc64[k].item(), rtol=1e-4)
+
+
+@pytest.mark.parametrize('name', ['retrain_wtoy_t1', 'retrain_wtoy_t2'])
+def test_retrain_loss_and_grads(name):
+    """VARGPRetrain (var_gp/vargp_retrain.py:119-233): the oracle's restatement against the reference's loss triple and
+    the gradients of the current and of the re-optimised earlier-task parameters."""
+    from helpers import load_retrain_case
+    g, params, prev, x, y, noise = load_retrain_case(name)
+    names = ['z', 'u_mean', 'u_tril_vec', 'log_mean', 'log_logvar']
+    leaf = dict(params)
+    for k in names:
+        leaf[k] = params[k].clone().requires_grad_(True)
+    retrain = [{k: v.clone().requires_grad_(True) for k, v in p.items()} for p in prev]
+    kl_h, kl_u, nll = orc.retrain_loss(leaf, retrain, prev, x, y, noise)
+    total = float(g['beta']) * kl_h + kl_u + (float(g['n_total']) / x.shape[0]) * nll
+    for k, v in [('kl_hypers', kl_h), ('kl_u', kl_u), ('nll', nll), ('total', total)]:
+        np.testing.assert_allclose(v.item(), float(g[k]), rtol=RTOL_SCALAR, err_msg=k)
+    total.backward()
+    for k in names:
+        assert rel_l2(leaf[k].grad, g[f'grad_{k}']) < REL_L2_GRAD, k
+    for i, p in enumerate(retrain):
+        for k in p:
+            assert rel_l2(p[k].grad, g[f'grad_retrain{i}_{k}']) < REL_L2_GRAD, (i, k)
+
+
+@pytest.mark.parametrize('name', ['dkl_t0', 'dkl_t1'])
+def test_deep_kernel_loss_and_grads(name):
+    """DeepRBFKernel (var_gp/kernels.py:80-96) inside VARGP.loss: the oracle with its feature-map hook against the
+    reference's loss triple and gradients (model parameters and the feature map's weights)."""
+    g = np.load(f'{GOLDEN}/{name}.npz')
+    S, F_, C, M, D, B, n_prev, seed = [int(v) for v in g['meta']]
+    params, prev, x, y, noise, phi = orc.make_dkl_problem(S, F_, C, M, D, B, n_prev, seed)
+    names = ['z', 'u_mean', 'u_tril_vec', 'log_mean', 'log_logvar']
+    leaf = dict(params)
+    for k in names:
+        leaf[k] = params[k].clone().requires_grad_(True)
+    phi = {k: v.clone().requires_grad_(True) for k, v in phi.items()}
+    with orc.deep_kernel(phi):
+        kl_h, kl_u, nll = orc.loss(leaf, prev, x, y, noise)
+        total = float(g['beta']) * kl_h + kl_u + (float(g['n_total']) / B) * nll
+        total.backward()
+        with torch.no_grad():
+            probs = orc.predict(params, prev, x, noise)
+    for k, v in [('kl_hypers', kl_h), ('kl_u', kl_u), ('nll', nll), ('total', total)]:
+        np.testing.assert_allclose(v.item(), float(g[k]), rtol=RTOL_SCALAR, err_msg=k)
+    for k in names:
+        assert rel_l2(leaf[k].grad, g[f'grad_{k}']) < REL_L2_GRAD, k
+    for k, v in phi.items():
+        if k == '4.bias':      # the RBF kernel is translation-invariant in feature space: this gradient is exactly 0
+            assert v.grad.abs().max().item() < 1e-4 and np.abs(g[f'grad_phi_{k}']).max() < 1e-4
+            continue
+        assert rel_l2(v.grad, g[f'grad_phi_{k}']) < REL_L2_GRAD, k
+    np.testing.assert_allclose(probs.numpy(), g['probs'], atol=ATOL_PROBS)

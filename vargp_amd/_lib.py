@@ -90,6 +90,8 @@ _SIGNATURES = {
     'vargp_elbo_t0_workspace_bytes': (c_size_t, [c_int] * 6),
     'vargp_elbo_t0_fwd': (c_int, [POINTER(ElboT0Desc), _P]),
     'vargp_elbo_t0_bwd': (c_int, [POINTER(ElboT0Desc)] + [_P] * 7),
+    'vargp_bias_act_fwd': (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P]),
+    'vargp_bias_act_bwd': (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, _P]),
     'vargp_elbo_tn_workspace_bytes': (c_size_t, [c_int] * 7),
     'vargp_elbo_tn_fwd': (c_int, [POINTER(ElboTnDesc), _P]),
     'vargp_elbo_tn_bwd': (c_int, [POINTER(ElboTnDesc)] + [_P] * 7),

@@ -312,6 +312,59 @@ __global__ void hyper_kl_bwd_kernel(const float* __restrict__ m, const float* __
 using namespace vargp;
 #define GRID1(total) dim3(cdiv((total), 256)), dim3(256), 0, as_stream(stream)
 
+// ---- bias + ReLU of the deep-kernel feature map (var_gp/kernels.py:80-96: Linear -> ReLU -> Linear -> ReLU -> Linear) --
+// y[r, c] = act(x[r, c] + bias[c]); one thread per element, rows x cols row-major
+__global__ void bias_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ bias, float* __restrict__ y,
+                                    int64_t total, int cols, int relu) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const float v = x[e] + bias[e % cols];
+  y[e] = relu ? fmaxf(v, 0.f) : v;
+}
+// gx = gy * (y > 0) (ReLU) or gy; gbias[c] = sum_r gx[r, c].  64 columns x 4 row lanes per block, kBiasRows rows per block;
+// column sums meet in gbias with float atomics (pre-zeroed by the launcher).
+constexpr int kBiasRows = 64;
+__global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float* __restrict__ y, const float* __restrict__ gy,
+                                                           float* __restrict__ gx, float* __restrict__ gbias, int64_t rows,
+                                                           int cols, int relu) {
+  __shared__ float red[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cx;
+  const int64_t r0 = (int64_t)blockIdx.y * kBiasRows;
+  float acc = 0.f;
+  if (col < cols) {
+    for (int64_t r = r0 + ry; r < rows && r < r0 + kBiasRows; r += 4) {
+      const int64_t e = r * cols + col;
+      const float g = (relu && !(y[e] > 0.f)) ? 0.f : gy[e];
+      gx[e] = g;
+      acc += g;
+    }
+  }
+  red[ry][cx] = acc;
+  __syncthreads();
+  if (ry == 0 && col < cols) atomicAdd(&gbias[col], red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx]);
+}
+
+extern "C" int vargp_bias_act_fwd(const float* x, const float* bias, float* y, int64_t rows, int cols, int relu,
+                                  vargp_stream_t stream) {
+  VARGP_REQUIRE(x && bias && y && rows >= 0 && cols > 0, "bias_act_fwd: bad arguments");
+  const int64_t total = rows * cols;
+  if (total == 0) return VARGP_OK;
+  hipLaunchKernelGGL(bias_act_fwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), x, bias, y, total, cols, relu);
+  return check_launch("bias_act_fwd");
+}
+
+extern "C" int vargp_bias_act_bwd(const float* y, const float* gy, float* gx, float* gbias, int64_t rows, int cols, int relu,
+                                  vargp_stream_t stream) {
+  VARGP_REQUIRE(y && gy && gx && gbias && rows >= 0 && cols > 0, "bias_act_bwd: bad arguments");
+  hipStream_t st = as_stream(stream);
+  zero_async(gbias, sizeof(float) * cols, st);
+  if (rows == 0) return VARGP_OK;
+  hipLaunchKernelGGL(bias_act_bwd_kernel, dim3(cdiv(cols, 64), cdiv(rows, kBiasRows)), dim3(256), 0, st, y, gy, gx, gbias, rows,
+                     cols, relu);
+  return check_launch("bias_act_bwd");
+}
+
 extern "C" int vargp_vec2tril_fwd(const float* vec, float* tril, int nbatch, int m, vargp_stream_t stream) {
   VARGP_REQUIRE(vec && tril && nbatch > 0 && m > 0, "vec2tril_fwd: bad arguments");
   const int64_t total = (int64_t)nbatch * m * m;

@@ -61,7 +61,30 @@ class RBFKernel(nn.Module):
 
 
 class DeepRBFKernel(RBFKernel):
-    """Deep-kernel ablation of the reference (kernels.py:80-96): out of scope for the HIP hot path."""
+    """RBF kernel on learned features phi(x) (reference: var_gp/kernels.py:80-96, the `dkl` ablation of
+    VARGP.create_clf).  `phi` is the reference's nn.Sequential (same parameter names, so state dicts and the
+    `kernel.phi.*` carry-over of create_clf are interchangeable); it is evaluated by ops.linear_act, i.e. the MFMA GEMM
+    with a fused bias / ReLU pass, forward and backward."""
 
-    def __init__(self, *a, **k):
-        raise NotImplementedError('DeepRBFKernel (dkl=True ablation) is outside the MI355X hot-path scope')
+    def __init__(self, in_size, feature_size=64, **kwargs):
+        super().__init__(feature_size, **kwargs)
+        self.phi = nn.Sequential(
+            nn.Linear(in_size, 256),
+            nn.ReLU(),
+            nn.Linear(256, 256),
+            nn.ReLU(),
+            nn.Linear(256, feature_size),
+        )
+
+    def features(self, x):
+        h = ops.linear_act(x, self.phi[0].weight, self.phi[0].bias, True)
+        h = ops.linear_act(h, self.phi[2].weight, self.phi[2].bias, True)
+        return ops.linear_act(h, self.phi[4].weight, self.phi[4].bias, False)
+
+    def compute(self, kern_samples, x, y=None):
+        x = self.features(x)
+        if y is not None:
+            if y.dim() > 2 and all(st == 0 or sz == 1 for st, sz in zip(y.stride()[:-2], y.shape[:-2])):
+                y = y[(0,) * (y.dim() - 2)]           # an expand() of one (N, D) block: map it once
+            y = self.features(y)
+        return super().compute(kern_samples, x, y=y)

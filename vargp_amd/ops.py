@@ -501,3 +501,38 @@ class _HyperKl(Function):
 
 def hyper_kl(mean, logvar, prior_mean, prior_logvar):
     return _HyperKl.apply(mean, logvar, prior_mean, prior_logvar)
+
+
+# ------------------------------------------------------------------------------------------------
+# deep-kernel feature map: Linear (+ ReLU) on the MFMA GEMM with a fused bias / activation pass
+# ------------------------------------------------------------------------------------------------
+class _LinearAct(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        require_device(x, weight, bias)
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        h = bgemm(x2, weight.mT)                                   # (rows, out)
+        y = torch.empty_like(h)
+        check(lib().vargp_bias_act_fwd(ptr(h), ptr(bias.contiguous()), ptr(y), h.shape[0], h.shape[1], int(relu),
+                                       stream_ptr()), 'vargp_bias_act_fwd')
+        ctx.save_for_backward(x2, weight, y)
+        ctx.relu, ctx.xshape = bool(relu), x.shape
+        return y.reshape(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x2, weight, y = ctx.saved_tensors
+        gy2 = gy.reshape(-1, weight.shape[0]).contiguous()
+        gh = torch.empty_like(gy2)
+        gb = torch.empty(weight.shape[0], dtype=torch.float32, device=gy.device)
+        check(lib().vargp_bias_act_bwd(ptr(y), ptr(gy2), ptr(gh), ptr(gb), gy2.shape[0], gy2.shape[1], int(ctx.relu),
+                                       stream_ptr()), 'vargp_bias_act_bwd')
+        gx = bgemm(gh, weight).reshape(ctx.xshape) if ctx.needs_input_grad[0] else None
+        gw = bgemm(gh.mT, x2) if ctx.needs_input_grad[1] else None
+        return gx, gw, gb, None
+
+
+def linear_act(x, weight, bias, relu):
+    """act(x @ weight^T + bias) over the last dim of x; weight (out, in) as torch.nn.Linear stores it."""
+    return _LinearAct.apply(x, weight, bias, relu)

@@ -50,7 +50,8 @@ class ElboTrainer:
         # directly: no autograd graph, gradients written straight into the optimiser's buffers
         is_model = gp is not None and loss_fn is None and params is None and hasattr(gp, 'draw_t0_noise')
         self._tn = bool(is_model and gp.prev_params and gp.var_mean_mask == 1.0 and gp._tn_applicable())   # csrc/elbo_tn.hip
-        self._t0 = bool(is_model and not gp.prev_params and gp.fused_first_task) or self._tn               # csrc/elbo_t0.hip
+        self._t0 = bool(is_model and not gp.prev_params and gp.fused_first_task
+                        and type(gp.kernel).__name__ == 'RBFKernel') or self._tn                           # csrc/elbo_t0.hip
         # one program (descriptor + workspace) PER SHAPE, never freed: a captured hipGraph holds raw pointers into the
         # program it was captured with, and the ragged last minibatch of an epoch runs eagerly through another shape
         self._progs, self._prog, self._seeds, self._own_grads = {}, None, {}, None

@@ -200,7 +200,7 @@ class VARGP(nn.Module):
     def loss(self, x, y):
         """(kl_hypers, kl_u, nll); the caller combines beta*kl_hypers + kl_u + (N/B)*nll
         (vargp.py:177-194, experiments/vargp.py:34)."""
-        if not self.prev_params and self.fused_first_task:
+        if not self.prev_params and self.fused_first_task and type(self.kernel) is RBFKernel:
             # first task: the native program (csrc/elbo_t0.hip) as one autograd node
             return fused.elbo_t0(self.kernel, self.z, self.u_mean, self.u_tril_vec, x, y, *self.draw_t0_noise(x))
         if self.prev_params and self.var_mean_mask == 1.0 and self._tn_applicable():
@@ -246,21 +246,27 @@ class VARGP(nn.Module):
         """Factory used by the experiment driver (vargp.py:200-243): inducing points at random data
         points per class, hyper-prior = previous task's hyper-posterior (popped from prev_params[-1],
         which is mutated like the reference does)."""
-        if dkl:
-            raise NotImplementedError('dkl=True (DeepRBFKernel ablation) is outside the MI355X hot-path scope')
         N = len(dataset)
         out_size = torch.unique(dataset.targets).size(0)
         z = torch.stack([dataset[torch.randperm(N)[:M]][0] for _ in range(out_size)])
 
-        prior_log_mean, prior_log_logvar = None, None
+        prior_log_mean, prior_log_logvar, phi_params = None, None, None
         if prev_params:
             prior_log_mean = prev_params[-1].get('kernel.log_mean')
             prior_log_logvar = prev_params[-1].get('kernel.log_logvar')
+            if dkl:      # the feature map starts from the last task's (vargp.py:218-219)
+                phi_params = {k[11:]: v for k, v in prev_params[-1].items() if k.startswith('kernel.phi.')}
             for p in prev_params:
                 for k in [k for k in p if k.startswith('kernel')]:
                     p.pop(k)
-        kernel = RBFKernel(z.size(-1), prior_log_mean=prior_log_mean, prior_log_logvar=prior_log_logvar,
-                           map_est=map_est_hypers)
+        if dkl:
+            kernel = DeepRBFKernel(z.size(-1), prior_log_mean=prior_log_mean, prior_log_logvar=prior_log_logvar,
+                                   map_est=map_est_hypers)
+            if phi_params:
+                kernel.phi.load_state_dict(phi_params)
+        else:
+            kernel = RBFKernel(z.size(-1), prior_log_mean=prior_log_mean, prior_log_logvar=prior_log_logvar,
+                               map_est=map_est_hypers)
         likelihood = MulticlassSoftmax(n_f=n_f)
         return VARGP(z, kernel, likelihood, n_var_samples=n_var_samples, ep_var_mean=ep_var_mean,
                      prev_params=prev_params)
