@@ -100,6 +100,16 @@ int vargp_chol_inv_fwd(const float* A, float eps, float* L, float* T, float* log
 int vargp_chol_inv_bwd(const float* L, const float* T, const float* gL, const float* gT, float* gA, int nbatch,
                        int n, void* ws, size_t ws_bytes, vargp_stream_t stream);
 
+/* Triangular solve against a factor L whose inverse T = L^-1 came with it from vargp_chol_inv_fwd (reference:
+ * torch.triangular_solve(B, L, upper=False), var_gp/gp_utils.py:89,92,124-134,175-182).  By design a solve is a product
+ * with T on the MFMA; these entries exist so that the op list of SURVEY.md §8(b) is complete.
+ *   fwd: X[nb, n, nrhs] = T B.     bwd: gB = T^T gX,  gL = -tril(gB X^T)  (the adjoint w.r.t. L; either may be NULL;
+ *   gB == NULL needs a workspace of nb*n*nrhs floats).
+ */
+int vargp_trsm_lower_fwd(const float* T, const float* B, float* X, int nbatch, int n, int nrhs, vargp_stream_t stream);
+int vargp_trsm_lower_bwd(const float* T, const float* X, const float* gX, float* gB, float* gL, int nbatch, int n, int nrhs,
+                         void* ws, size_t ws_bytes, vargp_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Packed lower triangle <-> matrix with softplus on the diagonal (reference: vec2tril /
  * mat2trilvec, var_gp/gp_utils.py:22-65; packing order = torch.tril_indices, row-major).

@@ -238,3 +238,22 @@ def test_linear_gaussian_ops_golden(ops):
     mu, Sig = gp_utils.gp_cond(t['lg_m'], t['lg_Kzz'], t['lg_Kzx'], t['lg_Kxx'])
     np.testing.assert_allclose(mu.cpu().numpy(), g['gc_mu'], rtol=5e-4, atol=5e-5)
     np.testing.assert_allclose(Sig.cpu().numpy(), g['gc_Sig'], rtol=5e-4, atol=5e-5)
+
+
+def test_trsm_lower_fwd_bwd(ops):
+    """X = L^-1 B through T (vargp_trsm_lower_*) against torch.linalg.solve_triangular + autograd in fp64."""
+    nb, n, nrhs = 3, 70, 45
+    A = _hn((nb, n, n), 21)
+    A = A @ A.mT / n + torch.eye(n)
+    B = _hn((nb, n, nrhs), 22)
+    gX = _hn((nb, n, nrhs), 23)
+    L, T = ops.chol_inv(A.to(DEV), 0.0)
+    Ld, Bd = L.detach().requires_grad_(True), B.to(DEV).requires_grad_(True)
+    X = ops.trsm_lower(Ld, T.detach(), Bd)
+    (X * gX.to(DEV)).sum().backward()
+    L6, B6 = L.detach().cpu().double().requires_grad_(True), B.double().requires_grad_(True)
+    X6 = torch.linalg.solve_triangular(L6, B6, upper=False)
+    (X6 * gX.double()).sum().backward()
+    assert rel_l2(X.detach().cpu(), X6.detach()) < 1e-5
+    assert rel_l2(Bd.grad.cpu(), B6.grad) < 1e-5
+    assert rel_l2(Ld.grad.cpu(), L6.grad.tril()) < 1e-5

@@ -138,6 +138,7 @@ def test_trainer_direct_program_equals_autograd_route_t1():
 
     # graph replay == eager (native noise: same seed, same counter)
     ops.set_cholesky_error_mode('defer')
+    ops.reset_linalg_errors()
     try:
         res = []
         for mode in ('eager', 'graph'):

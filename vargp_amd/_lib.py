@@ -70,6 +70,8 @@ _SIGNATURES = {
     'vargp_chol_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'vargp_chol_inv_fwd': (c_int, [_P, c_float, _P, _P, _P, _P, c_int, c_int, _P, c_size_t, _P]),
     'vargp_chol_inv_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, c_size_t, _P]),
+    'vargp_trsm_lower_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
+    'vargp_trsm_lower_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P, c_size_t, _P]),
     'vargp_vec2tril_fwd': (c_int, [_P, _P, c_int, c_int, _P]),
     'vargp_vec2tril_bwd': (c_int, [_P, _P, _P, c_int, c_int, _P]),
     'vargp_mat2trilvec': (c_int, [_P, _P, c_int, c_int, _P]),
@@ -151,6 +153,27 @@ def ptr(t):
 
 def workspace(nbytes, device):
     return torch.empty((int(nbytes) + 3) // 4, dtype=torch.float32, device=device)
+
+
+_scratch_pool = {}
+
+
+def scratch(nbytes, device):
+    """Pooled per-op scratch: ONE growing buffer per (device, stream).  Every C-ABI op uses its workspace only inside the
+    call, and calls on a stream execute in order, so consecutive ops can share the buffer (no allocation per op; stable
+    addresses under hipGraph capture once it has reached its final size)."""
+    dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
+    need = (int(nbytes) + 3) // 4
+    if torch.cuda.is_current_stream_capturing():
+        # a captured graph keeps raw pointers: give it memory of its own (the graph's private pool keeps it alive), never
+        # the shared buffer, which may be re-allocated when it grows later
+        return torch.empty(need, dtype=torch.float32, device=device)
+    buf = _scratch_pool.get(key)
+    if buf is None or buf.numel() < need:
+        buf = _scratch_pool[key] = torch.empty(max(need, 2 * (buf.numel() if buf is not None else 0)),
+                                               dtype=torch.float32, device=device)
+    return buf
 
 
 def prof_enable(on=True):

@@ -433,3 +433,30 @@ int vargp::chol_inv_bwd_impl(const float* L, const float* T, const float* gL, co
   if (rc) return rc;
   return check_launch("chol_inv_bwd");
 }
+
+// Triangular solve against a factor whose inverse came with it (SURVEY §8b lists trsm_lower as an op of its own; here
+// it is, by design, a GEMM with T = L^-1):  X = L^-1 B = T B.
+extern "C" int vargp_trsm_lower_fwd(const float* T, const float* B, float* X, int nbatch, int n, int nrhs,
+                                    vargp_stream_t stream) {
+  VARGP_REQUIRE(T && B && X && nbatch > 0 && n > 0 && nrhs > 0, "trsm_lower_fwd: bad arguments");
+  return sq_gemm(T, n, (int64_t)n * n, 0, 1, B, nrhs, (int64_t)n * nrhs, 0, 0, X, nrhs, (int64_t)n * nrhs, nullptr, 1.f, 0.f, n,
+                 nrhs, n, 0, nbatch, as_stream(stream));
+}
+
+// Adjoint of X = L^-1 B (torch.triangular_solve backward, gp_utils.py:89-134 call sites):  gB = L^-T gX = T^T gX,
+// gL = -tril(gB X^T)  (either output may be NULL)
+extern "C" int vargp_trsm_lower_bwd(const float* T, const float* X, const float* gX, float* gB, float* gL, int nbatch, int n,
+                                    int nrhs, void* ws, size_t ws_bytes, vargp_stream_t stream) {
+  VARGP_REQUIRE(T && X && gX && nbatch > 0 && n > 0 && nrhs > 0, "trsm_lower_bwd: bad arguments");
+  hipStream_t st = as_stream(stream);
+  float* gBp = gB;
+  if (!gBp) {
+    VARGP_REQUIRE(ws && ws_bytes >= sizeof(float) * (size_t)nbatch * n * nrhs, "trsm_lower_bwd: workspace too small");
+    gBp = reinterpret_cast<float*>(ws);
+  }
+  int rc = sq_gemm(T, n, (int64_t)n * n, 1, 2, gX, nrhs, (int64_t)n * nrhs, 0, 0, gBp, nrhs, (int64_t)n * nrhs, nullptr, 1.f,
+                   0.f, n, nrhs, n, 0, nbatch, st);
+  if (rc || !gL) return rc;
+  return sq_gemm(gBp, nrhs, (int64_t)n * nrhs, 0, 0, X, nrhs, (int64_t)n * nrhs, 1, 0, gL, n, (int64_t)n * n, nullptr, -1.f, 0.f,
+                 n, n, nrhs, 1, nbatch, st);
+}

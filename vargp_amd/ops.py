@@ -6,7 +6,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from . import _lib
-from ._lib import GemmDesc, check, lib, ptr, require_device, stream_ptr, workspace
+from ._lib import GemmDesc, check, lib, ptr, require_device, scratch, stream_ptr
 
 NONE, LOWER, UPPER = 0, 1, 2
 _FLIP = {NONE: NONE, LOWER: UPPER, UPPER: LOWER}
@@ -178,7 +178,7 @@ class _RbfGram(Function):
         S, C, M, D = theta.shape[0], X.shape[0], X.shape[1], X.shape[2]
         N = M if Y is None else Y.shape[-2]
         K = torch.empty(S, C, M, N, dtype=torch.float32, device=X.device)
-        ws = workspace(lib().vargp_rbf_workspace_bytes(S, C, M, N, D, 0), X.device)
+        ws = scratch(lib().vargp_rbf_workspace_bytes(S, C, M, N, D, 0), X.device)
         check(lib().vargp_rbf_gram_fwd(ptr(theta), ptr(X), ptr(Y), ptr(K), S, C, M, N, D, int(y_shared), ptr(ws),
                                        ws.numel() * 4, stream_ptr()), 'vargp_rbf_gram_fwd')
         ctx.save_for_backward(theta, X, Y, K)
@@ -196,7 +196,7 @@ class _RbfGram(Function):
         want_gY = Y is not None and ctx.needs_input_grad[2]
         gY = torch.empty_like(Y) if want_gY else None
         gtheta = torch.empty_like(theta)
-        ws = workspace(lib().vargp_rbf_workspace_bytes(S, C, M, N, D, 1), X.device)
+        ws = scratch(lib().vargp_rbf_workspace_bytes(S, C, M, N, D, 1), X.device)
         check(lib().vargp_rbf_gram_bwd(ptr(theta), ptr(X), ptr(Y), ptr(K), ptr(gK), ptr(gX), ptr(gY), ptr(gtheta),
                                        S, C, M, N, D, ctx.y_shared, 0, ptr(ws), ws.numel() * 4, stream_ptr()),
               'vargp_rbf_gram_bwd')
@@ -236,7 +236,7 @@ class _CholInv(Function):
         need_T = want_inv or ctx.needs_input_grad[0]
         T = torch.empty_like(Ac) if need_T else None
         info = torch.empty(nb, dtype=torch.int32, device=A.device)
-        ws = workspace(lib().vargp_chol_workspace_bytes(nb, n, 0), A.device)
+        ws = scratch(lib().vargp_chol_workspace_bytes(nb, n, 0), A.device)
         check(lib().vargp_chol_inv_fwd(ptr(Ac), float(eps), ptr(L), ptr(T), None, ptr(info), nb, n, ptr(ws),
                                        ws.numel() * 4, stream_ptr()), 'vargp_chol_inv_fwd')
         _note_chol_errors(info)
@@ -259,7 +259,7 @@ class _CholInv(Function):
         gL = gL.contiguous() if gL is not None else None
         gT = gT.contiguous() if (ctx.want_inv and gT is not None) else None
         gA = torch.empty_like(L)
-        ws = workspace(lib().vargp_chol_workspace_bytes(nb, n, 1), L.device)
+        ws = scratch(lib().vargp_chol_workspace_bytes(nb, n, 1), L.device)
         check(lib().vargp_chol_inv_bwd(ptr(L), ptr(T), ptr(gL), ptr(gT), ptr(gA), nb, n, ptr(ws), ws.numel() * 4,
                                        stream_ptr()), 'vargp_chol_inv_bwd')
         return gA, None, None
@@ -536,3 +536,38 @@ class _LinearAct(Function):
 def linear_act(x, weight, bias, relu):
     """act(x @ weight^T + bias) over the last dim of x; weight (out, in) as torch.nn.Linear stores it."""
     return _LinearAct.apply(x, weight, bias, relu)
+
+
+# ------------------------------------------------------------------------------------------------
+# triangular solve against a factor that came with its inverse (an op of its own in SURVEY §8b's list)
+# ------------------------------------------------------------------------------------------------
+class _TrsmLower(Function):
+    @staticmethod
+    def forward(ctx, L, T, B):
+        require_device(L, T, B)
+        T, B = T.contiguous(), B.contiguous()
+        n, nrhs = B.shape[-2:]
+        nb = B.numel() // (n * nrhs)
+        assert T.shape[-1] == n and T.numel() == nb * n * n, 'trsm_lower: one factor per right-hand side block'
+        X = torch.empty_like(B)
+        check(lib().vargp_trsm_lower_fwd(ptr(T), ptr(B), ptr(X), nb, n, nrhs, stream_ptr()), 'vargp_trsm_lower_fwd')
+        ctx.save_for_backward(T, X)
+        return X
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gX):
+        T, X = ctx.saved_tensors
+        n, nrhs = X.shape[-2:]
+        nb = X.numel() // (n * nrhs)
+        gB = torch.empty_like(X)
+        gL = torch.empty_like(T) if ctx.needs_input_grad[0] else None
+        check(lib().vargp_trsm_lower_bwd(ptr(T), ptr(X), ptr(gX.contiguous()), ptr(gB), ptr(gL), nb, n, nrhs, None, 0,
+                                         stream_ptr()), 'vargp_trsm_lower_bwd')
+        return gL, None, gB
+
+
+def trsm_lower(L, T, B):
+    """X = L^-1 B for a factor L that came with T = L^-1 from chol_inv (gradients flow to L and B; T is L's inverse,
+    not an independent input)."""
+    return _TrsmLower.apply(L, T, B)
