@@ -10,6 +10,8 @@ D=784, B=512, synthetic data resident in HBM.  One step = zero_grad + VARGP.loss
 + (N>1: one RCCL all-reduce) + Yogi step, exactly as experiments/vargp.py:29-37 does it.
 N>1 is sample-parallel WEAK scaling: every rank evaluates its own 3 of the 3N hyper-samples, so the
 job does N Cfg2-steps worth of work per global step and `value` = N * global_steps / time.
+`--workload smnist_s64` is BASELINE config 4 as north_star states it: a FIXED total of 64 hyper-samples split over
+the N ranks (STRONG scaling, uneven shards if 64 % N != 0), `value` = global ELBO steps / s.
 Prints ONE JSON line (rank 0).
 """
 import argparse
@@ -33,7 +35,7 @@ DOMINANT_TAG = 'rbf_kuf'       # the K_uf distance GEMM incl. its split-K combin
 # Secondary workloads (not the driver's default line): other BASELINE configs, same step definition.
 WORKLOADS = {
     'smnist': dict(S=3, M=100, n_prev=0, desc='BASELINE config 2 (Split-MNIST t=0): S3 F10 C10 M100 D784 B512 ELBO step'),
-    'smnist_s64': dict(S=64, M=100, n_prev=0, desc='BASELINE config 4 (Split-MNIST t=0, 64 hyper-samples x 10 classes), samples split over the ranks'),
+    'smnist_s64': dict(S=64, M=100, n_prev=0, strong=True, desc='BASELINE config 4 (Split-MNIST t=0, 64 hyper-samples x 10 classes), samples split over the ranks'),
     'smnist_t1': dict(S=3, M=100, n_prev=1, desc='Split-MNIST task 1 (Mt=200), M=100, S=3 (native block-structured program)'),
     'smnist_t4': dict(S=3, M=100, n_prev=4, desc='Split-MNIST task 4 (Mt=500), M=100, S=3 (native block-structured program)'),
     'pmnist_t0': dict(S=10, M=200, n_prev=0, desc='BASELINE config 3 (Permuted-MNIST), task 0: M=200, S=10'),
@@ -184,13 +186,20 @@ def main():
                     help='skip the back-to-back re-launches that time the dominant kernels (keeps a rocprof trace clean)')
     args = ap.parse_args()
     global S, M, N_PREV
-    if args.workload != 'stress':
-        S, M, N_PREV = (WORKLOADS[args.workload][k] for k in ('S', 'M', 'n_prev'))
-    dominant_flops = 2.0 * S * C * M * (N_PREV + 1) * B * D     # one K_uf launch of compute_pf_diag (SURVEY §8d)
-
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    strong, counts, s_total = False, None, None
+    if args.workload != 'stress':
+        S, M, N_PREV = (WORKLOADS[args.workload][k] for k in ('S', 'M', 'n_prev'))
+        strong = bool(WORKLOADS[args.workload].get('strong'))
+        if strong:       # a fixed sample total divided over the ranks
+            from vargp_amd.train import split_samples
+            s_total = S
+            counts = split_samples(s_total, world)
+            S = counts[rank]
+    dominant_flops = 2.0 * S * C * M * (N_PREV + 1) * B * D     # one K_uf launch of compute_pf_diag (SURVEY §8d)
+
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
@@ -206,7 +215,7 @@ def main():
     gp, x, y = make_model(device)
     rtol, rtol_on = elbo_check(gp, x, y) if rank == 0 else (None, None)
     p0 = snapshot(gp) if rank == 0 else None     # the CPU baseline runs the same (initial) model
-    trainer = ElboTrainer(gp, lr=LR, beta=BETA, n_total=N_TOTAL)
+    trainer = ElboTrainer(gp, lr=LR, beta=BETA, n_total=N_TOTAL, sample_counts=counts if world > 1 else None)
 
     def sync():
         if world > 1:
@@ -289,15 +298,18 @@ def main():
     errs = ops.linalg_error_count()
 
     if rank == 0:
-        value = world * args.steps / dt
+        value = (1 if strong else world) * args.steps / dt
         avg_s = kern_ms / max(kern_n, 1) * 1e-3
         achieved = dominant_flops / avg_s / 1e12 if kern_n else None
-        res = dict(metric='ELBO steps/sec', value=value, unit='ELBO steps/s (Cfg2 step: S=3 hyper-samples per GPU)',
+        res = dict(metric='ELBO steps/sec', value=value,
+                   unit=('ELBO steps/s (global steps of the %d-sample ELBO)' % s_total) if strong
+                   else 'ELBO steps/s (Cfg2 step: S=%d hyper-samples per GPU)' % S,
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * dt / args.steps,
                    ms_per_step_median=median_ms,
-                   higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
-                   config=dict(workload=WORKLOADS[args.workload]['desc'], S_per_gpu=S, Mt=M * (N_PREV + 1),
-                               S_total=S * world, F=F_, C=C, M=M, D=D, B=B, N=N_TOTAL, beta=BETA,
+                   higher_is_better=True, scaling='strong' if strong else 'weak', vs_baseline=None, dtype='f32',
+                   data='synthetic',
+                   config=dict(workload=WORKLOADS[args.workload]['desc'], S_per_gpu=counts if strong else S, Mt=M * (N_PREV + 1),
+                               S_total=s_total if strong else S * world, F=F_, C=C, M=M, D=D, B=B, N=N_TOTAL, beta=BETA,
                                optimizer='yogi', parallelism=f'sample-parallel x{world}',
                                launch=('hipGraph replay' + (' (2 graphs around the all-reduce)' if world > 1 else '')) if use_graph
                                else 'eager'),

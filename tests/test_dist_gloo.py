@@ -27,7 +27,7 @@ def _problem(n_prev):
     return orc.make_problem(S_LOCAL * WORLD, F_, C, M, D, B, n_prev=n_prev, seed=9, kind='toy')
 
 
-def _worker(rank, port, n_prev, out):
+def _worker(rank, port, n_prev, out, counts=None):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD))
     dist.init_process_group('gloo', rank=rank, world_size=WORLD)
     try:
@@ -39,16 +39,18 @@ def _worker(rank, port, n_prev, out):
         leaves = {k: torch.nn.Parameter(params[k].clone()) for k in names}
         full = dict(params, **leaves)
         Mt_prev = n_prev * M
+        s_loc = S_LOCAL if counts is None else counts[rank]
+        s_tot = S_LOCAL * WORLD if counts is None else sum(counts)
 
         def loss_fn(xb, yb):
-            nz = dict(eps_theta=noise.draw('eps_theta', (S_LOCAL, D + 1), 'cpu'))
+            nz = dict(eps_theta=noise.draw('eps_theta', (s_loc, D + 1), 'cpu'))
             if n_prev:
-                nz['eps_u'] = noise.draw('eps_u', (S_LOCAL * WORLD, S_LOCAL, C, Mt_prev), 'cpu', sample_dim=1)
-            nz['eps_f'] = noise.draw('eps_f', (S_LOCAL, F_, C, B), 'cpu')
+                nz['eps_u'] = noise.draw('eps_u', (s_tot, s_loc, C, Mt_prev), 'cpu', sample_dim=1)
+            nz['eps_f'] = noise.draw('eps_f', (s_loc, F_, C, B), 'cpu')
             return orc.loss(full, prev, xb, yb, nz)
 
         tr = ElboTrainer(None, beta=2.0, n_total=64, noise_seed=SEED, params=[leaves[k] for k in names],
-                         loss_fn=loss_fn, optimizer=lambda ps: torch.optim.SGD(ps, lr=0.0))
+                         loss_fn=loss_fn, optimizer=lambda ps: torch.optim.SGD(ps, lr=0.0), sample_counts=counts)
         assert tr.world == WORLD and tr.rank == rank
         kl_h, kl_u, nll = tr.step(x, y)
         if rank == 0:
@@ -59,12 +61,13 @@ def _worker(rank, port, n_prev, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('n_prev', [0, 1])
-def test_sample_parallel_matches_single_process(n_prev):
+@pytest.mark.parametrize('n_prev,counts', [(0, None), (1, None), (0, [2, 1]), (1, [1, 2])])
+def test_sample_parallel_matches_single_process(n_prev, counts):
+    """counts: a sample total that the ranks cannot divide evenly (3 samples over 2 ranks): uneven shards, weights S_r / S."""
     ctx = mp.get_context('spawn')
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, port, n_prev, out)) for r in range(WORLD)]
+    procs = [ctx.Process(target=_worker, args=(r, port, n_prev, out, counts)) for r in range(WORLD)]
     for p in procs:
         p.start()
     got = out.get(timeout=120)
@@ -75,7 +78,7 @@ def test_sample_parallel_matches_single_process(n_prev):
     # single process, all S_LOCAL*WORLD samples, same global noise (same generator seed, same draw order)
     params, prev, x, y, _ = _problem(n_prev)
     gen = torch.Generator().manual_seed(SEED)
-    S = S_LOCAL * WORLD
+    S = S_LOCAL * WORLD if counts is None else sum(counts)
     nz = dict(eps_theta=torch.randn(S, D + 1, generator=gen))
     if n_prev:
         # each rank draws (n_v, world*S_local, ...) and keeps its slice of dim 1; n_v = S_total here
@@ -88,6 +91,22 @@ def test_sample_parallel_matches_single_process(n_prev):
     for k, g in grads.items():
         err = np.linalg.norm(got['grads'][k] - g.numpy()) / np.linalg.norm(g.numpy())
         assert err < 1e-4, (k, err)
+
+
+def test_split_samples_and_uneven_noise_shards():
+    from vargp_amd import noise
+    from vargp_amd.train import split_samples
+    assert split_samples(64, 8) == [8] * 8 and split_samples(64, 3) == [22, 21, 21] and split_samples(3, 2) == [2, 1]
+    try:
+        counts = [3, 1, 2]
+        parts = []
+        for r in range(3):
+            noise.set_shard(r, 3, 5, 'cpu', counts)
+            parts.append(noise.draw('eps_f', (counts[r], 2, 3, 4), 'cpu'))
+        gen = torch.Generator().manual_seed(5)
+        assert torch.equal(torch.cat(parts), torch.randn(6, 2, 3, 4, generator=gen))
+    finally:
+        noise.clear_shard()
 
 
 def test_noise_shards_tile_the_global_draw():

@@ -98,3 +98,50 @@ def test_two_ranks_equal_single_process(use_graph):
     for k in sd1:
         err = np.linalg.norm(sd2[k] - sd1[k]) / max(np.linalg.norm(sd1[k]), 1e-30)
         assert err < 1e-4, (k, err)
+
+
+def _worker_uneven(rank, port, counts, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(len(counts)))
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=len(counts))
+    try:
+        from vargp_amd.train import ElboTrainer
+        gp, x, y = _model(counts[rank])
+        tr = ElboTrainer(gp, lr=1e-3, beta=2.0, n_total=10 * B, noise_seed=SEED, sample_counts=counts)
+        outs = [[o.item() for o in tr.step(x, y)] for _ in range(2)]
+        torch.cuda.synchronize()
+        if rank == 0:
+            q.put((outs, {k: v.detach().cpu().numpy() for k, v in gp.state_dict().items()}))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_uneven_sample_split_equals_single_process():
+    """5 hyper-samples over 2 ranks (3 + 2): weights S_r / S, noise = slices of one global draw."""
+    counts = [3, 2]
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_uneven, args=(r, port, counts, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs2, sd2 = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    from vargp_amd import noise
+    from vargp_amd.train import ElboTrainer
+    try:
+        gp, x, y = _model(sum(counts))
+        tr = ElboTrainer(gp, lr=1e-3, beta=2.0, n_total=10 * B, noise_seed=SEED)
+        outs1 = [[o.item() for o in tr.step(x, y)] for _ in range(2)]
+        sd1 = {k: v.detach().cpu().numpy() for k, v in gp.state_dict().items()}
+    finally:
+        noise.clear_shard()
+    np.testing.assert_allclose(np.array(outs2), np.array(outs1), rtol=2e-4)
+    for k in sd1:
+        err = np.linalg.norm(sd2[k] - sd1[k]) / max(np.linalg.norm(sd1[k]), 1e-30)
+        assert err < 1e-4, (k, err)

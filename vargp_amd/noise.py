@@ -28,13 +28,14 @@ def inject(**tensors):
         _injected.update(old)
 
 
-def set_shard(rank, world, seed, device):
-    """Sample-parallel mode: every rank draws the same global tensor from a generator seeded with
-    `seed` and keeps rows [rank*S, (rank+1)*S) of a (world*S, ...) draw."""
+def set_shard(rank, world, seed, device, counts=None):
+    """Sample-parallel mode: every rank draws the same global tensor from a generator seeded with `seed` and keeps its
+    rows of the sample dimension.  `counts[r]` = hyper-samples of rank r (default: the same number on every rank, taken
+    from the requested shape); rank r owns rows [sum(counts[:r]), sum(counts[:r+1])) of a (sum(counts), ...) draw."""
     global _shard
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
-    _shard = (rank, world, gen)
+    _shard = (rank, world, gen, None if counts is None else [int(c) for c in counts])
 
 
 def clear_shard():
@@ -49,9 +50,15 @@ def draw(name, shape, device, sample_dim=0):
         assert tuple(t.shape) == tuple(shape), (name, tuple(t.shape), tuple(shape))
         return t.to(device)
     if _shard is not None:
-        rank, world, gen = _shard
+        rank, world, gen, counts = _shard
         full = list(shape)
-        full[sample_dim] *= world
+        if counts is None:
+            full[sample_dim] *= world
+            first = rank * shape[sample_dim]
+        else:
+            assert shape[sample_dim] == counts[rank], (name, shape, counts, rank)
+            full[sample_dim] = sum(counts)
+            first = sum(counts[:rank])
         g = torch.randn(*full, device=device, generator=gen)
-        return g.narrow(sample_dim, rank * shape[sample_dim], shape[sample_dim])
+        return g.narrow(sample_dim, first, shape[sample_dim])
     return torch.randn(*shape, device=device)

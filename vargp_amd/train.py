@@ -3,9 +3,12 @@
 sample-parallel multi-GPU exchange (one all-reduce of [grads | kl_u | nll]).
 
 Sample-parallel sharding: every rank holds all parameters and the same minibatch and
-evaluates `gp.n_v` of the world*gp.n_v hyper-parameter samples; the per-rank partial means combine
-linearly, so   total = beta*kl_hypers + mean_r kl_u_r + (N/B) mean_r nll_r.
-Each rank back-propagates its share divided by the world size and ONE all-reduce(sum) over a flat
+evaluates its `gp.n_v = S_r` of the S = sum_r S_r hyper-parameter samples; the per-rank partial means combine
+linearly with the weights w_r = S_r / S, so   total = beta*kl_hypers + sum_r w_r kl_u_r + (N/B) sum_r w_r nll_r.
+The S_r need not be equal (S not divisible by the number of ranks: `split_samples` hands the remainder to the first
+ranks, at most one sample of imbalance), which is how a fixed sample count -- BASELINE config 4: 64 samples over 8 GPUs --
+is divided without any exchange inside the step.
+Each rank back-propagates its share times w_r and ONE all-reduce(sum) over a flat
 fp32 buffer [grad(z) | grad(u_mean) | grad(u_tril_vec) | grad(log_mean) | grad(log_logvar) | kl_u | nll]
 yields identical gradients on every rank.  Gradients are views into that flat buffer, so there is no
 pack/unpack copy.
@@ -17,12 +20,18 @@ from . import noise
 from .optim import Yogi
 
 
+def split_samples(total, world):
+    """Per-rank hyper-sample counts for `total` samples over `world` ranks: total // world each, the first total % world
+    ranks one more."""
+    return [total // world + (1 if r < total % world else 0) for r in range(world)]
+
+
 class ElboTrainer:
     """`gp` is a vargp_amd VARGP module.  For tests of the exchange logic on CPU (gloo) the model can be
     replaced by any `loss_fn(x, y) -> (kl_hypers, kl_u, nll)` over an explicit `params` list."""
 
     def __init__(self, gp=None, lr=1e-2, beta=1.0, n_total=None, group=None, noise_seed=1234, optimizer=None,
-                 params=None, loss_fn=None, native_noise=True):
+                 params=None, loss_fn=None, native_noise=True, sample_counts=None):
         self.gp = gp
         self.loss_fn = loss_fn if loss_fn is not None else gp.loss
         self.beta = float(beta)
@@ -42,8 +51,18 @@ class ElboTrainer:
         self.optim = optimizer if optimizer is not None else Yogi(self.params, lr=lr)
         if callable(self.optim) and not hasattr(self.optim, 'step'):
             self.optim = self.optim(self.params)
+        # hyper-samples per rank (default: gp.n_v on every rank) -> this rank's weight and first global sample index
+        self.sample_counts = None if sample_counts is None else [int(c) for c in sample_counts]
+        if self.sample_counts is not None:
+            assert len(self.sample_counts) == self.world and min(self.sample_counts) > 0, self.sample_counts
+            assert gp is None or not hasattr(gp, 'n_v') or gp.kernel.map_est or gp.n_v == self.sample_counts[self.rank]
+            self.weight = self.sample_counts[self.rank] / float(sum(self.sample_counts))
+            self.sample_offset = sum(self.sample_counts[:self.rank])
+        else:
+            self.weight = 1.0 / self.world
+            self.sample_offset = None          # rank * S, S known at the first step
         if self.world > 1:
-            noise.set_shard(self.rank, self.world, noise_seed, dev)
+            noise.set_shard(self.rank, self.world, noise_seed, dev, self.sample_counts)
 
         self.graph = None
         # models on a native program (fused.T0Program: first task; fused.TnProgram: later tasks, ep_var_mean=True) drive it
@@ -195,7 +214,8 @@ class ElboTrainer:
             if shape not in self._progs:
                 self._progs[shape] = (TnProgram if self._tn else T0Program)(*shape, x.device, kern.map_est)
                 if self.native_noise:
-                    self._progs[shape].set_rng(self.noise_seed, self._rng_counter, self.rank * S)
+                    self._progs[shape].set_rng(self.noise_seed, self._rng_counter,
+                                               self.rank * S if self.sample_offset is None else self.sample_offset)
             self._prog = self._progs[shape]
         key = (scale, w)
         if key not in self._seeds:
@@ -209,15 +229,15 @@ class ElboTrainer:
         return scal
 
     def _local_part(self, x, y):
-        """This rank's share: gradients of (beta kl_h + kl_u_r + (N/B) nll_r) / world accumulated into the flat
-        buffer, whose tail carries kl_u_r / world and nll_r / world."""
+        """This rank's share: gradients of w_r (beta kl_h + kl_u_r + (N/B) nll_r) accumulated into the flat buffer, whose
+        tail carries w_r kl_u_r and w_r nll_r  (w_r = S_r / S; 1 / world for equal shards)."""
         scale = (self.n_total if self.n_total is not None else x.size(0)) / x.size(0)
         if self.params[0].grad is None or self.params[0].grad.data_ptr() != self.flat.data_ptr():
             off = 0
             for p in self.params:                      # (re-)attach the gradient views of the flat buffer
                 p.grad = self.flat[off:off + p.numel()].view_as(p)
                 off += p.numel()
-        w = 1.0 / self.world
+        w = self.weight
         if self._t0:
             scal = self._t0_fwd_bwd(x, y, scale, w)      # overwrites every gradient view of the flat buffer
             torch.mul(scal[1:3], w, out=self.scalars)
