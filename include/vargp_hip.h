@@ -259,6 +259,21 @@ int vargp_elbo_tn_fwd(const vargp_elbo_tn_desc* d, vargp_stream_t stream);
 int vargp_elbo_tn_bwd(const vargp_elbo_tn_desc* d, const float* seeds, float* g_log_mean, float* g_log_logvar, float* g_z,
                       float* g_u_mean, float* g_u_tril_vec, vargp_stream_t stream);
 int vargp_elbo_tn_moments(const vargp_elbo_tn_desc* d, float** mu, float** var);
+/* The same ELBO over a data set swept in minibatch tiles (BASELINE config 5: N = 1e6, M = 2048, K_uf tiled in HBM): loss
+ * AND gradient, with everything that does not depend on the data (kernel matrix of the inducing points, factorisation,
+ * small products, KL) computed once.  Workspace / descriptor as for fwd with d->B = the widest tile; d->y must be non-NULL
+ * (any label pointer), d->x is not read.
+ *   begin: theta, K(z_<=t), L, T, the small products, kl_hypers and kl_u into scalars[0..1], scalars[2] = 0, accumulators = 0
+ *   tile : x (Bt, D), y (Bt), Bt <= d->B, eps_f (S, F, C, Bt) or NULL (native noise, one generator step per tile):
+ *          scalars[2] += the tile's nll; the tile's share of every gradient is accumulated
+ *   end  : Cholesky / kernel-matrix backward of the accumulated gradients; OVERWRITES the five gradient buffers with the
+ *          gradient of seeds . (kl_hypers, kl_u, sum of the tiles' nll)
+ * seeds (device, 3 floats) must be the same pointer contents for every tile and for end. */
+int vargp_elbo_tn_begin(const vargp_elbo_tn_desc* d, vargp_stream_t stream);
+int vargp_elbo_tn_tile(const vargp_elbo_tn_desc* d, const float* seeds, const float* x, const int64_t* y, const float* eps_f,
+                       int Bt, vargp_stream_t stream);
+int vargp_elbo_tn_end(const vargp_elbo_tn_desc* d, const float* seeds, float* g_log_mean, float* g_log_logvar, float* g_z,
+                      float* g_u_mean, float* g_u_tril_vec, vargp_stream_t stream);
 
 /* Same update for up to 8 tensors in one launch.  `step` (device float) = the step count t.
  * step_mode 0: use t as is.  1: use t + 1 (the caller advances the stored count elsewhere, e.g. through the `bump`

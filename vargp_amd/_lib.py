@@ -97,6 +97,9 @@ _SIGNATURES = {
     'vargp_elbo_tn_workspace_bytes': (c_size_t, [c_int] * 7),
     'vargp_elbo_tn_fwd': (c_int, [POINTER(ElboTnDesc), _P]),
     'vargp_elbo_tn_bwd': (c_int, [POINTER(ElboTnDesc)] + [_P] * 7),
+    'vargp_elbo_tn_begin': (c_int, [POINTER(ElboTnDesc), _P]),
+    'vargp_elbo_tn_tile': (c_int, [POINTER(ElboTnDesc), _P, _P, _P, _P, c_int, _P]),
+    'vargp_elbo_tn_end': (c_int, [POINTER(ElboTnDesc)] + [_P] * 7),
     'vargp_elbo_tn_moments': (c_int, [POINTER(ElboTnDesc), POINTER(c_void_p), POINTER(c_void_p)]),
     'vargp_prof_enable': (c_int, [c_int]),
     'vargp_prof_read': (c_int, [c_char_p, POINTER(ctypes.c_double), POINTER(c_int64)]),

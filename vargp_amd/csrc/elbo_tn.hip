@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void tn_bwd_head_kernel(const float* __restric
                                                           float* __restrict__ gP, float* __restrict__ gQPs,
                                                           float* __restrict__ gkd, float eps, int S, int M, int Mt, int B,
                                                           int NRs, int npd, int nrest, float* __restrict__ zero_begin,
-                                                          int64_t zero_count) {
+                                                          int64_t zero_count, int accumulate) {
   __shared__ float red[4];
   const float g = seeds[1] / (float)S;
   if ((int)blockIdx.x >= npd + nrest) {       // zero-fill of the r / c / gtheta accumulators of the kernel-matrix backward
@@ -294,10 +294,14 @@ __global__ __launch_bounds__(256) void tn_bwd_head_kernel(const float* __restric
       accv += gv;
     }
     const float t = block_sum<256>(acc, red);
-    if (threadIdx.x == 0) gQPs[(b * Mt + m) * NRs] = t + (m >= Mt - M ? g * am : 0.f);
+    if (threadIdx.x == 0) {
+      // accumulate (N-tiled ELBO): this minibatch tile's share on top of the earlier tiles'; the KL term comes at the end
+      if (accumulate) gQPs[(b * Mt + m) * NRs] += t;
+      else gQPs[(b * Mt + m) * NRs] = t + (m >= Mt - M ? g * am : 0.f);
+    }
     if (m == 0) {
       const float tv = block_sum<256>(accv, red);
-      if (threadIdx.x == 0) gkd[b] = tv;
+      if (threadIdx.x == 0) { if (accumulate) gkd[b] += tv; else gkd[b] = tv; }
     }
     return;
   }
@@ -362,11 +366,59 @@ __global__ __launch_bounds__(256) void tn_unpack_kernel(const float* __restrict_
   g_z[e] = gz_all[(c * Mt + (Mt - M) + i) * D + d];
 }
 
-static int check_tn(const vargp_elbo_tn_desc* d, const char* who) {
+// N-tiled ELBO, start of a minibatch tile: zero the per-tile accumulators (softmax gradients, column sums of W_uf) and,
+// with native noise, draw this tile's likelihood noise (one generator step per tile).
+__global__ __launch_bounds__(256) void tn_tile_prep_kernel(float* __restrict__ z0, int64_t n0, float* __restrict__ z1, int64_t n1,
+                                                           int nzero, int native, uint64_t seed, const uint32_t* rng_counter,
+                                                           int64_t g0_f, int64_t n_f, float* __restrict__ eps_f_out) {
+  const int blk = blockIdx.x, tid = threadIdx.x;
+  if (blk < nzero) {
+    for (int64_t i = (int64_t)blk * 256 + tid; i < n0 + n1; i += (int64_t)nzero * 256) {
+      if (i < n0) z0[i] = 0.f; else z1[i - n0] = 0.f;
+    }
+    return;
+  }
+  if (!native) return;
+  const uint32_t step = rng_counter[0];
+  const int nr = (int)gridDim.x - nzero;
+  const int64_t gfirst = g0_f >> 2, glast = (g0_f + n_f + 3) >> 2;
+  for (int64_t G = gfirst + (int64_t)(blk - nzero) * 256 + tid; G < glast; G += (int64_t)nr * 256) {
+    float v[4];
+    normal4(seed, kStreamF, (uint64_t)G, step, v);
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      const int64_t i = 4 * G + l - g0_f;
+      if (i >= 0 && i < n_f) eps_f_out[i] = v[l];
+    }
+  }
+}
+
+// N-tiled ELBO, end: the KL's share of the small-product gradients on the current task's block (what the head kernel adds
+// in the one-minibatch program):  gQPs[.., 0] += g a_t,  gQPs[.., H columns] += g tril(H_t).     (g = seed_kl / S)
+__global__ void tn_kl_bwd_kernel(const float* __restrict__ QPs, float* __restrict__ gQPs, const float* __restrict__ seeds,
+                                 int S, int M, int Mt, int NRs, int64_t total) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // (b, i, col) over the last block's rows
+  if (e >= total) return;
+  const int col = e % NRs, i = (e / NRs) % M;
+  const int64_t b = e / ((int64_t)NRs * M);
+  const float g = seeds[1] / (float)S;
+  const int64_t off = (b * Mt + (Mt - M) + i) * NRs + col;
+  if (col == 0 || (col >= 4 && col - 4 <= i && col < 4 + M)) gQPs[off] += g * QPs[off];
+}
+
+static int check_tn(const vargp_elbo_tn_desc* d, const char* who, bool tiled = false) {
   VARGP_REQUIRE(d, "%s: null descriptor", who);
   VARGP_REQUIRE(d->S > 0 && d->C > 0 && d->M > 0 && d->D > 0 && d->B > 0 && d->F > 0 && d->nblk > 0, "%s: bad dims", who);
   VARGP_REQUIRE(d->log_mean && d->z && d->u_mean && d->u_tril_vec && d->z_all && d->rk_all && d->x && d->scalars && d->info &&
                     d->ws, "%s: null pointer", who);
+  if (tiled) {   // the tile calls bring x, y and the likelihood noise; begin only needs theta's noise (given or native)
+    VARGP_REQUIRE(d->map_est ? d->S == 1 : (d->log_logvar && d->prior_log_mean && d->prior_log_logvar &&
+                                            (d->eps_theta || (d->rng_counter && d->rng_sample_offset >= 0))),
+                  "%s: hyper-parameter arguments inconsistent", who);
+    VARGP_REQUIRE(d->ws_bytes >= vargp_elbo_tn_workspace_bytes(d->S, d->C, d->M, d->D, d->B, d->F, d->nblk),
+                  "%s: workspace too small", who);
+    return VARGP_OK;
+  }
   const bool native = d->eps_f == nullptr && d->y != nullptr;
   VARGP_REQUIRE(!native || (d->rng_counter && d->eps_theta == nullptr && d->rng_sample_offset >= 0),
                 "%s: native noise needs rng_counter, eps_theta == eps_f == NULL and a sample offset >= 0", who);
@@ -559,7 +611,7 @@ extern "C" int vargp_elbo_tn_bwd(const vargp_elbo_tn_desc* d, const float* seeds
     const int nz = (int)std::min<int64_t>(64, cdiv(zc, 1024));
     hipLaunchKernelGGL(tn_bwd_head_kernel, dim3(npd + nrest + nz), dim3(256), 0, st, o.P, o.W, o.V2, o.QPs, o.gmu, o.gvar,
                        fused_softmax ? seeds + 2 : nullptr, seeds, o.gP, o.gQPs, o.gkd, d->jitter, S, M, Mt, B, NRs, npd,
-                       nrest, o.r_uf, zc);
+                       nrest, o.r_uf, zc, 0);
   }
   float* gW = o.W;      // in place (tn_bwd_head_kernel)
   float* gV2 = o.V2;
@@ -692,4 +744,283 @@ extern "C" int vargp_elbo_tn_bwd(const vargp_elbo_tn_desc* d, const float* seeds
                      d->prior_log_mean, d->prior_log_logvar, eps_theta, o.gtheta, o.g2, o.gkd, seeds, g_log_mean,
                      g_log_logvar, S, C, D + 1, d->map_est);
   return check_launch("elbo_tn_bwd");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// N-tiled ELBO (BASELINE config 5: N = 1e6, M = 2048): loss AND gradient over a data set swept in minibatch tiles, with
+// everything that does not depend on the data -- kernel matrix of the inducing points, its factorisation, the small
+// products, the KL -- computed ONCE (begin), a forward + partial backward per tile that only accumulates (tile), and the
+// Cholesky / kernel-matrix backward of the accumulated gradients at the end (end).  The nll seed multiplies every tile, so
+// the seeds are needed from the first tile on.  Same kernels as the one-minibatch program.
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" int vargp_elbo_tn_begin(const vargp_elbo_tn_desc* d, vargp_stream_t stream) {
+  int rc = check_tn(d, "elbo_tn_begin", true);
+  if (rc) return rc;
+  VARGP_REQUIRE(d->D > kRbfDirectD, "elbo_tn_begin: the tiled ELBO needs D > %d (MFMA distance path)", kRbfDirectD);
+  hipStream_t st = as_stream(stream);
+  const int S = d->S, C = d->C, M = d->M, D = d->D, B = d->B, F = d->F, nblk = d->nblk, SC = S * C;
+  const TnWs o = carve_tn(d->ws, S, C, M, D, B, F, nblk);
+  const int Mt = o.Mt, NRs = o.NRs;
+  const int64_t MtMt = (int64_t)Mt * Mt, MtN = (int64_t)Mt * NRs, zrows = (int64_t)C * Mt;
+  {
+    TnProArgs a{};
+    a.mean = d->log_mean; a.logvar = d->log_logvar; a.pmean = d->prior_log_mean; a.plogvar = d->prior_log_logvar;
+    a.eps_theta = d->eps_theta; a.vec = d->u_tril_vec; a.u_mean = d->u_mean; a.z = d->z;
+    a.theta = o.theta; a.g2 = o.g2; a.kd = o.kd; a.scalars = d->scalars; a.bump = d->bump;
+    a.rk_last = d->rk_all + (int64_t)(nblk - 1) * M * NRs; a.z_all = d->z_all;
+    a.info = d->info; a.ninfo = SC;
+    a.zero_begin = o.gmu; a.zero_count = 0;
+    a.S = S; a.C = C; a.M = M; a.D = D; a.Mt = Mt; a.NRs = NRs; a.nblk = nblk; a.map_est = d->map_est;
+    a.nzero_blocks = 0;
+    const bool native_theta = d->eps_theta == nullptr && !d->map_est;
+    if (native_theta) {   // theta noise from the generator (the per-tile likelihood noise is drawn by the tile calls)
+      VARGP_REQUIRE(d->rng_counter, "elbo_tn_begin: native noise needs rng_counter");
+      a.native = 1; a.seed = d->rng_seed; a.rng_counter = d->rng_counter;
+      a.g0_theta = (int64_t)d->rng_sample_offset * (D + 1);
+      a.eps_theta_out = o.eps_theta; a.nrng_blocks = 0; a.n_f = 0;
+    }
+    a.npack_blocks = cdiv((int64_t)C * M * NRs, 256);
+    const int grid = 1 + S + a.npack_blocks + cdiv((int64_t)C * M * D, 256);
+    hipLaunchKernelGGL(tn_prologue_kernel, dim3(grid), dim3(256), 0, st, a);
+  }
+  // accumulators of the sweep
+  zero_async(o.gT, sizeof(float) * SC * MtMt, st);
+  zero_async(o.gQPs, sizeof(float) * SC * MtN, st);
+  zero_async(o.gkd, sizeof(float) * SC, st);
+  zero_async(o.r_uf, sizeof(float) * (size_t)(o.r_uu - o.r_uf), st);
+  zero_async(o.Puf, sizeof(float) * SC * Mt * D, st);
+  rc = rbf_prep_norm_launch(o.theta, d->z_all, zrows, nullptr, 0, o.w, o.g2, o.na, o.nb, S, D, o.Dp, st);
+  if (rc) return rc;
+  {
+    GemmParams p0{};
+    p0.A = d->z_all; p0.B = d->z_all; p0.C = o.Kall;
+    p0.M = Mt; p0.N = Mt; p0.K = D; p0.lda = D; p0.ldb = D; p0.ldc = Mt;
+    p0.nb1 = C; p0.nb2 = 1;
+    p0.sA[1] = (int64_t)Mt * D; p0.sB[1] = (int64_t)Mt * D;
+    p0.sC[0] = C * MtMt; p0.sC[1] = MtMt;
+    p0.alpha = 1.f;
+    p0.kscale = o.w; p0.ks_ld = o.Dp; p0.g2 = o.g2;
+    p0.na = o.na; p0.sNa[0] = zrows; p0.sNa[1] = Mt;
+    p0.nbv = o.na; p0.sNb[0] = zrows; p0.sNb[1] = Mt;
+    p0.same_xy = 1; p0.triC = 2; p0.symout = 1;
+    rc = launch_gemm(p0, 0, 1, SC, true, st, "rbf_kuu_gemm");
+    if (rc) return rc;
+  }
+  rc = chol_inv_fwd_impl(o.Kall, d->jitter, o.LL, o.TT, nullptr, d->info, SC, Mt, o.chol, o.chol_bytes, false, st);
+  if (rc) return rc;
+  {
+    const int64_t sA[3] = {C * MtMt, MtMt, (int64_t)M * Mt + M}, sB[3] = {0, (int64_t)nblk * M * NRs, (int64_t)M * NRs},
+                  sC[3] = {C * MtN, MtN, (int64_t)M * NRs};
+    GemmParams p = blk_gemm(o.TT, Mt, sA, d->rk_all, NRs, sB, o.QPs, NRs, sC, M, NRs, M, C, nblk);
+    p.triA = 1;
+    rc = launch_gemm(p, 0, 0, SC * nblk, false, st, "tn_small_gemm");
+    if (rc) return rc;
+  }
+  {   // the KL (data-independent): the KL role of the moments kernel alone
+    const int nkx = cdiv(M, kTnKlRows);
+    hipLaunchKernelGGL(tn_pdiag_kl_kernel, dim3(nkx * SC), dim3(256), 0, st, o.P, o.W, o.V2, o.QPs, o.kd, o.LL, d->rk_all, o.mu,
+                       o.var, d->scalars + 1, d->jitter, S, C, M, Mt, nblk, B, NRs, 1, 0, nkx, (uint32_t*)nullptr);
+  }
+  return check_launch("elbo_tn_begin");
+}
+
+// One minibatch tile: x (Bt, D), y (Bt), Bt <= d->B; eps_f (S, F, C, Bt) or NULL (native noise, one generator step per tile).
+// Adds the tile's nll to scalars[2] and its share of every gradient to the accumulators.
+extern "C" int vargp_elbo_tn_tile(const vargp_elbo_tn_desc* d, const float* seeds, const float* x, const int64_t* y,
+                                  const float* eps_f_in, int Bt, vargp_stream_t stream) {
+  VARGP_REQUIRE(d && seeds && x && y && d->ws && Bt > 0 && Bt <= d->B, "elbo_tn_tile: bad arguments");
+  VARGP_REQUIRE(eps_f_in || d->rng_counter, "elbo_tn_tile: native noise needs rng_counter");
+  hipStream_t st = as_stream(stream);
+  const int S = d->S, C = d->C, M = d->M, D = d->D, F = d->F, nblk = d->nblk, SC = S * C, B = Bt;
+  const TnWs o = carve_tn(d->ws, S, C, M, D, d->B, F, nblk);
+  const int Mt = o.Mt, NRs = o.NRs;
+  const int64_t MtMt = (int64_t)Mt * Mt, MtB = (int64_t)Mt * B, MtN = (int64_t)Mt * NRs, zrows = (int64_t)C * Mt;
+  const bool native = eps_f_in == nullptr;
+  const bool fused_softmax = C <= 16;
+  const float* eps_f = native ? o.eps_f : eps_f_in;
+  int rc;
+  {
+    const int64_t n0 = o.Kall - o.gmu, n1 = (int64_t)S * d->B;          // gmu | gvar, c_uf
+    const int64_t n_f = (int64_t)S * F * C * B;
+    const int nzero = (int)std::min<int64_t>(64, cdiv(n0 + n1, 1024));
+    const int nrng = native ? (int)std::min<int64_t>(512, cdiv(n_f + 7, 1024)) : 0;
+    hipLaunchKernelGGL(tn_tile_prep_kernel, dim3(nzero + nrng), dim3(256), 0, st, o.gmu, n0, o.c_uf, n1, nzero, native ? 1 : 0,
+                       d->rng_seed, d->rng_counter, (int64_t)d->rng_sample_offset * F * C * B, n_f, o.eps_f);
+  }
+  rc = rbf_prep_norm_launch(o.theta, nullptr, 0, x, B, o.w, o.g2, o.na, o.nb, S, D, o.Dp, st);
+  if (rc) return rc;
+  {
+    GemmParams pf{};
+    pf.A = d->z_all; pf.B = x; pf.C = o.Kuf;
+    pf.M = C * Mt; pf.N = B; pf.K = D; pf.lda = D; pf.ldb = D; pf.ldc = B;
+    pf.nb1 = 1; pf.nb2 = 1;
+    pf.sC[0] = (int64_t)C * MtB;
+    pf.alpha = 1.f;
+    pf.kscale = o.w; pf.ks_ld = o.Dp; pf.g2 = o.g2;
+    pf.na = o.na; pf.sNa[0] = zrows;
+    pf.nbv = o.nb; pf.sNb[0] = B;
+    rc = launch_gemm(pf, 0, 1, S, true, st, "rbf_kuf_gemm");
+    if (rc) return rc;
+  }
+  {
+    GemmParams p = flat_gemm(o.TT, Mt, MtMt, o.Kuf, B, MtB, o.P, B, MtB, Mt, B, Mt);
+    p.triA = 1;
+    rc = launch_gemm(p, 0, 0, SC, false, st, "tn_p_gemm");
+    if (rc) return rc;
+    GemmParams q = flat_gemm(o.TT, Mt, MtMt, o.P, B, MtB, o.V2, B, MtB, Mt, B, Mt);
+    q.triA = 2;
+    rc = launch_gemm(q, 1, 0, SC, false, st, "tn_v2_gemm");
+    if (rc) return rc;
+    const int64_t sA[3] = {C * MtN, MtN, (int64_t)M * NRs}, sB[3] = {C * MtB, MtB, (int64_t)M * B};
+    GemmParams r = blk_gemm(o.QPs + 4, NRs, sA, o.P, B, sB, o.W, B, sB, M, B, M, C, nblk);
+    r.triA = 2;
+    rc = launch_gemm(r, 1, 0, SC * nblk, false, st, "tn_w_gemm");
+    if (rc) return rc;
+  }
+  {
+    const int nbx = cdiv(B, 64), npd = nbx * SC;
+    hipLaunchKernelGGL(tn_pdiag_kl_kernel, dim3(npd), dim3(256), 0, st, o.P, o.W, o.V2, o.QPs, o.kd, o.LL, d->rk_all, o.mu, o.var,
+                       (float*)nullptr, d->jitter, S, C, M, Mt, nblk, B, NRs, nbx, npd, 1, native ? d->rng_counter : nullptr);
+  }
+  if (fused_softmax) {
+    const int64_t total = (int64_t)S * F * B;
+    hipLaunchKernelGGL(t0_softmax_kernel<16>, dim3(cdiv(total, 256)), dim3(256), 0, st, o.mu, o.var, eps_f, y, d->scalars + 2,
+                       o.gmu, o.gvar, S, F, C, B);
+  } else {
+    // the generic kernel overwrites nll: accumulate through a scratch scalar is not worth a kernel -- C <= 16 covers the configs
+    VARGP_REQUIRE(false, "elbo_tn_tile: more than 16 classes is not supported by the tiled ELBO");
+  }
+  // ---- the tile's share of the backward -------------------------------------------------------------------------------
+  {
+    const int npd = SC * Mt;
+    hipLaunchKernelGGL(tn_bwd_head_kernel, dim3(npd), dim3(256), 0, st, o.P, o.W, o.V2, o.QPs, o.gmu, o.gvar, seeds + 2, seeds, o.gP,
+                       o.gQPs, o.gkd, d->jitter, S, M, Mt, B, NRs, npd, 0, (float*)nullptr, (int64_t)0, 1);
+  }
+  float* gW = o.W;
+  float* gV2 = o.V2;
+  {
+    const int64_t sQ[3] = {C * MtN, MtN, (int64_t)M * NRs}, sP[3] = {C * MtB, MtB, (int64_t)M * B};
+    GemmParams p = blk_gemm(o.P, B, sP, gW, B, sP, o.gQPs + 4, NRs, sQ, M, M, B, C, nblk);
+    p.D = o.gQPs + 4; p.ldd = NRs; p.beta = 1.f;
+    for (int i = 0; i < 3; ++i) p.sD[i] = sQ[i];
+    rc = launch_gemm(p, 0, 1, SC * nblk, false, st, "tn_gh_gemm");
+    if (rc) return rc;
+    GemmParams q = blk_gemm(o.QPs + 4, NRs, sQ, gW, B, sP, o.gP, B, sP, M, B, M, C, nblk);
+    q.triA = 1; q.D = o.gP; q.ldd = B; q.beta = 1.f;
+    rc = launch_gemm(q, 0, 0, SC * nblk, false, st, "tn_gp_gemm");
+    if (rc) return rc;
+  }
+  {
+    GemmParams p = flat_gemm(o.TT, Mt, MtMt, gV2, B, MtB, o.gP, B, MtB, Mt, B, Mt);
+    p.triA = 1; p.D = o.gP; p.beta = 1.f;
+    rc = launch_gemm(p, 0, 0, SC, false, st, "tn_gp_v2_gemm");
+    if (rc) return rc;
+    GemmParams q = flat_gemm(o.gP, B, MtB, o.Kuf, B, MtB, o.gT, Mt, MtMt, Mt, Mt, B);
+    q.triC = 1; q.D = o.gT; q.beta = 1.f;
+    rc = launch_gemm(q, 0, 1, SC, false, st, "tn_gt_gemm");
+    if (rc) return rc;
+    GemmParams r = flat_gemm(o.P, B, MtB, gV2, B, MtB, o.gT, Mt, MtMt, Mt, Mt, B);
+    r.triC = 1; r.D = o.gT; r.beta = 1.f;
+    rc = launch_gemm(r, 0, 1, SC, false, st, "tn_gt_gemm");
+    if (rc) return rc;
+    GemmParams u = flat_gemm(o.TT, Mt, MtMt, o.gP, B, MtB, o.gKuf, B, MtB, Mt, B, Mt);
+    u.triA = 2;
+    rc = launch_gemm(u, 1, 0, SC, false, st, "tn_gkuf_gemm");
+    if (rc) return rc;
+  }
+  {   // W_uf = gK_uf o K_uf in place, row sums (accumulating over the tiles), column sums (this tile's)
+    const int gx = cdiv(B, 256), gy = cdiv(zrows, kWRows), nuf = gx * gy * S;
+    hipLaunchKernelGGL(t0_w_kernel, dim3(nuf), dim3(256), 0, st, o.Kuf, o.gKuf, o.Kall, o.gK, o.Wuu, o.r_uu, o.r_uf, o.c_uf, o.gtheta,
+                       S, C, Mt, B, D, 0, B, gx, gy, nuf, 0, (const float*)nullptr, (const float*)nullptr, seeds, (float*)nullptr, 1);
+    GemmParams p1{};
+    p1.A = o.gKuf; p1.B = x; p1.C = o.Puf; p1.D = o.Puf;
+    p1.M = C * Mt; p1.N = D; p1.K = B; p1.lda = B; p1.ldb = D; p1.ldc = D; p1.ldd = D;
+    p1.nb1 = 1; p1.nb2 = 1;
+    p1.sA[0] = C * MtB;
+    p1.sC[0] = zrows * D; p1.sD[0] = zrows * D;
+    p1.alpha = 1.f; p1.beta = 1.f;
+    rc = launch_gemm(p1, 0, 0, S, false, st, "rbf_kuf_bwd_gemm");
+    if (rc) return rc;
+    const int nxy = cdiv(B, kFinRows);      // minibatch side only: gtheta += w sum_n c_uf x^2
+    hipLaunchKernelGGL(t0_final_kernel, dim3(cdiv(D, 64), nxy), dim3(256), 0, st, d->z_all, x, o.r_uu, o.r_uf, o.c_uf, o.Puu,
+                       o.Puf, o.w, o.gz_all, o.gtheta, zrows, (int64_t)B, D, o.Dp, S, 0);
+  }
+  return check_launch("elbo_tn_tile");
+}
+
+extern "C" int vargp_elbo_tn_end(const vargp_elbo_tn_desc* d, const float* seeds, float* g_log_mean, float* g_log_logvar,
+                                 float* g_z, float* g_u_mean, float* g_u_tril_vec, vargp_stream_t stream) {
+  VARGP_REQUIRE(d && d->ws && seeds && g_log_mean && g_log_logvar && g_z && g_u_mean && g_u_tril_vec, "elbo_tn_end: null pointer");
+  hipStream_t st = as_stream(stream);
+  const int S = d->S, C = d->C, M = d->M, D = d->D, F = d->F, nblk = d->nblk, SC = S * C;
+  const TnWs o = carve_tn(d->ws, S, C, M, D, d->B, F, nblk);
+  const int Mt = o.Mt, NRs = o.NRs;
+  const int64_t MtMt = (int64_t)Mt * Mt, MtN = (int64_t)Mt * NRs, zrows = (int64_t)C * Mt;
+  const float* eps_theta = d->eps_theta ? d->eps_theta : o.eps_theta;
+  int rc;
+  {
+    const int64_t total = (int64_t)SC * M * NRs;
+    hipLaunchKernelGGL(tn_kl_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, o.QPs, o.gQPs, seeds, S, M, Mt, NRs, total);
+  }
+  {
+    const int64_t sQ[3] = {C * MtN, MtN, (int64_t)M * NRs}, sR[3] = {0, (int64_t)nblk * M * NRs, (int64_t)M * NRs},
+                  sT[3] = {C * MtMt, MtMt, (int64_t)M * Mt + M};
+    GemmParams r = blk_gemm(o.gQPs, NRs, sQ, d->rk_all, NRs, sR, o.gT, Mt, sT, M, M, NRs, C, nblk);
+    r.triC = 1; r.D = o.gT; r.ldd = Mt; r.beta = 1.f;
+    rc = launch_gemm(r, 0, 1, SC * nblk, false, st, "tn_gt_diag_gemm");
+    if (rc) return rc;
+    const int64_t off = (int64_t)(Mt - M) * Mt + (Mt - M);
+    GemmParams p = flat_gemm(o.TT + off, Mt, MtMt, o.gQPs + (int64_t)(Mt - M) * NRs, NRs, MtN, o.gRKt, NRs, (int64_t)M * NRs, M,
+                             NRs, M);
+    p.triA = 2;
+    rc = launch_gemm(p, 1, 0, SC, false, st, "tn_grk_gemm");
+    if (rc) return rc;
+  }
+  float* Smat = reinterpret_cast<float*>(o.chol);
+  float* tmp = Smat + SC * MtMt;
+  {
+    GemmParams p = flat_gemm(o.gT, Mt, MtMt, o.TT, Mt, MtMt, Smat, Mt, MtMt, Mt, Mt, Mt);
+    p.alpha = -0.5f; p.triA = 1; p.triB = 2; p.triC = 2; p.symout = 1;
+    rc = launch_gemm(p, 0, 1, SC, false, st, "tn_chol_bwd1");
+    if (rc) return rc;
+    const int64_t total = (int64_t)SC * M;
+    hipLaunchKernelGGL(tn_diag_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, Smat, seeds, S, M, Mt, total);
+    GemmParams q = flat_gemm(o.TT, Mt, MtMt, Smat, Mt, MtMt, tmp, Mt, MtMt, Mt, Mt, Mt);
+    q.triA = 2;
+    rc = launch_gemm(q, 1, 0, SC, false, st, "tn_chol_bwd2");
+    if (rc) return rc;
+    GemmParams r = flat_gemm(tmp, Mt, MtMt, o.TT, Mt, MtMt, o.gK, Mt, MtMt, Mt, Mt, Mt);
+    r.triB = 1;
+    rc = launch_gemm(r, 0, 0, SC, false, st, "tn_chol_bwd3");
+    if (rc) return rc;
+  }
+  {   // K_all: W + W^T = 2 gK o K, its row sums; the W.z product; the inducing-point side of the finalisation
+    const int nuu = SC * cdiv(Mt, kUuRows);
+    hipLaunchKernelGGL(t0_w_kernel, dim3(nuu), dim3(256), 0, st, o.Kuf, o.gKuf, o.Kall, o.gK, o.Wuu, o.r_uu, o.r_uf, o.c_uf, o.gtheta,
+                       S, C, Mt, d->B, D, 0, d->B, 1, 1, 0, nuu, (const float*)nullptr, (const float*)nullptr, seeds,
+                       (float*)nullptr, 1);
+    GemmParams p0{};
+    p0.A = o.Wuu; p0.B = d->z_all; p0.C = o.Puu;
+    p0.M = Mt; p0.N = D; p0.K = Mt; p0.lda = Mt; p0.ldb = D; p0.ldc = D;
+    p0.nb1 = C; p0.nb2 = 1;
+    p0.sA[0] = C * MtMt; p0.sA[1] = MtMt;
+    p0.sB[1] = (int64_t)Mt * D;
+    p0.sC[0] = zrows * D; p0.sC[1] = (int64_t)Mt * D;
+    p0.alpha = 1.f;
+    rc = launch_gemm(p0, 0, 0, SC, false, st, "rbf_kuu_bwd_gemm");
+    if (rc) return rc;
+    const int nzy = cdiv(zrows, kFinRows);
+    hipLaunchKernelGGL(t0_final_kernel, dim3(cdiv(D, 64), nzy), dim3(256), 0, st, d->z_all, (const float*)nullptr, o.r_uu, o.r_uf,
+                       o.c_uf, o.Puu, o.Puf, o.w, o.gz_all, o.gtheta, zrows, (int64_t)0, D, o.Dp, S, nzy);
+  }
+  {
+    const int nun = cdiv((int64_t)C * M * (M + 1), 256);
+    hipLaunchKernelGGL(tn_unpack_kernel, dim3(nun + cdiv((int64_t)C * M * D, 256)), dim3(256), 0, st, o.gRKt, d->u_tril_vec,
+                       d->rk_all + (int64_t)(nblk - 1) * M * NRs, seeds, o.gz_all, g_u_mean, g_u_tril_vec, g_z, S, C, M, Mt, D,
+                       NRs, nblk, nun);
+  }
+  hipLaunchKernelGGL(t0_hyper_bwd_kernel, dim3(cdiv(D + 1, 256)), dim3(256), 0, st, d->log_mean, d->log_logvar,
+                     d->prior_log_mean, d->prior_log_logvar, eps_theta, o.gtheta, o.g2, o.gkd, seeds, g_log_mean,
+                     g_log_logvar, S, C, D + 1, d->map_est);
+  return check_launch("elbo_tn_end");
 }

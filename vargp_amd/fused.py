@@ -262,6 +262,41 @@ class TnProgram:
                                       ptr(g_u_mean), ptr(g_u_tril_vec), stream_ptr()), 'vargp_elbo_tn_bwd')
 
 
+    # -- N-tiled ELBO: loss and gradient over a data set swept in minibatch tiles (vargp_elbo_tn_begin / _tile / _end) ----
+    def tiled_step(self, log_mean, log_logvar, prior_log_mean, prior_log_logvar, z, u_mean, u_tril_vec, z_all, rk_all, x, y,
+                   seeds, grads, eps_theta=None, eps_f=None):
+        """x (N, D), y (N): swept in tiles of this program's B columns (the last one may be narrower).  seeds (3,) device =
+        d total / d (kl_hypers, kl_u, nll); grads = the five gradient buffers (log_mean, log_logvar, z, u_mean, u_tril_vec),
+        overwritten.  eps_f (S, F, C, N) / eps_theta (S, D+1): injected noise (tests); None: native noise (set_rng).
+        -> scalars (kl_hypers, kl_u, sum over the tiles of nll)."""
+        S, C, M, D, B, F_, nblk = self.shape
+        tensors = (log_mean, log_logvar, prior_log_mean, prior_log_logvar, z, u_mean, u_tril_vec, z_all, rk_all, x, y, seeds,
+                   eps_theta, eps_f) + tuple(grads)
+        require_device(*tensors)
+        assert x.dim() == 2 and x.shape[1] == D and x.is_contiguous() and y.dtype == torch.int64 and y.is_contiguous()
+        if eps_f is None:
+            assert self._rng is not None and (eps_theta is None), 'native noise: call set_rng() and pass no eps tensors'
+        d = self.desc
+        d.log_mean, d.log_logvar = _p(log_mean), _p(log_logvar)
+        d.prior_log_mean, d.prior_log_logvar = _p(prior_log_mean), _p(prior_log_logvar)
+        d.z, d.u_mean, d.u_tril_vec, d.x, d.y = _p(z), _p(u_mean), _p(u_tril_vec), _p(x), _p(y)
+        d.z_all, d.rk_all = _p(z_all), _p(rk_all)
+        d.eps_theta, d.eps_f = _p(eps_theta), None
+        d.bump = None
+        self._keep = tensors
+        st = stream_ptr()
+        check(lib().vargp_elbo_tn_begin(ctypes.byref(d), st), 'vargp_elbo_tn_begin')
+        N = x.shape[0]
+        for i in range(0, N, B):
+            bt = min(B, N - i)
+            ef = None if eps_f is None else eps_f[..., i:i + bt].contiguous()
+            check(lib().vargp_elbo_tn_tile(ctypes.byref(d), ptr(seeds), ptr(x[i:i + bt]), ptr(y[i:i + bt]), ptr(ef), bt, st),
+                  'vargp_elbo_tn_tile')
+        check(lib().vargp_elbo_tn_end(ctypes.byref(d), ptr(seeds), *(ptr(g) for g in grads), st), 'vargp_elbo_tn_end')
+        ops._note_chol_errors(self.info)
+        return self.scalars
+
+
 class _ElboTn(Function):
     @staticmethod
     def forward(ctx, log_mean, log_logvar, z, u_mean, u_tril_vec, x, y, eps_theta, eps_f, prior_log_mean,

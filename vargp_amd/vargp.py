@@ -218,6 +218,38 @@ class VARGP(nn.Module):
         kl_hypers = self.kernel.kl_hypers()
         return kl_hypers, kl_u, nll
 
+    def elbo_tiled(self, x, y, tile, beta=1.0, scale=1.0, noise_seed=0):
+        """ELBO terms and gradient over a whole data set x (N, D), y (N) swept in minibatch tiles of `tile` points
+        (BASELINE config 5: N = 1e6, M = 2048): one hyper-sample set, the kernel matrix of the inducing points and its
+        factorisation computed once, K_uf built tile by tile in HBM, every tile's share of the gradient accumulated on the
+        device (fused.TnProgram.tiled_step).  Returns (kl_hypers, kl_u, nll summed over the data) and writes the gradient of
+        beta kl_hypers + kl_u + scale nll into the .grad of the five trainable tensors.  ep_var_mean=True models only.
+        Injected noise (noise.inject: eps_theta (S, D+1), eps_f (S, F, C, N)) is honoured; otherwise the program draws its
+        own (counter-based generator keyed by `noise_seed`)."""
+        assert self._tn_applicable() and (not self.prev_params or self.var_mean_mask == 1.0)
+        kern = self.kernel
+        S = 1 if kern.map_est else self.n_v
+        shape = (S, self.z.size(0), self.M, self.z.size(-1), int(tile), self.likelihood.n_f, len(self.prev_params) + 1)
+        prog = self._tn_progs.get(shape)
+        if prog is None:
+            prog = self._tn_progs[shape] = fused.TnProgram(*shape, self.z.device, kern.map_est)
+        eps_theta, eps_f = noise._injected.get('eps_theta'), noise._injected.get('eps_f')
+        if eps_f is None:
+            if prog._rng is None:
+                self._tiled_counter = torch.zeros(1, dtype=torch.int32, device=x.device)
+                prog.set_rng(noise_seed, self._tiled_counter)
+            eps_theta = None
+        else:
+            eps_theta = None if kern.map_est else eps_theta.to(x.device).contiguous()
+            eps_f = eps_f.to(x.device)
+        params = [kern.log_mean, kern.log_logvar, self.z, self.u_mean, self.u_tril_vec]
+        grads = [torch.empty_like(p) for p in params]
+        seeds = torch.tensor([beta, 1.0, scale], dtype=torch.float32, device=x.device)
+        scal = prog.tiled_step(*self._tn_args(), x.contiguous(), y.contiguous(), seeds, grads, eps_theta, eps_f)
+        for p, g in zip(params, grads):
+            p.grad = g
+        return scal[0].clone(), scal[1].clone(), scal[2].clone()
+
     def predict(self, x, tile=None):
         """Class probabilities (B, C)  (vargp.py:196-198).  With `tile`, a large x is swept in blocks of
         `tile` points that share ONE hyper-sample and ONE set of x-independent factors (K_uu, its Cholesky
