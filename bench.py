@@ -154,12 +154,35 @@ def stress_cpu_baseline(gp, n_cpu=2048):
                 sample=f'one ELBO + gradient over {n_cpu} points (M=2048 C=10 S=1 D=784), the factorisations included')
 
 
-def measured_traffic(tag):
-    """HBM bytes of one launch of the kernel tagged `tag`, from the committed rocprofv3 PMC passes
-    (profiles/README.md); None if absent."""
+def _latest_profile(kind):
+    """profiles/rNN_<kind>.json of the most recent round that has one, or (None, None)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r[0-9][0-9]_{kind}.json')))
+    if not files:
+        return None, None
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')) as f:
-            return json.load(f)[tag]['traffic_bytes']
+        with open(files[-1]) as f:
+            return json.load(f), os.path.relpath(files[-1], ROOT)
+    except Exception:
+        return None, None
+
+
+def measured_traffic(tag):
+    """HBM bytes of one launch of the kernel tagged `tag`, from the committed rocprofv3 PMC passes of the same command
+    (profiles/README.md: separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 correction applied); None if absent.
+    A bench run cannot read PMC counters itself: the figure is labelled with its source file."""
+    data, _ = _latest_profile('traffic')
+    try:
+        return data[tag]['traffic_bytes']
+    except Exception:
+        return None
+
+
+def measured_mfma_util(tag):
+    """MFMA utilisation of the kernel tagged `tag` from the committed SQ counter pass (profiles/rNN_mfma.json)."""
+    data, _ = _latest_profile('mfma')
+    try:
+        return data[tag]['mfma_util']
     except Exception:
         return None
 
@@ -373,13 +396,16 @@ def main():
                                  achieved=achieved, peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
                                  frac=(achieved / MFMA_F32_PEAK_TFLOPS) if achieved else None,
                                  launches=kern_n, avg_us=avg_s * 1e6,
-                                 traffic=measured_traffic(primary) if args.workload == 'smnist' else None))
+                                 traffic=measured_traffic(primary) if args.workload == 'smnist' else None,
+                                 mfma_util=measured_mfma_util(primary) if args.workload == 'smnist' else None,
+                                 counters_from=_latest_profile('traffic')[1] if args.workload == 'smnist' else None))
         if 'rbf_kuu_bwd_gemm' in kernels and primary != 'rbf_kuu_bwd_gemm':
             us2, fl2, desc2 = kernels['rbf_kuu_bwd_gemm']
             res['roofline_gemm'] = dict(bound='mfma', kernel=desc2, achieved=fl2 / (us2 * 1e-6) / 1e12,
                                         peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
                                         frac=fl2 / (us2 * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, launches=kern_n, avg_us=us2,
-                                        traffic=measured_traffic('rbf_kuu_bwd_gemm') if args.workload == 'smnist' else None)
+                                        traffic=measured_traffic('rbf_kuu_bwd_gemm') if args.workload == 'smnist' else None,
+                                        mfma_util=measured_mfma_util('rbf_kuu_bwd_gemm') if args.workload == 'smnist' else None)
         if world == 1 and not args.no_cpu_baseline and args.workload == 'smnist':
             res['cpu_baseline'] = cpu_baseline(p0, x, y)
         print(json.dumps(res))

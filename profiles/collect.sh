@@ -1,0 +1,27 @@
+#!/bin/bash
+# Raw rocprofv3 inputs of one round's committed profile summaries.  Run on the GPU box from the repo root:
+#     bash profiles/collect.sh r02
+# Writes under gpurun_out/<tag>_* (scratch); `python profiles/summarize.py <tag>` then turns them into profiles/<tag>_*.
+# Counter passes are separate runs with --kernel-trace only (FETCH_SIZE and WRITE_SIZE do not fit one pass; no other trace
+# domain next to --pmc).  The program under the profiler is python3 itself (no wrapper process).
+set -u
+TAG=${1:-r02}
+R=$(pwd)
+OUT=$R/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+B="python3 $R/bench.py --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_graph -o p -- $B --steps 100 --warmup 10 > $OUT/${TAG}_graph.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_eager -o p -- $B --eager --no-replay --steps 50 --warmup 5 > $OUT/${TAG}_eager.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_replay -o p -- $B --eager --steps 5 --warmup 2 > $OUT/${TAG}_replay.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch -o p -- $B --eager --no-replay --steps 10 --warmup 3 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write -o p -- $B --eager --no-replay --steps 10 --warmup 3 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_sq -o p -- $B --eager --no-replay --steps 10 --warmup 3 > /dev/null 2>&1
+# calibration of the MFMA-utilisation formula on a kernel of known efficiency (4096^3 NT GEMM, ~90 % of peak by its clock)
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_sqcal -o p -- $R/tests/native/bench_kernels gemm4k 5 > $OUT/${TAG}_sqcal.log 2>&1
+# secondary workloads: bench lines only
+for w in smnist_s64 smnist_t1 smnist_t4 pmnist_t0 pmnist_t1 pmnist_t4; do
+  python3 $R/bench.py --workload $w --steps 30 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_line_$w.log 2>&1
+done
+python3 $R/bench.py --workload stress > $OUT/${TAG}_line_stress.log 2>&1
+python3 $R/bench.py > $OUT/${TAG}_line_smnist.log 2>&1
+ls $OUT | grep ${TAG}_ | head -40

@@ -1,15 +1,23 @@
-"""Turn the raw rocprofv3 output of one round (under gpurun_out/, scratch) into the committed summaries here.
+"""Turn the raw rocprofv3 output of one round (under gpurun_out/, scratch: produced by `bash profiles/collect.sh <tag>` on
+the GPU box) into the committed summaries here.
 
-Commands that produce the inputs (run from /tmp on the GPU box, R = repo root; separate passes for the two PMC
-counters, no other trace domain with --pmc):
-  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/p_graph -- python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline
-  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/p_eager -- python $R/bench.py --eager --steps 50 --warmup 5 --no-cpu-baseline
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/p_fetch -- python $R/bench.py --eager --steps 20 --warmup 3 --no-cpu-baseline
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/p_write -- python $R/bench.py --eager --steps 20 --warmup 3 --no-cpu-baseline
-Usage: python profiles/summarize.py r01 [bench-line.json]
+    python profiles/summarize.py r02
+
+Outputs (profiles/<tag>_*):
+  bench.json                       the default `python bench.py` line of this round
+  lines.json                       the bench lines of the secondary workloads (other BASELINE configs)
+  bench_{graph,eager}_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the default bench (graph replay / eager)
+  replay_kernel_stats.csv          same for the run that includes bench.py's back-to-back re-launches (the roofline timing)
+  top_kernels.md                   per-step table from the eager run (exact launches per step)
+  pmc_<counter>_<kernel>.csv       PMC rows of the headline kernels (evidence behind traffic.json / mfma.json)
+  traffic.json                     HBM traffic per launch: 1024 * (2 * FETCH_SIZE + WRITE_SIZE)  [FETCH_SIZE in KB reports half
+                                   the bytes of wide coalesced reads on gfx950, MI355X_MICROARCH.md HBM section]
+  mfma.json                        MFMA utilisation per launch = SQ_VALU_MFMA_BUSY_CYCLES / (128 * GRBM_GUI_ACTIVE)
+                                   (GRBM_GUI_ACTIVE is summed over the 8 XCDs, 1024 SIMDs: calibrated on the 4096^3 GEMM, where the
+                                   formula gives 0.90 against 141 TFLOP/s = 0.90 of the f32-MFMA peak by the clock), and the
+                                   wave-cycle split ACTIVE / WAIT_INST (issue stalls) / WAIT (parked at waitcnt or barrier)
 """
 import csv
-import glob
 import json
 import os
 import shutil
@@ -17,89 +25,116 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, 'profiles')
-# kernels whose HBM traffic bench.py reports: tag (bench.py) -> (kernel-name prefix, algorithmic bytes per launch)
 S, C, M, D, B = 3, 10, 100, 784, 512
-NR = (4 + 2 * M + 3) // 4 * 4
-LD = (NR + B + 3) // 4 * 4
+# headline kernels of the default workload: tag -> (kernel-name prefix, algorithmic bytes per launch, flops per launch)
 KERNELS = {
     # factorisations: read K_uu/S_u, write L and T ((S*C + C) matrices); GEMM: read z and x once, write K_uf
     'chol_rbf_gemm': ('void vargp::chol_rbf_gemm_kernel',
-                      4 * (3 * (S * C + C) * M * M + C * M * D + B * D + S * C * M * B)),
+                      4 * (3 * (S * C + C) * M * M + C * M * D + B * D + S * C * M * B), 2.0 * S * C * M * B * D),
     # W.Y products: read W_uf (S*C*M*B), W_uu (S*C*M*M), x, z once; write P_uf, P_uu (S*C*M*D each)
     'rbf_kuu_bwd_gemm': ('void vargp::gemm_pair_kernel<64, 64, 64, true, false, true, false>',
-                         4 * (S * C * M * B + S * C * M * M + B * D + C * M * D + 2 * S * C * M * D)),
+                         4 * (S * C * M * B + S * C * M * M + B * D + C * M * D + 2 * S * C * M * D),
+                         2.0 * S * C * M * D * (B + M)),
 }
+SECONDARY = ['smnist_s64', 'smnist_t1', 'smnist_t4', 'pmnist_t0', 'pmnist_t1', 'pmnist_t4', 'stress']
 
 
-def one(pattern):
-    files = glob.glob(os.path.join(ROOT, 'gpurun_out', pattern))
-    assert files, pattern
-    return max(files, key=os.path.getmtime)
+def last_json(path):
+    for line in reversed(open(path).read().splitlines()):
+        if line.startswith('{'):
+            return json.loads(line)
+    return None
 
 
-def stats_rows(path):
-    return list(csv.DictReader(open(path)))
+def pmc_rows(path, prefix):
+    return [r for r in csv.DictReader(open(path)) if r['Kernel_Name'].startswith(prefix)]
 
 
-def pmc_avg(path, prefix, counter):
-    vals = [float(r['Counter_Value']) for r in csv.DictReader(open(path))
-            if r['Kernel_Name'].startswith(prefix) and r['Counter_Name'] == counter]
-    return sum(vals) / len(vals), len(vals)
+def avg(rows, counter):
+    v = [float(r['Counter_Value']) for r in rows if r['Counter_Name'] == counter]
+    return (sum(v) / len(v), len(v)) if v else (None, 0)
+
+
+def keep(rows, name):
+    if not rows:
+        return
+    with open(os.path.join(OUT, name), 'w', newline='') as g:
+        w = csv.DictWriter(g, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        w.writerows(rows[:200])
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
-    graph, eager = one('p_graph/*/*kernel_stats.csv'), one('p_eager/*/*kernel_stats.csv')
-    shutil.copy(graph, os.path.join(OUT, f'{tag}_bench_graph_kernel_stats.csv'))
-    shutil.copy(eager, os.path.join(OUT, f'{tag}_bench_eager_kernel_stats.csv'))
-    fetch, write = one('p_fetch/*/*counter_collection.csv'), one('p_write/*/*counter_collection.csv')
-    traffic = {}
-    for name, (prefix, algo) in KERNELS.items():
-        f_kb, nf = pmc_avg(fetch, prefix, 'FETCH_SIZE')
-        w_kb, nw = pmc_avg(write, prefix, 'WRITE_SIZE')
-        # keep the rows of this kernel as evidence
-        for src, cname in ((fetch, 'FETCH_SIZE'), (write, 'WRITE_SIZE')):
-            rows = [r for r in csv.DictReader(open(src)) if r['Kernel_Name'].startswith(prefix)]
-            with open(os.path.join(OUT, f'{tag}_pmc_{cname}_{name}.csv'), 'w', newline='') as g:
-                wtr = csv.DictWriter(g, fieldnames=list(rows[0].keys()))
-                wtr.writeheader()
-                wtr.writerows(rows)
-        traffic[name] = dict(kernel=prefix, FETCH_SIZE_KB=f_kb, WRITE_SIZE_KB=w_kb, dispatches=[nf, nw],
-                             fetch_correction=2.0,
-                             note='gfx950: FETCH_SIZE reports half the bytes of wide coalesced reads '
-                                  '(MI355X_MICROARCH.md, HBM / rocprofv3); WRITE_SIZE exact',
-                             traffic_bytes=1024.0 * (2.0 * f_kb + w_kb), algorithmic_bytes=algo)
-    with open(os.path.join(OUT, f'{tag}_traffic.json'), 'w') as g:
-        json.dump(traffic, g, indent=1)
-    if len(sys.argv) > 2:
-        shutil.copy(sys.argv[2], os.path.join(OUT, f'{tag}_bench.json'))
+    tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
+    G = os.path.join(ROOT, 'gpurun_out')
+    src = lambda d, f: os.path.join(G, f'{tag}_{d}', f)
+    shutil.copy(src('graph', 'p_kernel_stats.csv'), os.path.join(OUT, f'{tag}_bench_graph_kernel_stats.csv'))
+    shutil.copy(src('eager', 'p_kernel_stats.csv'), os.path.join(OUT, f'{tag}_bench_eager_kernel_stats.csv'))
+    shutil.copy(src('replay', 'p_kernel_stats.csv'), os.path.join(OUT, f'{tag}_replay_kernel_stats.csv'))
+    line = last_json(os.path.join(G, f'{tag}_line_smnist.log'))
+    json.dump(line, open(os.path.join(OUT, f'{tag}_bench.json'), 'w'), indent=1)
+    lines = {w: last_json(os.path.join(G, f'{tag}_line_{w}.log')) for w in SECONDARY
+             if os.path.exists(os.path.join(G, f'{tag}_line_{w}.log'))}
+    json.dump(lines, open(os.path.join(OUT, f'{tag}_lines.json'), 'w'), indent=1)
 
-    # README table from the eager run (exact launches per step)
-    rows = stats_rows(eager)
-    steps = 50 + 5 + 1          # timed + warm-up + the recording step of bench.py
-    lines = []
-    tot = 0.0
-    nlaunch = 0.0
-    # bench.py re-launches three recorded kernels 3 + 100 times each for its live timing: not part of a step
-    replayed = ('void vargp::chol_rbf_gemm_kernel', 'void vargp::gemm_pair_kernel<64, 64, 64, true, false, true, false>',
-                'void vargp::gemm_kernel<64, 64, 64, true, true, true, true>')
+    traffic, mfma = {}, {}
+    for name, (prefix, algo, flops) in KERNELS.items():
+        fr, wr, sq = (pmc_rows(src(d, 'p_counter_collection.csv'), prefix) for d in ('fetch', 'write', 'sq'))
+        keep([r for r in fr if r['Counter_Name'] == 'FETCH_SIZE'], f'{tag}_pmc_FETCH_SIZE_{name}.csv')
+        keep([r for r in wr if r['Counter_Name'] == 'WRITE_SIZE'], f'{tag}_pmc_WRITE_SIZE_{name}.csv')
+        keep(sq, f'{tag}_pmc_SQ_{name}.csv')
+        f_kb, nf = avg(fr, 'FETCH_SIZE')
+        w_kb, nw = avg(wr, 'WRITE_SIZE')
+        if f_kb is not None and w_kb is not None:
+            traffic[name] = dict(kernel=prefix, FETCH_SIZE_KB=f_kb, WRITE_SIZE_KB=w_kb, dispatches=[nf, nw], fetch_correction=2.0,
+                                 note='gfx950: FETCH_SIZE reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, '
+                                      'HBM / rocprofv3); WRITE_SIZE exact',
+                                 traffic_bytes=1024.0 * (2.0 * f_kb + w_kb), algorithmic_bytes=algo)
+        busy, n = avg(sq, 'SQ_VALU_MFMA_BUSY_CYCLES')
+        gui, _ = avg(sq, 'GRBM_GUI_ACTIVE')
+        if busy is not None and gui:
+            wave, _ = avg(sq, 'SQ_WAVE_CYCLES')
+            act, _ = avg(sq, 'SQ_ACTIVE_INST_ANY')
+            wi, _ = avg(sq, 'SQ_WAIT_INST_ANY')
+            wa, _ = avg(sq, 'SQ_WAIT_ANY')
+            mops, _ = avg(sq, 'SQ_INSTS_VALU_MFMA_MOPS_F32')
+            mfma[name] = dict(kernel=prefix, dispatches=n, SQ_VALU_MFMA_BUSY_CYCLES=busy, GRBM_GUI_ACTIVE=gui,
+                              mfma_util=busy / (128.0 * gui), mfma_flops_executed=(mops * 512.0) if mops else None,
+                              algorithmic_flops=flops,
+                              wave_cycle_split=dict(active=act / wave, wait_inst=wi / wave, wait=wa / wave) if wave else None,
+                              note='mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (128 * GRBM_GUI_ACTIVE): busy cycles summed over 1024 '
+                                   'SIMDs, GRBM_GUI_ACTIVE summed over 8 XCDs; calibrated on the 4096^3 GEMM (0.90)')
+    cal = os.path.join(G, f'{tag}_sqcal', 'p_counter_collection.csv')
+    if os.path.exists(cal):
+        rows = pmc_rows(cal, 'void vargp::gemm_kernel')
+        busy, n = avg(rows, 'SQ_VALU_MFMA_BUSY_CYCLES')
+        gui, _ = avg(rows, 'GRBM_GUI_ACTIVE')
+        mfma['calibration_gemm_4096'] = dict(dispatches=n, mfma_util=busy / (128.0 * gui),
+                                             timing=[l for l in open(os.path.join(G, f'{tag}_sqcal.log')).read().splitlines()
+                                                     if l.startswith('gemm4k')])
+    json.dump(traffic, open(os.path.join(OUT, f'{tag}_traffic.json'), 'w'), indent=1)
+    json.dump(mfma, open(os.path.join(OUT, f'{tag}_mfma.json'), 'w'), indent=1)
+
+    # per-step table from the eager run (no re-launches in it: --no-replay)
+    rows = list(csv.DictReader(open(src('eager', 'p_kernel_stats.csv'))))
+    steps = 50 + 5 + 1 + 1          # timed + warm-up + the recording step + the ELBO check
+    out, tot, nl = [], 0.0, 0.0
     for r in rows:
-        calls, avg = int(r['Calls']), float(r['AverageNs']) / 1e3
-        if r['Name'].startswith(replayed):
-            calls -= 103
+        calls, a = int(r['Calls']), float(r['AverageNs']) / 1e3
         if calls < steps // 2:
             continue
         per = calls / steps
-        tot += calls * avg / steps
-        nlaunch += per
-        if len(lines) < 24:
-            lines.append(f"| `{r['Name'][:76]}` | {per:.1f} | {avg:.1f} | {calls * avg / steps:.1f} |")
+        tot += calls * a / steps
+        nl += per
+        if len(out) < 26:
+            out.append(f"| `{r['Name'][:78]}` | {per:.1f} | {a:.1f} | {calls * a / steps:.1f} |")
     with open(os.path.join(OUT, f'{tag}_top_kernels.md'), 'w') as g:
-        g.write('| kernel | launches/step | avg µs | µs/step |\n|---|---|---|---|\n' + '\n'.join(lines) + '\n\n')
-        g.write(f'Sum of kernel time: {tot:.0f} µs per step over {nlaunch:.0f} launches (eager run, {steps} steps; the 103 '
-                f're-launches per timed kernel of bench.py\'s live measurement are subtracted).\n')
-    print(json.dumps(traffic, indent=1))
+        g.write('| kernel | launches/step | avg µs | µs/step |\n|---|---|---|---|\n' + '\n'.join(out) + '\n\n')
+        g.write(f'Sum of kernel time: {tot:.0f} µs per step over {nl:.0f} launches (eager run, {steps} program runs).\n')
+    print(json.dumps(dict(traffic=traffic, mfma=mfma), indent=1)[:3000])
     print(open(os.path.join(OUT, f'{tag}_top_kernels.md')).read())
+    for w, l in lines.items():
+        print(w, l and l.get('value'))
 
 
 if __name__ == '__main__':

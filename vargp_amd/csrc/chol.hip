@@ -26,7 +26,7 @@ constexpr int kCholP = 5;        // threads per matrix row of chol_inv_small_ker
 // A co-launched GEMM pays while it is about as long as a diagonal block's pivot chain (~50 us); a much longer one is
 // faster on its own with the big tiles (measured: Permuted-MNIST K_uf, 5040 tiles: 481 us merged vs 394 + 57 separate)
 static bool co_gemm_is_comparable(const GemmParams& p, int nbatch) {
-  return (int64_t)cdiv(p.M, 64) * cdiv(p.N, 64) * nbatch <= 1024;
+  return (int64_t)cdiv(p.M, 64) * cdiv(p.N, 64) * nbatch <= 1536;
 }
 // Packed lower-triangular index.
 __device__ __forceinline__ int pk(int i, int j) { return i * (i + 1) / 2 + j; }
@@ -285,21 +285,24 @@ extern "C" int vargp_chol_inv_fwd(const float* A, float eps, float* L, float* T,
 }
 
 // zero_info = false: the caller has already cleared the status words (the fused ELBO program does it in its prologue).
-// co / co_nbatch / co_done: an RBF kernel-matrix GEMM of the caller that does not depend on the factorisation; if the
-// first diagonal block qualifies (50 < width <= 100, T wanted, no logdet) the two share ONE launch (the pivot chain of a
-// diagonal block keeps nbatch of the 256 CUs busy for ~50 us: the GEMM runs on the others) and *co_done is set.
+// co[0 .. nco) / co_nbatch / co_done: RBF kernel-matrix GEMMs of the caller that do not depend on the factorisation (e.g.
+// row slices of K_uf).  Diagonal block k shares ONE launch with co[k] if it qualifies (50 < width <= 100, T wanted, no
+// logdet): its pivot chain keeps nbatch of the 256 CUs busy for ~50 us, the GEMM runs on the others.  *co_done = number of
+// GEMMs consumed (always a prefix co[0 .. *co_done)); the caller launches the rest itself.
 int vargp::chol_inv_fwd_impl(const float* A, float eps, float* L, float* T, float* logdet, int32_t* info, int nbatch,
                              int n, void* ws, size_t ws_bytes, bool zero_info, hipStream_t st, const GemmParams* co,
-                             int co_nbatch, bool* co_done) {
+                             int co_nbatch, int* co_done, int nco) {
   VARGP_REQUIRE(A && L, "chol_inv_fwd: null pointer");
   VARGP_REQUIRE(nbatch > 0 && n > 0, "chol_inv_fwd: bad dims");
   const int64_t nn = (int64_t)n * n;
-  if (co_done) *co_done = false;
+  int ndone = 0;
+  if (co_done) *co_done = 0;
+  if (!co) nco = 0;
   if (info && zero_info) zero_async(info, sizeof(int32_t) * nbatch, st);
   if (n <= kSmallMax) {
-    if (co && T && !logdet && info && chol_rbf_gemm_applicable(n, *co) && co_gemm_is_comparable(*co, co_nbatch)) {
-      if (co_done) *co_done = true;
-      return launch_chol_rbf_gemm_ld(A, n, nn, eps, L, n, nn, T, n, nn, info, nbatch, n, *co, co_nbatch, st);
+    if (nco > 0 && T && !logdet && info && chol_rbf_gemm_applicable(n, co[0]) && co_gemm_is_comparable(co[0], co_nbatch)) {
+      if (co_done) *co_done = 1;
+      return launch_chol_rbf_gemm_ld(A, n, nn, eps, L, n, nn, T, n, nn, info, nbatch, n, co[0], co_nbatch, st);
     }
     return launch_small(A, n, nn, eps, L, n, nn, T, n, nn, logdet, info, 0, nbatch, n, 0, st);
   }
@@ -321,9 +324,13 @@ int vargp::chol_inv_fwd_impl(const float* A, float eps, float* L, float* T, floa
     float* Tkk = Tout ? Tout + dkk : tmp;
     const int ldt = Tout ? n : kb;
     const int64_t sT = Tout ? nn : stmp;
-    if (k0 == 0 && co && Tout && !logdet && info && chol_rbf_gemm_applicable(kb, *co) && co_gemm_is_comparable(*co, co_nbatch)) {
-      rc = launch_chol_rbf_gemm_ld(W, n, nn, 0.f, L, n, nn, Tkk, ldt, sT, info, nbatch, kb, *co, co_nbatch, st);
-      if (co_done) *co_done = true;
+    const int kpanel = k0 / kNbSmall;
+    if (kpanel < nco && Tout && !logdet && info && chol_rbf_gemm_applicable(kb, co[kpanel]) &&
+        co_gemm_is_comparable(co[kpanel], co_nbatch)) {
+      // (chol3_body reports a failing pivot as info_base + j + 1; the merged kernel has no info_base: only the first
+      // panel's index is exact, later panels report the index within the panel -- non-zero is what callers test)
+      rc = launch_chol_rbf_gemm_ld(W + dkk, n, nn, 0.f, L + dkk, n, nn, Tkk, ldt, sT, info, nbatch, kb, co[kpanel], co_nbatch, st);
+      ++ndone;
     } else {
       rc = launch_small(W + dkk, n, nn, 0.f, L + dkk, n, nn, Tkk, ldt, sT, logdet, info, k0, nbatch, kb, k0 > 0, st);
     }
@@ -343,6 +350,7 @@ int vargp::chol_inv_fwd_impl(const float* A, float eps, float* L, float* T, floa
       if (rc) return rc;
     }
   }
+  if (co_done) *co_done = ndone;
   if (Tout) {
     // off-diagonal blocks of T, last block column first:  T[j1:, j] = -T[j1:, j1:] (L[j1:, j] T_jj)
     const int nblk = cdiv(n, kNbSmall);

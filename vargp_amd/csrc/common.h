@@ -113,7 +113,7 @@ int rbf_gram_bwd_impl(const float* theta, const float* X, const float* Y, const 
                       size_t ws_bytes, int sym_gk, hipStream_t st);
 int chol_inv_fwd_impl(const float* A, float eps, float* L, float* T, float* logdet, int32_t* info, int nbatch, int n,
                       void* ws, size_t ws_bytes, bool zero_info, hipStream_t st, const GemmParams* co = nullptr,
-                      int co_nbatch = 0, bool* co_done = nullptr);
+                      int co_nbatch = 0, int* co_done = nullptr, int nco = 1);
 // factorisations of nchol matrices (n in (50, 100]) with explicit leading dimensions / batch strides + one RBF GEMM
 int launch_chol_rbf_gemm_ld(const float* A, int lda, int64_t sA, float eps, float* L, int ldl, int64_t sL, float* T, int ldt,
                             int64_t sT, int32_t* info, int nchol, int n, const GemmParams& p, int nbatch, hipStream_t st);

@@ -532,12 +532,36 @@ extern "C" int vargp_elbo_tn_fwd(const vargp_elbo_tn_desc* d, vargp_stream_t str
   }
   // L = chol(K_all + eps I), T = L^-1: every factor of the reference's chain is a leading block of these.  The K_uf
   // GEMM, which nothing needs before T exists, shares the launch of the first diagonal block's pivot chain.
+  // With a blocked factorisation (Mt > 100) every diagonal block has a pivot chain of its own: the K_uf GEMM is cut into
+  // row slices (whole 64-row tiles of the [C*Mt x B] product), one per chain.
+  constexpr int kMaxSlices = 8;
+  GemmParams slices[kMaxSlices];
+  int nsl = 0, consumed = 0;
+  if (!kuf_done) {
+    const int npanel = Mt <= 100 ? 1 : cdiv(Mt, 100);
+    nsl = std::min(std::min(npanel, kMaxSlices), std::max(1, (int)(zrows / 128)));
+    const int64_t per = round_up(cdiv(zrows, nsl), 64);
+    nsl = cdiv(zrows, per);
+    for (int i = 0; i < nsl; ++i) {
+      const int64_t r0 = i * per, rows = std::min<int64_t>(per, zrows - r0);
+      slices[i] = pf;
+      slices[i].A = pf.A + r0 * D; slices[i].C = pf.C + r0 * B; slices[i].M = (int)rows;
+      slices[i].na = pf.na + r0;
+    }
+  }
   rc = chol_inv_fwd_impl(o.Kall, d->jitter, o.LL, o.TT, nullptr, d->info, SC, Mt, o.chol, o.chol_bytes, false, st,
-                         kuf_done ? nullptr : &pf, S, &kuf_done);
+                         nsl ? slices : nullptr, S, &consumed, nsl);
   if (rc) return rc;
   if (!kuf_done) {
-    rc = launch_gemm(pf, 0, 1, S, true, st, "rbf_kuf_gemm");
-    if (rc) return rc;
+    if (consumed == 0) {
+      rc = launch_gemm(pf, 0, 1, S, true, st, "rbf_kuf_gemm");
+      if (rc) return rc;
+    } else {
+      for (int i = consumed; i < nsl; ++i) {
+        rc = launch_gemm(slices[i], 0, 1, S, true, st, "rbf_kuf_gemm");
+        if (rc) return rc;
+      }
+    }
   }
   {  // [a_i | . | H_i] = T_ii [m_i | 0 | Lu_i] for every (s, c, block i)
     const int64_t sA[3] = {C * MtMt, MtMt, (int64_t)M * Mt + M}, sB[3] = {0, (int64_t)nblk * M * NRs, (int64_t)M * NRs},

@@ -840,7 +840,7 @@ int launch_gemm(const GemmParams& p, int transA, int transB, int nbatch, bool rb
   else if (force == 2) dispatch_tile<128, 64, 32>(p, transA, transB, nbatch, rbf, vec, st);
   else if (force == 3) dispatch_tile<64, 64, 64>(p, transA, transB, nbatch, rbf, vec, st);
   else if (t12864 >= 384 && tri && pad64_less) dispatch_tile<64, 64, 64>(p, transA, transB, nbatch, rbf, vec, st);
-  else if (t128 >= 2048 && !tri && p.M >= 1024 && p.N >= 1024) dispatch_tile<128, 128, 16>(p, transA, transB, nbatch, rbf, vec, st);
+  else if (t128 >= 512 && !tri && p.M >= 1024 && p.N >= 1024) dispatch_tile<128, 128, 16>(p, transA, transB, nbatch, rbf, vec, st);
   else if (t12864 >= 384 && p.M > 64) dispatch_tile<128, 64, 32>(p, transA, transB, nbatch, rbf, vec, st);
   else dispatch_tile<64, 64, 64>(p, transA, transB, nbatch, rbf, vec, st);
   return check_launch("bgemm");
