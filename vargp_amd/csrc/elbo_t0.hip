@@ -337,6 +337,254 @@ __global__ __launch_bounds__(256) void t0_pdiag_kl_fwd_kernel(const float* __res
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The middle of the forward as ONE LDS-resident MFMA kernel (M <= 104): for every (s, c) and 64-column tile of the minibatch
+//     P = T K_uf[:, tile]   (T = Lz^-1, lower)        W = G^T P   (G = Lz^-1 L_S, lower)
+//     mu = sum_m P a,  var = kd - sum_m P^2 + sum_m W^2                                   (gp_utils.py:178-186)
+// T, G (from the small-column product QP[:, 0:NR] = T RK[:, 0:NR], computed just before) and the K_uf tile sit in LDS for
+// the whole workgroup (55 + 55 + 28 KB of the CU's 160 KB), P goes back into the tile's place as the second product's
+// operand, the column reductions run on the accumulators: three launches (QP GEMM, W GEMM, moments) and two HBM round trips
+// of P and W become one launch.  256 threads = 4 waves; wave w owns the 32-column half (w & 1) and the row blocks {0, 3}
+// or {1, 2} -- with the triangular K ranges ([0, 32 rb + 32) for T, [32 rb, M) for G^T) both pairs carry the same work.
+// f32 MFMA 32x32x2 with the k-pairing of gemm.hip: half-wave h supplies k = 8 g + 4 h + j, j < 4, one b128 fragment read
+// per lane and group for the K-contiguous operand (T), four b32 reads for the row-major ones.
+// The tile workgroups of an (s, c) share out the rows of the KL of q(u) against p(u) (vargp.py:182-190).
+constexpr int kFusedTS = 108;    // row stride of T in LDS: 108 mod 64 = 44 -> the 16 rows of a b128 read group hit 16 bank quads
+constexpr int kFusedGS = 132;    // row stride of G (k-major)
+constexpr int kFusedKS = 68;     // row stride of the K_uf / P tile
+constexpr int kFusedK = 104;     // padded inner dimension (M <= 104, multiple of 8)
+constexpr size_t kFusedLdsBytes = sizeof(float) * (128 * kFusedTS + kFusedK * kFusedGS + kFusedK * kFusedKS + 128 + 3 * 64);
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void t0_fwd_fused_kernel(const float* __restrict__ TT, float* __restrict__ QP,
+                                                           const float* __restrict__ RK, float* __restrict__ W,
+                                                           const float* __restrict__ kd, const float* __restrict__ Lz,
+                                                           const float* __restrict__ Lu, float* __restrict__ mu,
+                                                           float* __restrict__ var, float* __restrict__ kl_u, int S, int C,
+                                                           int M, int B, int NR, int LD, int ntile, uint32_t* rng_counter) {
+  extern __shared__ __attribute__((aligned(16))) float lds_f[];
+  float* sT = lds_f;                              // [128][TS]   T[i][k]
+  float* sG = sT + 128 * kFusedTS;                // [K][GS]     G[k][i]
+  float* sK = sG + kFusedK * kFusedGS;            // [K][KS]     K_uf tile [k][n], then P[m][n]
+  float* sa = sK + kFusedK * kFusedKS;            // [128]       a = Lz^-1 m
+  float* red = sa + 128;                          // [3][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int64_t b = blockIdx.y;
+  const int64_t MM = (int64_t)M * M, MLD = (int64_t)M * LD;
+  if (rng_counter && blockIdx.x == 0 && b == 0 && tid == 0) rng_counter[0] += 1u;   // this step's noise has been drawn
+  const int n0 = (int)blockIdx.x * 64;
+  // ---- stage T, G, the K_uf tile and a (zero-padded: rows / inner indices >= M, columns >= B) ----------------------------
+  const float* Tb = TT + b * MM;
+  const float* Qb = QP + b * MLD;
+  const float* Kb = RK + b * MLD + NR + n0;
+  // ---- KL of q(u) against p(u) for this (s, c) (vargp.py:182-190), its rows shared out over the tile workgroups:
+  //      kl[s,c] = sum log diag Lz - sum log diag Lu + (|G2|_F^2 + |a|^2 - M) / 2,   kl_u = (1/S) sum kl[s,c]
+  // Evaluated first: its (latency-bound) global loads are in flight together with the staging loads below.
+  float kl_acc = 0.f;
+  {
+    const int c = b % C;
+    const int per = (M + ntile - 1) / ntile, i0 = (int)blockIdx.x * per, i1 = min(M, i0 + per);
+    for (int e = tid; e < (i1 - i0) * M; e += 256) {      // branch-free: upper entries are stored zeros
+      const int i = i0 + e / M, j = e % M;
+      const float v = Qb[(int64_t)i * LD + 4 + M + j];
+      kl_acc = fmaf(j <= i ? v : 0.f, v, kl_acc);
+    }
+    for (int i = i0 + tid; i < i1; i += 256) {
+      const float a = Qb[(int64_t)i * LD];
+      kl_acc = fmaf(a, a, kl_acc);
+      kl_acc += 2.f * (logf(Lz[(b * M + i) * M + i]) - logf(Lu[((int64_t)c * M + i) * M + i])) - 1.f;
+    }
+  }
+  // (branch-free: a branch around a load makes the compiler wait for every load before issuing the next; indices are
+  //  clamped into the operand and the padding is selected in afterwards, so that each loop issues its loads back to back)
+  {
+    constexpr int NT_ = 128 * (kFusedK / 4) / 256;          // 13 float4 per thread
+    float4 rt[NT_];
+#pragma unroll
+    for (int u = 0; u < NT_; ++u) {
+      const int e = tid + 256 * u;
+      const int i = e / (kFusedK / 4), k = (e - i * (kFusedK / 4)) * 4;
+      rt[u] = *reinterpret_cast<const float4*>(Tb + (int64_t)min(i, M - 1) * M + min(k, M - 4));
+    }
+#pragma unroll
+    for (int u = 0; u < NT_; ++u) {
+      const int e = tid + 256 * u;
+      const int i = e / (kFusedK / 4), k = (e - i * (kFusedK / 4)) * 4;
+      const bool ok = i < M && k < M;
+      *reinterpret_cast<float4*>(&sT[i * kFusedTS + k]) = ok ? rt[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  {
+    constexpr int NG_ = kFusedK * 32 / 256;                 // 13
+    float4 rg[NG_];
+#pragma unroll
+    for (int u = 0; u < NG_; ++u) {
+      const int e = tid + 256 * u;
+      const int k = e >> 5, i = (e & 31) * 4;
+      rg[u] = *reinterpret_cast<const float4*>(Qb + (int64_t)min(k, M - 1) * LD + 4 + min(i, M - 4));
+    }
+#pragma unroll
+    for (int u = 0; u < NG_; ++u) {
+      const int e = tid + 256 * u;
+      const int k = e >> 5, i = (e & 31) * 4;
+      *reinterpret_cast<float4*>(&sG[k * kFusedGS + i]) = (k < M && i < M) ? rg[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  {
+    constexpr int NK_ = (kFusedK * 16 + 255) / 256;          // 7 (the last one partly out of range)
+    float4 rk[NK_];
+    const bool full = n0 + 64 <= B;                         // (uniform) all 64 columns exist: plain float4 loads
+#pragma unroll
+    for (int u = 0; u < NK_; ++u) {
+      const int e = min(tid + 256 * u, kFusedK * 16 - 1);
+      const int k = e >> 4, n = (e & 15) * 4;
+      const float* src = Kb + (int64_t)min(k, M - 1) * LD;
+      if (full) rk[u] = *reinterpret_cast<const float4*>(src + n);
+      else {
+        rk[u].x = n0 + n < B ? src[n] : 0.f;         rk[u].y = n0 + n + 1 < B ? src[n + 1] : 0.f;
+        rk[u].z = n0 + n + 2 < B ? src[n + 2] : 0.f; rk[u].w = n0 + n + 3 < B ? src[n + 3] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NK_; ++u) {
+      const int e = tid + 256 * u;
+      if (e < kFusedK * 16) {
+        const int k = e >> 4, n = (e & 15) * 4;
+        *reinterpret_cast<float4*>(&sK[k * kFusedKS + n]) = k < M ? rk[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  }
+  if (tid < 128) sa[tid] = tid < M ? Qb[(int64_t)tid * LD] : 0.f;
+  if (tid < 192) red[tid] = 0.f;
+  __syncthreads();
+  const int cb = wave & 1;
+  const int rbs[2] = {(wave >> 1) ? 1 : 0, (wave >> 1) ? 2 : 3};
+  // ---- P = T K: row block rb needs k < 32 rb + 32.  The wave's two blocks advance together (two independent accumulators:
+  // back-to-back MFMAs on ONE accumulator wait for each other), the longer one finishes alone.
+  f32x16_t accP[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accP[u][r] = 0.f;
+  {
+    const int kend0 = min(kFusedK, 32 * rbs[0] + 32), kend1 = min(kFusedK, 32 * rbs[1] + 32);     // kend0 <= kend1
+    const float* arow0 = sT + (32 * rbs[0] + li) * kFusedTS + 4 * lh;
+    const float* arow1 = sT + (32 * rbs[1] + li) * kFusedTS + 4 * lh;
+    const float* bcol = sK + (4 * lh) * kFusedKS + 32 * cb + li;
+    int k = 0;
+    for (; k < kend0; k += 8) {
+      const float4 a0 = *reinterpret_cast<const float4*>(arow0 + k), a1 = *reinterpret_cast<const float4*>(arow1 + k);
+      const float b0 = bcol[(k + 0) * kFusedKS], b1 = bcol[(k + 1) * kFusedKS], b2 = bcol[(k + 2) * kFusedKS],
+                  b3 = bcol[(k + 3) * kFusedKS];
+      accP[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0, accP[0], 0, 0, 0);
+      accP[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0, accP[1], 0, 0, 0);
+      accP[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b1, accP[0], 0, 0, 0);
+      accP[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1, accP[1], 0, 0, 0);
+      accP[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b2, accP[0], 0, 0, 0);
+      accP[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b2, accP[1], 0, 0, 0);
+      accP[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b3, accP[0], 0, 0, 0);
+      accP[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b3, accP[1], 0, 0, 0);
+    }
+    for (; k < kend1; k += 8) {
+      const float4 a1 = *reinterpret_cast<const float4*>(arow1 + k);
+      const float b0 = bcol[(k + 0) * kFusedKS], b1 = bcol[(k + 1) * kFusedKS], b2 = bcol[(k + 2) * kFusedKS],
+                  b3 = bcol[(k + 3) * kFusedKS];
+      accP[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0, accP[1], 0, 0, 0);
+      accP[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1, accP[1], 0, 0, 0);
+      accP[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b2, accP[1], 0, 0, 0);
+      accP[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b3, accP[1], 0, 0, 0);
+    }
+  }
+  __syncthreads();                                // everybody is done with the K_uf tile
+  // P into the tile's place (second product's operand) and out to QP; column sums of P a and P^2 on the way
+  const int col = n0 + 32 * cb + li;
+  float s_mu = 0.f, s_p2 = 0.f, s_w2 = 0.f;
+  float* Pout = QP + b * MLD + NR;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = 32 * rbs[u] + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const float v = accP[u][r];
+      if (m < kFusedK) sK[m * kFusedKS + 32 * cb + li] = v;
+      if (m < M) {
+        if (col < B) Pout[(int64_t)m * LD + col] = v;
+        s_mu = fmaf(v, sa[m], s_mu);
+        s_p2 = fmaf(v, v, s_p2);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- W = G^T P: row block rb needs k >= 32 rb (G is lower triangular); rbs[0] < ... the block with the smaller rb starts
+  // alone, then both advance together
+  float* Wb = W + b * (int64_t)M * B;
+  {
+    const int rlo = min(rbs[0], rbs[1]), rhi = max(rbs[0], rbs[1]);
+    f32x16_t accW[2];        // [0]: row block rlo, [1]: row block rhi
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accW[u][r] = 0.f;
+    const float* acol0 = sG + (4 * lh) * kFusedGS + 32 * rlo + li;
+    const float* acol1 = sG + (4 * lh) * kFusedGS + 32 * rhi + li;
+    const float* bcol = sK + (4 * lh) * kFusedKS + 32 * cb + li;
+    int k = 32 * rlo;
+    for (; k < 32 * rhi; k += 8) {
+      const float a0 = acol0[(k + 0) * kFusedGS], a1 = acol0[(k + 1) * kFusedGS], a2 = acol0[(k + 2) * kFusedGS],
+                  a3 = acol0[(k + 3) * kFusedGS];
+      const float b0 = bcol[(k + 0) * kFusedKS], b1 = bcol[(k + 1) * kFusedKS], b2 = bcol[(k + 2) * kFusedKS],
+                  b3 = bcol[(k + 3) * kFusedKS];
+      accW[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, accW[0], 0, 0, 0);
+      accW[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, accW[0], 0, 0, 0);
+      accW[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2, accW[0], 0, 0, 0);
+      accW[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b3, accW[0], 0, 0, 0);
+    }
+    for (; k < kFusedK; k += 8) {
+      const float a0 = acol0[(k + 0) * kFusedGS], a1 = acol0[(k + 1) * kFusedGS], a2 = acol0[(k + 2) * kFusedGS],
+                  a3 = acol0[(k + 3) * kFusedGS];
+      const float c0 = acol1[(k + 0) * kFusedGS], c1 = acol1[(k + 1) * kFusedGS], c2 = acol1[(k + 2) * kFusedGS],
+                  c3 = acol1[(k + 3) * kFusedGS];
+      const float b0 = bcol[(k + 0) * kFusedKS], b1 = bcol[(k + 1) * kFusedKS], b2 = bcol[(k + 2) * kFusedKS],
+                  b3 = bcol[(k + 3) * kFusedKS];
+      accW[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, accW[0], 0, 0, 0);
+      accW[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(c0, b0, accW[1], 0, 0, 0);
+      accW[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, accW[0], 0, 0, 0);
+      accW[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(c1, b1, accW[1], 0, 0, 0);
+      accW[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2, accW[0], 0, 0, 0);
+      accW[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(c2, b2, accW[1], 0, 0, 0);
+      accW[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b3, accW[0], 0, 0, 0);
+      accW[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(c3, b3, accW[1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int rb = u ? rhi : rlo;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < M) {
+          const float v = accW[u][r];
+          if (col < B) Wb[(int64_t)m * B + col] = v;
+          s_w2 = fmaf(v, v, s_w2);
+        }
+      }
+    }
+  }
+  // ---- column reductions: the two half-waves hold different rows of the same column, the waves different row blocks ----------
+  s_mu += __shfl_xor(s_mu, 32, 64); s_p2 += __shfl_xor(s_p2, 32, 64); s_w2 += __shfl_xor(s_w2, 32, 64);
+  if (lh == 0) {
+    atomicAdd(&red[32 * cb + li], s_mu); atomicAdd(&red[64 + 32 * cb + li], s_p2); atomicAdd(&red[128 + 32 * cb + li], s_w2);
+  }
+  __syncthreads();
+  if (tid < 64 && n0 + tid < B) {
+    mu[b * B + n0 + tid] = red[tid];
+    var[b * B + n0 + tid] = kd[b] - red[64 + tid] + red[128 + tid];
+  }
+  // ---- KL (partial sum from the top of the kernel)
+  __syncthreads();
+  const float tkl = block_sum<256>(kl_acc, red);
+  if (tid == 0) atomicAdd(kl_u, 0.5f * tkl / (float)S);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // backward kernels
 // ---------------------------------------------------------------------------------------------------------------
 // First backward launch, three roles by block index.
@@ -556,19 +804,35 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
     hipLaunchKernelGGL(t0_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, d->u_mean, o.LL + SC * MM, o.Lu, o.RK, C,
                        M, NR, LD, total);
   }
-  {  // QP = T RK
-    GemmParams p = flat_gemm(o.TT, M, MM, o.RK, LD, MLD, o.QP, LD, MLD, M, NR + B, M);
+  static const int fused_env = [] { const char* e = getenv("VARGP_T0_FUSED"); return e ? atoi(e) : 1; }();   // tuning aid
+  const int ntile = cdiv(B, 64);
+  const bool fused_mid = fused_env && M <= kFusedK && (M % 4) == 0 && (LD % 4) == 0 && (int64_t)SC * ntile <= 2048;
+  if (fused_mid) {
+    // small columns first (a = T m, G = T L_S, G2 = T Lu: one M x NR x M product per (s, c)), then the LDS-resident kernel
+    GemmParams p = flat_gemm(o.TT, M, MM, o.RK, LD, MLD, o.QP, LD, MLD, M, NR, M);
     p.triA = 1;
-    rc = launch_gemm(p, 0, 0, SC, false, st, "t0_qp_gemm");
+    rc = launch_gemm(p, 0, 0, SC, false, st, "t0_qps_gemm");
     if (rc) return rc;
-  }
-  {  // W = G^T P
-    GemmParams p = flat_gemm(o.QP + 4, LD, MLD, o.QP + NR, LD, MLD, o.W, B, (int64_t)M * B, M, B, M);
-    p.triA = 2;
-    rc = launch_gemm(p, 1, 0, SC, false, st, "t0_w_gemm");
-    if (rc) return rc;
-  }
-  {
+    static const bool attr_set = [] {
+      return hipFuncSetAttribute(reinterpret_cast<const void*>(t0_fwd_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)kFusedLdsBytes) == hipSuccess;
+    }();
+    VARGP_REQUIRE(attr_set, "elbo_t0_fwd: cannot reserve %zu bytes of LDS", kFusedLdsBytes);
+    hipLaunchKernelGGL(t0_fwd_fused_kernel, dim3(ntile, SC), dim3(256), kFusedLdsBytes, st, o.TT, o.QP, o.RK, o.W, o.kd, o.LL,
+                       o.Lu, o.mu, o.var, d->scalars + 1, S, C, M, B, NR, LD, ntile, native ? d->rng_counter : nullptr);
+  } else {
+    {  // QP = T RK
+      GemmParams p = flat_gemm(o.TT, M, MM, o.RK, LD, MLD, o.QP, LD, MLD, M, NR + B, M);
+      p.triA = 1;
+      rc = launch_gemm(p, 0, 0, SC, false, st, "t0_qp_gemm");
+      if (rc) return rc;
+    }
+    {  // W = G^T P
+      GemmParams p = flat_gemm(o.QP + 4, LD, MLD, o.QP + NR, LD, MLD, o.W, B, (int64_t)M * B, M, B, M);
+      p.triA = 2;
+      rc = launch_gemm(p, 1, 0, SC, false, st, "t0_w_gemm");
+      if (rc) return rc;
+    }
     const int nbx = cdiv(B, 64), npd = nbx * SC, nkx = cdiv(M, kKlRows);
     hipLaunchKernelGGL(t0_pdiag_kl_fwd_kernel, dim3(npd + nkx * SC), dim3(256), 0, st, o.QP, o.W, o.kd, o.LL, o.Lu, o.mu,
                        o.var, d->scalars + 1, S, C, M, B, NR, LD, nbx, npd, nkx, native ? d->rng_counter : nullptr);
