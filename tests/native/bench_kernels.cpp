@@ -139,6 +139,24 @@ int main(int argc, char** argv) {
       printf("   auto %8.1f us\n", us);
     }
   }
+  if (which == "kufbig") {   // the stress-config K_uf tile: [10*2048 x 784] x [8192 x 784]^T, RBF epilogue vs plain NT product
+    const int S = 1, C = 10, M = 2048, B = 8192, D = 784;
+    float* th = dev_rand((size_t)S * (D + 1), 0.05f, 1);
+    float* z = dev_rand((size_t)C * M * D, 0.02f, 2);
+    float* x = dev_rand((size_t)B * D, 0.02f, 3);
+    float* K; CK(hipMalloc(&K, (size_t)S * C * M * B * 4));
+    size_t wsb = vargp_rbf_workspace_bytes(S, C, M, B, D, 0);
+    void* ws; CK(hipMalloc(&ws, wsb));
+    const double fl = 2.0 * C * M * (double)B * D;
+    for (int tile = 0; tile <= 2; ++tile) {
+      vargp_tune_gemm_tile(tile);
+      double us = time_us([&] { vargp_rbf_gram_fwd(th, z, x, K, S, C, M, B, D, 1, ws, wsb, nullptr); }, iters);
+      printf("kufbig rbf   tile %d  %8.1f us -> %.1f TFLOP/s\n", tile, us, fl / us * 1e-6);
+      us = time_us([&] { gemm(z, x, K, C * M, B, D, 0, 1, 1, 0, 0, 0); }, iters);
+      printf("kufbig plain tile %d  %8.1f us -> %.1f TFLOP/s\n", tile, us, fl / us * 1e-6);
+    }
+    vargp_tune_gemm_tile(0);
+  }
   if (want("chol")) {
     for (int n : {20, 40, 64, 100}) {
       const int nb = 30;

@@ -119,8 +119,9 @@ int launch_chol_rbf_gemm_ld(const float* A, int lda, int64_t sA, float eps, floa
                             int64_t sT, int32_t* info, int nchol, int n, const GemmParams& p, int nbatch, hipStream_t st);
 // w = exp(-2 theta) (zero-padded to Dp), g2 = exp(2 theta_D) and the weighted squared row norms of x (xrows x D) and of
 // y (yrows x D, may be 0 rows) for every hyper-sample, in one launch
+// ys (nullable): also write y o w, [S][yrows][D] (the pre-scaled operand of an unscaled RBF GEMM: GemmParams.kscale = NULL)
 int rbf_prep_norm_launch(const float* theta, const float* x, int64_t xrows, const float* y, int64_t yrows, float* w,
-                         float* g2, float* na, float* nb, int S, int D, int64_t Dp, hipStream_t st);
+                         float* g2, float* na, float* nb, int S, int D, int64_t Dp, hipStream_t st, float* ys = nullptr);
 
 int chol_inv_bwd_first(const float* T, const float* gT, int nbatch, int n, void* ws, size_t ws_bytes,
                        const GemmParams* other, int oA, int oB, int onb, hipStream_t st);

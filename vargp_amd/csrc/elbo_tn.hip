@@ -24,7 +24,7 @@ namespace vargp {
 
 struct TnWs {
   float *theta, *eps_theta, *eps_f;          // first, in this order (vargp_amd/fused.py exposes them as views)
-  float *g2, *kd, *w, *na, *nb, *mu, *var, *gmu, *gvar;   // gmu, gvar adjacent: one zero range (accumulated by the softmax kernel)
+  float *g2, *kd, *w, *na, *nb, *xs, *mu, *var, *gmu, *gvar;   // gmu, gvar adjacent: one zero range (accumulated by the softmax kernel)
   int64_t Dp;
   float *Kall, *Kuf, *LL, *TT, *QPs, *P, *V2, *W;
   float *gQPs, *gP, *gT, *gKuf, *gK, *gRKt, *gkd, *gz_all;
@@ -47,6 +47,7 @@ static TnWs carve_tn(void* ws, int S, int C, int M, int D, int B, int F, int nbl
   o.Dp = round_up(D, 4);
   o.g2 = take(S); o.kd = take(SC);
   o.w = take(S * o.Dp); o.na = take(SC * Mt); o.nb = take((int64_t)S * B);
+  o.xs = take((int64_t)S * B * D);           // x o w per hyper-sample: the K_uf GEMM then needs no per-k scaling
   o.mu = take(SC * B); o.var = take(SC * B);
   o.gmu = take(SC * B); o.gvar = take(SC * B);
   o.Kall = take(SC * Mt * Mt); o.Kuf = take(SC * Mt * B);
@@ -497,7 +498,7 @@ extern "C" int vargp_elbo_tn_fwd(const vargp_elbo_tn_desc* d, vargp_stream_t str
   const bool mfma = D > kRbfDirectD;
   bool kuf_done = false;
   GemmParams pf{};       // K_uf = rbf(z_all, x): the classes' inducing points are just more rows of one [C*Mt, D] x [D, B] product
-  rc = rbf_prep_norm_launch(o.theta, d->z_all, zrows, d->x, B, o.w, o.g2, o.na, o.nb, S, D, o.Dp, st);
+  rc = rbf_prep_norm_launch(o.theta, d->z_all, zrows, d->x, B, o.w, o.g2, o.na, o.nb, S, D, o.Dp, st, o.xs);
   if (rc) return rc;
   if (!mfma) {           // small input dimension: direct (cancellation-free) distances
     rc = rbf_direct_launch(d->z_all, nullptr, o.w, o.g2, o.Kall, Mt, S, C, Mt, Mt, D, o.Dp, 0, st);
@@ -521,12 +522,13 @@ extern "C" int vargp_elbo_tn_fwd(const vargp_elbo_tn_desc* d, vargp_stream_t str
     if (ksym) { p0.triC = 2; p0.symout = 1; }
     rc = launch_gemm(p0, 0, 1, SC, true, st, "rbf_kuu_gemm");
     if (rc) return rc;
-    pf.A = d->z_all; pf.B = d->x; pf.C = o.Kuf;
+    pf.A = d->z_all; pf.B = o.xs; pf.C = o.Kuf;
     pf.M = C * Mt; pf.N = B; pf.K = D; pf.lda = D; pf.ldb = D; pf.ldc = B;
     pf.nb1 = 1; pf.nb2 = 1;
+    pf.sB[0] = (int64_t)B * D;
     pf.sC[0] = (int64_t)C * MtB;
     pf.alpha = 1.f;
-    pf.kscale = o.w; pf.ks_ld = o.Dp; pf.g2 = o.g2;
+    pf.kscale = nullptr; pf.ks_ld = o.Dp; pf.g2 = o.g2;      // pre-scaled B operand
     pf.na = o.na; pf.sNa[0] = zrows;
     pf.nbv = o.nb; pf.sNb[0] = B;
   }
@@ -871,16 +873,17 @@ extern "C" int vargp_elbo_tn_tile(const vargp_elbo_tn_desc* d, const float* seed
     hipLaunchKernelGGL(tn_tile_prep_kernel, dim3(nzero + nrng), dim3(256), 0, st, o.gmu, n0, o.c_uf, n1, nzero, native ? 1 : 0,
                        d->rng_seed, d->rng_counter, (int64_t)d->rng_sample_offset * F * C * B, n_f, o.eps_f);
   }
-  rc = rbf_prep_norm_launch(o.theta, nullptr, 0, x, B, o.w, o.g2, o.na, o.nb, S, D, o.Dp, st);
+  rc = rbf_prep_norm_launch(o.theta, nullptr, 0, x, B, o.w, o.g2, o.na, o.nb, S, D, o.Dp, st, o.xs);
   if (rc) return rc;
   {
     GemmParams pf{};
-    pf.A = d->z_all; pf.B = x; pf.C = o.Kuf;
+    pf.A = d->z_all; pf.B = o.xs; pf.C = o.Kuf;
     pf.M = C * Mt; pf.N = B; pf.K = D; pf.lda = D; pf.ldb = D; pf.ldc = B;
     pf.nb1 = 1; pf.nb2 = 1;
+    pf.sB[0] = (int64_t)B * D;
     pf.sC[0] = (int64_t)C * MtB;
     pf.alpha = 1.f;
-    pf.kscale = o.w; pf.ks_ld = o.Dp; pf.g2 = o.g2;
+    pf.kscale = nullptr; pf.ks_ld = o.Dp; pf.g2 = o.g2;      // pre-scaled B operand
     pf.na = o.na; pf.sNa[0] = zrows;
     pf.nbv = o.nb; pf.sNb[0] = B;
     rc = launch_gemm(pf, 0, 1, S, true, st, "rbf_kuf_gemm");

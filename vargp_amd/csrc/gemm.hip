@@ -252,9 +252,20 @@ constexpr int gemm_lds_floats() {
 }
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
-template <int BM, int BN, int BK, bool AKC, bool BKC, bool VEC, bool RBF>
-__device__ __forceinline__ void gemm_body(const GemmParams& p, const int tile_id, const int batch_id, const int split_id,
+// SCALED (RBF only): the K-contiguous A slab is multiplied by kscale[k] = 1/sigma_k^2 on its way into LDS.  Callers that
+// hand over a pre-scaled B operand (x o w, written once per hyper-sample by the norm pass) pass kscale = NULL and get the
+// unscaled instantiation: the scale loads and multiplies sit in the main loop, where nothing overlaps them with the MFMAs
+// (stress K_uf tile [20480 x 784] x [8192 x 784]^T: 93 TFLOP/s scaled in the loop, 133 as a plain product).
+template <int BM, int BN, int BK, bool AKC, bool BKC, bool VEC, bool RBF, bool SCALED = true>
+__device__ __forceinline__ void gemm_body(const GemmParams& p, const int tile_id_, const int batch_id_, const int split_id_,
                                           float* __restrict__ lds) {
+  // The workgroup's tile / batch / split indices are wave-uniform, but they come out of integer divisions that the
+  // compiler carries out on the vector unit, so it treats everything derived from them as divergent: operand base
+  // pointers in VGPRs, and a waterfall loop (v_readfirstlane / v_cmp / s_and_saveexec) around EVERY buffer load of the
+  // main loop, whose descriptor must be scalar.  One readfirstlane here makes all of it scalar.
+  const int tile_id = __builtin_amdgcn_readfirstlane(tile_id_);
+  const int batch_id = __builtin_amdgcn_readfirstlane(batch_id_);
+  const int split_id = __builtin_amdgcn_readfirstlane(split_id_);
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   using LA = LdsLayout<AKC, BM, BK>;
   using LB = LdsLayout<BKC, BN, BK>;
@@ -263,14 +274,15 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int tile_id
   constexpr int kStage = ((LA::kSize + 3) & ~3) + ((LB::kSize + 3) & ~3);
 
   const int tiles_n = (p.N + BN - 1) / BN;
-  int tm = tile_id / tiles_n, tn = tile_id % tiles_n;
+  int tm = __builtin_amdgcn_readfirstlane(tile_id / tiles_n), tn = __builtin_amdgcn_readfirstlane(tile_id % tiles_n);
   // triangular operands clip the K range per tile: hand out the long tiles of a matrix first, so that the launch does not
   // end on them (workgroups are dispatched in id order)
   if (p.triA == 1) tm = (p.M + BM - 1) / BM - 1 - tm;
   if (p.triB == 2) tn = tiles_n - 1 - tn;
   const int m0 = tm * BM, n0 = tn * BN;
   const int b = batch_id;
-  const int i2 = b % p.nb2, i1 = (b / p.nb2) % p.nb1, i0 = b / (p.nb2 * p.nb1);
+  const int i2 = __builtin_amdgcn_readfirstlane(b % p.nb2), i1 = __builtin_amdgcn_readfirstlane((b / p.nb2) % p.nb1),
+            i0 = __builtin_amdgcn_readfirstlane(b / (p.nb2 * p.nb1));
   const float* A = p.A + i0 * p.sA[0] + i1 * p.sA[1] + i2 * p.sA[2];
   const float* B = p.B + i0 * p.sB[0] + i1 * p.sB[1] + i2 * p.sB[2];
   float* C = p.C + i0 * p.sC[0] + i1 * p.sC[1] + i2 * p.sC[2];
@@ -313,7 +325,8 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int tile_id
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
 
-  const float* kscale = RBF ? p.kscale + i0 * p.ks_ld : nullptr;
+  constexpr bool SC = RBF && SCALED;
+  const float* kscale = SC ? p.kscale + i0 * p.ks_ld : nullptr;
 
   float ra[BM * BK / 256], rb[BN * BK / 256], rs[4] = {1.f, 1.f, 1.f, 1.f};
   float* const stage0 = lds;
@@ -404,10 +417,10 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int tile_id
         for (int c = 0; c < NPA; ++c) load_piece_fast<BM, BK>(rsA, offA[c], slab * stepA, c, xa);
 #pragma unroll
         for (int c = 0; c < NPB; ++c) load_piece_fast<BN, BK>(rsB, offB[c], slab * stepB, c, xb);
-        if constexpr (RBF) load_scale<BK, true>(kscale, ks + slab * BK, ke, xs);
+        if constexpr (SC) load_scale<BK, true>(kscale, ks + slab * BK, ke, xs);
       };
       load_set(0, ra, rb, rs);
-      store_slab<AKC, BM, BK, true, RBF>(stage0, ra, rs);
+      store_slab<AKC, BM, BK, true, SC>(stage0, ra, rs);
       store_slab<BKC, BN, BK, true, false>(stage0 + kBoff, rb, rs);
       load_set(min(1, nfull - 1), ra, rb, rs);              // slab 1 -> set X
       __syncthreads();
@@ -428,13 +441,13 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int tile_id
               if (pc < NPA) load_piece_fast<BM, BK>(rsA, offA[pc], soA, pc, ya);
               else if (pc < NP) load_piece_fast<BN, BK>(rsB, offB[pc - NPA], soB, pc - NPA, yb);
             }
-            if constexpr (RBF) { if (g == HALF - 1) load_scale<BK, true>(kscale, ks + nxt * BK, ke, ys); }
+            if constexpr (SC) { if (g == HALF - 1) load_scale<BK, true>(kscale, ks + nxt * BK, ke, ys); }
           }
           if (g >= HALF) {                                  // register set X (slab sl+1) -> idle LDS stage
 #pragma unroll
             for (int u = 0; u < PERS; ++u) {
               const int pc = (g - HALF) * PERS + u;
-              if (pc < NPA) store_piece<AKC, BM, BK, true, RBF>(An, xa, xs, pc);
+              if (pc < NPA) store_piece<AKC, BM, BK, true, SC>(An, xa, xs, pc);
               else if (pc < NP) store_piece<BKC, BN, BK, true, false>(An + kBoff, xb, xs, pc - NPA);
             }
           }
@@ -452,9 +465,9 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int tile_id
   for (int k0 = kdone; k0 < ke; k0 += BK) {
     load_slab<AKC, BM, BK, VEC>(A, p.lda, m0, p.M, k0, ke, ra);
     load_slab<BKC, BN, BK, VEC>(B, p.ldb, n0, p.N, k0, ke, rb);
-    if constexpr (RBF) load_scale<BK, VEC>(kscale, k0, ke, rs);
+    if constexpr (SC) load_scale<BK, VEC>(kscale, k0, ke, rs);
     __syncthreads();                                        // previous slab fully consumed
-    store_slab<AKC, BM, BK, VEC, RBF>(stage0, ra, rs);
+    store_slab<AKC, BM, BK, VEC, SC>(stage0, ra, rs);
     store_slab<BKC, BN, BK, VEC, false>(stage0 + kBoff, rb, rs);
     __syncthreads();
     slab_mfma(stage0, stage0 + kBoff, [](int) {});
@@ -511,6 +524,92 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int tile_id
     }
     return;
   }
+  // Interior tiles (the whole BM x BN tile inside the result: a workgroup-uniform test) take a straight-line epilogue: every
+  // load up front, then arithmetic, then unconditional stores.  With a per-element bounds check each element becomes a
+  // branch, and the compiler puts an `s_waitcnt vmcnt(0)` into every one of them -- which also waits for the PREVIOUS
+  // element's store (measured on the stress K_uf tile: 64 exposed store round trips per thread, 30 % of the kernel; the
+  // same for every accumulating product, whose D loads sat behind the branch).
+  const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+  if constexpr (RBF) {
+    if (p.splitk <= 1 && full) {
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+        float nar[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) nar[r] = na[m0 + wm0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lh];
+#pragma unroll
+        for (int c = 0; c < TN; ++c) {
+          const int col = n0 + wn0 + 32 * c + li;
+          const float nbc = nbv[col];
+          float v[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float d2 = nar[r] + nbc - 2.f * acc[a][c][r];
+            v[r] = (p.same_xy && row == col) ? g2 : g2 * expf(-0.5f * d2);
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            C[(int64_t)row * p.ldc + col] = v[r];
+          }
+        }
+      }
+      return;
+    }
+    if (p.splitk <= 1) {
+      // edge tiles: row norms loaded up front with clamped indices, masked stores
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+        float nar[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) nar[r] = na[min(m0 + wm0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lh, p.M - 1)];
+#pragma unroll
+        for (int c = 0; c < TN; ++c) {
+          const int col = n0 + wn0 + 32 * c + li;
+          const float nbc = nbv[min(col, p.N - 1)];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float d2 = nar[r] + nbc - 2.f * acc[a][c][r];
+            const float v = (p.same_xy && row == col) ? g2 : g2 * expf(-0.5f * d2);
+            if (row < p.M && col < p.N) C[(int64_t)row * p.ldc + col] = v;
+          }
+        }
+      }
+      return;
+    }
+  }
+  if constexpr (!RBF) {
+    if (full && p.splitk <= 1) {      // plain product, interior tile (symout was handled above)
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+#pragma unroll
+        for (int c = 0; c < TN; ++c) {
+          const int col = n0 + wn0 + 32 * c + li;
+          // (four rows at a time: the D values of a group are in flight together, and the kernel stays under 256 VGPRs,
+          //  i.e. two workgroups per CU)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int rbase = m0 + wm0 + 32 * a + 8 * q + 4 * lh;
+            float dv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (D) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) dv[j] = D[(int64_t)(rbase + j) * p.ldd + col];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float v = p.alpha * acc[a][c][4 * q + j];
+              if (D) v += p.beta * dv[j];
+              if (p.triC == 1 && col > rbase + j) v = 0.f;
+              C[(int64_t)(rbase + j) * p.ldc + col] = v;
+            }
+          }
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
 #pragma unroll
@@ -558,12 +657,12 @@ __device__ __forceinline__ int xcd_remap(int lin, int total) {
   return xcd * q + (xcd < r ? xcd : r) + idx;
 }
 
-template <int BM, int BN, int BK, bool AKC, bool BKC, bool VEC, bool RBF>
+template <int BM, int BN, int BK, bool AKC, bool BKC, bool VEC, bool RBF, bool SCALED = true>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   __shared__ __attribute__((aligned(16))) float lds[gemm_lds_floats<BM, BN, BK, AKC, BKC>()];
   const int lin = (int)(blockIdx.y * gridDim.x + blockIdx.x), total = (int)(gridDim.x * gridDim.y);
   const int id = p.xcd_remap ? xcd_remap(lin, total) : lin;
-  gemm_body<BM, BN, BK, AKC, BKC, VEC, RBF>(p, id % (int)gridDim.x, id / (int)gridDim.x, blockIdx.z, lds);
+  gemm_body<BM, BN, BK, AKC, BKC, VEC, RBF, SCALED>(p, id % (int)gridDim.x, id / (int)gridDim.x, blockIdx.z, lds);
 }
 
 // Two independent problems of the same kernel flavour in ONE launch (1-D grid: the workgroups of problem 0, then
@@ -599,7 +698,8 @@ static void dispatch_layout(const GemmParams& p, int transA, int transB, dim3 gr
   // op(A) K-contiguous <=> transA == 0;  op(B) K-contiguous <=> transB == 1
   const bool akc = transA == 0, bkc = transB == 1;
   if constexpr (RBF) {
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, true, true, VEC, true>), grid, dim3(256), 0, st, p);
+    if (p.kscale) hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, true, true, VEC, true, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, true, true, VEC, true, false>), grid, dim3(256), 0, st, p);
   } else {
     if (akc && bkc) hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, true, true, VEC, false>), grid, dim3(256), 0, st, p);
     else if (akc && !bkc) hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, true, false, VEC, false>), grid, dim3(256), 0, st, p);
@@ -649,7 +749,7 @@ struct CholArgs {
   int32_t* info; int n; int nchol;
   CholExtra extra;   // base == nullptr: none
 };
-template <int KC, int SETS, int BM, int BK>
+template <int KC, int SETS, int BM, int BK, bool SCALED = true>
 __global__ __launch_bounds__(256) void chol_rbf_gemm_kernel(const CholArgs c, const GemmParams p, const int tiles) {
   // one LDS array for both roles (the factorisation stages its matrix through 40 KB of it): 2 workgroups per CU
   __shared__ __attribute__((aligned(16))) float lds[cmax(gemm_lds_floats<BM, 64, BK, true, true>(), chol3_stage_floats<KC>())];
@@ -659,7 +759,7 @@ __global__ __launch_bounds__(256) void chol_rbf_gemm_kernel(const CholArgs c, co
     return;
   }
   const int id = xcd_remap((int)blockIdx.x - c.nchol, (int)gridDim.x - c.nchol);
-  gemm_body<BM, 64, BK, true, true, true, true>(p, id % tiles, id / tiles, 0, lds);
+  gemm_body<BM, 64, BK, true, true, true, true, SCALED>(p, id % tiles, id / tiles, 0, lds);
 }
 
 static bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -762,10 +862,13 @@ int launch_chol_rbf_gemm_ld(const float* A, int lda, int64_t sA, float eps, floa
   const int total = nchol + tiles * nbatch;
   // factorising CUs exclusive (see launch_chol_rbf_gemm_impl) only while the GEMM fits one round on the other CUs
   const unsigned pad = tiles * nbatch <= free_cus ? (big ? 40u : 24u) * 1024u : 0u;
-#define VARGP_MERGED(KC, SETS)                                                                                        \
-  do {                                                                                                                  \
-    if (big) hipLaunchKernelGGL((chol_rbf_gemm_kernel<KC, SETS, 128, 32>), dim3(total), dim3(256), pad, st, c, q, tiles); \
-    else hipLaunchKernelGGL((chol_rbf_gemm_kernel<KC, SETS, 64, 64>), dim3(total), dim3(256), pad, st, c, q, tiles);    \
+  const bool scaled = p.kscale != nullptr;      // NULL: the caller's B operand is pre-scaled (rbf_prep_norm_launch: ys)
+#define VARGP_MERGED(KC, SETS)                                                                                              \
+  do {                                                                                                                        \
+    if (big && scaled) hipLaunchKernelGGL((chol_rbf_gemm_kernel<KC, SETS, 128, 32, true>), dim3(total), dim3(256), pad, st, c, q, tiles);   \
+    else if (big) hipLaunchKernelGGL((chol_rbf_gemm_kernel<KC, SETS, 128, 32, false>), dim3(total), dim3(256), pad, st, c, q, tiles);      \
+    else if (scaled) hipLaunchKernelGGL((chol_rbf_gemm_kernel<KC, SETS, 64, 64, true>), dim3(total), dim3(256), pad, st, c, q, tiles);     \
+    else hipLaunchKernelGGL((chol_rbf_gemm_kernel<KC, SETS, 64, 64, false>), dim3(total), dim3(256), pad, st, c, q, tiles);                \
   } while (0)
   if (n <= 64) VARGP_MERGED(16, 1); else VARGP_MERGED(25, 2);
 #undef VARGP_MERGED

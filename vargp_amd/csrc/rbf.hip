@@ -13,7 +13,7 @@
 namespace vargp {
 
 struct RbfWs {
-  float *w, *g2, *na, *nb, *part, *Wm, *r, *c, *P, *Q;
+  float *w, *g2, *na, *nb, *part, *ys, *Wm, *r, *c, *P, *Q;
   int64_t Dp;
   size_t bytes;
 };
@@ -29,6 +29,7 @@ static RbfWs carve(void* ws, int S, int C, int M, int N, int D, bool backward) {
     o.na = take((int64_t)S * C * M);
     o.nb = take((int64_t)S * C * N);
     o.part = take((int64_t)2 * S * C * M * N);      // split-K partial products (at most 2 splits)
+    o.ys = take((int64_t)S * N * D);                // y o w of a shared y (one copy per hyper-sample)
   } else {
     o.Wm = take((int64_t)S * C * M * N);
     o.r = take((int64_t)S * C * M);
@@ -90,11 +91,12 @@ __global__ __launch_bounds__(256) void rbf_combine_kernel(const float* __restric
 // prep + both norm passes in one launch: nrm_x[s][row] = sum_d w_sd x[row][d]^2 (likewise y), w_sd = exp(-2 theta_sd)
 // evaluated on the fly; the blocks with blockIdx.x == 0 also store w (zero-padded to Dp) and g2 = exp(2 theta_sD) for the
 // GEMM that follows.  One wave per row; grid (ceil((xrows + yrows) / 4), S).
+// ys (nullable): the scaled copy y o w of the y rows, [S][yrows][D] -- with it the distance GEMM needs no per-k scaling.
 __global__ __launch_bounds__(256) void rbf_prep_norm_kernel(const float* __restrict__ theta, const float* __restrict__ x,
                                                             const float* __restrict__ y, float* __restrict__ w,
                                                             float* __restrict__ g2, float* __restrict__ na,
                                                             float* __restrict__ nb, int64_t xrows, int64_t yrows, int D,
-                                                            int64_t Dp) {
+                                                            int64_t Dp, float* __restrict__ ys) {
   const int s = blockIdx.y, lane = threadIdx.x & 63;
   const float* th = theta + (int64_t)s * (D + 1);
   if (blockIdx.x == 0) {
@@ -106,7 +108,12 @@ __global__ __launch_bounds__(256) void rbf_prep_norm_kernel(const float* __restr
   const bool isx = row < xrows;
   const float* xr = isx ? x + row * D : y + (row - xrows) * D;
   float acc = 0.f;
-  for (int d = lane; d < D; d += 64) { const float v = xr[d]; acc = fmaf(v * v, expf(-2.f * th[d]), acc); }
+  float* yo = (!isx && ys) ? ys + ((int64_t)s * yrows + (row - xrows)) * D : nullptr;
+  for (int d = lane; d < D; d += 64) {
+    const float v = xr[d], wv = expf(-2.f * th[d]);
+    acc = fmaf(v * v, wv, acc);
+    if (yo) yo[d] = v * wv;
+  }
   acc = wave_sum(acc);
   if (lane == 0) {
     if (isx) na[(int64_t)s * xrows + row] = acc; else nb[(int64_t)s * yrows + (row - xrows)] = acc;
@@ -229,9 +236,9 @@ __global__ __launch_bounds__(256) void rbf_final_kernel(const float* __restrict_
 }
 
 int rbf_prep_norm_launch(const float* theta, const float* x, int64_t xrows, const float* y, int64_t yrows, float* w,
-                         float* g2, float* na, float* nb, int S, int D, int64_t Dp, hipStream_t st) {
+                         float* g2, float* na, float* nb, int S, int D, int64_t Dp, hipStream_t st, float* ys) {
   hipLaunchKernelGGL(rbf_prep_norm_kernel, dim3(cdiv(xrows + yrows, 4), S), dim3(256), 0, st, theta, x, y, w, g2, na, nb,
-                     xrows, yrows, D, Dp);
+                     xrows, yrows, D, Dp, ys);
   return check_launch("rbf_prep_norm");
 }
 
@@ -271,8 +278,11 @@ int vargp::rbf_gram_fwd_impl(const float* theta, const float* X, const float* Y,
     return rbf_direct_launch(X, Y, o.w, o.g2, K, N, S, C, M, N, D, o.Dp, y_shared, st);
   }
   const int64_t xrows = (int64_t)C * M, yrows = y_shared ? N : (int64_t)C * N;
+  // shared y (the minibatch): pre-scaled once per hyper-sample by the norm pass, so that the GEMM's main loop carries no
+  // scale loads / multiplies
+  const bool prescale = y_shared && !self;
   hipLaunchKernelGGL(rbf_prep_norm_kernel, dim3(cdiv(xrows + (self ? 0 : yrows), 4), S), dim3(256), 0, st, theta, X, Y, o.w,
-                     o.g2, o.na, o.nb, xrows, self ? (int64_t)0 : yrows, D, o.Dp);
+                     o.g2, o.na, o.nb, xrows, self ? (int64_t)0 : yrows, D, o.Dp, prescale ? o.ys : (float*)nullptr);
   // shared Y: the classes' inducing points are just more rows of one [C*M, D] x [D, N] product
   const int Cb = y_shared ? 1 : C, Mb = y_shared ? C * M : M;
   GemmParams p{};
@@ -287,6 +297,7 @@ int vargp::rbf_gram_fwd_impl(const float* theta, const float* X, const float* Y,
   p.na = o.na; p.sNa[0] = xrows; p.sNa[1] = Mb;
   p.nbv = self ? o.na : o.nb; p.sNb[0] = self ? xrows : yrows; p.sNb[1] = (self || !y_shared) ? N : 0;
   p.same_xy = self ? 1 : 0;
+  if (prescale) { p.B = o.ys; p.sB[0] = (int64_t)N * D; p.kscale = nullptr; }
   const int nsplit = (self && sym_out) ? 1 : rbf_splitk(Mb, N, D, S * Cb);
   if (self && sym_out) { p.triC = 2; p.symout = 1; }
   int rc;
