@@ -75,6 +75,7 @@ struct GemmParams {
   int same_xy;
   int nofast;   // tuning aid: force the guarded (non-pipelined) slab loop
   int xcd_remap;   // set by launch_gemm: XCD-compact workgroup -> tile map (small grids)
+  int tile;        // 0: launch_gemm's heuristic; 1 / 2 / 3: 128x128x16 / 128x64x32 / 64x64x64 (callers that measured)
   int symout;      // plain products: write C_ij = C_ji = value for j <= i, nothing from above the diagonal (use with triC = 2)
   // split-K: each split covers a BK-aligned share of [0, K).  RBF products write their partial inner products to
   // C + split * sSplit and a second kernel applies the epilogue; plain products (sSplit = 0) accumulate into a

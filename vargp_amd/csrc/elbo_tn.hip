@@ -589,6 +589,8 @@ extern "C" int vargp_elbo_tn_fwd(const vargp_elbo_tn_desc* d, vargp_stream_t str
     const int64_t sA[3] = {C * MtN, MtN, (int64_t)M * NRs}, sB[3] = {C * MtB, MtB, (int64_t)M * B};
     GemmParams p = blk_gemm(o.QPs + 4, NRs, sA, o.P, B, sB, o.W, B, sB, M, B, M, C, nblk);
     p.triA = 2;
+    static const int wt = [] { const char* e = getenv("VARGP_TN_WTILE"); return e ? atoi(e) : 0; }();   // tuning aid
+    p.tile = wt;
     rc = launch_gemm(p, 1, 0, SC * nblk, false, st, "tn_w_gemm");
     if (rc) return rc;
   }
@@ -653,10 +655,16 @@ extern "C" int vargp_elbo_tn_bwd(const vargp_elbo_tn_desc* d, const float* seeds
       rc = launch_gemm_pair2(p, 0, 1, SC * nblk, q, 0, 0, SC * nblk, st, "tn_gh_gp_gemm");
       if (rc) return rc;
     } else {               // each fills the chip by itself: own launches with the tile shape that suits them
-      p.splitk = 1; p.D = o.gQPs + 4; p.ldd = NRs; p.beta = 1.f;
+      // (only tril(gH_i) is used: by tril(gH_i Lu_i^T) in gT and by the packed-vector gradient; the head kernel left
+      //  zeros above the diagonal)
+      p.splitk = 1; p.D = o.gQPs + 4; p.ldd = NRs; p.beta = 1.f; p.triC = 1;
       for (int i = 0; i < 3; ++i) p.sD[i] = sQ[i];
+      static const int ht = [] { const char* e = getenv("VARGP_TN_GHTILE"); return e ? atoi(e) : 0; }();   // tuning aid
+      p.tile = ht;
       rc = launch_gemm(p, 0, 1, SC * nblk, false, st, "tn_gh_gemm");
       if (rc) return rc;
+      static const int gt = [] { const char* e = getenv("VARGP_TN_GPTILE"); return e ? atoi(e) : 0; }();   // tuning aid
+      q.tile = gt;
       rc = launch_gemm(q, 0, 0, SC * nblk, false, st, "tn_gp_gemm");
       if (rc) return rc;
     }
@@ -709,13 +717,15 @@ extern "C" int vargp_elbo_tn_bwd(const vargp_elbo_tn_desc* d, const float* seeds
     if (rc) return rc;
     const int64_t total = (int64_t)SC * M;
     hipLaunchKernelGGL(tn_diag_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, Smat, seeds, S, M, Mt, total);
-    GemmParams q = flat_gemm(o.TT, Mt, MtMt, Smat, Mt, MtMt, tmp, Mt, MtMt, Mt, Mt, Mt);
-    q.triA = 2;
-    rc = launch_gemm(q, 1, 0, SC, false, st, "tn_chol_bwd2");
+    // gK = T^T (Smat T) is symmetric: its lower triangle needs tril(Smat T) only, and as T^T [.] the tiles of the lower
+    // triangle are the ones with the SHORT K ranges (k >= row), 40 % of the work of the full product
+    GemmParams q = flat_gemm(Smat, Mt, MtMt, o.TT, Mt, MtMt, tmp, Mt, MtMt, Mt, Mt, Mt);
+    q.triB = 1; q.triC = 1;
+    rc = launch_gemm(q, 0, 0, SC, false, st, "tn_chol_bwd2");
     if (rc) return rc;
-    GemmParams r = flat_gemm(tmp, Mt, MtMt, o.TT, Mt, MtMt, o.gK, Mt, MtMt, Mt, Mt, Mt);
-    r.triB = 1;
-    rc = launch_gemm(r, 0, 0, SC, false, st, "tn_chol_bwd3");
+    GemmParams r = flat_gemm(o.TT, Mt, MtMt, tmp, Mt, MtMt, o.gK, Mt, MtMt, Mt, Mt, Mt);
+    r.triA = 2; r.triB = 1; r.triC = 2; r.symout = 1;
+    rc = launch_gemm(r, 1, 0, SC, false, st, "tn_chol_bwd3");
     if (rc) return rc;
   }
   // kernel matrices -> theta, z  (the fused passes of the first-task program, elbo_shared.h):
@@ -749,6 +759,8 @@ extern "C" int vargp_elbo_tn_bwd(const vargp_elbo_tn_desc* d, const float* seeds
       rc = launch_gemm_pair(p0, SC, p1, S, 0, 0, false, st, "rbf_kuu_bwd_gemm", "rbf_kuf_bwd_gemm");
       if (rc) return rc;
     } else {
+      static const int wyt = [] { const char* e = getenv("VARGP_TN_WYTILE"); return e ? atoi(e) : 0; }();   // tuning aid
+      p0.tile = wyt % 10; p1.tile = wyt / 10;
       rc = launch_gemm(p0, 0, 0, SC, false, st, "rbf_kuu_bwd_gemm");
       if (rc) return rc;
       rc = launch_gemm(p1, 0, 0, S, false, st, "rbf_kuf_bwd_gemm");
@@ -1012,13 +1024,15 @@ extern "C" int vargp_elbo_tn_end(const vargp_elbo_tn_desc* d, const float* seeds
     if (rc) return rc;
     const int64_t total = (int64_t)SC * M;
     hipLaunchKernelGGL(tn_diag_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, Smat, seeds, S, M, Mt, total);
-    GemmParams q = flat_gemm(o.TT, Mt, MtMt, Smat, Mt, MtMt, tmp, Mt, MtMt, Mt, Mt, Mt);
-    q.triA = 2;
-    rc = launch_gemm(q, 1, 0, SC, false, st, "tn_chol_bwd2");
+    // gK = T^T (Smat T) is symmetric: its lower triangle needs tril(Smat T) only, and as T^T [.] the tiles of the lower
+    // triangle are the ones with the SHORT K ranges (k >= row), 40 % of the work of the full product
+    GemmParams q = flat_gemm(Smat, Mt, MtMt, o.TT, Mt, MtMt, tmp, Mt, MtMt, Mt, Mt, Mt);
+    q.triB = 1; q.triC = 1;
+    rc = launch_gemm(q, 0, 0, SC, false, st, "tn_chol_bwd2");
     if (rc) return rc;
-    GemmParams r = flat_gemm(tmp, Mt, MtMt, o.TT, Mt, MtMt, o.gK, Mt, MtMt, Mt, Mt, Mt);
-    r.triB = 1;
-    rc = launch_gemm(r, 0, 0, SC, false, st, "tn_chol_bwd3");
+    GemmParams r = flat_gemm(o.TT, Mt, MtMt, tmp, Mt, MtMt, o.gK, Mt, MtMt, Mt, Mt, Mt);
+    r.triA = 2; r.triB = 1; r.triC = 2; r.symout = 1;
+    rc = launch_gemm(r, 1, 0, SC, false, st, "tn_chol_bwd3");
     if (rc) return rc;
   }
   {   // K_all: W + W^T = 2 gK o K, its row sums; the W.z product; the inducing-point side of the finalisation

@@ -932,12 +932,13 @@ int launch_gemm(const GemmParams& p, int transA, int transB, int nbatch, bool rb
   const int64_t t128 = (int64_t)cdiv(p.M, 128) * cdiv(p.N, 128) * nbatch;
   const int64_t t12864 = (int64_t)cdiv(p.M, 128) * cdiv(p.N, 64) * nbatch;
   static const int force_env = [] { const char* e = getenv("VARGP_GEMM_TILE"); return e ? atoi(e) : 0; }();   // tuning aid
-  const int force = g_tile_force ? g_tile_force : force_env;
+  const int force = g_tile_force ? g_tile_force : (force_env ? force_env : p.tile);
   // Tile choice, from the sweep `tests/native/bench_kernels tiles` on MI355X (mid-size batched products of the ELBO
   // programs): 128x64x32 is the robust mid-size shape; 64x64x64 when it pads M less and K ranges are clipped by a
   // triangular operand (finer clipping, better balance: 400x512x400 b100 140 vs 182/192 us) or when the problem is small
   // (more workgroups); 128x128x16 only for large square-ish problems (>= 1024 both ways), where it reaches 80-90 % of peak.
-  const bool tri = p.triA != 0 || p.triB != 0;
+  static const int tric64 = [] { const char* e = getenv("VARGP_GEMM_TRIC64"); return e ? atoi(e) : 1; }();   // tuning aid
+  const bool tri = p.triA != 0 || p.triB != 0 || (tric64 && p.triC != 0);
   const bool pad64_less = round_up(p.M, 64) < round_up(p.M, 128);
   if (force == 1) dispatch_tile<128, 128, 16>(p, transA, transB, nbatch, rbf, vec, st);
   else if (force == 2) dispatch_tile<128, 64, 32>(p, transA, transB, nbatch, rbf, vec, st);
