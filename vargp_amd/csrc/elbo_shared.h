@@ -62,12 +62,21 @@ static __global__ __launch_bounds__(256) void t0_softmax_kernel(const float* __r
     const int b = e % B, f = (e / B) % F, s = e / ((int64_t)B * F);
     const int yb = (int)y[b];
     float sd[CMAX], ev[CMAX], v[CMAX], mx = -INFINITY, fy = 0.f;
+    // all 3 CMAX loads first, unconditional on a clamped class index (a load behind `c < C` gets a branch and a
+    // `s_waitcnt vmcnt(0)` of its own: CMAX memory round trips in a row), values of the padding classes replaced after
 #pragma unroll
     for (int c = 0; c < CMAX; ++c) {
-      const int64_t i = ((int64_t)s * C + c) * B + b;
-      sd[c] = c < C ? sqrtf(var[i]) : 1.f;
-      ev[c] = c < C ? eps[(((int64_t)s * F + f) * C + c) * B + b] : 0.f;
-      v[c] = c < C ? mu[i] + sd[c] * ev[c] : -INFINITY;
+      const int cc = c < C ? c : C - 1;
+      const int64_t i = ((int64_t)s * C + cc) * B + b;
+      sd[c] = var[i];
+      ev[c] = eps[(((int64_t)s * F + f) * C + cc) * B + b];
+      v[c] = mu[i];
+    }
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+      sd[c] = c < C ? sqrtf(sd[c]) : 1.f;
+      ev[c] = c < C ? ev[c] : 0.f;
+      v[c] = c < C ? v[c] + sd[c] * ev[c] : -INFINITY;
       mx = fmaxf(mx, v[c]);
       if (c == yb) fy = v[c];
     }
@@ -167,12 +176,23 @@ __device__ __forceinline__ void t0_gvec_role(int blk, const float* __restrict__ 
   const float* gs = gSu + (c * M + i) * M;
   const float* lu = Lu + c * M * M + k;
   float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-  int j = k & ~3;                       // Lu[j][k] = 0 (stored) for j < k: start at the aligned group containing k
-  for (; j + 4 <= M; j += 4) {
-    acc0 = fmaf(gs[j], lu[(int64_t)j * M], acc0); acc1 = fmaf(gs[j + 1], lu[(int64_t)(j + 1) * M], acc1);
-    acc2 = fmaf(gs[j + 2], lu[(int64_t)(j + 2) * M], acc2); acc3 = fmaf(gs[j + 3], lu[(int64_t)(j + 3) * M], acc3);
+  // Lu[j][k] = 0 (stored) for j < k: start at the aligned group containing k.  16 products per batch, their loads in
+  // flight together (clamped index, masked value): M / 16 memory round trips in a row instead of M / 4.
+  for (int j0 = k & ~3; j0 < M; j0 += 16) {
+    float gv[16], lv[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int j = min(j0 + q, M - 1);
+      gv[q] = gs[j]; lv[q] = lu[(int64_t)j * M];
+    }
+#pragma unroll
+    for (int q = 0; q < 16; q += 4) {
+      acc0 = fmaf(j0 + q < M ? gv[q] : 0.f, lv[q], acc0);
+      acc1 = fmaf(j0 + q + 1 < M ? gv[q + 1] : 0.f, lv[q + 1], acc1);
+      acc2 = fmaf(j0 + q + 2 < M ? gv[q + 2] : 0.f, lv[q + 2], acc2);
+      acc3 = fmaf(j0 + q + 3 < M ? gv[q + 3] : 0.f, lv[q + 3], acc3);
+    }
   }
-  for (; j < M; ++j) acc0 = fmaf(gs[j], lu[(int64_t)j * M], acc0);
   float g = 2.f * ((acc0 + acc1) + (acc2 + acc3));
   for (int s = 0; s < S; ++s) g += gRK[(((int64_t)s * C + c) * M + i) * LD + 4 + M + k];
   const int64_t idx = c * ((int64_t)M * (M + 1) / 2) + (int64_t)i * (i + 1) / 2 + k;
@@ -214,12 +234,22 @@ static __global__ __launch_bounds__(256) void t0_w_kernel(const float* __restric
     const int row0 = ((id / gx) % gy) * kWRows;
     const int64_t s = id / (gx * gy);
     const bool cok = col < B;
+    const int cc = cok ? col : B - 1;
     float csum = 0.f;
     const int rend = min(kWRows, CM - row0);
-    for (int rr = 0; rr < rend; ++rr) {
-      const int64_t off = (s * CM + row0 + rr) * LD + NR + col;
-      float v = 0.f;
-      if (cok) { v = RK[off] * gRK[off]; gRK[off] = v; }
+    // every load of the block first (clamped indices, masked values), then stores and reductions: a load issued after a
+    // store, or inside a branch, waits for everything before it (vmcnt counts loads and stores in order)
+    float kv[kWRows], gv[kWRows];
+#pragma unroll
+    for (int rr = 0; rr < kWRows; ++rr) {
+      const int64_t off = (s * CM + row0 + min(rr, rend - 1)) * LD + NR + cc;
+      kv[rr] = RK[off]; gv[rr] = gRK[off];
+    }
+#pragma unroll
+    for (int rr = 0; rr < kWRows; ++rr) {
+      const bool ok = cok && rr < rend;
+      const float v = ok ? kv[rr] * gv[rr] : 0.f;
+      if (ok) gRK[(s * CM + row0 + rr) * LD + NR + col] = v;
       csum += v;
       const float rs = wave_sum(v);
       if (lane == 0 && rs != 0.f) atomicAdd(&r_uf[s * CM + row0 + rr], rs);
@@ -237,18 +267,49 @@ static __global__ __launch_bounds__(256) void t0_w_kernel(const float* __restric
   const float* K = Kuu + b * M * M;
   const float* gK = gKuu + b * M * M;
   float tot = 0.f;
-  for (int i = i0 + (threadIdx.x >> 6); i < i1; i += 4) {
-    float acc = 0.f;
-    for (int j = lane; j < M; j += 64) {
-      // sym_guu: gK_uu is symmetric (it comes out of the Cholesky backward), so W + W^T = 2 W: no transposed reads
-      const float v = sym_guu ? 2.f * K[(int64_t)i * M + j] * gK[(int64_t)i * M + j]
-                              : K[(int64_t)i * M + j] * gK[(int64_t)i * M + j] + K[(int64_t)j * M + i] * gK[(int64_t)j * M + i];
-      Wuu[b * M * M + (int64_t)i * M + j] = v;
-      acc += v;
+  // a wave's rows (every 4th of the block's) advance together, two 64-column chunks at a time, all loads of a batch
+  // before its stores
+  constexpr int RW = kUuRows / 4;
+  const int wv = threadIdx.x >> 6;
+  float acc[RW];
+#pragma unroll
+  for (int r = 0; r < RW; ++r) acc[r] = 0.f;
+  for (int j0 = 0; j0 < M; j0 += 128) {
+    float kv[RW][2], gv[RW][2], kt[RW][2], gt[RW][2];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      const int i = min(i0 + wv + 4 * r, M - 1);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int j = min(j0 + 64 * h + lane, M - 1);
+        kv[r][h] = K[(int64_t)i * M + j]; gv[r][h] = gK[(int64_t)i * M + j];
+        kt[r][h] = 0.f; gt[r][h] = 0.f;
+        if (!sym_guu) { kt[r][h] = K[(int64_t)j * M + i]; gt[r][h] = gK[(int64_t)j * M + i]; }
+      }
     }
-    acc = wave_sum(acc);
-    if (lane == 0) r_uu[b * M + i] = acc;
-    tot += acc;
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      const int i = i0 + wv + 4 * r;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int j = j0 + 64 * h + lane;
+        if (i < i1 && j < M) {
+          // sym_guu: gK_uu is symmetric (it comes out of the Cholesky backward), so W + W^T = 2 W: no transposed reads
+          const float v = sym_guu ? 2.f * kv[r][h] * gv[r][h] : kv[r][h] * gv[r][h] + kt[r][h] * gt[r][h];
+          Wuu[b * M * M + (int64_t)i * M + j] = v;
+          acc[r] += v;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int i = i0 + wv + 4 * r;
+    const float a = wave_sum(acc[r]);
+    if (i < i1) {
+      if (lane == 0) r_uu[b * M + i] = a;
+      tot += a;
+    }
   }
   // every lane of a wave holds the wave's total: count it once
   const float t = block_sum<256>(lane == 0 ? tot : 0.f, red);
@@ -265,53 +326,78 @@ static __global__ __launch_bounds__(256) void t0_final_kernel(const float* __res
                                                        const float* __restrict__ Puf, const float* __restrict__ w,
                                                        float* __restrict__ gz, float* __restrict__ gtheta,
                                                        int64_t zrows, int64_t xrows, int D, int64_t Dp, int S, int nzy) {
-  __shared__ float red[4][64];
+  __shared__ float red[2][4][64];      // double-buffered by sample parity: one barrier per sample
   constexpr int RJ = kFinRows / 4;
   const int dx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int d = blockIdx.x * 64 + dx;
   const bool dok = d < D;
+  const int dc = dok ? d : D - 1;
   const bool zside = (int)blockIdx.y < nzy;
   const int64_t rows = zside ? zrows : xrows;
   const int64_t row0 = (int64_t)(zside ? blockIdx.y : blockIdx.y - nzy) * kFinRows;
   const float* src = zside ? z : x;
-  float xa[RJ], ga[RJ];
+  // Every load is unconditional, on clamped indices, and its value masked afterwards: a load inside a per-row branch is
+  // followed by its own `s_waitcnt vmcnt(0)`, i.e. one memory round trip per row and sample (8 x S of them in a row).
+  float xa[RJ], ga[RJ], msk[RJ];
+  int64_t rcl[RJ];
 #pragma unroll
   for (int j = 0; j < RJ; ++j) {
     const int64_t row = row0 + ry + 4 * j;
-    xa[j] = (dok && row < rows) ? src[row * D + d] : 0.f;
+    msk[j] = (dok && row < rows) ? 1.f : 0.f;
+    rcl[j] = row < rows ? row : rows - 1;
+  }
+#pragma unroll
+  for (int j = 0; j < RJ; ++j) {
+    xa[j] = src[rcl[j] * D + dc] * msk[j];
     ga[j] = 0.f;
   }
-  for (int s = 0; s < S; ++s) {
-    const float wv = dok ? w[s * Dp + d] : 0.f;
-    float th = 0.f;
+  if (zside) {
+    for (int s = 0; s < S; ++s) {
+      const float wv = dok ? w[s * Dp + dc] : 0.f;
+      float p1[RJ], p2[RJ], r1[RJ], r2[RJ];
 #pragma unroll
-    for (int j = 0; j < RJ; ++j) {
-      const int64_t row = row0 + ry + 4 * j;
-      if (row < rows) {
-        if (zside) {
-          const int64_t sr = (int64_t)s * rows + row;
-          const float p1 = dok ? Puu[sr * D + d] : 0.f, p2 = dok ? Puf[sr * D + d] : 0.f;
-          const float rx1 = r_uu[sr] * xa[j], rx2 = r_uf[sr] * xa[j];
-          ga[j] -= wv * ((rx1 - p1) + (rx2 - p2));
-          th += xa[j] * ((rx1 - p1) + (rx2 - 2.f * p2));
-        } else {
-          th += xa[j] * (c_uf[(int64_t)s * rows + row] * xa[j]);
-        }
+      for (int j = 0; j < RJ; ++j) {
+        const int64_t sr = (int64_t)s * rows + rcl[j];
+        p1[j] = Puu[sr * D + dc]; p2[j] = Puf[sr * D + dc];
+        r1[j] = r_uu[sr]; r2[j] = r_uf[sr];
+      }
+      float th = 0.f;
+#pragma unroll
+      for (int j = 0; j < RJ; ++j) {
+        const float rx1 = r1[j] * xa[j], rx2 = r2[j] * xa[j];
+        const float q1 = p1[j] * msk[j], q2 = p2[j] * msk[j];
+        ga[j] -= wv * ((rx1 - q1) + (rx2 - q2));
+        th += xa[j] * ((rx1 - q1) + (rx2 - 2.f * q2));
+      }
+      red[s & 1][ry][dx] = th;
+      __syncthreads();
+      if (ry == 0 && dok) {
+        const float t = red[s & 1][0][dx] + red[s & 1][1][dx] + red[s & 1][2][dx] + red[s & 1][3][dx];
+        atomicAdd(&gtheta[(int64_t)s * (D + 1) + d], wv * t);
       }
     }
-    __syncthreads();
-    red[ry][dx] = th;
-    __syncthreads();
-    if (ry == 0 && dok) {
-      const float t = red[0][dx] + red[1][dx] + red[2][dx] + red[3][dx];
-      atomicAdd(&gtheta[(int64_t)s * (D + 1) + d], wv * t);
-    }
-  }
-  if (zside && dok) {
+    if (dok) {
 #pragma unroll
-    for (int j = 0; j < RJ; ++j) {
-      const int64_t row = row0 + ry + 4 * j;
-      if (row < rows) gz[row * D + d] = ga[j];
+      for (int j = 0; j < RJ; ++j) {
+        const int64_t row = row0 + ry + 4 * j;
+        if (row < rows) gz[row * D + d] = ga[j];
+      }
+    }
+  } else {
+    for (int s = 0; s < S; ++s) {
+      const float wv = dok ? w[s * Dp + dc] : 0.f;
+      float cu[RJ];
+#pragma unroll
+      for (int j = 0; j < RJ; ++j) cu[j] = c_uf[(int64_t)s * rows + rcl[j]];
+      float th = 0.f;
+#pragma unroll
+      for (int j = 0; j < RJ; ++j) th += xa[j] * (cu[j] * xa[j]);
+      red[s & 1][ry][dx] = th;
+      __syncthreads();
+      if (ry == 0 && dok) {
+        const float t = red[s & 1][0][dx] + red[s & 1][1][dx] + red[s & 1][2][dx] + red[s & 1][3][dx];
+        atomicAdd(&gtheta[(int64_t)s * (D + 1) + d], wv * t);
+      }
     }
   }
 }

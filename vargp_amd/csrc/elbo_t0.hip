@@ -201,6 +201,26 @@ __global__ __launch_bounds__(256) void t0_prologue_kernel(const ProArgs a) {
   }
 }
 
+// sum_d x_d^2 w_d of one row by one wave.  Four 64-wide chunks of loads are issued before the first use (a plain loop
+// keeps one chunk in flight: D / 64 memory round trips in a row), on clamped indices with the overhang masked.
+__device__ __forceinline__ float row_norm_wave(const float* __restrict__ xr, const float* __restrict__ ws, int D, int lane) {
+  float acc0 = 0.f, acc1 = 0.f;
+  for (int d0 = 0; d0 < D; d0 += 256) {
+    float xv[4], wv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int d = min(d0 + 64 * q + lane, D - 1);
+      xv[q] = xr[d]; wv[q] = ws[d];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float v = (d0 + 64 * q + lane < D) ? xv[q] : 0.f;
+      if (q & 1) acc1 = fmaf(v * v, wv[q], acc1); else acc0 = fmaf(v * v, wv[q], acc0);
+    }
+  }
+  return wave_sum(acc0 + acc1);
+}
+
 // weighted squared row norms of the inducing points (na) and of the minibatch (nb), one wave per row; grid (rows/4, S)
 __global__ __launch_bounds__(256) void t0_norm_kernel(const float* __restrict__ z, const float* __restrict__ x,
                                                       const float* __restrict__ w, float* __restrict__ na,
@@ -212,9 +232,7 @@ __global__ __launch_bounds__(256) void t0_norm_kernel(const float* __restrict__ 
   const bool isz = row < zrows;
   const float* xr = isz ? z + row * D : x + (row - zrows) * D;
   const float* ws = w + s * Dp;
-  float acc = 0.f;
-  for (int d = lane; d < D; d += 64) { const float v = xr[d]; acc = fmaf(v * v, ws[d], acc); }
-  acc = wave_sum(acc);
+  const float acc = row_norm_wave(xr, ws, D, lane);
   if (lane == 0) {
     if (isz) na[(int64_t)s * zrows + row] = acc; else nb[(int64_t)s * xrows + (row - zrows)] = acc;
   }
@@ -237,9 +255,17 @@ __global__ __launch_bounds__(256) void t0_combine_norm_kernel(const float* __res
     const int64_t b = e / ((int64_t)M * M);        // s * C + c
     const int64_t base = b * M * M;
     float gij = 0.f, gii = 0.f, gjj = 0.f;
-    for (int k = 0; k < nsplit; ++k) {
-      const float* pk = part + k * sSplit + base;
-      gij += pk[(int64_t)i * M + j]; gii += pk[(int64_t)i * M + i]; gjj += pk[(int64_t)j * M + j];
+    for (int k0 = 0; k0 < nsplit; k0 += 4) {       // four splits' loads in flight together
+      float vij[4], vii[4], vjj[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float* pk = part + min(k0 + q, nsplit - 1) * sSplit + base;
+        vij[q] = pk[(int64_t)i * M + j]; vii[q] = pk[(int64_t)i * M + i]; vjj[q] = pk[(int64_t)j * M + j];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (k0 + q < nsplit) { gij += vij[q]; gii += vii[q]; gjj += vjj[q]; }
+      }
     }
     const float gam = g2[b / C];
     Kuu[e] = i == j ? gam : gam * expf(-0.5f * (gii + gjj - 2.f * gij));
@@ -252,9 +278,7 @@ __global__ __launch_bounds__(256) void t0_combine_norm_kernel(const float* __res
   const bool isz = row < zrows;
   const float* xr = isz ? z + row * D : x + (row - zrows) * D;
   const float* ws = w + s * Dp;
-  float acc = 0.f;
-  for (int d = lane; d < D; d += 64) { const float v = xr[d]; acc = fmaf(v * v, ws[d], acc); }
-  acc = wave_sum(acc);
+  const float acc = row_norm_wave(xr, ws, D, lane);
   if (lane == 0) {
     if (isz) na[(int64_t)s * zrows + row] = acc; else nb[(int64_t)s * xrows + (row - zrows)] = acc;
   }
@@ -614,13 +638,27 @@ __global__ __launch_bounds__(256) void t0_bwd_head_kernel(const float* __restric
     const float am = QP[(b * M + m) * LD];
     const float gs = gscale ? gscale[0] : 1.f;
     float acc = 0.f, accv = 0.f;
-    for (int col = threadIdx.x; col < B; col += 256) {
-      const float gm = gs * gmu[b * B + col], gv = gs * gvar[b * B + col];
-      const float pv = QP[offp + col], wv = W[offw + col];
-      gQP[offp + col] = am * gm - 2.f * pv * gv;
-      gW[offw + col] = 2.f * wv * gv;
-      acc = fmaf(pv, gm, acc);
-      accv += gv;
+    // four 256-column chunks per batch: their 16 loads first (clamped index), then the stores -- a load behind a store
+    // waits for the store as well (vmcnt counts both in order)
+    for (int c0 = 0; c0 < B; c0 += 1024) {
+      float gm[4], gv[4], pv[4], wv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = min(c0 + 256 * q + (int)threadIdx.x, B - 1);
+        gm[q] = gmu[b * B + col]; gv[q] = gvar[b * B + col];
+        pv[q] = QP[offp + col]; wv[q] = W[offw + col];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = c0 + 256 * q + (int)threadIdx.x;
+        if (col < B) {
+          const float m_ = gs * gm[q], v_ = gs * gv[q];
+          gQP[offp + col] = am * m_ - 2.f * pv[q] * v_;
+          gW[offw + col] = 2.f * wv[q] * v_;
+          acc = fmaf(pv[q], m_, acc);
+          accv += v_;
+        }
+      }
     }
     const float t = block_sum<256>(acc, red);
     if (threadIdx.x == 0) gQP[(b * M + m) * LD] = t + g * am;
@@ -641,14 +679,29 @@ __global__ __launch_bounds__(256) void t0_bwd_head_kernel(const float* __restric
   const int i0 = (id % nkx) * kKlRows, i1 = min(M, i0 + kKlRows);
   const float* q = QP + b * M * LD;
   float* gq = gQP + b * M * LD;
-  for (int e0 = threadIdx.x; e0 < (i1 - i0) * M; e0 += 256) {
-    const int i = i0 + e0 / M, j = e0 % M;
-    const int e = i * M + j;
-    gq[(int64_t)i * LD + 4 + M + j] = (j <= i) ? g * q[(int64_t)i * LD + 4 + M + j] : 0.f;
-    gq[(int64_t)i * LD + 4 + j] = 0.f;               // G block and gT: accumulated by K-split GEMMs (float atomics)
-    gThead[b * M * M + e] = 0.f;
-    gLz[b * M * M + e] = (i == j) ? g / Lz[b * M * M + e] : 0.f;
-    if (s == 0) gTtail[(int64_t)c * M * M + e] = 0.f;
+  const int nel = (i1 - i0) * M;
+  for (int e00 = 0; e00 < nel; e00 += 1024) {        // four elements per thread and batch: loads first, then stores
+    float qv[4], lv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e0 = min(e00 + 256 * u + (int)threadIdx.x, nel - 1);
+      const int i = i0 + e0 / M, j = e0 % M;
+      qv[u] = q[(int64_t)i * LD + 4 + M + j];
+      lv[u] = Lz[b * M * M + i * M + j];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e0 = e00 + 256 * u + (int)threadIdx.x;
+      if (e0 < nel) {
+        const int i = i0 + e0 / M, j = e0 % M;
+        const int e = i * M + j;
+        gq[(int64_t)i * LD + 4 + M + j] = (j <= i) ? g * qv[u] : 0.f;
+        gq[(int64_t)i * LD + 4 + j] = 0.f;             // G block and gT: accumulated by K-split GEMMs (float atomics)
+        gThead[b * M * M + e] = 0.f;
+        gLz[b * M * M + e] = (i == j) ? g / lv[u] : 0.f;
+        if (s == 0) gTtail[(int64_t)c * M * M + e] = 0.f;
+      }
+    }
   }
   for (int i = i0 + threadIdx.x; i < i1; i += 256) {
     gq[(int64_t)i * LD + 1] = 0.f; gq[(int64_t)i * LD + 2] = 0.f; gq[(int64_t)i * LD + 3] = 0.f;
