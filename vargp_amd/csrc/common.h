@@ -75,6 +75,10 @@ struct GemmParams {
   int same_xy;
   int nofast;   // tuning aid: force the guarded (non-pipelined) slab loop
   int xcd_remap;   // set by launch_gemm: XCD-compact workgroup -> tile map (small grids)
+  // symout products only: C_ii += diag_scale * diag_ptr[0] for i >= diag_from (diag_ptr: device scalar, NULL: off)
+  const float* diag_ptr;
+  float diag_scale;
+  int diag_from;
   int tile;        // 0: launch_gemm's heuristic; 1 / 2 / 3: 128x128x16 / 128x64x32 / 64x64x64 (callers that measured)
   int symout;      // plain products: write C_ij = C_ji = value for j <= i, nothing from above the diagonal (use with triC = 2)
   // split-K: each split covers a BK-aligned share of [0, K).  RBF products write their partial inner products to
@@ -120,9 +124,11 @@ int launch_chol_rbf_gemm_ld(const float* A, int lda, int64_t sA, float eps, floa
                             int64_t sT, int32_t* info, int nchol, int n, const GemmParams& p, int nbatch, hipStream_t st);
 // w = exp(-2 theta) (zero-padded to Dp), g2 = exp(2 theta_D) and the weighted squared row norms of x (xrows x D) and of
 // y (yrows x D, may be 0 rows) for every hyper-sample, in one launch
-// ys (nullable): also write y o w, [S][yrows][D] (the pre-scaled operand of an unscaled RBF GEMM: GemmParams.kscale = NULL)
+// ys / xs (nullable): also write y o w, [S][yrows][D], and x o w, [S][xrows][D] (the pre-scaled operand of an unscaled RBF
+// GEMM: GemmParams.kscale = NULL)
 int rbf_prep_norm_launch(const float* theta, const float* x, int64_t xrows, const float* y, int64_t yrows, float* w,
-                         float* g2, float* na, float* nb, int S, int D, int64_t Dp, hipStream_t st, float* ys = nullptr);
+                         float* g2, float* na, float* nb, int S, int D, int64_t Dp, hipStream_t st, float* ys = nullptr,
+                         float* xs = nullptr);
 
 int chol_inv_bwd_first(const float* T, const float* gT, int nbatch, int n, void* ws, size_t ws_bytes,
                        const GemmParams* other, int oA, int oB, int onb, hipStream_t st);

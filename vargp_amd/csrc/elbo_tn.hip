@@ -30,6 +30,7 @@ struct TnWs {
   float *gQPs, *gP, *gT, *gKuf, *gK, *gRKt, *gkd, *gz_all;
   float *r_uf, *c_uf, *gtheta;               // adjacent: one zero range (accumulators of the kernel-matrix backward)
   float *r_uu, *Wuu, *Puu, *Puf;             // Wuu aliases gT (dead once the Cholesky backward has consumed it)
+  float* zs;                                 // aliases Puu
   void *chol, *rbf;
   size_t chol_bytes, rbf_bytes;
   int NRs, Mt;
@@ -60,6 +61,7 @@ static TnWs carve_tn(void* ws, int S, int C, int M, int D, int B, int F, int nbl
   o.gz_all = take((int64_t)C * Mt * D);
   o.r_uf = take(SC * Mt); o.c_uf = take((int64_t)S * B); o.gtheta = take(S * D1);
   o.r_uu = take(SC * Mt); o.Wuu = o.gT; o.Puu = take(SC * Mt * D); o.Puf = take(SC * Mt * D);
+  o.zs = o.Puu;       // z_all o w per hyper-sample (forward only; P_uu is written by the backward)
   const size_t cf = vargp_chol_workspace_bytes((int)SC, o.Mt, 0), cb = vargp_chol_workspace_bytes((int)SC, o.Mt, 1);
   o.chol_bytes = cf > cb ? cf : cb;
   o.chol = p;
@@ -320,17 +322,6 @@ __global__ __launch_bounds__(256) void tn_bwd_head_kernel(const float* __restric
   gQPs[row * NRs + col] = v;
 }
 
-// Smat_jj += g / 2 on the current task's block (the diagonal gL = g / L_jj of the log-determinant, see the backward),
-// and, sharing the launch, nothing else.  One thread per (b, i).
-__global__ void tn_diag_kernel(float* __restrict__ Smat, const float* __restrict__ seeds, int S, int M, int Mt, int64_t total) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= total) return;
-  const int i = e % M;
-  const int64_t b = e / M;
-  const int j = Mt - M + i;
-  Smat[(b * Mt + j) * Mt + j] += 0.5f * seeds[1] / (float)S;
-}
-
 // Parameter gradients of the current task from gRKt[s,c] = T_tt^T [ga_t | . | gH_t]:
 //   g_u_mean[c,i] = sum_s gRKt[s,c,i,0]
 //   gLu[c,i,k]    = sum_s gRKt[s,c,i,4+k]  (k <= i)  - seed_kl / Lu_ii on the diagonal, through vec2tril (softplus')
@@ -498,7 +489,7 @@ extern "C" int vargp_elbo_tn_fwd(const vargp_elbo_tn_desc* d, vargp_stream_t str
   const bool mfma = D > kRbfDirectD;
   bool kuf_done = false;
   GemmParams pf{};       // K_uf = rbf(z_all, x): the classes' inducing points are just more rows of one [C*Mt, D] x [D, B] product
-  rc = rbf_prep_norm_launch(o.theta, d->z_all, zrows, d->x, B, o.w, o.g2, o.na, o.nb, S, D, o.Dp, st, o.xs);
+  rc = rbf_prep_norm_launch(o.theta, d->z_all, zrows, d->x, B, o.w, o.g2, o.na, o.nb, S, D, o.Dp, st, o.xs, o.zs);
   if (rc) return rc;
   if (!mfma) {           // small input dimension: direct (cancellation-free) distances
     rc = rbf_direct_launch(d->z_all, nullptr, o.w, o.g2, o.Kall, Mt, S, C, Mt, Mt, D, o.Dp, 0, st);
@@ -508,13 +499,13 @@ extern "C" int vargp_elbo_tn_fwd(const vargp_elbo_tn_desc* d, vargp_stream_t str
     kuf_done = true;
   } else {
     GemmParams p0{};     // K_all: tiles touching the lower triangle, mirrored (the matrix is symmetric)
-    p0.A = d->z_all; p0.B = d->z_all; p0.C = o.Kall;
+    p0.A = o.zs; p0.B = d->z_all; p0.C = o.Kall;        // A pre-scaled by the norm pass: no per-k scaling in the main loop
     p0.M = Mt; p0.N = Mt; p0.K = D; p0.lda = D; p0.ldb = D; p0.ldc = Mt;
     p0.nb1 = C; p0.nb2 = 1;
-    p0.sA[1] = (int64_t)Mt * D; p0.sB[1] = (int64_t)Mt * D;
+    p0.sA[0] = zrows * D; p0.sA[1] = (int64_t)Mt * D; p0.sB[1] = (int64_t)Mt * D;
     p0.sC[0] = C * MtMt; p0.sC[1] = MtMt;
     p0.alpha = 1.f;
-    p0.kscale = o.w; p0.ks_ld = o.Dp; p0.g2 = o.g2;
+    p0.kscale = nullptr; p0.ks_ld = o.Dp; p0.g2 = o.g2;
     p0.na = o.na; p0.sNa[0] = zrows; p0.sNa[1] = Mt;
     p0.nbv = o.na; p0.sNb[0] = zrows; p0.sNb[1] = Mt;
     static const int ksym = [] { const char* e = getenv("VARGP_TN_KSYM"); return e ? atoi(e) : 1; }();   // tuning aid
@@ -713,10 +704,9 @@ extern "C" int vargp_elbo_tn_bwd(const vargp_elbo_tn_desc* d, const float* seeds
   {
     GemmParams p = flat_gemm(o.gT, Mt, MtMt, o.TT, Mt, MtMt, Smat, Mt, MtMt, Mt, Mt, Mt);
     p.alpha = -0.5f; p.triA = 1; p.triB = 2; p.triC = 2; p.symout = 1;
+    p.diag_ptr = seeds + 1; p.diag_scale = 0.5f / (float)S; p.diag_from = Mt - M;     // + g / 2 on the current task's diagonal
     rc = launch_gemm(p, 0, 1, SC, false, st, "tn_chol_bwd1");
     if (rc) return rc;
-    const int64_t total = (int64_t)SC * M;
-    hipLaunchKernelGGL(tn_diag_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, Smat, seeds, S, M, Mt, total);
     // gK = T^T (Smat T) is symmetric: its lower triangle needs tril(Smat T) only, and as T^T [.] the tiles of the lower
     // triangle are the ones with the SHORT K ranges (k >= row), 40 % of the work of the full product
     GemmParams q = flat_gemm(Smat, Mt, MtMt, o.TT, Mt, MtMt, tmp, Mt, MtMt, Mt, Mt, Mt);
@@ -827,17 +817,17 @@ extern "C" int vargp_elbo_tn_begin(const vargp_elbo_tn_desc* d, vargp_stream_t s
   zero_async(o.gkd, sizeof(float) * SC, st);
   zero_async(o.r_uf, sizeof(float) * (size_t)(o.r_uu - o.r_uf), st);
   zero_async(o.Puf, sizeof(float) * SC * Mt * D, st);
-  rc = rbf_prep_norm_launch(o.theta, d->z_all, zrows, nullptr, 0, o.w, o.g2, o.na, o.nb, S, D, o.Dp, st);
+  rc = rbf_prep_norm_launch(o.theta, d->z_all, zrows, nullptr, 0, o.w, o.g2, o.na, o.nb, S, D, o.Dp, st, nullptr, o.zs);
   if (rc) return rc;
   {
     GemmParams p0{};
-    p0.A = d->z_all; p0.B = d->z_all; p0.C = o.Kall;
+    p0.A = o.zs; p0.B = d->z_all; p0.C = o.Kall;        // A pre-scaled by the norm pass: no per-k scaling in the main loop
     p0.M = Mt; p0.N = Mt; p0.K = D; p0.lda = D; p0.ldb = D; p0.ldc = Mt;
     p0.nb1 = C; p0.nb2 = 1;
-    p0.sA[1] = (int64_t)Mt * D; p0.sB[1] = (int64_t)Mt * D;
+    p0.sA[0] = zrows * D; p0.sA[1] = (int64_t)Mt * D; p0.sB[1] = (int64_t)Mt * D;
     p0.sC[0] = C * MtMt; p0.sC[1] = MtMt;
     p0.alpha = 1.f;
-    p0.kscale = o.w; p0.ks_ld = o.Dp; p0.g2 = o.g2;
+    p0.kscale = nullptr; p0.ks_ld = o.Dp; p0.g2 = o.g2;
     p0.na = o.na; p0.sNa[0] = zrows; p0.sNa[1] = Mt;
     p0.nbv = o.na; p0.sNb[0] = zrows; p0.sNb[1] = Mt;
     p0.same_xy = 1; p0.triC = 2; p0.symout = 1;
@@ -1020,10 +1010,9 @@ extern "C" int vargp_elbo_tn_end(const vargp_elbo_tn_desc* d, const float* seeds
   {
     GemmParams p = flat_gemm(o.gT, Mt, MtMt, o.TT, Mt, MtMt, Smat, Mt, MtMt, Mt, Mt, Mt);
     p.alpha = -0.5f; p.triA = 1; p.triB = 2; p.triC = 2; p.symout = 1;
+    p.diag_ptr = seeds + 1; p.diag_scale = 0.5f / (float)S; p.diag_from = Mt - M;     // + g / 2 on the current task's diagonal
     rc = launch_gemm(p, 0, 1, SC, false, st, "tn_chol_bwd1");
     if (rc) return rc;
-    const int64_t total = (int64_t)SC * M;
-    hipLaunchKernelGGL(tn_diag_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, Smat, seeds, S, M, Mt, total);
     // gK = T^T (Smat T) is symmetric: its lower triangle needs tril(Smat T) only, and as T^T [.] the tiles of the lower
     // triangle are the ones with the SHORT K ranges (k >= row), 40 % of the work of the full product
     GemmParams q = flat_gemm(Smat, Mt, MtMt, o.TT, Mt, MtMt, tmp, Mt, MtMt, Mt, Mt, Mt);

@@ -487,6 +487,8 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int tile_id
     // 32 x 32 accumulator block is transposed through LDS first (a private 32 x 33 patch per wave: conflict-free both
     // ways) and then stored along rows as well.  (Uniform control flow: every wave of the workgroup runs all blocks.)
     float* patch = lds + wave * (32 * 33);
+    float dadd = 0.f;
+    if constexpr (!RBF) { if (p.diag_ptr) dadd = p.diag_scale * p.diag_ptr[0]; }
     __syncthreads();                                          // the K loop is done with the LDS stages
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
@@ -506,6 +508,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int tile_id
           } else {
             v = p.alpha * acc[a][c][r];
             if (D && row < p.M && col < p.N) v += p.beta * D[(int64_t)row * p.ldd + col];
+            if (row == col && row >= p.diag_from) v += dadd;
           }
           if (row < p.M && col < p.N && col <= row) C[(int64_t)row * p.ldc + col] = v;
           patch[rl * 33 + li] = v;

@@ -91,12 +91,13 @@ __global__ __launch_bounds__(256) void rbf_combine_kernel(const float* __restric
 // prep + both norm passes in one launch: nrm_x[s][row] = sum_d w_sd x[row][d]^2 (likewise y), w_sd = exp(-2 theta_sd)
 // evaluated on the fly; the blocks with blockIdx.x == 0 also store w (zero-padded to Dp) and g2 = exp(2 theta_sD) for the
 // GEMM that follows.  One wave per row; grid (ceil((xrows + yrows) / 4), S).
-// ys (nullable): the scaled copy y o w of the y rows, [S][yrows][D] -- with it the distance GEMM needs no per-k scaling.
+// ys / xs (nullable): the scaled copies y o w, [S][yrows][D], and x o w, [S][xrows][D] -- with a pre-scaled operand the
+// distance GEMM needs no per-k scaling (GemmParams.kscale = NULL).
 __global__ __launch_bounds__(256) void rbf_prep_norm_kernel(const float* __restrict__ theta, const float* __restrict__ x,
                                                             const float* __restrict__ y, float* __restrict__ w,
                                                             float* __restrict__ g2, float* __restrict__ na,
                                                             float* __restrict__ nb, int64_t xrows, int64_t yrows, int D,
-                                                            int64_t Dp, float* __restrict__ ys) {
+                                                            int64_t Dp, float* __restrict__ ys, float* __restrict__ xs) {
   const int s = blockIdx.y, lane = threadIdx.x & 63;
   const float* th = theta + (int64_t)s * (D + 1);
   if (blockIdx.x == 0) {
@@ -107,14 +108,28 @@ __global__ __launch_bounds__(256) void rbf_prep_norm_kernel(const float* __restr
   if (row >= xrows + yrows) return;
   const bool isx = row < xrows;
   const float* xr = isx ? x + row * D : y + (row - xrows) * D;
-  float acc = 0.f;
-  float* yo = (!isx && ys) ? ys + ((int64_t)s * yrows + (row - xrows)) * D : nullptr;
-  for (int d = lane; d < D; d += 64) {
-    const float v = xr[d], wv = expf(-2.f * th[d]);
-    acc = fmaf(v * v, wv, acc);
-    if (yo) yo[d] = v * wv;
+  float* yo = isx ? (xs ? xs + ((int64_t)s * xrows + row) * D : nullptr)
+                  : (ys ? ys + ((int64_t)s * yrows + (row - xrows)) * D : nullptr);
+  // four 64-wide chunks per batch, their loads first (clamped index), then the stores: a plain load / store loop is
+  // D / 64 memory round trips in a row (a load behind a store waits for the store as well)
+  float acc0 = 0.f, acc1 = 0.f;
+  for (int d0 = 0; d0 < D; d0 += 256) {
+    float xv[4], tv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int d = min(d0 + 64 * q + lane, D - 1);
+      xv[q] = xr[d]; tv[q] = th[d];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int d = d0 + 64 * q + lane;
+      const float wv = expf(-2.f * tv[q]);
+      const float v = d < D ? xv[q] : 0.f;
+      if (q & 1) acc1 = fmaf(v * v, wv, acc1); else acc0 = fmaf(v * v, wv, acc0);
+      if (yo && d < D) yo[d] = v * wv;
+    }
   }
-  acc = wave_sum(acc);
+  const float acc = wave_sum(acc0 + acc1);
   if (lane == 0) {
     if (isx) na[(int64_t)s * xrows + row] = acc; else nb[(int64_t)s * yrows + (row - xrows)] = acc;
   }
@@ -236,9 +251,9 @@ __global__ __launch_bounds__(256) void rbf_final_kernel(const float* __restrict_
 }
 
 int rbf_prep_norm_launch(const float* theta, const float* x, int64_t xrows, const float* y, int64_t yrows, float* w,
-                         float* g2, float* na, float* nb, int S, int D, int64_t Dp, hipStream_t st, float* ys) {
+                         float* g2, float* na, float* nb, int S, int D, int64_t Dp, hipStream_t st, float* ys, float* xs) {
   hipLaunchKernelGGL(rbf_prep_norm_kernel, dim3(cdiv(xrows + yrows, 4), S), dim3(256), 0, st, theta, x, y, w, g2, na, nb,
-                     xrows, yrows, D, Dp, ys);
+                     xrows, yrows, D, Dp, ys, xs);
   return check_launch("rbf_prep_norm");
 }
 
@@ -282,7 +297,7 @@ int vargp::rbf_gram_fwd_impl(const float* theta, const float* X, const float* Y,
   // scale loads / multiplies
   const bool prescale = y_shared && !self;
   hipLaunchKernelGGL(rbf_prep_norm_kernel, dim3(cdiv(xrows + (self ? 0 : yrows), 4), S), dim3(256), 0, st, theta, X, Y, o.w,
-                     o.g2, o.na, o.nb, xrows, self ? (int64_t)0 : yrows, D, o.Dp, prescale ? o.ys : (float*)nullptr);
+                     o.g2, o.na, o.nb, xrows, self ? (int64_t)0 : yrows, D, o.Dp, prescale ? o.ys : (float*)nullptr, (float*)nullptr);
   // shared Y: the classes' inducing points are just more rows of one [C*M, D] x [D, N] product
   const int Cb = y_shared ? 1 : C, Mb = y_shared ? C * M : M;
   GemmParams p{};
