@@ -561,29 +561,38 @@ extern "C" int vargp_elbo_tn_fwd(const vargp_elbo_tn_desc* d, vargp_stream_t str
                   sC[3] = {C * MtN, MtN, (int64_t)M * NRs};
     GemmParams p = blk_gemm(o.TT, Mt, sA, d->rk_all, NRs, sB, o.QPs, NRs, sC, M, NRs, M, C, nblk);
     p.triA = 1;
-    rc = launch_gemm(p, 0, 0, SC * nblk, false, st, "tn_small_gemm");
-    if (rc) return rc;
+    // P = T K_uf: independent of the small products -- mid-size shapes share one launch
+    GemmParams q = flat_gemm(o.TT, Mt, MtMt, o.Kuf, B, MtB, o.P, B, MtB, Mt, B, Mt);
+    q.triA = 1;
+    const int64_t wgs = (int64_t)SC * (nblk * cdiv(M, 64) * cdiv(NRs, 64) + cdiv(Mt, 64) * cdiv(B, 64));
+    static const int pair_fwd = [] { const char* e = getenv("VARGP_TN_PAIRFWD"); return e ? atoi(e) : 1; }();   // tuning aid
+    if (pair_fwd && wgs <= 4096) {
+      rc = launch_gemm_pair2(p, 0, 0, SC * nblk, q, 0, 0, SC, st, "tn_p_gemm");
+      if (rc) return rc;
+    } else {
+      rc = launch_gemm(p, 0, 0, SC * nblk, false, st, "tn_small_gemm");
+      if (rc) return rc;
+      rc = launch_gemm(q, 0, 0, SC, false, st, "tn_p_gemm");
+      if (rc) return rc;
+    }
   }
-  {  // P = T K_uf
-    GemmParams p = flat_gemm(o.TT, Mt, MtMt, o.Kuf, B, MtB, o.P, B, MtB, Mt, B, Mt);
-    p.triA = 1;
-    rc = launch_gemm(p, 0, 0, SC, false, st, "tn_p_gemm");
-    if (rc) return rc;
-  }
-  {  // V2 = T^T P  (= K'^-1 K_uf: the eps term of the variance)
+  {  // V2 = T^T P  (= K'^-1 K_uf: the eps term of the variance)  and  W_i = H_i^T P_i: both only need P
     GemmParams p = flat_gemm(o.TT, Mt, MtMt, o.P, B, MtB, o.V2, B, MtB, Mt, B, Mt);
     p.triA = 2;
-    rc = launch_gemm(p, 1, 0, SC, false, st, "tn_v2_gemm");
-    if (rc) return rc;
-  }
-  {  // W_i = H_i^T P_i
     const int64_t sA[3] = {C * MtN, MtN, (int64_t)M * NRs}, sB[3] = {C * MtB, MtB, (int64_t)M * B};
-    GemmParams p = blk_gemm(o.QPs + 4, NRs, sA, o.P, B, sB, o.W, B, sB, M, B, M, C, nblk);
-    p.triA = 2;
-    static const int wt = [] { const char* e = getenv("VARGP_TN_WTILE"); return e ? atoi(e) : 0; }();   // tuning aid
-    p.tile = wt;
-    rc = launch_gemm(p, 1, 0, SC * nblk, false, st, "tn_w_gemm");
-    if (rc) return rc;
+    GemmParams q = blk_gemm(o.QPs + 4, NRs, sA, o.P, B, sB, o.W, B, sB, M, B, M, C, nblk);
+    q.triA = 2;
+    const int64_t wgs = (int64_t)SC * cdiv(B, 64) * (cdiv(Mt, 64) + nblk * cdiv(M, 64));
+    static const int pair_fwd = [] { const char* e = getenv("VARGP_TN_PAIRFWD"); return e ? atoi(e) : 1; }();   // tuning aid
+    if (pair_fwd && wgs <= 4096) {
+      rc = launch_gemm_pair2(p, 1, 0, SC, q, 1, 0, SC * nblk, st, "tn_v2_gemm");
+      if (rc) return rc;
+    } else {
+      rc = launch_gemm(p, 1, 0, SC, false, st, "tn_v2_gemm");
+      if (rc) return rc;
+      rc = launch_gemm(q, 1, 0, SC * nblk, false, st, "tn_w_gemm");
+      if (rc) return rc;
+    }
   }
   {
     const int nbx = cdiv(B, 64), npd = nbx * SC, nkx = cdiv(M, kTnKlRows);

@@ -884,7 +884,8 @@ int launch_gemm_pair2(const GemmParams& p0, int tA0, int tB0, int nbatch0, const
                       int nbatch1, hipStream_t st, const char* tag) {
   const bool a0 = tA0 == 0, b0 = tB0 == 1, a1 = tA1 == 0, b1 = tB1 == 1;   // operand K-contiguous?
   const bool nt_nn = a0 && b0 && a1 && !b1, nt_tn = a0 && b0 && !a1 && !b1;
-  if (!(gemm_vec_ok(p0) && gemm_vec_ok(p1) && (nt_nn || nt_tn))) {
+  const bool nn_nn = a0 && !b0 && a1 && !b1, tn_tn = !a0 && !b0 && !a1 && !b1;
+  if (!(gemm_vec_ok(p0) && gemm_vec_ok(p1) && (nt_nn || nt_tn || nn_nn || tn_tn))) {
     int rc = launch_gemm(p0, tA0, tB0, nbatch0, false, st, tag);
     if (rc) return rc;
     return launch_gemm(p1, tA1, tB1, nbatch1, false, st, tag);
@@ -907,7 +908,9 @@ int launch_gemm_pair2(const GemmParams& p0, int tA0, int tB0, int nbatch0, const
   pp.nwg0 = pp.per_split[0] * pp.p[0].splitk;
   const int total = pp.nwg0 + pp.per_split[1] * pp.p[1].splitk;
   if (nt_nn) hipLaunchKernelGGL((gemm_pair2_kernel<true, true, true, false>), dim3(total), dim3(256), 0, st, pp);
-  else hipLaunchKernelGGL((gemm_pair2_kernel<true, true, false, false>), dim3(total), dim3(256), 0, st, pp);
+  else if (nt_tn) hipLaunchKernelGGL((gemm_pair2_kernel<true, true, false, false>), dim3(total), dim3(256), 0, st, pp);
+  else if (nn_nn) hipLaunchKernelGGL((gemm_pair2_kernel<true, false, true, false>), dim3(total), dim3(256), 0, st, pp);
+  else hipLaunchKernelGGL((gemm_pair2_kernel<false, false, false, false>), dim3(total), dim3(256), 0, st, pp);
   return check_launch("gemm_pair2");
 }
 
