@@ -675,34 +675,41 @@ extern "C" int vargp_elbo_tn_bwd(const vargp_elbo_tn_desc* d, const float* seeds
     rc = launch_gemm(p, 0, 0, SC, false, st, "tn_gp_v2_gemm");
     if (rc) return rc;
   }
-  {  // gT = tril(gP K_uf^T + P gV2^T)  (P = T K_uf and V2 = T^T P), then the diagonal blocks' share from the small products
+  {  // gT = tril(gP K_uf^T + P gV2^T)  (P = T K_uf and V2 = T^T P), then the diagonal blocks' share from the small products;
+     // gK_uf = T^T gP and the parameter gradients of the current task, [g m_t | . | g Lu_t] = T_tt^T [ga_t | . | gH_t], do not
+     // depend on gT: at mid-size shapes they ride in the launches of its two big products
     GemmParams p = flat_gemm(o.gP, B, MtB, o.Kuf, B, MtB, o.gT, Mt, MtMt, Mt, Mt, B);
     p.triC = 1;
-    rc = launch_gemm(p, 0, 1, SC, false, st, "tn_gt_gemm");
-    if (rc) return rc;
     GemmParams q = flat_gemm(o.P, B, MtB, gV2, B, MtB, o.gT, Mt, MtMt, Mt, Mt, B);
     q.triC = 1; q.D = o.gT; q.beta = 1.f;
-    rc = launch_gemm(q, 0, 1, SC, false, st, "tn_gt_gemm");
-    if (rc) return rc;
+    GemmParams ku = flat_gemm(o.TT, Mt, MtMt, o.gP, B, MtB, o.gKuf, B, MtB, Mt, B, Mt);
+    ku.triA = 2;
+    const int64_t off = (int64_t)(Mt - M) * Mt + (Mt - M);
+    GemmParams rk = flat_gemm(o.TT + off, Mt, MtMt, o.gQPs + (int64_t)(Mt - M) * NRs, NRs, MtN, o.gRKt, NRs, (int64_t)M * NRs, M,
+                              NRs, M);
+    rk.triA = 2;
+    const int64_t wgs = (int64_t)SC * cdiv(Mt, 64) * (cdiv(Mt, 64) + cdiv(B, 64));
+    static const int pair_bwd = [] { const char* e = getenv("VARGP_TN_PAIRBWD"); return e ? atoi(e) : 1; }();   // tuning aid
+    if (pair_bwd && wgs <= 4096) {
+      rc = launch_gemm_pair2(p, 0, 1, SC, ku, 1, 0, SC, st, "tn_gt_gemm");
+      if (rc) return rc;
+      rc = launch_gemm_pair2(q, 0, 1, SC, rk, 1, 0, SC, st, "tn_gt_gemm");
+      if (rc) return rc;
+    } else {
+      rc = launch_gemm(p, 0, 1, SC, false, st, "tn_gt_gemm");
+      if (rc) return rc;
+      rc = launch_gemm(q, 0, 1, SC, false, st, "tn_gt_gemm");
+      if (rc) return rc;
+      rc = launch_gemm(ku, 1, 0, SC, false, st, "tn_gkuf_gemm");
+      if (rc) return rc;
+      rc = launch_gemm(rk, 1, 0, SC, false, st, "tn_grk_gemm");
+      if (rc) return rc;
+    }
     const int64_t sQ[3] = {C * MtN, MtN, (int64_t)M * NRs}, sR[3] = {0, (int64_t)nblk * M * NRs, (int64_t)M * NRs},
                   sT[3] = {C * MtMt, MtMt, (int64_t)M * Mt + M};
     GemmParams r = blk_gemm(o.gQPs, NRs, sQ, d->rk_all, NRs, sR, o.gT, Mt, sT, M, M, NRs, C, nblk);
     r.triC = 1; r.D = o.gT; r.ldd = Mt; r.beta = 1.f;
     rc = launch_gemm(r, 0, 1, SC * nblk, false, st, "tn_gt_diag_gemm");
-    if (rc) return rc;
-  }
-  {  // gK_uf = T^T gP
-    GemmParams p = flat_gemm(o.TT, Mt, MtMt, o.gP, B, MtB, o.gKuf, B, MtB, Mt, B, Mt);
-    p.triA = 2;
-    rc = launch_gemm(p, 1, 0, SC, false, st, "tn_gkuf_gemm");
-    if (rc) return rc;
-  }
-  {  // parameter gradients of the current task: [g m_t | . | g Lu_t] = T_tt^T [ga_t | . | gH_t]
-    const int64_t off = (int64_t)(Mt - M) * Mt + (Mt - M);
-    GemmParams p = flat_gemm(o.TT + off, Mt, MtMt, o.gQPs + (int64_t)(Mt - M) * NRs, NRs, MtN, o.gRKt, NRs, (int64_t)M * NRs, M,
-                             NRs, M);
-    p.triA = 2;
-    rc = launch_gemm(p, 1, 0, SC, false, st, "tn_grk_gemm");
     if (rc) return rc;
   }
   // Cholesky backward.  Only diag(L_tt) is used forward (log-determinant), so gL = diag(g / L_jj) on the current block:
