@@ -375,7 +375,8 @@ def main():
                        '([Mt x Mt] x [Mt x D] per (sample, class))'),
                       ('rbf_kuf_bwd_gemm', 2.0 * S * C * Mt * B * D, 'gemm_kernel W_uf x of the kernel-matrix backward '
                        '([C*Mt x B] x [B x D] per sample)'),
-                      ('tn_chol_bwd3', 1.0 * S * C * Mt * Mt * Mt, 'gemm_kernel (T^T S) T of the Cholesky adjoint (T lower triangular)')]
+                      ('tn_chol_bwd3', S * C * Mt * Mt * Mt / 3.0, 'gemm_kernel gK = T^T tril(Smat T), lower triangle mirrored '
+                       '(both factors lower triangular: S*C*Mt^3/3 flop)')]
     for tag, fl, desc in candidates:
         if args.no_replay:
             break
