@@ -496,14 +496,20 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int tile_id
       for (int c = 0; c < TN; ++c) {
         const int R0 = m0 + wm0 + 32 * a, C0 = n0 + wn0 + 32 * c;
         const int col = C0 + li;
-        float nbc = 0.f;
-        if constexpr (RBF) nbc = (col < p.N) ? nbv[col] : 0.f;
+        // norms up front on clamped indices (a load inside a bounds branch is a memory round trip of its own: 17 of them in
+        // a row per block made this epilogue as long as the K loop); rows / columns past the edge are never stored
+        float nbc = 0.f, nar[16];
+        if constexpr (RBF) {
+          nbc = nbv[min(col, p.N - 1)];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) nar[r] = na[min(R0 + (r & 3) + 8 * (r >> 2) + 4 * lh, p.M - 1)];
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int rl = (r & 3) + 8 * (r >> 2) + 4 * lh, row = R0 + rl;
           float v;
           if constexpr (RBF) {
-            const float d2 = ((row < p.M) ? na[row] : 0.f) + nbc - 2.f * acc[a][c][r];
+            const float d2 = nar[r] + nbc - 2.f * acc[a][c][r];
             v = (p.same_xy && row == col) ? g2 : g2 * expf(-0.5f * d2);
           } else {
             v = p.alpha * acc[a][c][r];
@@ -931,7 +937,15 @@ int launch_gemm(const GemmParams& p, int transA, int transB, int nbatch, bool rb
     // M = 2048 predictive sweep: 25 MB of B per XCD) the plain map, which spreads neighbours over the XCDs, is faster
     static const int xcd_force = [] { const char* e = getenv("VARGP_GEMM_XCD"); return e ? atoi(e) : -1; }();   // tuning aid
     const int64_t wgs = (int64_t)cdiv(p.M, 64) * cdiv(p.N, 64) * nbatch;
-    const_cast<GemmParams&>(p).xcd_remap = xcd_force >= 0 ? xcd_force : (wgs <= 4096 ? 1 : 0);
+    // ... except with triangular operands / results, whose tiles differ in length: there the compact ranges (whole
+    // matrices per XCD, long tiles first) balance much better at any size (1000 x 512 x 1000, batch 100: 633 -> 507 us;
+    // Permuted-MNIST t=4 step 55 -> 70 steps/s).  Dense products are within 2 % either way (4096^3, 1000^3 batch 100;
+    // a grouped 2-D tile order changed nothing for them: they are not limited by L2 misses).
+    // (batches of matrices up to ~2000 x 2000; the M = 2048 x 8192 products of the N = 1e6 sweep, 10 matrices on 8 XCDs,
+    //  are 3 % faster with the plain map)
+    const bool tri_any = p.triA != 0 || p.triB != 0 || p.triC != 0;
+    const bool tri_batch = tri_any && (int64_t)cdiv(p.M, 64) * cdiv(p.N, 64) <= 2048;
+    const_cast<GemmParams&>(p).xcd_remap = xcd_force >= 0 ? xcd_force : ((wgs <= 4096 || tri_batch) ? 1 : 0);
   }
   bool vec = aligned16(p.A) && aligned16(p.B) && (p.lda % 4 == 0) && (p.ldb % 4 == 0);
   for (int i = 0; i < 3; ++i) vec = vec && (p.sA[i] % 4 == 0) && (p.sB[i] % 4 == 0);
