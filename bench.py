@@ -41,6 +41,7 @@ WORKLOADS = {
     'pmnist_t0': dict(S=10, M=200, n_prev=0, desc='BASELINE config 3 (Permuted-MNIST), task 0: M=200, S=10'),
     'pmnist_t1': dict(S=10, M=200, n_prev=1, desc='Permuted-MNIST task 1 (Mt=400), M=200, S=10'),
     'pmnist_t4': dict(S=10, M=200, n_prev=4, desc='Permuted-MNIST task 4 (Mt=1000), M=200, S=10'),
+    'pmnist_t9': dict(S=10, M=200, n_prev=9, desc='Permuted-MNIST task 9, the last of the 10-task sequence (Mt=2000), M=200, S=10'),
 }
 
 
