@@ -127,7 +127,9 @@ def stress(args, device):
                roofline=dict(bound='mfma', kernel='gemm_kernel<RBF> K_uf tile [10*2048 x 784] x [784 x 8192]',
                              achieved=flops / avg_s / 1e12 if kern_n else None, peak=MFMA_F32_PEAK_TFLOPS,
                              unit='TFLOP/s', frac=flops / avg_s / 1e12 / MFMA_F32_PEAK_TFLOPS if kern_n else None,
-                             launches=kern_n, avg_us=avg_s * 1e6, traffic=None),
+                             launches=kern_n, avg_us=avg_s * 1e6, traffic=measured_traffic('stress_kuf_tile'),
+                             mfma_util=measured_mfma_util('stress_kuf_tile'),
+                             counters_from=_latest_profile('traffic')[1] if measured_traffic('stress_kuf_tile') else None),
                roofline_chol=dict(bound='mfma', kernel='blocked Cholesky + inverse factor, n=2048, 10 matrices (register '
                                   'diagonal blocks + MFMA panel / trailing / inverse GEMMs)', achieved=chol_flops / (chol_ms * 1e-3) / 1e12,
                                   peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',

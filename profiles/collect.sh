@@ -18,8 +18,13 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_wri
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_sq -o p -- $B --eager --no-replay --steps 10 --warmup 3 > /dev/null 2>&1
 # calibration of the MFMA-utilisation formula on a kernel of known efficiency (4096^3 NT GEMM, ~90 % of peak by its clock)
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_sqcal -o p -- $R/tests/native/bench_kernels gemm4k 5 > $OUT/${TAG}_sqcal.log 2>&1
+# counters of the N = 1e6 sweep's kernels on a short sweep (8 tiles: the per-launch figures do not depend on N)
+BS="python3 $R/bench.py --workload stress --stress-n 65536 --no-cpu-baseline"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_stfetch -o p -- $BS > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_stwrite -o p -- $BS > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_stsq -o p -- $BS > /dev/null 2>&1
 # secondary workloads: bench lines only
-for w in smnist_s64 smnist_t1 smnist_t4 pmnist_t0 pmnist_t1 pmnist_t4; do
+for w in smnist_s64 smnist_t1 smnist_t4 pmnist_t0 pmnist_t1 pmnist_t4 pmnist_t9; do
   python3 $R/bench.py --workload $w --steps 30 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_line_$w.log 2>&1
 done
 python3 $R/bench.py --workload stress > $OUT/${TAG}_line_stress.log 2>&1

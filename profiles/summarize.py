@@ -36,7 +36,18 @@ KERNELS = {
                          4 * (S * C * M * B + S * C * M * M + B * D + C * M * D + 2 * S * C * M * D),
                          2.0 * S * C * M * D * (B + M)),
 }
-SECONDARY = ['smnist_s64', 'smnist_t1', 'smnist_t4', 'pmnist_t0', 'pmnist_t1', 'pmnist_t4', 'stress']
+SECONDARY = ['smnist_s64', 'smnist_t1', 'smnist_t4', 'pmnist_t0', 'pmnist_t1', 'pmnist_t4', 'pmnist_t9', 'stress']
+# kernels of the N = 1e6 sweep (M = 2048, C = 10, S = 1, tile 8192), counters from the short sweep of collect.sh:
+# tag -> (kernel-name prefix, grid size in threads, algorithmic bytes, flops)
+MS, TL = 2048, 8192
+STRESS_KERNELS = {
+    # K_uf tile: read z (C*M x D) and the pre-scaled minibatch tile once, write K_uf
+    'stress_kuf_tile': ('void vargp::gemm_kernel<128, 128, 16, true, true, true, true, false>', 10 * (MS // 128) * (TL // 128) * 256,
+                        4 * (C * MS * D + TL * D + C * MS * TL), 2.0 * C * MS * TL * D),
+    # P = T K_uf (T lower triangular): read T and K_uf, write P
+    'stress_p_gemm': ('void vargp::gemm_kernel<128, 64, 32, true, false, true, false, true>', 10 * (MS // 128) * (TL // 64) * 256,
+                      4 * (C * MS * MS // 2 + 2 * C * MS * TL), 1.0 * C * MS * MS * TL),
+}
 
 
 def last_json(path):
@@ -104,6 +115,21 @@ def main():
                               wave_cycle_split=dict(active=act / wave, wait_inst=wi / wave, wait=wa / wave) if wave else None,
                               note='mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (128 * GRBM_GUI_ACTIVE): busy cycles summed over 1024 '
                                    'SIMDs, GRBM_GUI_ACTIVE summed over 8 XCDs; calibrated on the 4096^3 GEMM (0.90)')
+    if os.path.exists(src('stfetch', 'p_counter_collection.csv')):
+        for name, (prefix, grid, algo, flops) in STRESS_KERNELS.items():
+            sel = lambda d: [r for r in pmc_rows(src(d, 'p_counter_collection.csv'), prefix) if int(r['Grid_Size']) == grid]
+            fr, wr, sq = sel('stfetch'), sel('stwrite'), sel('stsq')
+            f_kb, nf = avg(fr, 'FETCH_SIZE')
+            w_kb, nw = avg(wr, 'WRITE_SIZE')
+            if f_kb is not None and w_kb is not None:
+                traffic[name] = dict(kernel=prefix, grid_threads=grid, FETCH_SIZE_KB=f_kb, WRITE_SIZE_KB=w_kb, dispatches=[nf, nw],
+                                     fetch_correction=2.0, traffic_bytes=1024.0 * (2.0 * f_kb + w_kb), algorithmic_bytes=algo)
+            busy, n = avg(sq, 'SQ_VALU_MFMA_BUSY_CYCLES')
+            gui, _ = avg(sq, 'GRBM_GUI_ACTIVE')
+            if busy is not None and gui:
+                mops, _ = avg(sq, 'SQ_INSTS_VALU_MFMA_MOPS_F32')
+                mfma[name] = dict(kernel=prefix, dispatches=n, mfma_util=busy / (128.0 * gui),
+                                  mfma_flops_executed=(mops * 512.0) if mops else None, algorithmic_flops=flops)
     cal = os.path.join(G, f'{tag}_sqcal', 'p_counter_collection.csv')
     if os.path.exists(cal):
         rows = pmc_rows(cal, 'void vargp::gemm_kernel')
