@@ -74,7 +74,8 @@ struct GemmParams {
   int64_t sNa[3], sNb[3];
   int same_xy;
   int nofast;   // tuning aid: force the guarded (non-pipelined) slab loop
-  int xcd_remap;   // set by launch_gemm: XCD-compact workgroup -> tile map (small grids)
+  int xcd_remap;   // set by launch_gemm: XCD-compact workgroup -> tile map
+  int group_m;     // set by launch_gemm: > 1: tiles of a matrix are visited group_m tile rows at a time (L2 reuse on large grids)
   // symout products only: C_ii += diag_scale * diag_ptr[0] for i >= diag_from (diag_ptr: device scalar, NULL: off)
   const float* diag_ptr;
   float diag_scale;
