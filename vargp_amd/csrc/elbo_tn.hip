@@ -527,7 +527,7 @@ extern "C" int vargp_elbo_tn_fwd(const vargp_elbo_tn_desc* d, vargp_stream_t str
   // GEMM, which nothing needs before T exists, shares the launch of the first diagonal block's pivot chain.
   // With a blocked factorisation (Mt > 100) every diagonal block has a pivot chain of its own: the K_uf GEMM is cut into
   // row slices (whole 64-row tiles of the [C*Mt x B] product), one per chain.
-  constexpr int kMaxSlices = 8;
+  constexpr int kMaxSlices = 24;   // one slice per pivot chain up to Mt = 2400
   GemmParams slices[kMaxSlices];
   int nsl = 0, consumed = 0;
   if (!kuf_done) {
