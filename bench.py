@@ -290,7 +290,10 @@ def main():
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
-    if world > 1:
+    # VARGP_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL group, two-graph capture around the all-reduce, barriers)
+    # with a single rank -- a smoke test of that path on a one-GPU box
+    use_dist = world > 1 or os.environ.get('VARGP_BENCH_FORCE_DIST', '0') == '1'
+    if use_dist:
         dist.init_process_group('nccl', device_id=device)
 
     from vargp_amd import _lib, ops
@@ -302,10 +305,12 @@ def main():
     gp, x, y = make_model(device)
     rtol, rtol_on = elbo_check(gp, x, y) if rank == 0 else (None, None)
     p0 = snapshot(gp) if rank == 0 else None     # the CPU baseline runs the same (initial) model
-    trainer = ElboTrainer(gp, lr=LR, beta=BETA, n_total=N_TOTAL, sample_counts=counts if world > 1 else None)
+    trainer = ElboTrainer(gp, lr=LR, beta=BETA, n_total=N_TOTAL,
+                          sample_counts=(counts if counts is not None else ([S] * world if use_dist else None)) if use_dist else None,
+                          force_exchange=use_dist)
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -314,13 +319,13 @@ def main():
         try:
             trainer.capture(x, y)
         except Exception as e:                      # never lose the bench line to a capture problem: run eagerly instead
-            if world > 1:                           # (every rank takes the same decision)
+            if use_dist:                            # (every rank takes the same decision)
                 flag = torch.tensor([1.0], device=device)
                 dist.all_reduce(flag)
             print(f'[bench] hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager steps', file=sys.stderr)
             use_graph = False
         else:
-            if world > 1:
+            if use_dist:
                 flag = torch.tensor([0.0], device=device)
                 dist.all_reduce(flag)
                 if flag.item() > 0:                 # some other rank failed to capture
@@ -421,7 +426,7 @@ def main():
                    config=dict(workload=WORKLOADS[args.workload]['desc'], S_per_gpu=counts if strong else S, Mt=M * (N_PREV + 1),
                                S_total=s_total if strong else S * world, F=F_, C=C, M=M, D=D, B=B, N=N_TOTAL, beta=BETA,
                                optimizer='yogi', parallelism=f'sample-parallel x{world}',
-                               launch=('hipGraph replay' + (' (2 graphs around the all-reduce)' if world > 1 else '')) if use_graph
+                               launch=('hipGraph replay' + ((' (all-reduce captured)' if trainer.graph_opt is None else ' (2 graphs around the all-reduce)') if use_dist else '')) if use_graph
                                else 'eager'),
                    elbo_rtol_vs_cpu=rtol, elbo_rtol_checked_on=rtol_on, finite=bool(finite), cholesky_failures=errs,
                    final_loss=dict(kl_hypers=out[0].item(), kl_u=out[1].item(), nll=out[2].item()),
@@ -446,7 +451,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.workload == 'smnist':
             res['cpu_baseline'] = cpu_baseline(p0, x, y)
         print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -13,6 +13,8 @@ fp32 buffer [grad(z) | grad(u_mean) | grad(u_tril_vec) | grad(log_mean) | grad(l
 yields identical gradients on every rank.  Gradients are views into that flat buffer, so there is no
 pack/unpack copy.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -31,7 +33,7 @@ class ElboTrainer:
     replaced by any `loss_fn(x, y) -> (kl_hypers, kl_u, nll)` over an explicit `params` list."""
 
     def __init__(self, gp=None, lr=1e-2, beta=1.0, n_total=None, group=None, noise_seed=1234, optimizer=None,
-                 params=None, loss_fn=None, native_noise=True, sample_counts=None):
+                 params=None, loss_fn=None, native_noise=True, sample_counts=None, force_exchange=False):
         self.gp = gp
         self.loss_fn = loss_fn if loss_fn is not None else gp.loss
         self.beta = float(beta)
@@ -39,6 +41,9 @@ class ElboTrainer:
         self.group = group
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
+        # force_exchange: take the multi-rank path (all-reduce of the flat buffer, two-graph capture) with one rank too --
+        # a smoke test of that path where only one GPU is available (bench.py, VARGP_BENCH_FORCE_DIST=1)
+        self.multi = self.world > 1 or (bool(force_exchange) and dist.is_available() and dist.is_initialized())
         self.params = list(params) if params is not None else [p for p in gp.parameters() if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
@@ -61,10 +66,11 @@ class ElboTrainer:
         else:
             self.weight = 1.0 / self.world
             self.sample_offset = None          # rank * S, S known at the first step
-        if self.world > 1:
+        if self.multi:
             noise.set_shard(self.rank, self.world, noise_seed, dev, self.sample_counts)
 
         self.graph = None
+        self.graph_opt = None
         # models on a native program (fused.T0Program: first task; fused.TnProgram: later tasks, ep_var_mean=True) drive it
         # directly: no autograd graph, gradients written straight into the optimiser's buffers
         is_model = gp is not None and loss_fn is None and params is None and hasattr(gp, 'draw_t0_noise')
@@ -110,9 +116,17 @@ class ElboTrainer:
             # the composed (t > 0) path draws its noise from the shared torch generator inside the captured region;
             # the first-task program has its own counter-based generator and needs no generator bookkeeping per replay
             self.graph.register_generator_state(noise._shard[2])
-        if self.world == 1:
+        if not self.multi:
             with torch.cuda.graph(self.graph):
                 self._sout = self.step(self._sx, self._sy)
+        elif os.environ.get('VARGP_CAPTURE_ALLREDUCE', '0') == '1':
+            # opt-in: the RCCL all-reduce captured with the rest (one graph per step).  Off by default: only validated with a
+            # single rank (one GPU per box here); the two-graph form below is the one the multi-GPU tests cover.
+            with torch.cuda.graph(self.graph):
+                self._sout = self._local_part(self._sx, self._sy)
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+                self.optim.step()
+            self.graph_opt = None
         else:
             with torch.cuda.graph(self.graph):
                 self._sout = self._local_part(self._sx, self._sy)
@@ -166,7 +180,7 @@ class ElboTrainer:
             self._sx.copy_(x, non_blocking=True)
             self._sy.copy_(y, non_blocking=True)
         self.graph.replay()
-        if self.world > 1:
+        if self.multi and self.graph_opt is not None:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
             self.graph_opt.replay()
         return self._sout
@@ -174,7 +188,7 @@ class ElboTrainer:
     def step(self, x, y):
         """-> (kl_hypers, kl_u, nll) as 0-dim device tensors (global values on every rank)."""
         scale = (self.n_total if self.n_total is not None else x.size(0)) / x.size(0)
-        if self._t0 and self.world == 1:
+        if self._t0 and not self.multi:
             if self._own_grads is None:
                 self._own_grads = [torch.empty_like(p) for p in self.params]
             for p, g in zip(self.params, self._own_grads):
@@ -182,7 +196,7 @@ class ElboTrainer:
             scal = self._t0_fwd_bwd(x, y, scale, 1.0)
             self.optim.step()
             return scal[0], scal[1], scal[2]
-        if self.world == 1:
+        if not self.multi:
             # single GPU: let autograd hand the gradients over (no zero-fill, no accumulate kernels)
             for p in self.params:
                 p.grad = None
