@@ -145,3 +145,60 @@ def test_uneven_sample_split_equals_single_process():
     for k in sd1:
         err = np.linalg.norm(sd2[k] - sd1[k]) / max(np.linalg.norm(sd1[k]), 1e-30)
         assert err < 1e-4, (k, err)
+
+
+def _worker_rccl(port, mode, q):
+    """One rank on RCCL ('nccl' backend), the multi-rank path forced (force_exchange): the flat buffer goes through a real
+    RCCL all-reduce -- eager, between the two step graphs, or captured into one graph (VARGP_CAPTURE_ALLREDUCE=1)."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1')
+    if mode == 'captured':
+        os.environ['VARGP_CAPTURE_ALLREDUCE'] = '1'
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        from vargp_amd import ops
+        from vargp_amd.train import ElboTrainer
+        ops.set_cholesky_error_mode('defer')
+        gp, x, y = _model(S_LOCAL)
+        tr = ElboTrainer(gp, lr=1e-3, beta=2.0, n_total=10 * B, noise_seed=SEED, sample_counts=[S_LOCAL], force_exchange=True)
+        assert tr.multi
+        if mode != 'eager':
+            tr.capture(x, y, warmup=1)                 # (the warm-up is undone by capture itself)
+            assert (tr.graph_opt is None) == (mode == 'captured')
+        outs = []
+        for _ in range(3):
+            out = tr.step_graph(x, y) if mode != 'eager' else tr.step(x, y)
+            outs.append([o.item() for o in out])
+        torch.cuda.synchronize()
+        q.put((outs, {k: v.detach().cpu().numpy() for k, v in gp.state_dict().items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('mode', ['eager', 'two_graphs', 'captured'])
+def test_rccl_single_rank_exchange_equals_plain_step(mode):
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_rccl, args=(port, mode, q))
+    p.start()
+    outs2, sd2 = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    from vargp_amd import noise, ops
+    ops.set_cholesky_error_mode('defer')
+    try:
+        gp, x, y = _model(S_LOCAL)
+        from vargp_amd.train import ElboTrainer
+        tr = ElboTrainer(gp, lr=1e-3, beta=2.0, n_total=10 * B, noise_seed=SEED)
+        outs1 = [[o.item() for o in tr.step(x, y)] for _ in range(3)]
+        sd1 = {k: v.detach().cpu().numpy() for k, v in gp.state_dict().items()}
+    finally:
+        noise.clear_shard()
+        ops.set_cholesky_error_mode('raise')
+    np.testing.assert_allclose(np.array(outs2), np.array(outs1), rtol=2e-4)
+    for k in sd1:
+        err = np.linalg.norm(sd2[k] - sd1[k]) / max(np.linalg.norm(sd1[k]), 1e-30)
+        assert err < 1e-4, (k, err)
