@@ -659,12 +659,8 @@ extern "C" int vargp_elbo_tn_bwd(const vargp_elbo_tn_desc* d, const float* seeds
       //  zeros above the diagonal)
       p.splitk = 1; p.D = o.gQPs + 4; p.ldd = NRs; p.beta = 1.f; p.triC = 1;
       for (int i = 0; i < 3; ++i) p.sD[i] = sQ[i];
-      static const int ht = [] { const char* e = getenv("VARGP_TN_GHTILE"); return e ? atoi(e) : 0; }();   // tuning aid
-      p.tile = ht;
       rc = launch_gemm(p, 0, 1, SC * nblk, false, st, "tn_gh_gemm");
       if (rc) return rc;
-      static const int gt = [] { const char* e = getenv("VARGP_TN_GPTILE"); return e ? atoi(e) : 0; }();   // tuning aid
-      q.tile = gt;
       rc = launch_gemm(q, 0, 0, SC * nblk, false, st, "tn_gp_gemm");
       if (rc) return rc;
     }
@@ -765,8 +761,6 @@ extern "C" int vargp_elbo_tn_bwd(const vargp_elbo_tn_desc* d, const float* seeds
       rc = launch_gemm_pair(p0, SC, p1, S, 0, 0, false, st, "rbf_kuu_bwd_gemm", "rbf_kuf_bwd_gemm");
       if (rc) return rc;
     } else {
-      static const int wyt = [] { const char* e = getenv("VARGP_TN_WYTILE"); return e ? atoi(e) : 0; }();   // tuning aid
-      p0.tile = wyt % 10; p1.tile = wyt / 10;
       rc = launch_gemm(p0, 0, 0, SC, false, st, "rbf_kuu_bwd_gemm");
       if (rc) return rc;
       rc = launch_gemm(p1, 0, 0, S, false, st, "rbf_kuf_bwd_gemm");
