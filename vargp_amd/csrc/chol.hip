@@ -218,18 +218,26 @@ static int launch_small(const float* A, int lda, int64_t sA, float eps, float* L
   return check_launch("chol_inv_small");
 }
 
-// Prologue of the blocked path in one pass: W[b] = A[b] + eps I (dense copy incl. the upper part, which is never read),
-// L[b] = 0, T[b] = 0 (the panel GEMMs only write below the diagonal blocks; the zeros above them must be real zeros)
+// Prologue of the blocked path in one pass, by nb x nb block (nb = panel width):
+//   blocks on / below the diagonal: W[b] = A[b] + eps I -- the factorisation never reads above the diagonal blocks, and
+//       everything of L and T there is written later (diagonal blocks by the pivot-chain kernel incl. their zeros, the
+//       rest by the panel products);
+//   blocks above the diagonal: L[b] = 0, T[b] = 0 -- the products that read the factors clip K per TILE, so the zeros
+//       next to the diagonal blocks must be real zeros.
+// Half the traffic of copying and zero-filling everything.
 __global__ void chol_prep_kernel(const float* __restrict__ A, float* __restrict__ W, float* __restrict__ L,
-                                 float* __restrict__ T, int n, float eps) {
+                                 float* __restrict__ T, int n, float eps, int nb) {
   const int64_t b = blockIdx.y;
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (int64_t)n * n) return;
   const int i = e / n, j = e % n;
   const int64_t o = b * n * n + e;
-  W[o] = A[o] + (i == j ? eps : 0.f);
-  L[o] = 0.f;
-  if (T) T[o] = 0.f;
+  if (j / nb <= i / nb) {
+    W[o] = A[o] + (i == j ? eps : 0.f);
+  } else {
+    L[o] = 0.f;
+    if (T) T[o] = 0.f;
+  }
 }
 
 // out = tril(gL) - tril(G2)   (either input may be null)
@@ -313,7 +321,7 @@ int vargp::chol_inv_fwd_impl(const float* A, float eps, float* L, float* T, floa
   const int kNbSmall = panel_width();
   const int64_t stmp = (int64_t)n * kNbSmall;
   float* Tout = T;
-  hipLaunchKernelGGL(chol_prep_kernel, dim3(cdiv(nn, 256), nbatch), dim3(256), 0, st, A, W, L, Tout, n, eps);
+  hipLaunchKernelGGL(chol_prep_kernel, dim3(cdiv(nn, 256), nbatch), dim3(256), 0, st, A, W, L, Tout, n, eps, kNbSmall);
   int rc;
   for (int k0 = 0; k0 < n; k0 += kNbSmall) {
     const int kb = (n - k0 < kNbSmall) ? n - k0 : kNbSmall;
