@@ -9,7 +9,9 @@ import math
 import torch
 
 
-def mnist_like(n, d=784, n_classes=10, kind='gauss', seed=0):
+def mnist_like(n, d=784, n_classes=10, kind='gauss', seed=0, sample_seed=None):
+    """sample_seed ('mnist_classes' only): seed of the per-sample randomness, so that several draws (train / test) share
+    the class prototypes that `seed` fixes."""
     g = torch.Generator().manual_seed(seed)
     y = torch.arange(n) % n_classes
     if kind == 'mnist':
@@ -20,6 +22,8 @@ def mnist_like(n, d=784, n_classes=10, kind='gauss', seed=0):
         # random intensities, so same-class points are far from identical (no near-singular K_uu)
         n_proto = 16
         protos = (torch.rand(n_classes, n_proto, d, generator=g) < 0.19).float()
+        if sample_seed is not None:
+            g = torch.Generator().manual_seed(sample_seed)
         which = torch.randint(0, n_proto, (n,), generator=g)
         keep = (torch.rand(n, d, generator=g) < 0.5).float()
         extra = (torch.rand(n, d, generator=g) < 0.03).float()
