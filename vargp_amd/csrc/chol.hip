@@ -343,35 +343,72 @@ int vargp::chol_inv_fwd_impl(const float* A, float eps, float* L, float* T, floa
       rc = launch_small(W + dkk, n, nn, 0.f, L + dkk, n, nn, Tkk, ldt, sT, logdet, info, k0, nbatch, kb, k0 > 0, st);
     }
     if (rc) return rc;
-    if (rem > 0) {
-      if (!Tout) {
-        // T_kk sits in tmp: panel result must go elsewhere -> write directly into L (inputs are W, tmp)
+    // After the pivot chain of block k two independent pairs of products are due:
+    //   (a) the panel below it,           L_ik = W_ik T_kk^T                      (rem x kb),       then W_22 -= L_ik L_ik^T;
+    //   (b) block row k of T = L^-1,      T[k, :k0] = -T_kk (L[k, :k0] T[:k0, :k0])  (kb x k0)      (from L T = I: everything it
+    //       needs -- the earlier rows of T, row k of L, T_kk -- exists at this point; the column-wise order, which waits
+    //       for ALL chains, cost 2 (nblk - 1) launches of its own).
+    // The first product of (a) shares a launch with the first of (b), the second with the second, when they are mid-size.
+    const bool trow = Tout != nullptr && k0 > 0;
+    auto mk = [&](const float* A_, int lda, const float* B_, int ldb, float* C_, int ldc, const float* D_, float alpha,
+                  float beta, int M_, int N_, int K_, int triA, int triB, int triC) {
+      GemmParams p{};
+      p.A = A_; p.B = B_; p.C = C_; p.D = D_;
+      p.M = M_; p.N = N_; p.K = K_; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldd = ldc;
+      p.nb1 = 1; p.nb2 = 1;
+      p.sA[0] = (A_ == tmp) ? stmp : nn; p.sB[0] = (B_ == tmp) ? stmp : nn;
+      p.sC[0] = (C_ == tmp) ? stmp : nn; p.sD[0] = p.sC[0];
+      p.alpha = alpha; p.beta = D_ ? beta : 0.f;
+      p.triA = triA; p.triB = triB; p.triC = triC;
+      return p;
+    };
+    // strides of T_kk when it is parked in tmp (no T wanted) differ: only (a) runs then, through sq_gemm as before
+    if (!Tout) {
+      if (rem > 0) {
+        rc = sq_gemm(W + (int64_t)k1 * n + k0, n, nn, 0, 0, Tkk, ldt, sT, 1, 2, L + (int64_t)k1 * n + k0, n, nn,
+                     nullptr, 1.f, 0.f, rem, kb, kb, 0, nbatch, st);
+        if (rc) return rc;
+        float* W22 = W + (int64_t)k1 * n + k1;
+        rc = sq_gemm(L + (int64_t)k1 * n + k0, n, nn, 0, 0, L + (int64_t)k1 * n + k0, n, nn, 1, 0, W22, n, nn, W22,
+                     -1.f, 1.f, rem, rem, kb, 2, nbatch, st);
+        if (rc) return rc;
       }
-      // L_ik = W_ik T_kk^T   (rem x kb)
-      rc = sq_gemm(W + (int64_t)k1 * n + k0, n, nn, 0, 0, Tkk, ldt, sT, 1, 2, L + (int64_t)k1 * n + k0, n, nn,
-                   nullptr, 1.f, 0.f, rem, kb, kb, 0, nbatch, st);
+      continue;
+    }
+    float* W22 = W + (int64_t)k1 * n + k1;
+    // (a1) L_ik = W_ik T_kk^T (NT, T_kk lower: K clipped per column tile)   (b1) tmp = L[k, :k0] T[:k0, :k0] (NN, T lower)
+    const GemmParams a1 = mk(W + (int64_t)k1 * n + k0, n, Tkk, n, L + (int64_t)k1 * n + k0, n, nullptr, 1.f, 0.f, rem, kb, kb, 0, 2, 0);
+    const GemmParams b1 = mk(L + (int64_t)k0 * n, n, Tout, n, tmp, k0 > 0 ? k0 : 1, nullptr, 1.f, 0.f, kb, k0, k0, 0, 1, 0);
+    // (a2) W_22 -= L_ik L_ik^T (NT, lower tiles only, in place)            (b2) T[k, :k0] = -T_kk tmp (NN, T_kk lower)
+    const GemmParams a2 = mk(L + (int64_t)k1 * n + k0, n, L + (int64_t)k1 * n + k0, n, W22, n, W22, -1.f, 1.f, rem, rem, kb, 0, 0, 2);
+    const GemmParams b2 = mk(Tkk, n, tmp, k0 > 0 ? k0 : 1, Tout + (int64_t)k0 * n, n, nullptr, -1.f, 0.f, kb, k0, kb, 1, 0, 0);
+    auto wgs = [&](const GemmParams& p) { return (int64_t)cdiv(p.M, 64) * cdiv(p.N, 64) * nbatch; };
+    static const int trow_pair = [] { const char* e = getenv("VARGP_CHOL_TROW_PAIR"); return e ? atoi(e) : 1; }();   // tuning aid
+    if (rem > 0 && trow && trow_pair && wgs(a1) + wgs(b1) <= 4096 && wgs(a2) + wgs(b2) <= 4096) {
+      rc = launch_gemm_pair2(a1, 0, 1, nbatch, b1, 0, 0, nbatch, st, "chol_panel");
       if (rc) return rc;
-      // W_22 -= L_panel L_panel^T  (lower tiles only, in place)
-      float* W22 = W + (int64_t)k1 * n + k1;
-      rc = sq_gemm(L + (int64_t)k1 * n + k0, n, nn, 0, 0, L + (int64_t)k1 * n + k0, n, nn, 1, 0, W22, n, nn, W22,
-                   -1.f, 1.f, rem, rem, kb, 2, nbatch, st);
+      rc = launch_gemm_pair2(a2, 0, 1, nbatch, b2, 0, 0, nbatch, st, "chol_panel");
       if (rc) return rc;
+    } else {
+      if (rem > 0) {
+        rc = launch_gemm(a1, 0, 1, nbatch, false, st);
+        if (rc) return rc;
+      }
+      if (trow) {
+        rc = launch_gemm(b1, 0, 0, nbatch, false, st);
+        if (rc) return rc;
+      }
+      if (rem > 0) {
+        rc = launch_gemm(a2, 0, 1, nbatch, false, st);
+        if (rc) return rc;
+      }
+      if (trow) {
+        rc = launch_gemm(b2, 0, 0, nbatch, false, st);
+        if (rc) return rc;
+      }
     }
   }
   if (co_done) *co_done = ndone;
-  if (Tout) {
-    // off-diagonal blocks of T, last block column first:  T[j1:, j] = -T[j1:, j1:] (L[j1:, j] T_jj)
-    const int nblk = cdiv(n, kNbSmall);
-    for (int jb = nblk - 2; jb >= 0; --jb) {
-      const int j0 = jb * kNbSmall, j1 = j0 + kNbSmall, rem = n - j1;
-      rc = sq_gemm(L + (int64_t)j1 * n + j0, n, nn, 0, 0, Tout + (int64_t)j0 * n + j0, n, nn, 0, 1, tmp, kNbSmall,
-                   stmp, nullptr, 1.f, 0.f, rem, kNbSmall, kNbSmall, 0, nbatch, st);
-      if (rc) return rc;
-      rc = sq_gemm(Tout + (int64_t)j1 * n + j1, n, nn, 0, 1, tmp, kNbSmall, stmp, 0, 0,
-                   Tout + (int64_t)j1 * n + j0, n, nn, nullptr, -1.f, 0.f, rem, kNbSmall, rem, 0, nbatch, st);
-      if (rc) return rc;
-    }
-  }
   return check_launch("chol_inv_fwd");
 }
 
