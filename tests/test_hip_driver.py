@@ -39,3 +39,13 @@ def test_split_mnist_synthetic_graph_mode(tmp_path):
     assert all(v == v for v in sc.values())            # no NaN anywhere (losses, accuracies)
     assert sc[('task0/loss/lik', 4)] < sc[('task0/loss/lik', 2)] * 1.5
     assert os.path.exists(log / 'ckpt4.pt')            # all five tasks ran and checkpointed
+
+
+def test_split_mnist_synthetic_learns(tmp_path):
+    """The synthetic surrogate is scaled so that the reference's default kernel initialisation sees informative distances
+    (vargp_amd/datasets.py): the first two tasks must be learnt, on held-out samples too (train and test share the class
+    prototypes)."""
+    log, sc = _run(['s-mnist', '--synthetic', '--n_synth', '12000', '--epochs', '120', '--eval_interval', '60', '--M', '60',
+                    '--graph', '--seed', '1'], tmp_path)
+    assert sc[('task0/train/acc', 120)] > 0.9 and sc[('task0/test/acc', 120)] > 0.9      # 2 classes of the 10-way head
+    assert sc[('task1/train/acc', 120)] > 0.8                                            # the second task's own classes
