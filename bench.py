@@ -426,7 +426,7 @@ def main():
                    config=dict(workload=WORKLOADS[args.workload]['desc'], S_per_gpu=counts if strong else S, Mt=M * (N_PREV + 1),
                                S_total=s_total if strong else S * world, F=F_, C=C, M=M, D=D, B=B, N=N_TOTAL, beta=BETA,
                                optimizer='yogi', parallelism=f'sample-parallel x{world}',
-                               launch=('hipGraph replay' + ((' (all-reduce captured)' if trainer.graph_opt is None else ' (2 graphs around the all-reduce)') if use_dist else '')) if use_graph
+                               launch=('hipGraph replay' + (' (2 graphs around the all-reduce)' if use_dist else '')) if use_graph
                                else 'eager'),
                    elbo_rtol_vs_cpu=rtol, elbo_rtol_checked_on=rtol_on, finite=bool(finite), cholesky_failures=errs,
                    final_loss=dict(kl_hypers=out[0].item(), kl_u=out[1].item(), nll=out[2].item()),

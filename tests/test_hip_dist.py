@@ -149,10 +149,8 @@ def test_uneven_sample_split_equals_single_process():
 
 def _worker_rccl(port, mode, q):
     """One rank on RCCL ('nccl' backend), the multi-rank path forced (force_exchange): the flat buffer goes through a real
-    RCCL all-reduce -- eager, between the two step graphs, or captured into one graph (VARGP_CAPTURE_ALLREDUCE=1)."""
+    RCCL all-reduce -- eager, or between the two step graphs."""
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1')
-    if mode == 'captured':
-        os.environ['VARGP_CAPTURE_ALLREDUCE'] = '1'
     torch.cuda.set_device(0)
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
     try:
@@ -164,7 +162,6 @@ def _worker_rccl(port, mode, q):
         assert tr.multi
         if mode != 'eager':
             tr.capture(x, y, warmup=1)                 # (the warm-up is undone by capture itself)
-            assert (tr.graph_opt is None) == (mode == 'captured')
         outs = []
         for _ in range(3):
             out = tr.step_graph(x, y) if mode != 'eager' else tr.step(x, y)
@@ -175,7 +172,7 @@ def _worker_rccl(port, mode, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('mode', ['eager', 'two_graphs', 'captured'])
+@pytest.mark.parametrize('mode', ['eager', 'two_graphs'])
 def test_rccl_single_rank_exchange_equals_plain_step(mode):
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
@@ -184,8 +181,12 @@ def test_rccl_single_rank_exchange_equals_plain_step(mode):
     q = ctx.Queue()
     p = ctx.Process(target=_worker_rccl, args=(port, mode, q))
     p.start()
-    outs2, sd2 = q.get(timeout=300)
-    p.join(timeout=120)
+    try:
+        outs2, sd2 = q.get(timeout=240)
+    finally:
+        p.join(timeout=60)
+        if p.is_alive():
+            p.kill()
     assert p.exitcode == 0
     from vargp_amd import noise, ops
     ops.set_cholesky_error_mode('defer')

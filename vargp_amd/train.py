@@ -74,7 +74,8 @@ class ElboTrainer:
         # models on a native program (fused.T0Program: first task; fused.TnProgram: later tasks, ep_var_mean=True) drive it
         # directly: no autograd graph, gradients written straight into the optimiser's buffers
         is_model = gp is not None and loss_fn is None and params is None and hasattr(gp, 'draw_t0_noise')
-        self._tn = bool(is_model and gp.prev_params and gp.var_mean_mask == 1.0 and gp._tn_applicable())   # csrc/elbo_tn.hip
+        self._tn = bool(is_model and (gp.prev_params or gp.first_task_as_block()) and gp.var_mean_mask == 1.0
+                        and gp._tn_applicable())                                                          # csrc/elbo_tn.hip
         self._t0 = bool(is_model and not gp.prev_params and gp.fused_first_task
                         and type(gp.kernel).__name__ == 'RBFKernel') or self._tn                           # csrc/elbo_t0.hip
         # one program (descriptor + workspace) PER SHAPE, never freed: a captured hipGraph holds raw pointers into the
@@ -119,14 +120,6 @@ class ElboTrainer:
         if not self.multi:
             with torch.cuda.graph(self.graph):
                 self._sout = self.step(self._sx, self._sy)
-        elif os.environ.get('VARGP_CAPTURE_ALLREDUCE', '0') == '1':
-            # opt-in: the RCCL all-reduce captured with the rest (one graph per step).  Off by default: only validated with a
-            # single rank (one GPU per box here); the two-graph form below is the one the multi-GPU tests cover.
-            with torch.cuda.graph(self.graph):
-                self._sout = self._local_part(self._sx, self._sy)
-                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-                self.optim.step()
-            self.graph_opt = None
         else:
             with torch.cuda.graph(self.graph):
                 self._sout = self._local_part(self._sx, self._sy)
@@ -180,7 +173,7 @@ class ElboTrainer:
             self._sx.copy_(x, non_blocking=True)
             self._sy.copy_(y, non_blocking=True)
         self.graph.replay()
-        if self.multi and self.graph_opt is not None:
+        if self.multi:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
             self.graph_opt.replay()
         return self._sout

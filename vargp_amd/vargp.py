@@ -14,6 +14,8 @@ Differences that do not change results:
     op-by-op composition (API surface, the ep_var_mean=False ablation, and what the program is tested against);
     gradient-free `forward` / `predict` use the same program for every model.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -101,6 +103,20 @@ class VARGP(nn.Module):
         return linear_marginal_diag(mu_leq_t, S_leq_t, Kzz, Kzx, Kxx_diag, cache=cache)
 
     # -- the block-structured native program (csrc/elbo_tn.hip) ------------------------------------------------------
+    def first_task_as_block(self):
+        """First-task models outside the range of the LDS-resident forward middle of csrc/elbo_t0.hip (M <= 104 and at most
+        2048 (sample, class, 64-column) tiles, i.e. S C <= 256 at B = 512) run faster as the one-block case of the block
+        program (csrc/elbo_tn.hip: symmetric K_uu tiles, the factorisation's pivot chains beside the K_uf row slices, paired
+        mid-size products).  Measured: Permuted-MNIST task 0 (M = 200, S = 10) 557 -> 572 steps/s, the 64-sample Split-MNIST
+        step 254 -> 270; BASELINE config 2 (M = 100, S = 3) stays on elbo_t0 (3120 vs 2740).  VARGP_T0_AS_TN=0 / 1 forces it."""
+        if self.prev_params:
+            return False
+        env = os.environ.get('VARGP_T0_AS_TN')
+        if env is not None:
+            return env == '1'
+        n_v = 1 if self.kernel.map_est else self.n_v
+        return self.M > 104 or n_v * self.z.size(0) > 256
+
     def _tn_applicable(self):
         return (self.fused_tasks and type(self.kernel) is RBFKernel and self.z.is_cuda
                 and all(p['z'].shape[-2] == self.M for p in self.prev_params))
@@ -200,10 +216,11 @@ class VARGP(nn.Module):
     def loss(self, x, y):
         """(kl_hypers, kl_u, nll); the caller combines beta*kl_hypers + kl_u + (N/B)*nll
         (vargp.py:177-194, experiments/vargp.py:34)."""
-        if not self.prev_params and self.fused_first_task and type(self.kernel) is RBFKernel:
+        if not self.prev_params and self.fused_first_task and type(self.kernel) is RBFKernel and not (
+                self.first_task_as_block() and self._tn_applicable()):
             # first task: the native program (csrc/elbo_t0.hip) as one autograd node
             return fused.elbo_t0(self.kernel, self.z, self.u_mean, self.u_tril_vec, x, y, *self.draw_t0_noise(x))
-        if self.prev_params and self.var_mean_mask == 1.0 and self._tn_applicable():
+        if (self.prev_params or self.first_task_as_block()) and self.var_mean_mask == 1.0 and self._tn_applicable():
             # later tasks: the block-structured program (csrc/elbo_tn.hip) as one autograd node
             eps_theta, eps_f = self.draw_t0_noise(x)
             return fused.elbo_tn(self.kernel, self.z, self.u_mean, self.u_tril_vec, x, y, eps_theta, eps_f,
