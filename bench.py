@@ -364,7 +364,8 @@ def main():
     kernels = {}
     flops_kuf = 2.0 * S * C * M * (N_PREV + 1) * B * D
     Mt = M * (N_PREV + 1)
-    if N_PREV == 0:
+    block_prog = N_PREV > 0 or gp.first_task_as_block()      # which native program runs this model (vargp.py)
+    if not block_prog:
         candidates = [('chol_rbf_gemm', flops_kuf, 'chol_rbf_gemm_kernel (K_uu/S_u factorisations, fp64, latency-bound, sharing '
                        'one launch with the K_uf = rbf(z, x) distance GEMM; flops counted: the GEMM)'),
                       ('rbf_kuu_bwd_gemm', 2.0 * S * C * M * D * (B + M), 'gemm_pair_kernel (W.Y products of the kernel-matrix '
@@ -392,14 +393,14 @@ def main():
             kernels[tag] = (_lib.prof_replay(tag, kern_n), fl, desc)
         except _lib.VargpHipError:
             pass
-    if N_PREV > 0 and 'rbf_kuu_bwd_gemm' in kernels and 'rbf_kuf_bwd_gemm' not in kernels:
+    if block_prog and 'rbf_kuu_bwd_gemm' in kernels and 'rbf_kuf_bwd_gemm' not in kernels:
         # mid-size shapes run both W.Y products in ONE pair launch (recorded under the first tag)
         us, _, _ = kernels['rbf_kuu_bwd_gemm']
         kernels['rbf_kuu_bwd_gemm'] = (us, 2.0 * S * C * Mt * D * (Mt + B), 'gemm_pair_kernel (both W.Y products of the '
                                        'kernel-matrix backward in one launch)')
     if not kernels:
         kernels['none'] = (float('nan'), 0.0, 'not timed (--no-replay)')
-    if N_PREV == 0:
+    if not block_prog:
         primary = next(t for t in ('chol_rbf_gemm', 'rbf_kuf_gemm', 'rbf_kuu_gemm', 'none') if t in kernels)
     else:
         primary = max(kernels, key=lambda t: kernels[t][0] if kernels[t][0] == kernels[t][0] else -1.0)
