@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void tn_pdiag_kl_kernel(const float* __restric
       const float* w = W + b * Mt * B + col;
       const float* v = V2 + b * Mt * B + col;
       const float* q = QPs + b * Mt * NRs;
-#pragma unroll 4
+#pragma unroll 8
       for (int m = ry; m < Mt; m += 4) {
         const float pv = p[(int64_t)m * B], wv = w[(int64_t)m * B], vv = v[(int64_t)m * B];
         m0 = fmaf(pv, q[(int64_t)m * NRs], m0);
