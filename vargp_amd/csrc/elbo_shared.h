@@ -107,44 +107,47 @@ static __global__ void t0_hyper_bwd_kernel(const float* __restrict__ mean, const
                                     const float* __restrict__ g2, const float* __restrict__ gkd,
                                     const float* __restrict__ seeds, float* __restrict__ gmean,
                                     float* __restrict__ glogvar, int S, int C, int D1, int map_est) {
+  __shared__ float red[4];
   const int d = blockIdx.x * blockDim.x + threadIdx.x;
-  if (d >= D1) return;
-  const float hs = map_est ? 0.f : 0.5f * expf(0.5f * logvar[d]);
+  const bool live = d < D1;
+  const int dc = live ? d : D1 - 1;
+  const float hs = map_est ? 0.f : 0.5f * expf(0.5f * logvar[dc]);
   float gm = 0.f, gv = 0.f;
   // eight samples per batch, loads first (S = 64 made the one-load-at-a-time loop 55 us long)
   for (int s0 = 0; s0 < S; s0 += 8) {
-    float gt[8], ev[8], gk[8];
+    float gt[8], ev[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int s = min(s0 + u, S - 1);
-      gt[u] = gtheta[s * D1 + d];
-      ev[u] = map_est ? 0.f : eps[s * D1 + d];
-      gk[u] = 0.f;
-    }
-    if (d == D1 - 1) {          // gamma^2 of the predictive variance: + 2 g2[s] sum_c gkd[s, c]
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int s = min(s0 + u, S - 1);
-        float acc = 0.f;
-        for (int c0 = 0; c0 < C; c0 += 4) {
-          float t[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) t[q] = gkd[s * C + min(c0 + q, C - 1)];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) acc += (c0 + q < C) ? t[q] : 0.f;
-        }
-        gk[u] = 2.f * g2[s] * acc;
-      }
+      gt[u] = gtheta[s * D1 + dc];
+      ev[u] = map_est ? 0.f : eps[s * D1 + dc];
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       if (s0 + u < S) {
-        const float g = gt[u] + gk[u];
-        gm += g;
-        if (!map_est) gv = fmaf(g * hs, ev[u], gv);
+        gm += gt[u];
+        if (!map_est) gv = fmaf(gt[u] * hs, ev[u], gv);
       }
     }
   }
+  // gamma^2 of the predictive variance (theta_D):  g_s += 2 g2[s] sum_c gkd[s, c].  The whole last block shares out the
+  // S C terms (one thread walking them was 40 of this kernel's 45 us at S = 64) and reduces the two sums they feed.
+  if (blockIdx.x == gridDim.x - 1) {          // (uniform) the block that holds d = D1 - 1
+    const int D = D1 - 1;
+    const float hsD = map_est ? 0.f : 0.5f * expf(0.5f * logvar[D]);
+    float am = 0.f, av = 0.f;
+    for (int e = threadIdx.x; e < S * C; e += blockDim.x) {
+      const int s = e / C;
+      const float t = 2.f * g2[s] * gkd[e];
+      am += t;
+      if (!map_est) av = fmaf(t * hsD, eps[s * D1 + D], av);
+    }
+    const float tm = block_sum<256>(am, red);
+    __syncthreads();
+    const float tv = block_sum<256>(av, red);
+    if (d == D) { gm += tm; gv += tv; }
+  }
+  if (!live) return;
   if (!map_est) {
     const float g = seeds[0];
     gm += g * (mean[d] - pmean[d]) * expf(-plogvar[d]);
