@@ -718,7 +718,13 @@ __global__ void t0_unpack_kernel(const float* __restrict__ gRK, float* __restric
   const int64_t ci = e / (M + 1);        // c * M + i
   const int col = jj == 0 ? 0 : 3 + jj;
   float acc = 0.f;
-  for (int s = 0; s < S; ++s) acc += gRK[((int64_t)s * C * M + ci) * LD + col];
+  for (int s0 = 0; s0 < S; s0 += 8) {            // eight samples' loads in flight together
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = gRK[((int64_t)min(s0 + u, S - 1) * C * M + ci) * LD + col];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += (s0 + u < S) ? t[u] : 0.f;
+  }
   if (jj == 0) g_u_mean[ci] = acc; else gLS[ci * M + (jj - 1)] = acc;
 }
 

@@ -340,7 +340,13 @@ __global__ __launch_bounds__(256) void tn_unpack_kernel(const float* __restrict_
     if (k > i) return;
     const int col = jj == 0 ? 0 : 3 + jj;
     float acc = 0.f;
-    for (int s = 0; s < S; ++s) acc += gRKt[(((int64_t)s * C + c) * M + i) * NRs + col];
+    for (int s0 = 0; s0 < S; s0 += 8) {          // eight samples' loads in flight together
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = gRKt[(((int64_t)min(s0 + u, S - 1) * C + c) * M + i) * NRs + col];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += (s0 + u < S) ? t[u] : 0.f;
+    }
     if (jj == 0) { g_u_mean[c * M + i] = acc; return; }
     const int64_t idx = c * ((int64_t)M * (M + 1) / 2) + (int64_t)i * (i + 1) / 2 + k;
     if (i == k) {
