@@ -5,13 +5,16 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Workload at N=1: BASELINE config 2 (BASELINE.json configs[1]) — Split-MNIST task 0 shape, S=3 hyper-samples, F=10, C=10, M=100,
-D=784, B=512, synthetic data resident in HBM.  One step = zero_grad + VARGP.loss + combine + backward
-+ (N>1: one RCCL all-reduce) + Yogi step, exactly as experiments/vargp.py:29-37 does it.
-N>1 is sample-parallel WEAK scaling: every rank evaluates its own 3 of the 3N hyper-samples, so the
-job does N Cfg2-steps worth of work per global step and `value` = N * global_steps / time.
-`--workload smnist_s64` is BASELINE config 4 as north_star states it: a FIXED total of 64 hyper-samples split over
-the N ranks (STRONG scaling, uneven shards if 64 % N != 0), `value` = global ELBO steps / s.
+N=1 (default line): BASELINE config 2 (BASELINE.json configs[1]) — Split-MNIST task 0 shape, S=3 hyper-samples, F=10, C=10,
+M=100, D=784, B=512, synthetic data resident in HBM.  One step = zero_grad + VARGP.loss + combine + backward
++ (N>1: one RCCL all-reduce) + Yogi step, exactly as experiments/vargp.py:29-37 does it.  The same line carries a
+`secondary` object: short runs of the other BASELINE configs (Cfg3 Permuted-MNIST tasks 0 / 1 / 4 / 9, Split-MNIST task 1,
+Cfg4's 64 samples on one GPU = the base of the multi-GPU curve, Cfg5 stress sweep), each with ms_per_step, roofline.frac
+and elbo_rtol_vs_cpu (`--no-secondary` skips them).
+N>1 (default): BASELINE config 4 as north_star states it — a FIXED total of 64 hyper-samples x 10 classes split over the N
+ranks (`smnist_s64`, STRONG scaling, uneven shards if 64 % N != 0), `value` = global ELBO steps / s; its N=1 base is
+`secondary.smnist_s64` of the N=1 line.  `--scaling weak` instead gives every rank its own 3 samples of a 3N-sample step
+(`value` = global steps / s of that growing step; nothing is multiplied by the world size).
 Prints ONE JSON line (rank 0).
 """
 import argparse
@@ -66,22 +69,23 @@ def make_model(device, seed=0):
     return gp, xall[:B].to(device), yall[:B].to(device)
 
 
-def stress(args, device):
+def stress(args, device, cpu=True, n=None):
     """BASELINE config 5: N=1e6, D=784, M=2048, C=10, S=1.  One ELBO evaluation WITH its gradient over all N points,
     K_uf built tile by tile in HBM (VARGP.elbo_tiled -> vargp_elbo_tn_begin/_tile/_end: kernel matrix of the inducing
     points and its n=2048 factorisation once, forward + partial backward per tile), then the forward-only predictive sweep.
-    `value` = data points per second of the ELBO+gradient sweep."""
+    `value` = data points per second of the ELBO+gradient sweep.  -> the result dict."""
     from vargp_amd import _lib, ops
     from vargp_amd.kernels import RBFKernel
     from vargp_amd.likelihoods import MulticlassSoftmax
     from vargp_amd.vargp import VARGP
-    n, m, tile = args.stress_n, 2048, 8192
+    n, m, tile = n or args.stress_n, 2048, 8192
     torch.manual_seed(0)
     x = torch.randn(n, D, device=device) * (0.25 / D) ** 0.5
     y = (torch.arange(n, device=device) % C).to(torch.int64)
     z = torch.stack([x[c * m:(c + 1) * m] + 0.01 * torch.randn(m, D, device=device) for c in range(C)])
     gp = VARGP(z.cpu(), RBFKernel(D), MulticlassSoftmax(n_f=F_), n_var_samples=1).to(device)
     ops.set_cholesky_error_mode('defer')
+    rtol, rtol_on = stress_elbo_check(gp, x, y)
     # ---- ELBO + gradient sweep ------------------------------------------------------------------------------------
     gp.elbo_tiled(x[:2 * tile], y[:2 * tile], tile, beta=BETA)                      # warm-up (two tiles)
     torch.cuda.synchronize()
@@ -122,6 +126,7 @@ def stress(args, device):
                cholesky_failures=ops.linalg_error_count(),
                config=dict(workload='BASELINE config 5: ELBO + gradient over N=%d points, D=784 M=2048 C=10 S=1, K_uf tiled in '
                                     'HBM (tile %d)' % (n, tile)),
+               elbo_rtol_vs_cpu=rtol, elbo_rtol_checked_on=rtol_on,
                elbo=dict(kl_hypers=out[0].item(), kl_u=out[1].item(), nll=out[2].item()),
                predictive_sweep=dict(points_per_s=n / dt_pred, seconds=dt_pred),
                roofline=dict(bound='mfma', kernel='gemm_kernel<RBF> K_uf tile [10*2048 x 784] x [784 x 8192]',
@@ -135,9 +140,30 @@ def stress(args, device):
                                   peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
                                   frac=chol_flops / (chol_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, avg_us=chol_ms * 1e3,
                                   traffic=None))
-    if not args.no_cpu_baseline:
+    if cpu:
         res['cpu_baseline'] = stress_cpu_baseline(gp)
-    print(json.dumps(res))
+    gp.release_programs()
+    return res
+
+
+def stress_elbo_check(gp, x, y, n_chk=1024, tile=512):
+    """ELBO terms of the tiled HIP sweep (two tiles of the same M=2048 C=10 S=1 model, injected noise) against the fp32 CPU
+    oracle on the same points: max relative error over (kl_hypers, kl_u, nll summed over the points, total)."""
+    from oracle import vargp_oracle as orc
+    from vargp_amd import noise
+    xs, ys = x[:n_chk].contiguous(), y[:n_chk].contiguous()
+    nz = dict(eps_theta=torch.randn(1, D + 1), eps_f=torch.randn(1, F_, C, n_chk))
+    with noise.inject(**{k: v.to(x.device) for k, v in nz.items()}):
+        got = [float(v) for v in gp.elbo_tiled(xs, ys, tile, beta=BETA)]
+    for p in gp.parameters():
+        p.grad = None
+    threads = min(os.cpu_count(), 32)
+    torch.set_num_threads(threads)
+    with torch.no_grad():
+        ref = [float(v) for v in orc.loss(snapshot(gp), [], xs.cpu(), ys.cpu(), nz)]
+    tot = lambda t: BETA * t[0] + t[1] + t[2]
+    errs = [abs(a - b) / abs(b) for a, b in zip(got + [tot(got)], ref + [tot(ref)]) if b != 0.0]
+    return max(errs), 'sub-sample: the first %d points in tiles of %d (same M=2048 C=10 S=1 model)' % (n_chk, tile)
 
 
 def stress_cpu_baseline(gp, n_cpu=2048):
@@ -259,54 +285,30 @@ def elbo_check(gp, x, y):
     return max(errs), ('sub-sample S=%d B=%d' % (Sc, Bc)) if big else 'full workload'
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--eager', action='store_true', help='do not replay the step from a captured hipGraph')
-    ap.add_argument('--workload', default='smnist', choices=sorted(WORKLOADS) + ['stress'],
-                    help='default: the BASELINE metric workload; the others are secondary measurements')
-    ap.add_argument('--stress-n', type=int, default=1000000)
-    ap.add_argument('--no-replay', action='store_true',
-                    help='skip the back-to-back re-launches that time the dominant kernels (keeps a rocprof trace clean)')
-    args = ap.parse_args()
+SECONDARY = ['smnist_s64', 'smnist_t1', 'pmnist_t0', 'pmnist_t1', 'pmnist_t4', 'pmnist_t9']   # + 'stress'
+
+
+def run_workload(name, args, device, world, rank, use_dist, steps, warmup, primary=True, kern_n=100):
+    """One ELBO-step workload: build the model, check it against the CPU oracle, capture, time `steps` steps, time the dominant
+    kernels.  -> result dict (rank 0) or None.  primary: the line's top-level fields incl. the CPU baseline."""
     global S, M, N_PREV
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
-    strong, counts, s_total = False, None, None
-    if args.workload != 'stress':
-        S, M, N_PREV = (WORKLOADS[args.workload][k] for k in ('S', 'M', 'n_prev'))
-        strong = bool(WORKLOADS[args.workload].get('strong'))
-        if strong:       # a fixed sample total divided over the ranks
-            from vargp_amd.train import split_samples
-            s_total = S
-            counts = split_samples(s_total, world)
-            S = counts[rank]
-    dominant_flops = 2.0 * S * C * M * (N_PREV + 1) * B * D     # one K_uf launch of compute_pf_diag
-
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
-    torch.cuda.set_device(local)
-    device = torch.device('cuda', local)
-    # VARGP_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL group, two-graph capture around the all-reduce, barriers)
-    # with a single rank -- a smoke test of that path on a one-GPU box
-    use_dist = world > 1 or os.environ.get('VARGP_BENCH_FORCE_DIST', '0') == '1'
-    if use_dist:
-        dist.init_process_group('nccl', device_id=device)
-
     from vargp_amd import _lib, ops
-    from vargp_amd.train import ElboTrainer
-    if args.workload == 'stress':
-        return stress(args, device)
+    from vargp_amd.train import ElboTrainer, split_samples
+    S, M, N_PREV = (WORKLOADS[name][k] for k in ('S', 'M', 'n_prev'))
+    strong = bool(WORKLOADS[name].get('strong'))
+    weak_multi = (not strong) and world > 1
+    counts, s_total = None, None
+    if strong:       # a fixed sample total divided over the ranks
+        s_total = S
+        counts = split_samples(s_total, world)
+        S = counts[rank]
     ops.set_cholesky_error_mode('defer')
     ops.reset_linalg_errors()
     gp, x, y = make_model(device)
     rtol, rtol_on = elbo_check(gp, x, y) if rank == 0 else (None, None)
-    p0 = snapshot(gp) if rank == 0 else None     # the CPU baseline runs the same (initial) model
+    p0 = snapshot(gp) if rank == 0 and primary else None     # the CPU baseline runs the same (initial) model
     trainer = ElboTrainer(gp, lr=LR, beta=BETA, n_total=N_TOTAL,
-                          sample_counts=(counts if counts is not None else ([S] * world if use_dist else None)) if use_dist else None,
+                          sample_counts=(counts if counts is not None else [S] * world) if use_dist else None,
                           force_exchange=use_dist)
 
     def sync():
@@ -334,18 +336,18 @@ def main():
         run = trainer.step_graph
     else:
         run = lambda: trainer.step(x, y)
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         run()
     sync()
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
     evs[0].record()
-    for i in range(args.steps):
+    for i in range(steps):
         out = run()
         evs[i + 1].record()              # per-step device time (median below); `value` uses the wall clock of all K steps
     sync()
     dt = time.perf_counter() - t0
-    per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
+    per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
     median_ms = per_step[len(per_step) // 2]
     # Dominant kernels: hipEvents cannot bracket a node of a replayed graph, and an event pair around a single launch
     # also times the dispatch gap (+10 us here).  So one more (eager) step is run with launch recording on, and the
@@ -360,9 +362,8 @@ def main():
     trainer.step(x, y)
     sync()
     _lib.prof_remember(False)
-    kern_n = 100
     kernels = {}
-    flops_kuf = 2.0 * S * C * M * (N_PREV + 1) * B * D
+    flops_kuf = 2.0 * S * C * M * (N_PREV + 1) * B * D     # one K_uf launch of compute_pf_diag
     Mt = M * (N_PREV + 1)
     block_prog = N_PREV > 0 or gp.first_task_as_block()      # which native program runs this model (vargp.py)
     if not block_prog:
@@ -401,30 +402,34 @@ def main():
     if not kernels:
         kernels['none'] = (float('nan'), 0.0, 'not timed (--no-replay)')
     if not block_prog:
-        primary = next(t for t in ('chol_rbf_gemm', 'rbf_kuf_gemm', 'rbf_kuu_gemm', 'none') if t in kernels)
+        dom = next(t for t in ('chol_rbf_gemm', 'rbf_kuf_gemm', 'rbf_kuu_gemm', 'none') if t in kernels)
     else:
-        primary = max(kernels, key=lambda t: kernels[t][0] if kernels[t][0] == kernels[t][0] else -1.0)
-    kern_us, dominant_flops, dominant_desc = kernels[primary]
-    kern_ms = kern_us * kern_n * 1e-3
+        dom = max(kernels, key=lambda t: kernels[t][0] if kernels[t][0] == kernels[t][0] else -1.0)
+    kern_us, dominant_flops, dominant_desc = kernels[dom]
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     finite = all(torch.isfinite(v).item() for v in out)
     errs = ops.linalg_error_count()
-
+    res = None
     if rank == 0:
-        value = (1 if strong else world) * args.steps / dt
-        avg_s = kern_ms / max(kern_n, 1) * 1e-3
-        achieved = dominant_flops / avg_s / 1e12 if kern_n else None
-        res = dict(metric='ELBO steps/sec', value=value,
-                   unit=('ELBO steps/s (global steps of the %d-sample ELBO)' % s_total) if strong
-                   else 'ELBO steps/s (Cfg2 step: S=%d hyper-samples per GPU)' % S,
-                   n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * dt / args.steps,
+        value = steps / dt                         # GLOBAL steps per second (strong and weak alike)
+        avg_s = kern_us * 1e-6
+        achieved = dominant_flops / avg_s / 1e12 if kern_us == kern_us and kern_us > 0 else None
+        cfg2 = name == 'smnist'
+        if strong:
+            unit = 'ELBO steps/s (global steps of the %d-sample ELBO)' % s_total
+        elif weak_multi:
+            unit = 'ELBO steps/s (global steps of a %d-sample ELBO: %d hyper-samples per GPU)' % (S * world, S)
+        else:
+            unit = 'ELBO steps/s (%s step: S=%d hyper-samples)' % ('Cfg2' if cfg2 else name, S)
+        res = dict(metric='ELBO steps/sec', value=value, unit=unit,
+                   n_gpus=world, steps=steps, warmup=warmup, ms_per_step=1e3 * dt / steps,
                    ms_per_step_median=median_ms,
-                   higher_is_better=True, scaling='strong' if strong else 'weak', vs_baseline=None, dtype='f32',
-                   data='synthetic',
-                   config=dict(workload=WORKLOADS[args.workload]['desc'], S_per_gpu=counts if strong else S, Mt=M * (N_PREV + 1),
+                   higher_is_better=True, scaling='strong' if strong and world > 1 else 'weak', vs_baseline=None,
+                   dtype='f32', data='synthetic',
+                   config=dict(workload=WORKLOADS[name]['desc'], S_per_gpu=counts if strong else S, Mt=M * (N_PREV + 1),
                                S_total=s_total if strong else S * world, F=F_, C=C, M=M, D=D, B=B, N=N_TOTAL, beta=BETA,
                                optimizer='yogi', parallelism=f'sample-parallel x{world}',
                                launch=('hipGraph replay' + (' (2 graphs around the all-reduce)' if use_dist else '')) if use_graph
@@ -435,22 +440,109 @@ def main():
                                  achieved=achieved, peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
                                  frac=(achieved / MFMA_F32_PEAK_TFLOPS) if achieved else None,
                                  launches=kern_n, avg_us=avg_s * 1e6,
-                                 traffic=measured_traffic(primary) if args.workload == 'smnist' else None,
-                                 mfma_util=measured_mfma_util(primary) if args.workload == 'smnist' else None,
-                                 counters_from=_latest_profile('traffic')[1] if args.workload == 'smnist' else None))
+                                 traffic=measured_traffic(dom) if cfg2 else None,
+                                 mfma_util=measured_mfma_util(dom) if cfg2 else None,
+                                 counters_from=_latest_profile('traffic')[1] if cfg2 else None,
+                                 counters_commit=(_latest_profile('traffic')[0] or {}).get('commit') if cfg2 else None))
         if N_PREV > 0:
             res['roofline_others'] = [dict(kernel=dsc, avg_us=us, achieved=fl / (us * 1e-6) / 1e12,
                                            frac=fl / (us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS)
-                                      for t, (us, fl, dsc) in kernels.items() if t != primary and us == us and fl > 0]
-        if N_PREV == 0 and 'rbf_kuu_bwd_gemm' in kernels and primary != 'rbf_kuu_bwd_gemm':
+                                      for t, (us, fl, dsc) in kernels.items() if t != dom and us == us and fl > 0]
+        if N_PREV == 0 and 'rbf_kuu_bwd_gemm' in kernels and dom != 'rbf_kuu_bwd_gemm':
             us2, fl2, desc2 = kernels['rbf_kuu_bwd_gemm']
             res['roofline_gemm'] = dict(bound='mfma', kernel=desc2, achieved=fl2 / (us2 * 1e-6) / 1e12,
                                         peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
                                         frac=fl2 / (us2 * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, launches=kern_n, avg_us=us2,
-                                        traffic=measured_traffic('rbf_kuu_bwd_gemm') if args.workload == 'smnist' else None,
-                                        mfma_util=measured_mfma_util('rbf_kuu_bwd_gemm') if args.workload == 'smnist' else None)
-        if world == 1 and not args.no_cpu_baseline and args.workload == 'smnist':
+                                        traffic=measured_traffic('rbf_kuu_bwd_gemm') if cfg2 else None,
+                                        mfma_util=measured_mfma_util('rbf_kuu_bwd_gemm') if cfg2 else None)
+        if world == 1 and primary and not args.no_cpu_baseline and cfg2:
             res['cpu_baseline'] = cpu_baseline(p0, x, y)
+    # hand the workspaces back before the next workload (12 GB at Permuted-MNIST task 9)
+    del trainer, run, out
+    gp.release_programs()
+    del gp
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
+
+
+def secondary_summary(res):
+    """The fields of a secondary workload's result that go into the default line."""
+    keep = ('value', 'unit', 'ms_per_step', 'ms_per_step_median', 'steps', 'warmup', 'elbo_rtol_vs_cpu', 'elbo_rtol_checked_on',
+            'finite', 'cholesky_failures', 'predictive_sweep', 'roofline_chol')
+    out = {k: res[k] for k in keep if k in res}
+    out['workload'] = res['config']['workload']
+    if 'launch' in res['config']:
+        out['launch'] = res['config']['launch']
+    r = res['roofline']
+    out['roofline'] = dict(kernel=r['kernel'][:90], frac=r['frac'], achieved=r['achieved'], unit=r['unit'], avg_us=r['avg_us'])
+    if res.get('roofline_others'):
+        out['roofline_others'] = [dict(kernel=o['kernel'][:60], frac=o['frac'], avg_us=o['avg_us']) for o in res['roofline_others']]
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--eager', action='store_true', help='do not replay the step from a captured hipGraph')
+    ap.add_argument('--workload', default=None, choices=sorted(WORKLOADS) + ['stress'],
+                    help='default: the BASELINE metric workload (Cfg2) on one GPU, BASELINE config 4 (smnist_s64, a fixed 64 '
+                         'samples split over the ranks) on several; the others are secondary measurements')
+    ap.add_argument('--scaling', default=None, choices=['strong', 'weak'],
+                    help='several GPUs only: strong (default) = smnist_s64; weak = Cfg2 with 3 hyper-samples per rank')
+    ap.add_argument('--no-secondary', action='store_true',
+                    help='one GPU, default workload: skip the short runs of the other BASELINE configs (`secondary`)')
+    ap.add_argument('--secondary-budget', type=float, default=240.0,
+                    help='seconds after which no further secondary workload is started')
+    ap.add_argument('--stress-n', type=int, default=1000000)
+    ap.add_argument('--no-replay', action='store_true',
+                    help='skip the back-to-back re-launches that time the dominant kernels (keeps a rocprof trace clean)')
+    args = ap.parse_args()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+    default_line = args.workload is None
+    if args.workload is None:
+        args.workload = 'smnist' if (world == 1 or args.scaling == 'weak') else 'smnist_s64'
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    # VARGP_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL group, two-graph capture around the all-reduce, barriers)
+    # with a single rank -- a smoke test of that path on a one-GPU box
+    use_dist = world > 1 or os.environ.get('VARGP_BENCH_FORCE_DIST', '0') == '1'
+    if use_dist:
+        dist.init_process_group('nccl', device_id=device)
+
+    if args.workload == 'stress':
+        print(json.dumps(stress(args, device, cpu=not args.no_cpu_baseline)))
+        return
+    res = run_workload(args.workload, args, device, world, rank, use_dist, args.steps, args.warmup, primary=True)
+    if rank == 0 and world == 1 and default_line and not args.no_secondary and not use_dist:
+        # short, driver-timed runs of the other BASELINE configs in the same line (their own step counts are stated)
+        t_start = time.perf_counter()
+        sec = {}
+        for name in SECONDARY + ['stress']:
+            if time.perf_counter() - t_start > args.secondary_budget:
+                sec[name] = dict(skipped='secondary budget of %.0f s used up' % args.secondary_budget)
+                continue
+            try:
+                if name == 'stress':
+                    r = stress(args, device, cpu=False)
+                else:
+                    big = WORKLOADS[name]['n_prev'] >= 4
+                    r = run_workload(name, args, device, 1, 0, False, 10 if big else 30, 3, primary=False,
+                                     kern_n=10 if big else 50)
+                sec[name] = secondary_summary(r)
+            except Exception as e:           # a secondary workload never costs the headline line
+                sec[name] = dict(error=f'{type(e).__name__}: {e}'[:300])
+                torch.cuda.empty_cache()
+        res['secondary'] = sec
+        res['secondary_seconds'] = time.perf_counter() - t_start
+    if rank == 0:
         print(json.dumps(res))
     if use_dist:
         dist.destroy_process_group()

@@ -50,7 +50,7 @@ class JsonlLogger:
 def train(task_id, train_set, val_set, test_set, ep_var_mean=True, map_est_hypers=False, dkl=False,
           epochs=1, M=20, n_f=10, n_var_samples=3, batch_size=512, lr=1e-2, beta=1.0,
           eval_interval=10, patience=20, prev_params=None, logger=None, device=None, graph=False, seed=None,
-          retrain=False):
+          retrain=False, eval_shared_hypers=False):
     if retrain:      # the variant of experiments/vargp_retrain.py:14-19 (earlier tasks' inducing parameters re-optimised)
         from vargp_amd.vargp_retrain import VARGPRetrain
         gp = VARGPRetrain.create_clf(train_set, M=M, n_f=n_f, n_var_samples=n_var_samples, prev_params=prev_params).to(device)
@@ -85,9 +85,9 @@ def train(task_id, train_set, val_set, test_set, ep_var_mean=True, map_est_hyper
 
         if (e + 1) % eval_interval == 0:
             acc_summary = {
-                f'task{task_id}/train/acc': compute_accuracy(train_set, gp, device=device),
-                f'task{task_id}/val/acc': compute_accuracy(val_set, gp, device=device),
-                f'task{task_id}/test/acc': compute_accuracy(test_set, gp, device=device),
+                f'task{task_id}/train/acc': compute_accuracy(train_set, gp, device=device, shared_hypers=eval_shared_hypers),
+                f'task{task_id}/val/acc': compute_accuracy(val_set, gp, device=device, shared_hypers=eval_shared_hypers),
+                f'task{task_id}/test/acc': compute_accuracy(test_set, gp, device=device, shared_hypers=eval_shared_hypers),
             }
             loss_summary = {
                 f'task{task_id}/loss/kl_hypers': kl_hypers.item(),
@@ -132,7 +132,8 @@ def toy(args):
         sd = train(t, toy_train, toy_val, toy_test, epochs=args.epochs, M=args.M, lr=args.lr, beta=args.beta,
                    batch_size=args.batch_size, ep_var_mean=args.ep_var_mean, map_est_hypers=args.map_est_hypers,
                    dkl=args.dkl, prev_params=prev_params, logger=logger, device=device, patience=-1,
-                   eval_interval=args.eval_interval, graph=args.graph, seed=args.seed, retrain=args.retrain)
+                   eval_interval=args.eval_interval, graph=args.graph, seed=args.seed, retrain=args.retrain,
+                   eval_shared_hypers=args.eval_shared_hypers, n_var_samples=args.n_var_samples)
         prev_params.append(sd)
     logger.close()
 
@@ -156,7 +157,8 @@ def split_mnist(args):
         sd = train(t, mnist_train, mnist_val, mnist_test, epochs=args.epochs, M=args.M, lr=args.lr, beta=args.beta,
                    batch_size=args.batch_size, ep_var_mean=args.ep_var_mean, map_est_hypers=args.map_est_hypers,
                    dkl=args.dkl, prev_params=prev_params, logger=logger, device=device,
-                   eval_interval=args.eval_interval, graph=args.graph, seed=args.seed)
+                   eval_interval=args.eval_interval, graph=args.graph, seed=args.seed,
+                   eval_shared_hypers=args.eval_shared_hypers, n_var_samples=args.n_var_samples)
         prev_params.append(sd)
     logger.close()
 
@@ -183,7 +185,8 @@ def permuted_mnist(args):
         sd = train(t, mnist_train, ConcatDataset(mnist_val), ConcatDataset(mnist_test), epochs=args.epochs, M=args.M,
                    lr=args.lr, beta=args.beta, batch_size=args.batch_size, ep_var_mean=args.ep_var_mean,
                    map_est_hypers=args.map_est_hypers, dkl=args.dkl, prev_params=prev_params, logger=logger,
-                   device=device, eval_interval=args.eval_interval, graph=args.graph, seed=args.seed)
+                   device=device, eval_interval=args.eval_interval, graph=args.graph, seed=args.seed,
+                   eval_shared_hypers=args.eval_shared_hypers, n_var_samples=args.n_var_samples)
         prev_params.append(sd)
     logger.close()
 
@@ -214,6 +217,12 @@ def main(argv=None):
                         help='force the MNIST-shaped synthetic surrogate (default: only if IDX files are missing)')
         sp.add_argument('--n_synth', type=int, default=None, help='size of the synthetic training set')
         sp.add_argument('--graph', action='store_true', help='replay the training step from a captured hipGraph')
+        sp.add_argument('--n_var_samples', type=int, default=3,
+                        help='Monte-Carlo samples of the kernel hyper-parameters per step (reference: fixed at 3, '
+                             'experiments/vargp.py:16; BASELINE config 3 quotes 10)')
+        sp.add_argument('--eval_shared_hypers', action='store_true',
+                        help='accuracy sweeps draw the kernel hyper-parameters once per data set (one factorisation of '
+                             'K(z_<=t) per sweep) instead of once per batch as the reference does')
         if name == 'toy':
             sp.add_argument('--retrain', action='store_true',
                             help='VARGPRetrain (reference: experiments/vargp_retrain.py toy): re-optimise the earlier '

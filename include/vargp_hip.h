@@ -253,8 +253,12 @@ typedef struct vargp_elbo_tn_desc {
   uint64_t rng_seed;
   uint32_t* rng_counter;
   int32_t rng_sample_offset;
+  int32_t forward_only; /* 1: workspace sized by vargp_elbo_tn_workspace_bytes_fwd; moments only (y == NULL), no bwd / end */
 } vargp_elbo_tn_desc;
 size_t vargp_elbo_tn_workspace_bytes(int S, int C, int M, int D, int B, int F, int nblk);
+/* Workspace of a program that only ever evaluates predictive moments (VARGP.forward / predict, var_gp/vargp.py:115-131,
+ * 196-198: no likelihood, no KL, no backward): none of the gradient buffers.  Set d->forward_only = 1. */
+size_t vargp_elbo_tn_workspace_bytes_fwd(int S, int C, int M, int D, int B, int F, int nblk);
 int vargp_elbo_tn_fwd(const vargp_elbo_tn_desc* d, vargp_stream_t stream);
 int vargp_elbo_tn_bwd(const vargp_elbo_tn_desc* d, const float* seeds, float* g_log_mean, float* g_log_logvar, float* g_z,
                       float* g_u_mean, float* g_u_tril_vec, vargp_stream_t stream);
@@ -265,7 +269,11 @@ int vargp_elbo_tn_moments(const vargp_elbo_tn_desc* d, float** mu, float** var);
  * (any label pointer), d->x is not read.
  *   begin: theta, K(z_<=t), L, T, the small products, kl_hypers and kl_u into scalars[0..1], scalars[2] = 0, accumulators = 0
  *   tile : x (Bt, D), y (Bt), Bt <= d->B, eps_f (S, F, C, Bt) or NULL (native noise, one generator step per tile):
- *          scalars[2] += the tile's nll; the tile's share of every gradient is accumulated
+ *          scalars[2] += the tile's nll; the tile's share of every gradient is accumulated.
+ *          y == NULL (seeds, eps_f ignored): the predictive moments mu, var (S, C, Bt) of the tile only, left where
+ *          vargp_elbo_tn_moments says (row stride Bt) -- the predictive sweep VARGP.predict(x, tile=) of a model with or
+ *          without previous tasks (var_gp/vargp.py:196-198 called per batch by var_gp/train_utils.py:21-35), with the
+ *          x-independent part (begin) done once; the only tile mode of a forward_only program
  *   end  : Cholesky / kernel-matrix backward of the accumulated gradients; OVERWRITES the five gradient buffers with the
  *          gradient of seeds . (kl_hypers, kl_u, sum of the tiles' nll)
  * seeds (device, 3 floats) must be the same pointer contents for every tile and for end. */

@@ -98,6 +98,58 @@ def test_chain_mt1000_vs_fp64_oracle():
 
 
 # ------------------------------------------------------------------------------------------------------------
+# Cfg3, the LAST task of the 10-task sequence: M = 200, nine earlier tasks, Mt = 2000, D = 784 (full), reduced S, C, B so
+# that the fp64 oracle (which walks the reference's nine-fold linear_joint chain, vargp.py:35-88) runs in seconds
+# ------------------------------------------------------------------------------------------------------------
+def test_chain_mt2000_task9_vs_fp64_oracle():
+    from vargp_amd import noise, ops
+    from gpu_common import build_gp, grads_of
+    S, F_, C, M, D, B = 2, 4, 2, 200, 784, 128
+    params, prev, x, y, nz = orc.make_problem(S, F_, C, M, D, B, n_prev=9, seed=37, kind='gauss')
+    gp = build_gp(params, prev, S, F_)
+    assert gp._use_block_program() and len(gp.prev_params) == 9
+    with noise.inject(**to_dev(nz, DEV)):
+        kl_h, kl_u, nll = gp.loss(x.to(DEV), y.to(DEV))
+        (1.64 * kl_h + kl_u + 50.0 * nll).backward()
+        with torch.no_grad():
+            pmu, pvar = gp(x.to(DEV))
+            probs = gp.predict(x.to(DEV))
+    assert ops.linalg_error_count() == 0
+    p64, q64 = _d(params), [_d(p) for p in prev]
+    sc, og = orc.elbo_step(p64, q64, x.double(), y, _d(nz), beta=1.64, n_total=50 * B)
+    for k, v in [('kl_hypers', kl_h), ('kl_u', kl_u), ('nll', nll)]:
+        np.testing.assert_allclose(v.item(), sc[k].item(), rtol=RTOL_SCALAR, err_msg=k)
+    for k, g in grads_of(gp).items():
+        assert rel_l2(g.cpu(), og[k]) < REL_L2_GRAD, k
+    m64, v64, _ = orc.forward(p64, q64, x.double(), _d(nz))
+    np.testing.assert_allclose(pmu.cpu().numpy(), m64.numpy(), rtol=RTOL_PRED, atol=ATOL_PRED)
+    np.testing.assert_allclose(pvar.cpu().numpy(), v64.numpy(), rtol=RTOL_PRED, atol=ATOL_PRED)
+    np.testing.assert_allclose(probs.cpu().numpy(), orc.predict(p64, q64, x.double(), _d(nz)).numpy(), atol=ATOL_PROBS)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Cfg5: M = 2048, D = 784 -- the N-tiled ELBO AND its five gradients (vargp_elbo_tn_begin / _tile / _end), even and ragged tiles
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('N,tile', [(1536, 512), (1300, 512)])
+def test_tiled_elbo_m2048_vs_fp64_oracle(N, tile):
+    from vargp_amd import noise, ops
+    from gpu_common import build_gp, grads_of
+    S, F_, C, M, D = 1, 4, 2, 2048, 784
+    params, prev, x, y, nz = orc.make_problem(S, F_, C, M, D, N, n_prev=0, seed=39, kind='gauss')
+    gp = build_gp(params, prev, S, F_)
+    with noise.inject(**to_dev(nz, DEV)):
+        sc_t = [v.item() for v in gp.elbo_tiled(x.to(DEV), y.to(DEV), tile, beta=10.0, scale=3.0)]
+    assert ops.linalg_error_count() == 0
+    g_t = {k: v.cpu().clone() for k, v in grads_of(gp).items()}
+    sc, og = orc.elbo_step(_d(params), [], x.double(), y, _d(nz), beta=10.0, n_total=3 * N)
+    # the oracle's nll is a sum over the N points (likelihoods.py:45-46), as the tiles' sum is
+    for v, k in zip(sc_t, ['kl_hypers', 'kl_u', 'nll']):
+        np.testing.assert_allclose(v, sc[k].item(), rtol=RTOL_SCALAR, err_msg=k)
+    for k in g_t:
+        assert rel_l2(g_t[k], og[k]) < REL_L2_GRAD, k
+
+
+# ------------------------------------------------------------------------------------------------------------
 # Cfg5: M = 2048, the tiled predictive sweep
 # ------------------------------------------------------------------------------------------------------------
 def test_predict_tiled_m2048_vs_untiled_and_oracle():

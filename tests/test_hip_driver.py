@@ -49,3 +49,24 @@ def test_split_mnist_synthetic_learns(tmp_path):
                     '--graph', '--seed', '1'], tmp_path)
     assert sc[('task0/train/acc', 120)] > 0.9 and sc[('task0/test/acc', 120)] > 0.9      # 2 classes of the 10-way head
     assert sc[('task1/train/acc', 120)] > 0.8                                            # the second task's own classes
+
+
+def test_permuted_mnist_ten_task_loop_at_config_size(tmp_path):
+    """BASELINE config 3 as it is stated: the Permuted-MNIST 10-task sequence at M = 200 with 10 hyper-samples (D = 784,
+    batch 512), the full continual loop of experiments/vargp.py:143-186 -- every task's model is built from the
+    checkpoints of all earlier ones (Mt = 200 .. 2000), trained from a captured hipGraph, evaluated on the union of the
+    tasks seen so far, checkpointed.  Synthetic MNIST-shaped data, two epochs per task (a smoke run of the loop at full
+    shapes, not a learning-curve claim).  Under --graph the driver raises if any factorisation was flagged, so exit
+    code 0 means linalg_error_count() == 0 throughout."""
+    log, sc = _run(['p-mnist', '--synthetic', '--n_synth', '3072', '--n_tasks', '10', '--M', '200', '--n_var_samples', '10',
+                    '--epochs', '2', '--eval_interval', '2', '--graph', '--seed', '3'], tmp_path)
+    assert all(v == v and abs(v) != float('inf') for v in sc.values())         # finite losses and accuracies
+    for t in range(10):
+        for k in ('kl_hypers', 'kl_u', 'lik'):
+            assert (f'task{t}/loss/{k}', 2) in sc, (t, k)
+        assert 0.0 <= sc[(f'task{t}/test/acc', 2)] <= 1.0
+        assert os.path.exists(log / f'ckpt{t}.pt')
+    sd9 = torch.load(log / 'ckpt9.pt')
+    assert tuple(sd9['z'].shape) == (10, 200, 784) and tuple(sd9['u_tril_vec'].shape) == (10, 200 * 201 // 2)
+    sd8 = torch.load(log / 'ckpt8.pt')
+    assert torch.allclose(sd9['kernel.prior_log_mean'].cpu(), sd8['kernel.log_mean'].cpu())

@@ -194,3 +194,119 @@ def test_tiled_elbo_equals_untiled_and_oracle(n_prev, M, N, tile):
     gp2 = build_gp(params, prev, S, F_)
     out = gp2.elbo_tiled(xd, yd, tile, noise_seed=5)
     assert all(torch.isfinite(v).item() for v in out) and all(bool(torch.isfinite(g).all()) for g in grads_of(gp2).values())
+
+
+# ------------------------------------------------------------------------------------------------------------
+# evaluation on the block program: predict(x, tile=) of models with previous tasks (reference: VARGP.predict
+# vargp.py:196-198 called per batch by compute_accuracy, train_utils.py:21-35)
+# ------------------------------------------------------------------------------------------------------------
+def _draw_by_columns(nz):
+    """noise.draw stand-in: eps_theta whole, eps_f handed out in column order (the tiled sweep asks once per tile)."""
+    calls = {'i': 0}
+
+    def draw(name, shape, device, sample_dim=0):
+        if name == 'eps_f':
+            i = calls['i']
+            calls['i'] += shape[-1]
+            return nz['eps_f'][..., i:i + shape[-1]].contiguous().to(device)
+        return nz[name].to(device)
+    return draw
+
+
+@pytest.mark.parametrize('n_prev,M,N,tile', [(1, 24, 150, 64), (3, 40, 200, 96), (0, 130, 100, 32)])
+def test_predict_tiled_block_program_equals_untiled_and_oracle(n_prev, M, N, tile):
+    from vargp_amd import noise as nmod
+    from gpu_common import build_gp
+    S, F_, C, D = 2, 3, 3, 40
+    params, prev, x, y, nz = orc.make_problem(S, F_, C, M, D, N, n_prev=n_prev, seed=51, kind='gauss')
+    gp = build_gp(params, prev, S, F_)
+    xd = x.to(DEV)
+    with torch.no_grad(), nmod.inject(**to_dev(nz, DEV)):
+        whole = gp.predict(xd)
+    real_draw = nmod.draw
+    nmod.draw = _draw_by_columns(nz)
+    try:
+        with torch.no_grad():
+            tiled = gp.predict(xd, tile=tile)
+    finally:
+        nmod.draw = real_draw
+    assert gp._tn_eval is not None and gp._tn_eval.forward_only           # the sweep ran on the forward-only program
+    np.testing.assert_allclose(tiled.cpu().numpy(), whole.cpu().numpy(), atol=2e-6)
+    want = orc.predict(_d(params), [_d(p) for p in prev], x.double(), _d(nz))
+    np.testing.assert_allclose(tiled.cpu().numpy(), want.numpy(), atol=ATOL_PROBS)
+
+
+def test_eval_program_serves_narrower_batches_and_compute_accuracy_syncs_once():
+    """One forward-only workspace per model: a ragged last batch runs on the program carved for the full batch (tile
+    calls), with the same moments as an exact-shape evaluation; compute_accuracy (per-batch and shared-hyper sweeps) agrees
+    with a plain loop."""
+    from torch.utils.data import TensorDataset
+    from vargp_amd import noise as nmod
+    from vargp_amd.train_utils import compute_accuracy
+    from gpu_common import build_gp
+    S, F_, C, M, D, N = 2, 3, 3, 20, 40, 150
+    params, prev, x, y, nz = orc.make_problem(S, F_, C, M, D, N, n_prev=2, seed=53, kind='gauss')
+    gp = build_gp(params, prev, S, F_)
+    xd = x.to(DEV)
+    et = nz['eps_theta'].to(DEV)
+    with torch.no_grad():
+        with nmod.inject(eps_theta=et):
+            mu64, var64 = gp(xd[:64])                       # carves the program for B = 64
+        prog = gp._tn_eval
+        with nmod.inject(eps_theta=et):
+            mu22, var22 = gp(xd[128:150])                   # 22 < 64: served by the same program
+        assert gp._tn_eval is prog
+    m64, v64, _ = orc.forward(_d(params), [_d(p) for p in prev], x.double(), _d(nz))
+    np.testing.assert_allclose(mu64.cpu().numpy(), m64[..., :64].numpy(), rtol=RTOL_PRED, atol=ATOL_PRED)
+    np.testing.assert_allclose(mu22.cpu().numpy(), m64[..., 128:150].numpy(), rtol=RTOL_PRED, atol=ATOL_PRED)
+    np.testing.assert_allclose(var22.cpu().numpy(), v64[..., 128:150].numpy(), rtol=RTOL_PRED, atol=ATOL_PRED)
+    # accuracy: map_est-like determinism is not available, so compare the two sweep modes against a loop under fixed noise
+    ds = TensorDataset(x, y)
+
+    def fixed_draw(name, shape, device, sample_dim=0):
+        return torch.zeros(shape, device=device)
+    real_draw = nmod.draw
+    nmod.draw = fixed_draw
+    try:
+        with torch.no_grad():
+            want = (gp.predict(xd).argmax(-1).cpu() == y).float().mean().item()
+        a = compute_accuracy(ds, gp, batch_size=64, device=DEV)
+        b = compute_accuracy(ds, gp, batch_size=64, device=DEV, shared_hypers=True)
+    finally:
+        nmod.draw = real_draw
+    assert abs(a - want) < 1e-6 and abs(b - want) < 1e-6, (a, b, want)
+
+
+def test_loss_without_backward_does_not_leak_programs():
+    """A validation ELBO under no_grad, or a loss whose graph is dropped, must hand the cached program back (ADVICE r2:
+    busy was only cleared by backward); two losses combined before one backward still work (a cached spare)."""
+    from vargp_amd import noise
+    from gpu_common import build_gp, grads_of
+    S, F_, C, M, D, B = 2, 3, 3, 16, 40, 32
+    params, prev, x, y, nz = orc.make_problem(S, F_, C, M, D, B, n_prev=1, seed=55, kind='gauss')
+    gp = build_gp(params, prev, S, F_)
+    xd, yd = x.to(DEV), y.to(DEV)
+    with noise.inject(**to_dev(nz, DEV)):
+        with torch.no_grad():
+            gp.loss(xd, yd)
+        prog = next(iter(gp._tn_progs.values()))
+        assert not prog.busy
+        out = gp.loss(xd, yd)                # graph recorded, then dropped without a backward
+        assert prog.busy
+        del out
+        assert not prog.busy
+        for _ in range(3):
+            gp.loss(xd, yd)                  # results dropped at once
+        assert len(gp._tn_progs) == 1 and not gp._tn_spares
+        a = gp.loss(xd, yd)
+        b = gp.loss(xd, yd)                  # second node while the first still owns the workspace -> spare
+        assert sum(len(v) for v in gp._tn_spares.values()) == 1
+        (a[1] + a[2] + b[1] + b[2] + a[0]).backward()
+        g2 = {k: v.clone() for k, v in grads_of(gp).items()}
+        for p in gp.parameters():
+            p.grad = None
+        c = gp.loss(xd, yd)
+        (2.0 * (c[1] + c[2]) + c[0]).backward()
+        assert sum(len(v) for v in gp._tn_spares.values()) == 1     # the spare is cached, not re-allocated
+    for k, g in grads_of(gp).items():
+        assert rel_l2(g2[k], g) < 1e-5, k

@@ -54,6 +54,7 @@ class ElboTnDesc(Structure):
         ('ws', c_void_p), ('ws_bytes', c_size_t),
         ('bump', c_void_p),
         ('rng_seed', ctypes.c_uint64), ('rng_counter', c_void_p), ('rng_sample_offset', c_int32),
+        ('forward_only', c_int32),
     ]
 
 
@@ -95,6 +96,7 @@ _SIGNATURES = {
     'vargp_bias_act_fwd': (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P]),
     'vargp_bias_act_bwd': (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, _P]),
     'vargp_elbo_tn_workspace_bytes': (c_size_t, [c_int] * 7),
+    'vargp_elbo_tn_workspace_bytes_fwd': (c_size_t, [c_int] * 7),
     'vargp_elbo_tn_fwd': (c_int, [POINTER(ElboTnDesc), _P]),
     'vargp_elbo_tn_bwd': (c_int, [POINTER(ElboTnDesc)] + [_P] * 7),
     'vargp_elbo_tn_begin': (c_int, [POINTER(ElboTnDesc), _P]),

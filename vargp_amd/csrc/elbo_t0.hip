@@ -15,6 +15,8 @@
 //   * folds the glue (hyper-parameter sampling and its KL, vec2tril, S_u, zero-fills, softmax likelihood with its
 //     gradient, KL reductions, gradient unpacking) into a handful of multi-role kernels.
 // About 30 launches per step instead of about 85; numerics are those of the per-op path (same kernels and formulas).
+#include <atomic>
+
 #include "common.h"
 #include "elbo_shared.h"
 
@@ -872,11 +874,16 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
     p.triA = 1;
     rc = launch_gemm(p, 0, 0, SC, false, st, "t0_qps_gemm");
     if (rc) return rc;
-    static const bool attr_set = [] {
-      return hipFuncSetAttribute(reinterpret_cast<const void*>(t0_fwd_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)kFusedLdsBytes) == hipSuccess;
-    }();
-    VARGP_REQUIRE(attr_set, "elbo_t0_fwd: cannot reserve %zu bytes of LDS", kFusedLdsBytes);
+    // the attribute is per DEVICE: one flag per device ordinal (a process that drives several GPUs sets it on each)
+    static std::atomic<unsigned> attr_set_mask[2] = {};      // 64 device ordinals
+    int dev = 0;
+    VARGP_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, "elbo_t0_fwd: hipGetDevice failed");
+    if (!((attr_set_mask[dev >> 5].load(std::memory_order_acquire) >> (dev & 31)) & 1u)) {
+      VARGP_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(t0_fwd_fused_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLdsBytes) == hipSuccess,
+                    "elbo_t0_fwd: cannot reserve %zu bytes of LDS", kFusedLdsBytes);
+      attr_set_mask[dev >> 5].fetch_or(1u << (dev & 31), std::memory_order_release);
+    }
     hipLaunchKernelGGL(t0_fwd_fused_kernel, dim3(ntile, SC), dim3(256), kFusedLdsBytes, st, o.TT, o.QP, o.RK, o.W, o.kd, o.LL,
                        o.Lu, o.mu, o.var, d->scalars + 1, S, C, M, B, NR, LD, ntile, native ? d->rng_counter : nullptr);
   } else {

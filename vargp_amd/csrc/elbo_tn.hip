@@ -37,14 +37,17 @@ struct TnWs {
   size_t bytes;
 };
 
-static TnWs carve_tn(void* ws, int S, int C, int M, int D, int B, int F, int nblk) {
+// fwd_only: the carve of a program that only ever evaluates predictive moments (VARGP.forward / predict, no backward):
+// the gradient buffers are not carved at all (null), z_all o w gets a buffer of its own.
+static TnWs carve_tn(void* ws, int S, int C, int M, int D, int B, int F, int nblk, bool fwd_only = false) {
   TnWs o{};
   o.Mt = M * nblk;
   o.NRs = (int)round_up(4 + M, 4);
   const int64_t SC = (int64_t)S * C, Mt = o.Mt, D1 = D + 1;
   float* p = reinterpret_cast<float*>(ws);
   auto take = [&](int64_t n) { float* q = p; p += round_up(n, 64); return q; };
-  o.theta = take(S * D1); o.eps_theta = take(S * D1); o.eps_f = take((int64_t)S * F * C * B);
+  auto takeb = [&](int64_t n) { return fwd_only ? (float*)nullptr : take(n); };      // backward-only buffers
+  o.theta = take(S * D1); o.eps_theta = take(S * D1); o.eps_f = takeb((int64_t)S * F * C * B);
   o.Dp = round_up(D, 4);
   o.g2 = take(S); o.kd = take(SC);
   o.w = take(S * o.Dp); o.na = take(SC * Mt); o.nb = take((int64_t)S * B);
@@ -55,14 +58,14 @@ static TnWs carve_tn(void* ws, int S, int C, int M, int D, int B, int F, int nbl
   o.LL = take(SC * Mt * Mt); o.TT = take(SC * Mt * Mt);
   o.QPs = take(SC * Mt * o.NRs);
   o.P = take(SC * Mt * B); o.V2 = take(SC * Mt * B); o.W = take(SC * Mt * B);
-  o.gQPs = take(SC * Mt * o.NRs); o.gP = take(SC * Mt * B);
-  o.gT = take(SC * Mt * Mt); o.gKuf = take(SC * Mt * B); o.gK = take(SC * Mt * Mt);
-  o.gRKt = take(SC * M * o.NRs); o.gkd = take(SC);
-  o.gz_all = take((int64_t)C * Mt * D);
-  o.r_uf = take(SC * Mt); o.c_uf = take((int64_t)S * B); o.gtheta = take(S * D1);
-  o.r_uu = take(SC * Mt); o.Wuu = o.gT; o.Puu = take(SC * Mt * D); o.Puf = take(SC * Mt * D);
+  o.gQPs = takeb(SC * Mt * o.NRs); o.gP = takeb(SC * Mt * B);
+  o.gT = takeb(SC * Mt * Mt); o.gKuf = takeb(SC * Mt * B); o.gK = takeb(SC * Mt * Mt);
+  o.gRKt = takeb(SC * M * o.NRs); o.gkd = takeb(SC);
+  o.gz_all = takeb((int64_t)C * Mt * D);
+  o.r_uf = takeb(SC * Mt); o.c_uf = takeb((int64_t)S * B); o.gtheta = takeb(S * D1);
+  o.r_uu = takeb(SC * Mt); o.Wuu = o.gT; o.Puu = take(SC * Mt * D); o.Puf = takeb(SC * Mt * D);
   o.zs = o.Puu;       // z_all o w per hyper-sample (forward only; P_uu is written by the backward)
-  const size_t cf = vargp_chol_workspace_bytes((int)SC, o.Mt, 0), cb = vargp_chol_workspace_bytes((int)SC, o.Mt, 1);
+  const size_t cf = vargp_chol_workspace_bytes((int)SC, o.Mt, 0), cb = fwd_only ? 0 : vargp_chol_workspace_bytes((int)SC, o.Mt, 1);
   o.chol_bytes = cf > cb ? cf : cb;
   o.chol = p;
   p += round_up((int64_t)(o.chol_bytes + 3) / 4, 64);
@@ -413,7 +416,7 @@ static int check_tn(const vargp_elbo_tn_desc* d, const char* who, bool tiled = f
     VARGP_REQUIRE(d->map_est ? d->S == 1 : (d->log_logvar && d->prior_log_mean && d->prior_log_logvar &&
                                             (d->eps_theta || (d->rng_counter && d->rng_sample_offset >= 0))),
                   "%s: hyper-parameter arguments inconsistent", who);
-    VARGP_REQUIRE(d->ws_bytes >= vargp_elbo_tn_workspace_bytes(d->S, d->C, d->M, d->D, d->B, d->F, d->nblk),
+    VARGP_REQUIRE(d->ws_bytes >= carve_tn(nullptr, d->S, d->C, d->M, d->D, d->B, d->F, d->nblk, d->forward_only != 0).bytes,
                   "%s: workspace too small", who);
     return VARGP_OK;
   }
@@ -423,7 +426,8 @@ static int check_tn(const vargp_elbo_tn_desc* d, const char* who, bool tiled = f
   VARGP_REQUIRE(d->map_est ? d->S == 1
                            : (d->log_logvar && d->prior_log_mean && d->prior_log_logvar && (native || d->eps_theta)),
                 "%s: hyper-parameter arguments inconsistent with map_est", who);
-  VARGP_REQUIRE(d->ws_bytes >= vargp_elbo_tn_workspace_bytes(d->S, d->C, d->M, d->D, d->B, d->F, d->nblk),
+  VARGP_REQUIRE(!d->forward_only || d->y == nullptr, "%s: a forward_only program evaluates moments only (y must be NULL)", who);
+  VARGP_REQUIRE(d->ws_bytes >= carve_tn(nullptr, d->S, d->C, d->M, d->D, d->B, d->F, d->nblk, d->forward_only != 0).bytes,
                 "%s: workspace too small", who);
   return VARGP_OK;
 }
@@ -448,9 +452,14 @@ extern "C" size_t vargp_elbo_tn_workspace_bytes(int S, int C, int M, int D, int 
   return carve_tn(nullptr, S, C, M, D, B, F, nblk).bytes + 256;
 }
 
+extern "C" size_t vargp_elbo_tn_workspace_bytes_fwd(int S, int C, int M, int D, int B, int F, int nblk) {
+  return carve_tn(nullptr, S, C, M, D, B, F, nblk, true).bytes + 256;
+}
+
+
 extern "C" int vargp_elbo_tn_moments(const vargp_elbo_tn_desc* d, float** mu, float** var) {
   VARGP_REQUIRE(d && d->ws && mu && var, "elbo_tn_moments: null pointer");
-  const TnWs o = carve_tn(d->ws, d->S, d->C, d->M, d->D, d->B, d->F, d->nblk);
+  const TnWs o = carve_tn(d->ws, d->S, d->C, d->M, d->D, d->B, d->F, d->nblk, d->forward_only != 0);
   *mu = o.mu; *var = o.var;
   return VARGP_OK;
 }
@@ -460,7 +469,7 @@ extern "C" int vargp_elbo_tn_fwd(const vargp_elbo_tn_desc* d, vargp_stream_t str
   if (rc) return rc;
   hipStream_t st = as_stream(stream);
   const int S = d->S, C = d->C, M = d->M, D = d->D, B = d->B, F = d->F, nblk = d->nblk, SC = S * C;
-  const TnWs o = carve_tn(d->ws, S, C, M, D, B, F, nblk);
+  const TnWs o = carve_tn(d->ws, S, C, M, D, B, F, nblk, d->forward_only != 0);
   const int Mt = o.Mt, NRs = o.NRs;
   const int64_t MtMt = (int64_t)Mt * Mt, MtB = (int64_t)Mt * B, MtN = (int64_t)Mt * NRs;
   const bool lik = d->y != nullptr;                 // y == NULL: predictive moments only (no likelihood, no KL)
@@ -624,6 +633,7 @@ extern "C" int vargp_elbo_tn_bwd(const vargp_elbo_tn_desc* d, const float* seeds
   int rc = check_tn(d, "elbo_tn_bwd");
   if (rc) return rc;
   VARGP_REQUIRE(seeds && g_log_mean && g_log_logvar && g_z && g_u_mean && g_u_tril_vec && d->y, "elbo_tn_bwd: null pointer");
+  VARGP_REQUIRE(!d->forward_only, "elbo_tn_bwd: the program was carved forward_only");
   hipStream_t st = as_stream(stream);
   const int S = d->S, C = d->C, M = d->M, D = d->D, B = d->B, F = d->F, nblk = d->nblk, SC = S * C;
   const TnWs o = carve_tn(d->ws, S, C, M, D, B, F, nblk);
@@ -803,7 +813,8 @@ extern "C" int vargp_elbo_tn_begin(const vargp_elbo_tn_desc* d, vargp_stream_t s
   VARGP_REQUIRE(d->D > kRbfDirectD, "elbo_tn_begin: the tiled ELBO needs D > %d (MFMA distance path)", kRbfDirectD);
   hipStream_t st = as_stream(stream);
   const int S = d->S, C = d->C, M = d->M, D = d->D, B = d->B, F = d->F, nblk = d->nblk, SC = S * C;
-  const TnWs o = carve_tn(d->ws, S, C, M, D, B, F, nblk);
+  const bool fwd_only = d->forward_only != 0;      // predictive sweep (VARGP.predict(x, tile=)): no accumulators
+  const TnWs o = carve_tn(d->ws, S, C, M, D, B, F, nblk, fwd_only);
   const int Mt = o.Mt, NRs = o.NRs;
   const int64_t MtMt = (int64_t)Mt * Mt, MtN = (int64_t)Mt * NRs, zrows = (int64_t)C * Mt;
   {
@@ -828,11 +839,13 @@ extern "C" int vargp_elbo_tn_begin(const vargp_elbo_tn_desc* d, vargp_stream_t s
     hipLaunchKernelGGL(tn_prologue_kernel, dim3(grid), dim3(256), 0, st, a);
   }
   // accumulators of the sweep
-  zero_async(o.gT, sizeof(float) * SC * MtMt, st);
-  zero_async(o.gQPs, sizeof(float) * SC * MtN, st);
-  zero_async(o.gkd, sizeof(float) * SC, st);
-  zero_async(o.r_uf, sizeof(float) * (size_t)(o.r_uu - o.r_uf), st);
-  zero_async(o.Puf, sizeof(float) * SC * Mt * D, st);
+  if (!fwd_only) {
+    zero_async(o.gT, sizeof(float) * SC * MtMt, st);
+    zero_async(o.gQPs, sizeof(float) * SC * MtN, st);
+    zero_async(o.gkd, sizeof(float) * SC, st);
+    zero_async(o.r_uf, sizeof(float) * (size_t)(o.r_uu - o.r_uf), st);
+    zero_async(o.Puf, sizeof(float) * SC * Mt * D, st);
+  }
   rc = rbf_prep_norm_launch(o.theta, d->z_all, zrows, nullptr, 0, o.w, o.g2, o.na, o.nb, S, D, o.Dp, st, nullptr, o.zs);
   if (rc) return rc;
   {
@@ -872,18 +885,21 @@ extern "C" int vargp_elbo_tn_begin(const vargp_elbo_tn_desc* d, vargp_stream_t s
 // Adds the tile's nll to scalars[2] and its share of every gradient to the accumulators.
 extern "C" int vargp_elbo_tn_tile(const vargp_elbo_tn_desc* d, const float* seeds, const float* x, const int64_t* y,
                                   const float* eps_f_in, int Bt, vargp_stream_t stream) {
-  VARGP_REQUIRE(d && seeds && x && y && d->ws && Bt > 0 && Bt <= d->B, "elbo_tn_tile: bad arguments");
-  VARGP_REQUIRE(eps_f_in || d->rng_counter, "elbo_tn_tile: native noise needs rng_counter");
+  VARGP_REQUIRE(d && x && d->ws && Bt > 0 && Bt <= d->B, "elbo_tn_tile: bad arguments");
+  const bool moments_only = y == nullptr;          // predictive sweep: mu, var (S, C, Bt) of this tile, nothing else
+  VARGP_REQUIRE(moments_only || seeds, "elbo_tn_tile: seeds missing");
+  VARGP_REQUIRE(moments_only || !d->forward_only, "elbo_tn_tile: a forward_only program takes y == NULL tiles only");
+  VARGP_REQUIRE(moments_only || eps_f_in || d->rng_counter, "elbo_tn_tile: native noise needs rng_counter");
   hipStream_t st = as_stream(stream);
   const int S = d->S, C = d->C, M = d->M, D = d->D, F = d->F, nblk = d->nblk, SC = S * C, B = Bt;
-  const TnWs o = carve_tn(d->ws, S, C, M, D, d->B, F, nblk);
+  const TnWs o = carve_tn(d->ws, S, C, M, D, d->B, F, nblk, d->forward_only != 0);
   const int Mt = o.Mt, NRs = o.NRs;
   const int64_t MtMt = (int64_t)Mt * Mt, MtB = (int64_t)Mt * B, MtN = (int64_t)Mt * NRs, zrows = (int64_t)C * Mt;
   const bool native = eps_f_in == nullptr;
   const bool fused_softmax = C <= 16;
   const float* eps_f = native ? o.eps_f : eps_f_in;
   int rc;
-  {
+  if (!moments_only) {
     const int64_t n0 = o.Kall - o.gmu, n1 = (int64_t)S * d->B;          // gmu | gvar, c_uf
     const int64_t n_f = (int64_t)S * F * C * B;
     const int nzero = (int)std::min<int64_t>(64, cdiv(n0 + n1, 1024));
@@ -925,8 +941,10 @@ extern "C" int vargp_elbo_tn_tile(const vargp_elbo_tn_desc* d, const float* seed
   {
     const int nbx = cdiv(B, 64), npd = nbx * SC;
     hipLaunchKernelGGL(tn_pdiag_kl_kernel, dim3(npd), dim3(256), 0, st, o.P, o.W, o.V2, o.QPs, o.kd, o.LL, d->rk_all, o.mu, o.var,
-                       (float*)nullptr, d->jitter, S, C, M, Mt, nblk, B, NRs, nbx, npd, 1, native ? d->rng_counter : nullptr);
+                       (float*)nullptr, d->jitter, S, C, M, Mt, nblk, B, NRs, nbx, npd, 1,
+                       (native && !moments_only) ? d->rng_counter : nullptr);
   }
+  if (moments_only) return check_launch("elbo_tn_tile");
   if (fused_softmax) {
     const int64_t total = (int64_t)S * F * B;
     hipLaunchKernelGGL(t0_softmax_kernel<16>, dim3(cdiv(total, 256)), dim3(256), 0, st, o.mu, o.var, eps_f, y, d->scalars + 2,

@@ -14,6 +14,7 @@ likelihood), the backward ~20.  This module holds
 into the optimiser's buffers).
 """
 import ctypes
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -179,19 +180,25 @@ class TnProgram:
     """Descriptor + workspace of `vargp_elbo_tn_*` for fixed (S, C, M, D, B, F, nblk).  One `backward` per `forward`;
     `forward(y=None)` evaluates the predictive moments only."""
 
-    def __init__(self, S, C, M, D, B, F, nblk, device, map_est=False):
+    def __init__(self, S, C, M, D, B, F, nblk, device, map_est=False, forward_only=False):
         self.shape = (S, C, M, D, B, F, nblk)
         self.map_est = bool(map_est)
-        nbytes = lib().vargp_elbo_tn_workspace_bytes(S, C, M, D, B, F, nblk)
+        # forward_only: predictive moments only (VARGP.forward / predict): none of the gradient buffers is carved
+        self.forward_only = bool(forward_only)
+        nbytes = (lib().vargp_elbo_tn_workspace_bytes_fwd if self.forward_only else lib().vargp_elbo_tn_workspace_bytes)(
+            S, C, M, D, B, F, nblk)
         self.ws = workspace(nbytes, device)
         self.scalars = torch.empty(3, dtype=torch.float32, device=device)
         self.info = torch.empty(S * C, dtype=torch.int32, device=device)
         self.desc = ElboTnDesc(S=S, C=C, M=M, D=D, B=B, F=F, nblk=nblk, map_est=int(self.map_est), jitter=JITTER,
                                scalars=_p(self.scalars), info=_p(self.info), ws=_p(self.ws),
-                               ws_bytes=self.ws.numel() * 4)
+                               ws_bytes=self.ws.numel() * 4, forward_only=int(self.forward_only))
         self._keep = None
         self._rng = None
-        self.busy = False          # forward done, backward pending (the workspace carries the intermediates)
+        # busy: a forward whose backward can still come owns the workspace (it carries the intermediates).  Set by the
+        # autograd node (_ElboTn) only when a graph is being recorded, cleared by its backward or when the node dies.
+        self.busy = False
+        self._gen = 0
 
     def set_rng(self, seed, counter, sample_offset=0):
         """Native noise, as T0Program.set_rng."""
@@ -215,14 +222,47 @@ class TnProgram:
         S, C, M, D, B, F_, nblk = self.shape
         return self._view(2, (S, F_, C, B))
 
-    def moments(self):
-        """(mu, var) (S, C, B) of the last forward: views into the workspace."""
+    def moments(self, Bt=None):
+        """(mu, var) (S, C, B) of the last forward (or (S, C, Bt) of the last moments-only tile): views into the workspace."""
         S, C, M, D, B, F_, nblk = self.shape
+        B = B if Bt is None else int(Bt)
         pm, pv = ctypes.c_void_p(), ctypes.c_void_p()
         check(lib().vargp_elbo_tn_moments(ctypes.byref(self.desc), ctypes.byref(pm), ctypes.byref(pv)), 'vargp_elbo_tn_moments')
         base = self.ws.data_ptr()
         om, ov = (pm.value - base) // 4, (pv.value - base) // 4
         return self.ws[om:om + S * C * B].view(S, C, B), self.ws[ov:ov + S * C * B].view(S, C, B)
+
+    # -- predictive sweep: the x-independent part once (sweep_begin), then moments per tile of <= B points --------------------
+    def sweep_begin(self, log_mean, log_logvar, prior_log_mean, prior_log_logvar, z, u_mean, u_tril_vec, z_all, rk_all, eps_theta):
+        """theta (from eps_theta (S, D+1); None under map_est), K(z_<=t), L, T and the small products: everything of the
+        predictive moments that does not depend on x (vargp_elbo_tn_begin)."""
+        tensors = (log_mean, log_logvar, prior_log_mean, prior_log_logvar, z, u_mean, u_tril_vec, z_all, rk_all, eps_theta)
+        require_device(*tensors)
+        for t in tensors:
+            if t is not None and not t.is_contiguous():
+                raise ValueError('TnProgram.sweep_begin needs contiguous tensors')
+        S, C, M, D, B, F_, nblk = self.shape
+        assert self.map_est or (eps_theta is not None and eps_theta.shape == (S, D + 1))
+        d = self.desc
+        d.log_mean, d.log_logvar = _p(log_mean), _p(log_logvar)
+        d.prior_log_mean, d.prior_log_logvar = _p(prior_log_mean), _p(prior_log_logvar)
+        d.z, d.u_mean, d.u_tril_vec = _p(z), _p(u_mean), _p(u_tril_vec)
+        d.x, d.y = _p(z), None              # x is not read by begin (any non-null device pointer)
+        d.z_all, d.rk_all = _p(z_all), _p(rk_all)
+        d.eps_theta, d.eps_f = _p(eps_theta), None
+        d.bump = None
+        self._keep = tensors
+        check(lib().vargp_elbo_tn_begin(ctypes.byref(d), stream_ptr()), 'vargp_elbo_tn_begin')
+        ops._note_chol_errors(self.info)
+
+    def sweep_moments(self, x):
+        """x (Bt <= B, D) -> (mu, var) (S, C, Bt): views into the workspace, valid until the next tile."""
+        S, C, M, D, B, F_, nblk = self.shape
+        require_device(x)
+        assert x.dim() == 2 and x.shape[1] == D and x.shape[0] <= B and x.is_contiguous()
+        check(lib().vargp_elbo_tn_tile(ctypes.byref(self.desc), None, ptr(x), None, None, x.shape[0], stream_ptr()),
+              'vargp_elbo_tn_tile')
+        return self.moments(x.shape[0])
 
     def forward(self, log_mean, log_logvar, prior_log_mean, prior_log_logvar, z, u_mean, u_tril_vec, z_all, rk_all, x, y,
                 eps_theta, eps_f, bump=None):
@@ -297,6 +337,11 @@ class TnProgram:
         return self.scalars
 
 
+def _release(prog, gen):
+    if prog._gen == gen:
+        prog.busy = False
+
+
 class _ElboTn(Function):
     @staticmethod
     def forward(ctx, log_mean, log_logvar, z, u_mean, u_tril_vec, x, y, eps_theta, eps_f, prior_log_mean,
@@ -305,7 +350,13 @@ class _ElboTn(Function):
                 for t in (log_mean, log_logvar, prior_log_mean, prior_log_logvar, z, u_mean, u_tril_vec)]
         scal = prog.forward(*args, z_all, rk_all, x.contiguous(), y.contiguous(),
                             None if eps_theta is None else eps_theta.contiguous(), eps_f.contiguous())
+        # The workspace is owned by this node until its backward has run -- or until the node dies without one (validation
+        # ELBO under no_grad: no graph is recorded and ctx is released as soon as apply() returns; a dropped graph; a
+        # skipped step).  grad mode is always off inside Function.forward, so the node's lifetime is the signal.
+        prog._gen += 1
         prog.busy = True
+        weakref.finalize(ctx, _release, prog, prog._gen)
+        ctx.gen = prog._gen
         ctx.prog = prog
         ctx.map_est = map_est
         ctx.shapes = (log_mean.shape, z.shape, u_mean.shape, u_tril_vec.shape)
@@ -315,13 +366,15 @@ class _ElboTn(Function):
     @once_differentiable
     def backward(ctx, g_klh, g_klu, g_nll):
         prog = ctx.prog
+        if prog._gen != ctx.gen:
+            raise RuntimeError('VARGP.loss: the workspace of this ELBO node was reused by a later forward before its backward ran')
         seeds = torch.stack([g_klh.reshape(()), g_klu.reshape(()), g_nll.reshape(())]).float()
         sh_mean, sh_z, sh_um, sh_uv = ctx.shapes
         dev = seeds.device
         g_mean, g_logvar = torch.empty(sh_mean, device=dev), torch.empty(sh_mean, device=dev)
         g_z, g_um, g_uv = torch.empty(sh_z, device=dev), torch.empty(sh_um, device=dev), torch.empty(sh_uv, device=dev)
         prog.backward(seeds, g_mean, g_logvar, g_z, g_um, g_uv)
-        prog.busy = False
+        _release(prog, ctx.gen)
         ctx.prog = None
         return (g_mean, None if ctx.map_est else g_logvar, g_z, g_um, g_uv) + (None,) * 10
 

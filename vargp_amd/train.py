@@ -74,8 +74,7 @@ class ElboTrainer:
         # models on a native program (fused.T0Program: first task; fused.TnProgram: later tasks, ep_var_mean=True) drive it
         # directly: no autograd graph, gradients written straight into the optimiser's buffers
         is_model = gp is not None and loss_fn is None and params is None and hasattr(gp, 'draw_t0_noise')
-        self._tn = bool(is_model and (gp.prev_params or gp.first_task_as_block()) and gp.var_mean_mask == 1.0
-                        and gp._tn_applicable())                                                          # csrc/elbo_tn.hip
+        self._tn = bool(is_model and gp._use_block_program())                                             # csrc/elbo_tn.hip
         self._t0 = bool(is_model and not gp.prev_params and gp.fused_first_task
                         and type(gp.kernel).__name__ == 'RBFKernel') or self._tn                           # csrc/elbo_t0.hip
         # one program (descriptor + workspace) PER SHAPE, never freed: a captured hipGraph holds raw pointers into the
@@ -134,6 +133,10 @@ class ElboTrainer:
             snap['rng'] = self._rng_counter.clone()
         if noise._shard is not None:
             snap['gen'] = noise._shard[2].get_state()
+        elif self._rng_counter is None and self.params[0].is_cuda:
+            # composed path on one GPU (DeepRBFKernel, the ep_var_mean=False ablation, a caller's loss_fn): noise.draw uses the
+            # device's global generator, which the warm-up steps advance
+            snap['cuda_rng'] = torch.cuda.get_rng_state(self.params[0].device)
         for grp in self.optim.param_groups:
             snap['opt'].append({k: v.clone() for k, v in grp.items() if torch.is_tensor(v)})
         snap['state'] = {id(p): {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()}
@@ -148,6 +151,8 @@ class ElboTrainer:
                 self._rng_counter.copy_(snap['rng'])
             if snap['gen'] is not None:
                 noise._shard[2].set_state(snap['gen'])
+            if snap.get('cuda_rng') is not None:
+                torch.cuda.set_rng_state(snap['cuda_rng'], self.params[0].device)
             for grp, saved in zip(self.optim.param_groups, snap['opt']):
                 for k, v in saved.items():
                     grp[k].copy_(v)                                   # in place: the kernels hold these pointers

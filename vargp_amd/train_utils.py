@@ -15,26 +15,42 @@ def set_seeds(seed=None):
         torch.cuda.manual_seed_all(seed)
 
 
-def compute_accuracy(dataset, gp, batch_size=512, device=None):
-    """Fraction of argmax(predict) == label; asserts on NaN predictions like the reference (:29)."""
-    with torch.no_grad():
-        count = 0
-        for x, y in DataLoader(dataset, batch_size=batch_size):
-            preds = gp.predict(x.to(device))
-            assert not torch.isnan(preds).any(), 'Found NaNs'
-            count += (preds.argmax(dim=-1) == y.to(device)).sum().item()
-    return count / len(dataset)
+def _sweep(dataset, gp, batch_size, device, shared_hypers):
+    """Class probabilities of `gp` over `dataset`, one (probs, labels) pair per chunk, everything left on the device.
+    shared_hypers: the whole set goes through ONE predict(x, tile=batch_size) call -- one hyper-parameter draw and one
+    factorisation of K(z_<=t) for the sweep instead of one per batch (the reference, train_utils.py:25-27, re-draws per
+    batch; every batch's prediction has the same distribution either way)."""
+    loader = DataLoader(dataset, batch_size=batch_size)
+    if shared_hypers:
+        xs, ys = zip(*[(x, y) for x, y in loader])
+        yield gp.predict(torch.cat(xs).to(device), tile=batch_size), torch.cat(ys).to(device)
+        return
+    for x, y in loader:
+        yield gp.predict(x.to(device)), y.to(device)
 
 
-def compute_acc_ent(dataset, gp, batch_size=512, device=None):
+def compute_accuracy(dataset, gp, batch_size=512, device=None, shared_hypers=False):
+    """Fraction of argmax(predict) == label; asserts on NaN predictions like the reference (:29).  The hit count and the
+    NaN flag are accumulated on the device: ONE host sync per data set, not one per batch."""
     with torch.no_grad():
-        corr, ent = 0, 0.
-        for x, y in DataLoader(dataset, batch_size=batch_size):
-            preds = gp.predict(x.to(device))
-            assert not torch.isnan(preds).any(), 'Found NaNs'
-            corr += (preds.argmax(dim=-1) == y.to(device)).sum().item()
-            ent += torch.distributions.Categorical(probs=preds).entropy().sum().item()
-    return corr / len(dataset), ent / len(dataset)
+        hits, bad = None, None
+        for preds, y in _sweep(dataset, gp, batch_size, device, shared_hypers):
+            h, b = (preds.argmax(dim=-1) == y).sum(), torch.isnan(preds).any()
+            hits, bad = (h, b) if hits is None else (hits + h, bad | b)
+        assert not bool(bad), 'Found NaNs'
+    return int(hits) / len(dataset)
+
+
+def compute_acc_ent(dataset, gp, batch_size=512, device=None, shared_hypers=False):
+    """(accuracy, mean predictive entropy), accumulated on the device like compute_accuracy."""
+    with torch.no_grad():
+        hits, ent, bad = None, None, None
+        for preds, y in _sweep(dataset, gp, batch_size, device, shared_hypers):
+            h, b = (preds.argmax(dim=-1) == y).sum(), torch.isnan(preds).any()
+            e = -(preds * preds.clamp_min(torch.finfo(preds.dtype).tiny).log()).sum()
+            hits, ent, bad = (h, e, b) if hits is None else (hits + h, ent + e, bad | b)
+        assert not bool(bad), 'Found NaNs'
+    return int(hits) / len(dataset), float(ent) / len(dataset)
 
 
 def compute_bwt(acc_mat):

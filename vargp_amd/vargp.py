@@ -32,7 +32,9 @@ class VARGP(nn.Module):
         self.var_mean_mask = float(ep_var_mean)
         self.fused_first_task = True     # VARGP.loss of a first-task model runs as one fused node (fused.py)
         self.fused_tasks = True          # ... and of a model with previous tasks as the block-structured program
-        self._tn_ops, self._tn_progs = None, {}
+        # native block programs: training programs per shape (+ spares while one is owned by a pending backward), ONE
+        # forward-only program (moments only, no gradient buffers) sized for the widest batch seen, serving narrower ones
+        self._tn_ops, self._tn_progs, self._tn_spares, self._tn_eval = None, {}, {}, None
         # frozen earlier tasks: plain dicts, not buffers (same as the reference, vargp.py:17-20);
         # u_tril is materialised lazily on first use because that needs the device the params live on
         self.prev_params = [dict(z=p['z'], u_mean=p['u_mean'], u_tril_vec=p['u_tril_vec'])
@@ -121,6 +123,16 @@ class VARGP(nn.Module):
         return (self.fused_tasks and type(self.kernel) is RBFKernel and self.z.is_cuda
                 and all(p['z'].shape[-2] == self.M for p in self.prev_params))
 
+    def _use_block_program(self):
+        """Does `loss` run on the block program (csrc/elbo_tn.hip)?  Models with previous tasks: ep_var_mean=True only (the
+        KL of the ablation depends on a u_<t sample); first-task models: when first_task_as_block() says so -- the mask is
+        irrelevant without previous tasks -- and fused_first_task has not been cleared."""
+        if not self._tn_applicable():
+            return False
+        if self.prev_params:
+            return self.var_mean_mask == 1.0
+        return self.fused_first_task and self.first_task_as_block()
+
     def _tn_operands(self):
         """z_all (C, Mt, D), rk_all (C, nblk, M, NR): earlier tasks packed once, the last block is the program's scratch."""
         dev = self.z.device
@@ -131,14 +143,37 @@ class VARGP(nn.Module):
         return self._tn_ops
 
     def _tn_program(self, B):
+        """The (cached) training program of this shape.  While a loss() whose backward has not run yet owns its workspace
+        (two losses combined before one backward), a spare of the same shape is used -- cached too, never re-allocated per
+        step."""
         S = 1 if self.kernel.map_est else self.n_v
         shape = (S, self.z.size(0), self.M, self.z.size(-1), B, self.likelihood.n_f, len(self.prev_params) + 1)
         prog = self._tn_progs.get(shape)
         if prog is None:
             prog = self._tn_progs[shape] = fused.TnProgram(*shape, self.z.device, self.kernel.map_est)
-        elif prog.busy:      # a loss() whose backward has not run yet still owns that workspace
-            prog = fused.TnProgram(*shape, self.z.device, self.kernel.map_est)
+        elif prog.busy:
+            spares = self._tn_spares.setdefault(shape, [])
+            prog = next((q for q in spares if not q.busy), None)
+            if prog is None:
+                prog = fused.TnProgram(*shape, self.z.device, self.kernel.map_est)
+                spares.append(prog)
         return prog
+
+    def _tn_eval_program(self, B, exact=False):
+        """The forward-only program (predictive moments, no gradient buffers): one per model, carved for the widest batch
+        asked for so far; narrower batches (the ragged last one of a sweep) run on it through the tile calls."""
+        prog = self._tn_eval
+        S = 1 if self.kernel.map_est else self.n_v
+        key = (S, self.z.size(0), self.M, self.z.size(-1), self.likelihood.n_f, len(self.prev_params) + 1)
+        if (prog is None or prog.shape[4] < B or (exact and prog.shape[4] != B) or (prog.shape[:4] + prog.shape[5:]) != key
+                or prog.ws.device != self.z.device):
+            self._tn_eval = None          # release the old workspace before carving the wider one
+            prog = self._tn_eval = fused.TnProgram(*key[:4], B, *key[4:], self.z.device, self.kernel.map_est, forward_only=True)
+        return prog
+
+    def release_programs(self):
+        """Drop every cached native program (workspaces of several GB at Mt ~ 2000); they are re-created on demand."""
+        self._tn_progs, self._tn_spares, self._tn_eval = {}, {}, None
 
     def _tn_args(self):
         k = self.kernel
@@ -152,9 +187,15 @@ class VARGP(nn.Module):
             # gradient-free evaluation (predict, accuracy sweeps): the native program, predictive moments only
             kern = self.kernel
             eps_theta = None if kern.map_est else noise.draw('eps_theta', (self.n_v, kern.log_mean.shape[0]), x.device)
-            prog = self._tn_program(x.size(0))
-            prog.forward(*self._tn_args(), x.contiguous(), None, None if eps_theta is None else eps_theta.contiguous(), None)
-            mu, var = prog.moments()
+            eps_theta = None if eps_theta is None else eps_theta.contiguous()
+            # (D <= 32, the direct distance form, has no tile mode: exact-shape program)
+            prog = self._tn_eval_program(x.size(0), exact=self.z.size(-1) <= 32)
+            if prog.shape[4] == x.size(0):
+                prog.forward(*self._tn_args(), x.contiguous(), None, eps_theta, None)
+                mu, var = prog.moments()
+            else:                                  # narrower than the program: x-independent part + one moments-only tile
+                prog.sweep_begin(*self._tn_args(), eps_theta)
+                mu, var = prog.sweep_moments(x.contiguous())
             return mu.clone(), var.clone()
         theta = self.kernel.sample_hypers(self.n_v)
 
@@ -216,11 +257,11 @@ class VARGP(nn.Module):
     def loss(self, x, y):
         """(kl_hypers, kl_u, nll); the caller combines beta*kl_hypers + kl_u + (N/B)*nll
         (vargp.py:177-194, experiments/vargp.py:34)."""
-        if not self.prev_params and self.fused_first_task and type(self.kernel) is RBFKernel and not (
-                self.first_task_as_block() and self._tn_applicable()):
+        block = self._use_block_program()
+        if not self.prev_params and self.fused_first_task and type(self.kernel) is RBFKernel and not block:
             # first task: the native program (csrc/elbo_t0.hip) as one autograd node
             return fused.elbo_t0(self.kernel, self.z, self.u_mean, self.u_tril_vec, x, y, *self.draw_t0_noise(x))
-        if (self.prev_params or self.first_task_as_block()) and self.var_mean_mask == 1.0 and self._tn_applicable():
+        if block:
             # later tasks: the block-structured program (csrc/elbo_tn.hip) as one autograd node
             eps_theta, eps_f = self.draw_t0_noise(x)
             return fused.elbo_tn(self.kernel, self.z, self.u_mean, self.u_tril_vec, x, y, eps_theta, eps_f,
@@ -246,13 +287,10 @@ class VARGP(nn.Module):
         assert self._tn_applicable() and (not self.prev_params or self.var_mean_mask == 1.0)
         kern = self.kernel
         S = 1 if kern.map_est else self.n_v
-        shape = (S, self.z.size(0), self.M, self.z.size(-1), int(tile), self.likelihood.n_f, len(self.prev_params) + 1)
-        prog = self._tn_progs.get(shape)
-        if prog is None:
-            prog = self._tn_progs[shape] = fused.TnProgram(*shape, self.z.device, kern.map_est)
+        prog = self._tn_program(int(tile))       # honours a pending backward of VARGP.loss on the same shape
         eps_theta, eps_f = noise._injected.get('eps_theta'), noise._injected.get('eps_f')
         if eps_f is None:
-            if prog._rng is None:
+            if prog._rng is None or prog._rng[0] != int(noise_seed):     # (re-)key the generator: a new seed is a new stream
                 self._tiled_counter = torch.zeros(1, dtype=torch.int32, device=x.device)
                 prog.set_rng(noise_seed, self._tiled_counter)
             eps_theta = None
@@ -274,6 +312,18 @@ class VARGP(nn.Module):
         if tile is None or x.size(0) <= tile:
             pred_mu, pred_var = self(x)
             return self.likelihood.predict(pred_mu, pred_var)
+        if not torch.is_grad_enabled() and self._tn_applicable() and self.z.size(-1) > 32:
+            # the block program, forward only: K(z_<=t), its factorisation and the small products ONCE (vargp_elbo_tn_begin),
+            # then K_uf, P, V2, W and the moments per tile -- for first-task models and models with previous tasks alike
+            kern = self.kernel
+            eps_theta = None if kern.map_est else noise.draw('eps_theta', (self.n_v, kern.log_mean.shape[0]), x.device)
+            prog = self._tn_eval_program(int(tile))
+            prog.sweep_begin(*self._tn_args(), None if eps_theta is None else eps_theta.contiguous())
+            out = []
+            for i in range(0, x.size(0), tile):
+                mu, var = prog.sweep_moments(x[i:i + tile].contiguous())
+                out.append(self.likelihood.predict(mu, var))
+            return torch.cat(out, dim=0)
         theta = self.kernel.sample_hypers(self.n_v)
         if self.prev_params:
             _, _, mu_leq_t, S_leq_t, z_leq_t = self.compute_q(theta)
