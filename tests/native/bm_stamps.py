@@ -1,0 +1,30 @@
+"""Per-phase cycle accounting of t0_bwd_mid_kernel (a -DBM_STAMPS build of the library, VARGP_HIP_LIB): runs a few Cfg2
+steps and prints the s_memtime differences between the stamps of workgroup (0, 0), thread 0.  GPU box only."""
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from vargp_amd import _lib, ops  # noqa: E402
+from vargp_amd.train import ElboTrainer  # noqa: E402
+
+dev = torch.device('cuda', 0)
+ops.set_cholesky_error_mode('defer')
+gp, x, y = bench.make_model(dev)
+tr = ElboTrainer(gp, lr=bench.LR, beta=bench.BETA, n_total=bench.N_TOTAL)
+for _ in range(5):
+    tr.step(x, y)
+torch.cuda.synchronize()
+out = (ctypes.c_ulonglong * 16)()
+fn = _lib.lib().vargp_debug_bm_stamps
+fn.restype, fn.argtypes = None, [ctypes.c_void_p]
+fn(out)
+names = ['issue loads', 'wait loads + LDS stores', 'barrier', 'phase 1 (gW, ga)', 'tri product 1 + atomics', 'product 2 (gP)',
+         'barrier', 'gP/T/K_uf -> LDS + barrier', 'tri product 3 + atomics', 'product 4 (gK_uf)', 'epilogue W_uf', 'barrier', 'tail']
+v = list(out)
+for i, n in enumerate(names):
+    print('%-32s %8d cycles' % (n, v[i + 1] - v[i]))
+print('%-32s %8d cycles' % ('total', v[12] - v[0]))

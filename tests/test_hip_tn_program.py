@@ -231,7 +231,7 @@ def test_predict_tiled_block_program_equals_untiled_and_oracle(n_prev, M, N, til
     finally:
         nmod.draw = real_draw
     assert gp._tn_eval is not None and gp._tn_eval.forward_only           # forward-only programs only (no gradient buffers)
-    assert n_prev == 0 or gp._tn_eval.shape[4] == tile                    # models with previous tasks: the sweep ran on it
+    assert gp._tn_eval.shape[4] >= tile
     np.testing.assert_allclose(tiled.cpu().numpy(), whole.cpu().numpy(), atol=2e-6)
     want = orc.predict(_d(params), [_d(p) for p in prev], x.double(), _d(nz))
     np.testing.assert_allclose(tiled.cpu().numpy(), want.numpy(), atol=ATOL_PROBS)

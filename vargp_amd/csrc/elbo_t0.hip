@@ -19,6 +19,7 @@
 
 #include "common.h"
 #include "elbo_shared.h"
+#include "t0_bwd_mid.h"
 
 namespace vargp {
 
@@ -630,7 +631,7 @@ __global__ __launch_bounds__(256) void t0_bwd_head_kernel(const float* __restric
                                                           float* __restrict__ gW, float* __restrict__ gkd,
                                                           float* __restrict__ gLz, float* __restrict__ gThead,
                                                           float* __restrict__ gTtail, float* __restrict__ zero_begin, int64_t zero_count, int S, int C,
-                                                          int M, int B, int NR, int LD, int npd, int nkx, int nkl) {
+                                                          int M, int B, int NR, int LD, int npd, int nkx, int nkl, int fused) {
   __shared__ float red[4];
   const float g = seeds[1] / (float)S;
   if ((int)blockIdx.x < npd) {
@@ -706,9 +707,12 @@ __global__ __launch_bounds__(256) void t0_bwd_head_kernel(const float* __restric
     }
   }
   for (int i = i0 + threadIdx.x; i < i1; i += 256) {
+    // fused: the moment role above did not run (npd = 0); ga and gkd are accumulated by t0_bwd_mid_kernel on top of these
+    if (fused) gq[(int64_t)i * LD] = g * q[(int64_t)i * LD];
     gq[(int64_t)i * LD + 1] = 0.f; gq[(int64_t)i * LD + 2] = 0.f; gq[(int64_t)i * LD + 3] = 0.f;
     for (int col = 4 + 2 * M; col < NR; ++col) gq[(int64_t)i * LD + col] = 0.f;
   }
+  if (fused && i0 == 0 && threadIdx.x == 0) gkd[b] = 0.f;
 }
 
 // sum over s of the m and L_S columns of gRK:  g_u_mean[c,i] and gL of the S_u factors (input of the Cholesky backward)
@@ -728,6 +732,19 @@ __global__ void t0_unpack_kernel(const float* __restrict__ gRK, float* __restric
     for (int u = 0; u < 8; ++u) acc += (s0 + u < S) ? t[u] : 0.f;
   }
   if (jj == 0) g_u_mean[ci] = acc; else gLS[ci * M + (jj - 1)] = acc;
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is per DEVICE: one flag per device ordinal and kernel (a process that drives
+// several GPUs sets it on each)
+static int ensure_dynamic_lds(const void* fn, size_t bytes, std::atomic<unsigned> (&mask)[2], const char* who) {
+  int dev = 0;
+  VARGP_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, "%s: hipGetDevice failed", who);
+  if (!((mask[dev >> 5].load(std::memory_order_acquire) >> (dev & 31)) & 1u)) {
+    VARGP_REQUIRE(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess,
+                  "%s: cannot reserve %zu bytes of LDS", who, bytes);
+    mask[dev >> 5].fetch_or(1u << (dev & 31), std::memory_order_release);
+  }
+  return VARGP_OK;
 }
 
 static int check_desc(const vargp_elbo_t0_desc* d, const char* who) {
@@ -874,16 +891,9 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
     p.triA = 1;
     rc = launch_gemm(p, 0, 0, SC, false, st, "t0_qps_gemm");
     if (rc) return rc;
-    // the attribute is per DEVICE: one flag per device ordinal (a process that drives several GPUs sets it on each)
     static std::atomic<unsigned> attr_set_mask[2] = {};      // 64 device ordinals
-    int dev = 0;
-    VARGP_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, "elbo_t0_fwd: hipGetDevice failed");
-    if (!((attr_set_mask[dev >> 5].load(std::memory_order_acquire) >> (dev & 31)) & 1u)) {
-      VARGP_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(t0_fwd_fused_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLdsBytes) == hipSuccess,
-                    "elbo_t0_fwd: cannot reserve %zu bytes of LDS", kFusedLdsBytes);
-      attr_set_mask[dev >> 5].fetch_or(1u << (dev & 31), std::memory_order_release);
-    }
+    rc = ensure_dynamic_lds(reinterpret_cast<const void*>(t0_fwd_fused_kernel), kFusedLdsBytes, attr_set_mask, "elbo_t0_fwd");
+    if (rc) return rc;
     hipLaunchKernelGGL(t0_fwd_fused_kernel, dim3(ntile, SC), dim3(256), kFusedLdsBytes, st, o.TT, o.QP, o.RK, o.W, o.kd, o.LL,
                        o.Lu, o.mu, o.var, d->scalars + 1, S, C, M, B, NR, LD, ntile, native ? d->rng_counter : nullptr);
   } else {
@@ -933,14 +943,40 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
     rc = vargp_softmax_nll_bwd(o.mu, o.var, eps_f, d->y, seeds + 2, o.gmu, o.gvar, S, F, C, B, stream);
     if (rc) return rc;
   }
+  // LDS-resident backward middle (t0_bwd_mid.h): same shapes as the forward's fused middle, plus B % 4 == 0 (float4 rows of W)
+  static const int fused_bwd_env = [] { const char* e = getenv("VARGP_T0_FUSED_BWD"); return e ? atoi(e) : 1; }();   // tuning aid
+  const int ntile = cdiv(B, 64);
+  const bool fused_bwd = fused_bwd_env && M <= kBmKP && M >= 4 && (M % 4) == 0 && (LD % 4) == 0 && (B % 4) == 0 &&
+                         (int64_t)SC * ntile <= 2048;
   {
-    const int npd = M * SC, nkx = cdiv(M, kKlRows), nkl = nkx * SC;
+    const int npd = fused_bwd ? 0 : M * SC, nkx = cdiv(M, kKlRows), nkl = nkx * SC;
     const int64_t zc = o.r_uu - o.r_uf;
     const int nz = (int)std::min<int64_t>(64, cdiv(zc, 1024));
     hipLaunchKernelGGL(t0_bwd_head_kernel, dim3(npd + nkl + nz), dim3(256), 0, st, o.QP, o.W, o.gmu, o.gvar,
                        fused_softmax ? seeds + 2 : nullptr, o.LL, seeds, o.gQP, o.gW, o.gkd, o.gLL, o.gTT, o.gTT + SC * MM, o.r_uf,
-                       zc, S, C, M, B, NR, LD, npd, nkx, nkl);
+                       zc, S, C, M, B, NR, LD, npd, nkx, nkl, fused_bwd ? 1 : 0);
   }
+  if (fused_bwd) {
+    static std::atomic<unsigned> attr_set_mask[2] = {};
+    rc = ensure_dynamic_lds(reinterpret_cast<const void*>(t0_bwd_mid_kernel), kBwdMidLdsBytes, attr_set_mask, "elbo_t0_bwd");
+    if (rc) return rc;
+    {
+      ProfScope prof("t0_bwd_mid", st);
+      hipLaunchKernelGGL(t0_bwd_mid_kernel, dim3(ntile, SC), dim3(256), kBwdMidLdsBytes, st, o.TT, o.QP, o.W, o.RK, o.gmu, o.gvar,
+                         fused_softmax ? seeds + 2 : nullptr, o.gQP, o.gTT, o.gRK, o.gkd, o.r_uf, o.c_uf, o.gtheta, S, C, M, B, D,
+                         NR, LD, ntile);
+    }
+    // what the tiles cannot see: the small columns [a | . | G | G2 | .] of QP = T RK (K = NR):
+    //   gT += tril(gQP[:, :NR] RK[:, :NR]^T)   on top of the tiles' atomics;   gRK[:, :NR] = T^T gQP[:, :NR]
+    GemmParams p = flat_gemm(o.gQP, LD, MLD, o.RK, LD, MLD, o.gTT, M, MM, M, M, NR);
+    p.triC = 1; p.D = o.gTT; p.ldd = M; p.beta = 1.f;
+    GemmParams q = flat_gemm(o.TT, M, MM, o.gQP, LD, MLD, o.gRK, LD, MLD, M, NR, M);
+    q.triA = 2;
+    rc = launch_gemm_pair2(p, 0, 1, SC, q, 1, 0, SC, st, "t0_gt_grk_small");
+    if (rc) return rc;
+    rc = chol_inv_bwd_first(o.TT, o.gTT, SC + C, M, o.chol, o.chol_bytes, nullptr, 0, 0, 0, st);
+    if (rc) return rc;
+  } else {
   {  // W = G^T P:  gG = P gW^T (G block of gQP),  gP += G gW   -- independent of each other: one launch
     GemmParams p = flat_gemm(o.QP + NR, LD, MLD, o.gW, B, MB, o.gQP + 4, LD, MLD, M, M, B);
     p.splitk = ksplit(B);     // 4 SC tiles with a B-long K loop: split K so that the chip is busy (atomic accumulation)
@@ -962,6 +998,7 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
   grk.triA = 2;
   rc = chol_inv_bwd_first(o.TT, o.gTT, SC + C, M, o.chol, o.chol_bytes, &grk, 1, 0, SC, st);
   if (rc) return rc;
+  }
   {
     const int64_t total = (int64_t)C * M * (M + 1);
     hipLaunchKernelGGL(t0_unpack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, o.gRK, g_u_mean, o.gLL + SC * MM, S, C,
@@ -973,7 +1010,7 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
   // kernel matrices -> z, theta
   const int64_t zrows = (int64_t)C * M;
   {
-    const int gx = cdiv(B, 256), gy = cdiv(zrows, kWRows), nuf = gx * gy * S;
+    const int gx = cdiv(B, 256), gy = cdiv(zrows, kWRows), nuf = fused_bwd ? 0 : gx * gy * S;   // fused: W_uf is done
     const int nuu = SC * cdiv(M, kUuRows);
     const int ngv = cdiv((int64_t)C * MM, 256);      // + the gradient of the packed Cholesky vector of q(u)
     hipLaunchKernelGGL(t0_w_kernel, dim3(nuf + nuu + ngv), dim3(256), 0, st, o.RK, o.gRK, o.KS, o.gKS, o.Wuu, o.r_uu, o.r_uf,
