@@ -18,6 +18,19 @@ tr = ElboTrainer(gp, lr=bench.LR, beta=bench.BETA, n_total=bench.N_TOTAL)
 for _ in range(5):
     tr.step(x, y)
 torch.cuda.synchronize()
+if len(sys.argv) > 1 and sys.argv[1] == 'mat':      # t0_bwd_mat_body (a -DBMAT_STAMPS build of gemm.hip)
+    out = (ctypes.c_ulonglong * 24)()
+    fn = _lib.lib().vargp_debug_bmat_stamps
+    fn.restype, fn.argtypes = None, [ctypes.c_void_p]
+    fn(out)
+    names = ['loads + stage T, gG, L_S', 'gG L_S^T', 'T^T gG', 'T^T ga + gRK stores', 'barrier', 'stage gG2, Lu', 'gG2 Lu^T, T^T gG2 + stores',
+             'gTT loads + barrier', 'gT -> X1 + barrier', 'w1 = gT T^T', 'S -> X2 + barrier', 'tmp = T^T S', 'tmp -> X1 + barriers',
+             'gK = tmp T', 'K loads, W -> X2 + barriers', 'rows out']
+    v = list(out)
+    for i, n in enumerate(names):
+        print('%-32s %8d cycles' % (n, v[i + 1] - v[i]))
+    print('%-32s %8d cycles' % ('total', v[16] - v[0]))
+    sys.exit(0)
 out = (ctypes.c_ulonglong * 16)()
 fn = _lib.lib().vargp_debug_bm_stamps
 fn.restype, fn.argtypes = None, [ctypes.c_void_p]

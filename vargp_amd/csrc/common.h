@@ -136,6 +136,19 @@ int chol_inv_bwd_first(const float* T, const float* gT, int nbatch, int n, void*
 int chol_inv_bwd_impl(const float* L, const float* T, const float* gL, const float* gT, float* gA, int nbatch, int n,
                       void* ws, size_t ws_bytes, bool gl_lower, hipStream_t st, bool first_done);
 
+// Per-matrix tail of the first-task backward (t0_bwd_mat.h) sharing ONE launch with a plain NN product that does not depend
+// on it (gemm.hip: t0_bwdmat_gemm_kernel).  Matrices [first, first + nmat): ids < S C are the K_uu role of (s, c) = id, ids
+// >= S C the S_u role of class id - S C (which reads nothing the K_uu roles write: one launch for all of them).
+struct BwdMatArgs {
+  const float *TT, *LL, *gQP, *RK, *KS, *seeds;     // TT / LL / KS: [S C + C][M][M]
+  const float* gTT;
+  float *gKS, *Wuu, *r_uu, *gtheta;
+  float *g_u_mean, *gLu_acc;                        // [C][M], [C][M][M]: sums over s, accumulated with atomics (pre-zeroed)
+  int S, C, M, D, NR, LD;
+};
+int launch_bwdmat_gemm(const BwdMatArgs& a, int first, int nmat, const GemmParams& p, int nbatch, hipStream_t st,
+                       const char* tag);
+
 // Launch replay (vargp_prof_remember / vargp_prof_replay): while remembering, tagged launch sites store a closure that
 // repeats the launch.
 bool prof_remembering();

@@ -191,10 +191,13 @@ constexpr int kFinRows = VARGP_FIN_ROWS;   // rows per workgroup of the RBF fina
 
 // gradient of the packed Cholesky vector of q(u):  gLu = sum_s gRK[.., Lu block] - seed_kl diag(1/Lu_ii) + 2 gS_u Lu,
 // through vec2tril (softplus on the diagonal).  One thread per (c, i, k <= i).  (A role of t0_w_kernel.)
+// gRK: [S][C][M][LD] with the Lu block at column 4 + M (summed over s here), or -- S = 1, LD = M, off = 0 -- the per-class sum
+// itself (t0_bwd_mat.h accumulates it with atomics).
 __device__ __forceinline__ void t0_gvec_role(int blk, const float* __restrict__ vec, const float* __restrict__ Lu,
                                              const float* __restrict__ gSu, const float* __restrict__ gRK,
                                              const float* __restrict__ seeds, float* __restrict__ gvec, int S, int C,
-                                             int M, int LD) {
+                                             int M, int LD, int off = -1) {
+  if (off < 0) off = 4 + M;
   const int64_t e = (int64_t)blk * 256 + threadIdx.x;
   if (e >= (int64_t)C * M * M) return;
   const int k = e % M, i = (e / M) % M;
@@ -221,7 +224,7 @@ __device__ __forceinline__ void t0_gvec_role(int blk, const float* __restrict__ 
     }
   }
   float g = 2.f * ((acc0 + acc1) + (acc2 + acc3));
-  for (int s = 0; s < S; ++s) g += gRK[(((int64_t)s * C + c) * M + i) * LD + 4 + M + k];
+  for (int s = 0; s < S; ++s) g += gRK[(((int64_t)s * C + c) * M + i) * LD + off + k];
   const int64_t idx = c * ((int64_t)M * (M + 1) / 2) + (int64_t)i * (i + 1) / 2 + k;
   if (i == k) {
     g -= seeds[1] / lu[(int64_t)i * M];
@@ -229,6 +232,13 @@ __device__ __forceinline__ void t0_gvec_role(int blk, const float* __restrict__ 
     g *= (x > 20.f) ? 1.f : sigmoid_t0(x);
   }
   gvec[idx] = g;
+}
+
+// the packed-Cholesky-vector gradient alone, from the per-class sums of t0_bwd_mat.h
+static __global__ __launch_bounds__(256) void t0_gvec_kernel(const float* __restrict__ vec, const float* __restrict__ Lu,
+                                                      const float* __restrict__ gSu, const float* __restrict__ gLu_acc,
+                                                      const float* __restrict__ seeds, float* __restrict__ gvec, int C, int M) {
+  t0_gvec_role((int)blockIdx.x, vec, Lu, gSu, gLu_acc, seeds, gvec, 1, C, M, M, 0);
 }
 
 // W = gK o K for both kernel matrices (see rbf.hip for the algebra).

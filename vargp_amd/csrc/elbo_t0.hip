@@ -631,7 +631,8 @@ __global__ __launch_bounds__(256) void t0_bwd_head_kernel(const float* __restric
                                                           float* __restrict__ gW, float* __restrict__ gkd,
                                                           float* __restrict__ gLz, float* __restrict__ gThead,
                                                           float* __restrict__ gTtail, float* __restrict__ zero_begin, int64_t zero_count, int S, int C,
-                                                          int M, int B, int NR, int LD, int npd, int nkx, int nkl, int fused) {
+                                                          int M, int B, int NR, int LD, int npd, int nkx, int nkl, int fused,
+                                                          float* __restrict__ g_u_mean, float* __restrict__ gLu_acc) {
   __shared__ float red[4];
   const float g = seeds[1] / (float)S;
   if ((int)blockIdx.x < npd) {
@@ -702,13 +703,17 @@ __global__ __launch_bounds__(256) void t0_bwd_head_kernel(const float* __restric
         gq[(int64_t)i * LD + 4 + j] = 0.f;             // G block and gT: accumulated by K-split GEMMs (float atomics)
         gThead[b * M * M + e] = 0.f;
         gLz[b * M * M + e] = (i == j) ? g / lv[u] : 0.f;
-        if (s == 0) gTtail[(int64_t)c * M * M + e] = 0.f;
+        if (s == 0) {
+          gTtail[(int64_t)c * M * M + e] = 0.f;
+          if (gLu_acc) gLu_acc[(int64_t)c * M * M + e] = 0.f;      // per-class sums accumulated by t0_bwd_mat.h's atomics
+        }
       }
     }
   }
   for (int i = i0 + threadIdx.x; i < i1; i += 256) {
     // fused: the moment role above did not run (npd = 0); ga and gkd are accumulated by t0_bwd_mid_kernel on top of these
     if (fused) gq[(int64_t)i * LD] = g * q[(int64_t)i * LD];
+    if (g_u_mean && s == 0) g_u_mean[(int64_t)c * M + i] = 0.f;
     gq[(int64_t)i * LD + 1] = 0.f; gq[(int64_t)i * LD + 2] = 0.f; gq[(int64_t)i * LD + 3] = 0.f;
     for (int col = 4 + 2 * M; col < NR; ++col) gq[(int64_t)i * LD + col] = 0.f;
   }
@@ -948,13 +953,20 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
   const int ntile = cdiv(B, 64);
   const bool fused_bwd = fused_bwd_env && M <= kBmKP && M >= 4 && (M % 4) == 0 && (LD % 4) == 0 && (B % 4) == 0 &&
                          (int64_t)SC * ntile <= 2048;
+  // ... and everything per matrix after it (small columns of gT / gRK, Cholesky adjoint, W_uu) as one LDS-resident workgroup
+  // per matrix inside the launches of the two W.Y products (t0_bwd_mat.h)
+  static const int mat_bwd_env = [] { const char* e = getenv("VARGP_T0_MAT_BWD"); return e ? atoi(e) : 1; }();   // tuning aid
+  // (the S_u matrices redo T_s^T gG_s for every hyper-sample: worth it for the few samples of the reference's configs)
+  const bool mat_bwd = fused_bwd && mat_bwd_env && (D % 4) == 0 && S <= 4 &&
+                       ((reinterpret_cast<uintptr_t>(d->z) | reinterpret_cast<uintptr_t>(d->x)) & 15) == 0;
   {
     const int npd = fused_bwd ? 0 : M * SC, nkx = cdiv(M, kKlRows), nkl = nkx * SC;
     const int64_t zc = o.r_uu - o.r_uf;
     const int nz = (int)std::min<int64_t>(64, cdiv(zc, 1024));
     hipLaunchKernelGGL(t0_bwd_head_kernel, dim3(npd + nkl + nz), dim3(256), 0, st, o.QP, o.W, o.gmu, o.gvar,
                        fused_softmax ? seeds + 2 : nullptr, o.LL, seeds, o.gQP, o.gW, o.gkd, o.gLL, o.gTT, o.gTT + SC * MM, o.r_uf,
-                       zc, S, C, M, B, NR, LD, npd, nkx, nkl, fused_bwd ? 1 : 0);
+                       zc, S, C, M, B, NR, LD, npd, nkx, nkl, fused_bwd ? 1 : 0, mat_bwd ? g_u_mean : nullptr,
+                       mat_bwd ? o.gLL + SC * MM : nullptr);
   }
   if (fused_bwd) {
     static std::atomic<unsigned> attr_set_mask[2] = {};
@@ -966,16 +978,18 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
                          fused_softmax ? seeds + 2 : nullptr, o.gQP, o.gTT, o.gRK, o.gkd, o.r_uf, o.c_uf, o.gtheta, S, C, M, B, D,
                          NR, LD, ntile);
     }
-    // what the tiles cannot see: the small columns [a | . | G | G2 | .] of QP = T RK (K = NR):
-    //   gT += tril(gQP[:, :NR] RK[:, :NR]^T)   on top of the tiles' atomics;   gRK[:, :NR] = T^T gQP[:, :NR]
-    GemmParams p = flat_gemm(o.gQP, LD, MLD, o.RK, LD, MLD, o.gTT, M, MM, M, M, NR);
-    p.triC = 1; p.D = o.gTT; p.ldd = M; p.beta = 1.f;
-    GemmParams q = flat_gemm(o.TT, M, MM, o.gQP, LD, MLD, o.gRK, LD, MLD, M, NR, M);
-    q.triA = 2;
-    rc = launch_gemm_pair2(p, 0, 1, SC, q, 1, 0, SC, st, "t0_gt_grk_small");
-    if (rc) return rc;
-    rc = chol_inv_bwd_first(o.TT, o.gTT, SC + C, M, o.chol, o.chol_bytes, nullptr, 0, 0, 0, st);
-    if (rc) return rc;
+    if (!mat_bwd) {
+      // what the tiles cannot see: the small columns [a | . | G | G2 | .] of QP = T RK (K = NR):
+      //   gT += tril(gQP[:, :NR] RK[:, :NR]^T)   on top of the tiles' atomics;   gRK[:, :NR] = T^T gQP[:, :NR]
+      GemmParams p = flat_gemm(o.gQP, LD, MLD, o.RK, LD, MLD, o.gTT, M, MM, M, M, NR);
+      p.triC = 1; p.D = o.gTT; p.ldd = M; p.beta = 1.f;
+      GemmParams q = flat_gemm(o.TT, M, MM, o.gQP, LD, MLD, o.gRK, LD, MLD, M, NR, M);
+      q.triA = 2;
+      rc = launch_gemm_pair2(p, 0, 1, SC, q, 1, 0, SC, st, "t0_gt_grk_small");
+      if (rc) return rc;
+      rc = chol_inv_bwd_first(o.TT, o.gTT, SC + C, M, o.chol, o.chol_bytes, nullptr, 0, 0, 0, st);
+      if (rc) return rc;
+    }
   } else {
   {  // W = G^T P:  gG = P gW^T (G block of gQP),  gP += G gW   -- independent of each other: one launch
     GemmParams p = flat_gemm(o.QP + NR, LD, MLD, o.gW, B, MB, o.gQP + 4, LD, MLD, M, M, B);
@@ -999,6 +1013,36 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
   rc = chol_inv_bwd_first(o.TT, o.gTT, SC + C, M, o.chol, o.chol_bytes, &grk, 1, 0, SC, st);
   if (rc) return rc;
   }
+  const int64_t zrows = (int64_t)C * M;
+  GemmParams p0{}, p1{};       // the W.Y products of the kernel-matrix backward: P_uu = W_uu z per (s, c), P_uf = W_uf x per s
+  p0.A = o.Wuu; p0.B = d->z; p0.C = o.Puu;
+  p0.M = M; p0.N = D; p0.K = M; p0.lda = M; p0.ldb = D; p0.ldc = D;
+  p0.nb1 = C; p0.nb2 = 1;
+  p0.sA[0] = C * MM; p0.sA[1] = MM;
+  p0.sB[1] = (int64_t)M * D;
+  p0.sC[0] = zrows * D; p0.sC[1] = (int64_t)M * D;
+  p0.alpha = 1.f;
+  p1.A = o.gRK + NR; p1.B = d->x; p1.C = o.Puf;
+  p1.M = C * M; p1.N = D; p1.K = B; p1.lda = LD; p1.ldb = D; p1.ldc = D;
+  p1.nb1 = 1; p1.nb2 = 1;
+  p1.sA[0] = C * MLD;
+  p1.sC[0] = zrows * D;
+  p1.alpha = 1.f;
+  if (mat_bwd) {
+    BwdMatArgs ma{};
+    ma.TT = o.TT; ma.LL = o.LL; ma.gQP = o.gQP; ma.RK = o.RK; ma.KS = o.KS; ma.seeds = seeds; ma.gTT = o.gTT;
+    ma.gKS = o.gKS; ma.Wuu = o.Wuu; ma.r_uu = o.r_uu; ma.gtheta = o.gtheta;
+    ma.g_u_mean = g_u_mean; ma.gLu_acc = o.gLL + SC * MM;        // (the S_u part of gLL is free on this path)
+    ma.S = S; ma.C = C; ma.M = M; ma.D = D; ma.NR = NR; ma.LD = LD;
+    // all S C + C matrices next to P_uf = W_uf x (which only needs the tile kernel's W_uf) ...
+    rc = launch_bwdmat_gemm(ma, 0, SC + C, p1, S, st, "rbf_kuf_bwd_gemm");
+    if (rc) return rc;
+    // ... then P_uu = W_uu z and the gradient of the packed Cholesky vector of q(u)
+    rc = launch_gemm(p0, 0, 0, SC, false, st, "rbf_kuu_bwd_gemm");
+    if (rc) return rc;
+    hipLaunchKernelGGL(t0_gvec_kernel, dim3(cdiv((int64_t)C * MM, 256)), dim3(256), 0, st, d->u_tril_vec, o.Lu, o.gKS + SC * MM,
+                       o.gLL + SC * MM, seeds, g_u_tril_vec, C, M);
+  } else {
   {
     const int64_t total = (int64_t)C * M * (M + 1);
     hipLaunchKernelGGL(t0_unpack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, o.gRK, g_u_mean, o.gLL + SC * MM, S, C,
@@ -1008,7 +1052,6 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
   rc = chol_inv_bwd_impl(o.LL, o.TT, o.gLL, o.gTT, o.gKS, SC + C, M, o.chol, o.chol_bytes, true, st, true);
   if (rc) return rc;
   // kernel matrices -> z, theta
-  const int64_t zrows = (int64_t)C * M;
   {
     const int gx = cdiv(B, 256), gy = cdiv(zrows, kWRows), nuf = fused_bwd ? 0 : gx * gy * S;   // fused: W_uf is done
     const int nuu = SC * cdiv(M, kUuRows);
@@ -1016,23 +1059,8 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
     hipLaunchKernelGGL(t0_w_kernel, dim3(nuf + nuu + ngv), dim3(256), 0, st, o.RK, o.gRK, o.KS, o.gKS, o.Wuu, o.r_uu, o.r_uf,
                        o.c_uf, o.gtheta, S, C, M, B, D, NR, LD, gx, gy, nuf, nuu, d->u_tril_vec, o.Lu, seeds, g_u_tril_vec, 1);
   }
-  {
-    GemmParams p0{}, p1{};
-    p0.A = o.Wuu; p0.B = d->z; p0.C = o.Puu;
-    p0.M = M; p0.N = D; p0.K = M; p0.lda = M; p0.ldb = D; p0.ldc = D;
-    p0.nb1 = C; p0.nb2 = 1;
-    p0.sA[0] = C * MM; p0.sA[1] = MM;
-    p0.sB[1] = (int64_t)M * D;
-    p0.sC[0] = zrows * D; p0.sC[1] = (int64_t)M * D;
-    p0.alpha = 1.f;
-    p1.A = o.gRK + NR; p1.B = d->x; p1.C = o.Puf;
-    p1.M = C * M; p1.N = D; p1.K = B; p1.lda = LD; p1.ldb = D; p1.ldc = D;
-    p1.nb1 = 1; p1.nb2 = 1;
-    p1.sA[0] = C * MLD;
-    p1.sC[0] = zrows * D;
-    p1.alpha = 1.f;
-    rc = launch_gemm_pair(p0, SC, p1, S, 0, 0, false, st, "rbf_kuu_bwd_gemm", "rbf_kuf_bwd_gemm");
-    if (rc) return rc;
+  rc = launch_gemm_pair(p0, SC, p1, S, 0, 0, false, st, "rbf_kuu_bwd_gemm", "rbf_kuf_bwd_gemm");
+  if (rc) return rc;
   }
   {
     const int nzy = cdiv(zrows, kFinRows), nxy = cdiv(B, kFinRows);

@@ -16,6 +16,8 @@
 // cycles PLUS the issue cycles of everything else), so the kernel is written to minimise non-MFMA instructions.
 #include "common.h"
 #include "chol_small3.h"
+#include "t0_bwd_mat.h"
+#include <atomic>
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
@@ -783,6 +785,21 @@ __global__ __launch_bounds__(256) void chol_rbf_gemm_kernel(const CholArgs c, co
   gemm_body<BM, 64, BK, true, true, true, true, SCALED>(p, id % tiles, id / tiles, 0, lds);
 }
 
+// One launch, two independent roles (like chol_rbf_gemm_kernel in the forward): workgroups [0, nmat) walk the chain of
+// M x M products of one matrix of the first-task backward (t0_bwd_mat.h: ~20 us on nmat CUs), the others are 64 x 64 tiles of a
+// plain NN product the chain does not feed (P_uf = W_uf x next to the K_uu matrices, P_uu = W_uu z next to the S_u ones).
+// Every workgroup is carved the chain's 136 KB of LDS, i.e. one workgroup per CU.
+__global__ __launch_bounds__(256) void t0_bwdmat_gemm_kernel(const BwdMatArgs a, const int first, const int nmat,
+                                                             const GemmParams p, const int tiles) {
+  extern __shared__ __attribute__((aligned(16))) float bmat_lds[];
+  if ((int)blockIdx.x < nmat) {
+    t0_bwd_mat_body(a, first + (int)blockIdx.x, bmat_lds);
+    return;
+  }
+  const int id = xcd_remap((int)blockIdx.x - nmat, (int)gridDim.x - nmat);
+  gemm_body<64, 64, 64, true, false, true, false>(p, id % tiles, id / tiles, 0, bmat_lds);
+}
+
 static bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 static bool gemm_vec_ok(const GemmParams& p) {
   bool vec = aligned16(p.A) && aligned16(p.B) && (p.lda % 4 == 0) && (p.ldb % 4 == 0);
@@ -930,6 +947,38 @@ int launch_gemm_pair2(const GemmParams& p0, int tA0, int tB0, int nbatch0, const
   else if (nn_nn) hipLaunchKernelGGL((gemm_pair2_kernel<true, false, true, false>), dim3(total), dim3(256), 0, st, pp);
   else hipLaunchKernelGGL((gemm_pair2_kernel<false, false, false, false>), dim3(total), dim3(256), 0, st, pp);
   return check_launch("gemm_pair2");
+}
+
+int launch_bwdmat_gemm(const BwdMatArgs& a, int first, int nmat, const GemmParams& p, int nbatch, hipStream_t st,
+                       const char* tag) {
+  VARGP_REQUIRE(gemm_vec_ok(p), "bwdmat_gemm: the product's operands must be 16-byte aligned with strides % 4 == 0");
+  VARGP_REQUIRE(a.M <= kBmKP && a.M >= 4 && (a.M % 4) == 0 && (a.LD % 4) == 0, "bwdmat_gemm: M = %d out of range", a.M);
+  static_assert(kBwdMatLdsBytes >= sizeof(float) * gemm_lds_floats<64, 64, 64, true, false>(), "LDS of the GEMM role");
+  if (prof_remembering() && strcmp(tag, "replay") != 0) {
+    const GemmParams pc = p;
+    const BwdMatArgs ac = a;
+    prof_remember(tag, [=](hipStream_t s) { launch_bwdmat_gemm(ac, first, nmat, pc, nbatch, s, "replay"); });
+  }
+  // hipFuncAttributeMaxDynamicSharedMemorySize is per device
+  static std::atomic<unsigned> attr_mask[2] = {};
+  int dev = 0;
+  VARGP_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, "bwdmat_gemm: hipGetDevice failed");
+  if (!((attr_mask[dev >> 5].load(std::memory_order_acquire) >> (dev & 31)) & 1u)) {
+    VARGP_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(t0_bwdmat_gemm_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdMatLdsBytes) == hipSuccess,
+                  "bwdmat_gemm: cannot reserve %zu bytes of LDS", kBwdMatLdsBytes);
+    attr_mask[dev >> 5].fetch_or(1u << (dev & 31), std::memory_order_release);
+  }
+  ProfScope prof(tag, st);
+  GemmParams q = p;
+  q.splitk = 1; q.nofast = 0; q.group_m = 0; q.xcd_remap = 1;
+  const int tiles = cdiv(p.M, 64) * cdiv(p.N, 64);
+  // tuning aid (timing of one role alone; results are then incomplete): VARGP_EXP_BWDMAT = 1: matrices only, 2: product only
+  static const int exp_role = [] { const char* e = getenv("VARGP_EXP_BWDMAT"); return e ? atoi(e) : 0; }();
+  if (exp_role == 1) nbatch = 0;
+  if (exp_role == 2) nmat = 0;
+  hipLaunchKernelGGL(t0_bwdmat_gemm_kernel, dim3(nmat + tiles * nbatch), dim3(256), kBwdMatLdsBytes, st, a, first, nmat, q, tiles);
+  return check_launch("bwdmat_gemm");
 }
 
 static int g_tile_force = 0;   // vargp_tune_gemm_tile (measurement only)

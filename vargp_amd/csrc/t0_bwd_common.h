@@ -1,0 +1,56 @@
+// Device helpers shared by the LDS-resident kernels of the first-task backward (t0_bwd_mid.h: per (s, c, column tile);
+// t0_bwd_mat.h: per matrix): f32 MFMA 32x32x2 fragments with the k-pairing of gemm.hip, compile-time loops, staging loads.
+#pragma once
+#include "common.h"
+#include <type_traits>
+
+namespace vargp {
+
+
+constexpr int kBmKP = 104;      // padded inner dimension (M <= 104, multiple of 8)
+constexpr int kBmSA = 108;      // row stride of the M x M operand (G, then T): 108 / 4 odd -> conflict-free b128 rows
+constexpr int kBmST = 68;       // row stride of the M x 64 tiles
+constexpr size_t kBwdMidLdsBytes =
+    sizeof(float) * (kBmKP * kBmSA + 2 * kBmKP * kBmST + 128 /*a*/ + 64 + 64 /*gmu, gvar*/ + 64 /*column sums*/ + 8);
+typedef float bm_f32x16 __attribute__((ext_vector_type(16)));
+
+// fragment of a K-contiguous operand ([index][k]): the lane's 4 consecutive k of one row, one ds_read_b128
+__device__ __forceinline__ float4 bm_frag_kc(const float* __restrict__ rowp, int k) {
+  return *reinterpret_cast<const float4*>(rowp + k);
+}
+// fragment of a k-major operand ([k][index]): 4 rows, same column
+__device__ __forceinline__ float4 bm_frag_km(const float* __restrict__ colp, int k, int stride) {
+  const float* p = colp + k * stride;
+  return make_float4(p[0], p[stride], p[2 * stride], p[3 * stride]);
+}
+__device__ __forceinline__ void bm_mfma4(bm_f32x16& acc, const float4 a, const float4 b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+}
+
+// compile-time loop: f(integral_constant<int, I>) for I in [I0, I1)
+template <int I0, int I1, class F>
+__device__ __forceinline__ void bm_for(F&& f) {
+  if constexpr (I0 < I1) {
+    f(std::integral_constant<int, I0>{});
+    bm_for<I0 + 1, I1>(f);
+  }
+}
+__host__ __device__ constexpr int bm_min(int a, int b) { return a < b ? a : b; }
+
+constexpr int kBmNQ = kBmKP / 4;                          // float4 per row of an M x M operand (26)
+constexpr int kBmNA = (kBmKP * kBmNQ + 255) / 256;        // float4 per thread of one M x M operand (11)
+
+// one M x M matrix (row-major, row stride ld in global memory) -> registers (clamped indices)
+__device__ __forceinline__ void bm_load_mat(const float* __restrict__ base, int ld, int M, int tid, float4 (&dst)[kBmNA]) {
+#pragma unroll
+  for (int u = 0; u < kBmNA; ++u) {
+    const int e = min(tid + 256 * u, kBmKP * kBmNQ - 1);
+    const int i = e / kBmNQ, j = (e - i * kBmNQ) * 4;
+    dst[u] = *reinterpret_cast<const float4*>(base + (int64_t)min(i, M - 1) * ld + min(j, M - 4));
+  }
+}
+
+}  // namespace vargp
