@@ -23,9 +23,15 @@ if len(sys.argv) > 1 and sys.argv[1] == 'mat':      # t0_bwd_mat_body (a -DBMAT_
     fn = _lib.lib().vargp_debug_bmat_stamps
     fn.restype, fn.argtypes = None, [ctypes.c_void_p]
     fn(out)
-    names = ['loads + stage T, gG, L_S', 'gG L_S^T', 'T^T gG', 'T^T ga + gRK stores', 'barrier', 'stage gG2, Lu', 'gG2 Lu^T, T^T gG2 + stores',
-             'gTT loads + barrier', 'gT -> X1 + barrier', 'w1 = gT T^T', 'S -> X2 + barrier', 'tmp = T^T S', 'tmp -> X1 + barriers',
-             'gK = tmp T', 'K loads, W -> X2 + barriers', 'rows out']
+    names = {(0, 1): 'loads + stage T, gG, L_S', (1, 2): 'gG L_S^T', (2, 3): 'T^T ga', (3, 5): 'gTT loads + barrier',
+             (5, 6): 'stage gG2, Lu', (6, 7): 'gG2 Lu^T, T^T gG2 + atomics', (7, 8): 'barrier', (8, 9): 'gT -> X1 + barrier',
+             (9, 10): 'w1 = gT T^T', (10, 11): 'S -> X2 + barrier', (11, 12): 'K loads, tmp = T^T S', (12, 13): 'tmp -> X1 + barriers',
+             (13, 14): 'gK = tmp T', (14, 15): 'W -> X2 + barrier', (15, 16): 'rows out, row sums'}
+    v = list(out)
+    for (i, j), n in names.items():
+        print('%-32s %8d cycles' % (n, v[j] - v[i]))
+    print('%-32s %8d cycles' % ('total', v[16] - v[0]))
+    sys.exit(0)
     v = list(out)
     for i, n in enumerate(names):
         print('%-32s %8d cycles' % (n, v[i + 1] - v[i]))

@@ -234,6 +234,13 @@ __device__ __forceinline__ void t0_gvec_role(int blk, const float* __restrict__ 
   gvec[idx] = g;
 }
 
+// arguments of the packed-Cholesky-vector gradient when it rides in t0_final_kernel's launch (gvec == NULL: off)
+struct GvecArgs {
+  const float *vec, *Lu, *gSu, *gLu_acc, *seeds;
+  float* gvec;
+  int C, M, y0;
+};
+
 // the packed-Cholesky-vector gradient alone, from the per-class sums of t0_bwd_mat.h
 static __global__ __launch_bounds__(256) void t0_gvec_kernel(const float* __restrict__ vec, const float* __restrict__ Lu,
                                                       const float* __restrict__ gSu, const float* __restrict__ gLu_acc,
@@ -362,8 +369,14 @@ static __global__ __launch_bounds__(256) void t0_final_kernel(const float* __res
                                                        const float* __restrict__ c_uf, const float* __restrict__ Puu,
                                                        const float* __restrict__ Puf, const float* __restrict__ w,
                                                        float* __restrict__ gz, float* __restrict__ gtheta,
-                                                       int64_t zrows, int64_t xrows, int D, int64_t Dp, int S, int nzy) {
+                                                       int64_t zrows, int64_t xrows, int D, int64_t Dp, int S, int nzy,
+                                                       const GvecArgs gv = GvecArgs{}) {
   __shared__ float red[2][4][64];      // double-buffered by sample parity: one barrier per sample
+  if (gv.gvec && (int)blockIdx.y >= gv.y0) {      // extra rows of the grid: the packed-Cholesky-vector gradient (only shares the launch)
+    t0_gvec_role(((int)blockIdx.y - gv.y0) * (int)gridDim.x + (int)blockIdx.x, gv.vec, gv.Lu, gv.gSu, gv.gLu_acc, gv.seeds, gv.gvec,
+                 1, gv.C, gv.M, gv.M, 0);
+    return;
+  }
   constexpr int RJ = kFinRows / 4;
   const int dx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int d = blockIdx.x * 64 + dx;

@@ -1040,8 +1040,6 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
     // ... then P_uu = W_uu z and the gradient of the packed Cholesky vector of q(u)
     rc = launch_gemm(p0, 0, 0, SC, false, st, "rbf_kuu_bwd_gemm");
     if (rc) return rc;
-    hipLaunchKernelGGL(t0_gvec_kernel, dim3(cdiv((int64_t)C * MM, 256)), dim3(256), 0, st, d->u_tril_vec, o.Lu, o.gKS + SC * MM,
-                       o.gLL + SC * MM, seeds, g_u_tril_vec, C, M);
   } else {
   {
     const int64_t total = (int64_t)C * M * (M + 1);
@@ -1063,9 +1061,16 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
   if (rc) return rc;
   }
   {
-    const int nzy = cdiv(zrows, kFinRows), nxy = cdiv(B, kFinRows);
-    hipLaunchKernelGGL(t0_final_kernel, dim3(cdiv(D, 64), nzy + nxy), dim3(256), 0, st, d->z, d->x, o.r_uu, o.r_uf, o.c_uf,
-                       o.Puu, o.Puf, o.w, g_z, o.gtheta, zrows, (int64_t)B, D, o.Dp, S, nzy);
+    const int nzy = cdiv(zrows, kFinRows), nxy = cdiv(B, kFinRows), gx = cdiv(D, 64);
+    GvecArgs gv{};
+    int ngy = 0;
+    if (mat_bwd) {               // the gradient of the packed Cholesky vector of q(u) from the per-class sums: extra grid rows
+      gv.vec = d->u_tril_vec; gv.Lu = o.Lu; gv.gSu = o.gKS + SC * MM; gv.gLu_acc = o.gLL + SC * MM; gv.seeds = seeds;
+      gv.gvec = g_u_tril_vec; gv.C = C; gv.M = M; gv.y0 = nzy + nxy;
+      ngy = cdiv(cdiv((int64_t)C * MM, 256), gx);
+    }
+    hipLaunchKernelGGL(t0_final_kernel, dim3(gx, nzy + nxy + ngy), dim3(256), 0, st, d->z, d->x, o.r_uu, o.r_uf, o.c_uf,
+                       o.Puu, o.Puf, o.w, g_z, o.gtheta, zrows, (int64_t)B, D, o.Dp, S, nzy, gv);
   }
   hipLaunchKernelGGL(t0_hyper_bwd_kernel, dim3(cdiv(D + 1, 256)), dim3(256), 0, st, d->log_mean, d->log_logvar,
                      d->prior_log_mean, d->prior_log_logvar, eps_theta, o.gtheta, o.g2, o.gkd, seeds, g_log_mean,

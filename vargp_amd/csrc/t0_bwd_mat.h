@@ -154,11 +154,9 @@ __device__ __forceinline__ void mat_tail(float* __restrict__ sT, float* __restri
                                          const float* __restrict__ kmul, float* __restrict__ out, float* __restrict__ rsum_out,
                                          float* __restrict__ tot_out, int M, int id, int tid, int lane, int li, int lh) {
   bm_f32x16 acc[4];
-  // the factor the result is multiplied by, in the accumulator layout of the LAST product: requested now, used after two products
-  float kv[4][16];
-  mat_foreach<kFamC, WV>(li, lh, [&](int u, int rb, int cb, int r, int i, int j) {
-    kv[u][r] = kmul ? 2.f * kmul[(int64_t)min(i, M - 1) * M + min(j, M - 1)] : 1.f;
-  });
+  // the factor the result is multiplied by, row by row (coalesced float4): requested now, used in the last pass
+  float4 kr[kBmNA];
+  if (kmul) bm_load_mat(kmul, M, M, tid, kr);
   mat_product<false, false, kFamF, WV>(acc, sT, X2, true, li, lh);                 // tmp = T^T S
   BMAT_STAMP(12);
   __syncthreads();                                     // (X1 may still be read by a slower wave's previous product)
@@ -172,7 +170,7 @@ __device__ __forceinline__ void mat_tail(float* __restrict__ sT, float* __restri
   // (X2 = S was last read by the product before the previous barrier)
   mat_foreach<kFamC, WV>(li, lh, [&](int u, int rb, int cb, int r, int i, int j) {
     if (i < kBmKP && (rb != cb || j <= i)) {
-      const float v = i < M ? acc[u][r] * kv[u][r] : 0.f;
+      const float v = i < M ? acc[u][r] : 0.f;
       X2[i * kMatS + j] = v;
       X2[j * kMatS + i] = v;
     }
@@ -184,10 +182,17 @@ __device__ __forceinline__ void mat_tail(float* __restrict__ sT, float* __restri
   for (int u = 0; u < kBmNA; ++u) {
     const int e = tid + 256 * u;
     const int i = e / kBmNQ, j = (e - i * kBmNQ) * 4;
-    if (e < kBmKP * kBmNQ && i < M && j < M)
-      *reinterpret_cast<float4*>(&out[(int64_t)i * M + j]) = *reinterpret_cast<const float4*>(&X2[i * kMatS + j]);
+    if (e < kBmKP * kBmNQ && i < M && j < M) {
+      float4 v = *reinterpret_cast<const float4*>(&X2[i * kMatS + j]);
+      if (kmul) {
+        v.x *= 2.f * kr[u].x; v.y *= 2.f * kr[u].y; v.z *= 2.f * kr[u].z; v.w *= 2.f * kr[u].w;
+        *reinterpret_cast<float4*>(&X2[i * kMatS + j]) = v;       // (for the row sums below; each thread its own elements)
+      }
+      *reinterpret_cast<float4*>(&out[(int64_t)i * M + j]) = v;
+    }
   }
   if (rsum_out) {
+    __syncthreads();
     const int i = tid >> 1, h = tid & 1;
     const float* pr = X2 + min(i, kBmKP - 1) * kMatS + 52 * h;       // columns [0, 52) / [52, 104): the padding is zero
     float a0 = 0.f, a1 = 0.f;
@@ -238,6 +243,14 @@ __device__ __forceinline__ void mat_kuu(const BwdMatArgs& a, int id, float* __re
   if (tid < 128) { sga[tid] = tid < M ? gav : 0.f; smv[tid] = tid < M ? mvv : 0.f; }
   bm_load_mat(gq + 4 + M, LD, M, tid, r1);             // gG2 = g tril(G2)   (KL)
   bm_load_mat(rk + 4 + M, LD, M, tid, r2);             // Lu
+  // the tiles' share of gT (accumulated by t0_bwd_mid_kernel's atomics), read in the accumulator layout: needed after two products
+  float gtt[4][16];
+  {
+    const float* gTb = a.gTT + b * MM;
+    mat_foreach<kFamL, WV>(li, lh, [&](int u, int rb, int cb, int r, int i, int j) {
+      gtt[u][r] = gTb[(int64_t)min(i, M - 1) * M + min(j, M - 1)];
+    });
+  }
   __syncthreads();
   BMAT_STAMP(1);
   // ---- gT (small columns), part 1: gG L_S^T;  g_u_mean[c] += T^T ga --------------------------------------------------------------
@@ -252,14 +265,6 @@ __device__ __forceinline__ void mat_kuu(const BwdMatArgs& a, int id, float* __re
     srs[tid] = s0;
   }
   BMAT_STAMP(3);
-  // the tiles' share of gT (accumulated by t0_bwd_mid_kernel's atomics), read in the accumulator layout
-  float gtt[4][16];
-  {
-    const float* gTb = a.gTT + b * MM;
-    mat_foreach<kFamL, WV>(li, lh, [&](int u, int rb, int cb, int r, int i, int j) {
-      gtt[u][r] = gTb[(int64_t)min(i, M - 1) * M + min(j, M - 1)];
-    });
-  }
   __syncthreads();                                     // everybody is done with gG and L_S
   BMAT_STAMP(5);
   if (tid < M) atomicAdd(&a.g_u_mean[(int64_t)c * M + tid], srs[tid] + srs[tid + 128]);
