@@ -210,6 +210,9 @@ typedef struct vargp_elbo_t0_desc {
   uint64_t rng_seed;
   uint32_t* rng_counter;
   int32_t rng_sample_offset;
+  /* 1: bwd leaves the gradients of log_mean / log_logvar to vargp_yogi_step_multi_hyper (see vargp_hyper_grad_desc): it does
+   * not touch g_log_mean / g_log_logvar (they may be NULL) and launches one kernel less */
+  int32_t defer_hyper;
 } vargp_elbo_t0_desc;
 size_t vargp_elbo_t0_workspace_bytes(int S, int C, int M, int D, int B, int F);
 int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t stream);
@@ -254,6 +257,7 @@ typedef struct vargp_elbo_tn_desc {
   uint32_t* rng_counter;
   int32_t rng_sample_offset;
   int32_t forward_only; /* 1: workspace sized by vargp_elbo_tn_workspace_bytes_fwd; moments only (y == NULL), no bwd / end */
+  int32_t defer_hyper;  /* as vargp_elbo_t0_desc.defer_hyper (vargp_elbo_tn_bwd only) */
 } vargp_elbo_tn_desc;
 size_t vargp_elbo_tn_workspace_bytes(int S, int C, int M, int D, int B, int F, int nblk);
 /* Workspace of a program that only ever evaluates predictive moments (VARGP.forward / predict, var_gp/vargp.py:115-131,
@@ -282,6 +286,25 @@ int vargp_elbo_tn_tile(const vargp_elbo_tn_desc* d, const float* seeds, const fl
                        int Bt, vargp_stream_t stream);
 int vargp_elbo_tn_end(const vargp_elbo_tn_desc* d, const float* seeds, float* g_log_mean, float* g_log_logvar, float* g_z,
                       float* g_u_mean, float* g_u_tril_vec, vargp_stream_t stream);
+
+/* The last step of either program's backward -- theta-gradient -> variational hyper-parameters (RBFKernel.sample_hypers /
+ * kl_hypers, var_gp/kernels.py:62-77: theta = mean + eps exp(logvar / 2), plus the gamma^2 of the predictive variance and the
+ * gradient of kl_hypers scaled by its seed) -- as data: what the deferred form needs to finish it inside the optimiser's
+ * launch.  Filled by vargp_elbo_t0_hyper_desc / vargp_elbo_tn_hyper_desc after a bwd with defer_hyper = 1 (pointers into
+ * the program's workspace: valid until its next fwd). */
+typedef struct vargp_hyper_grad_desc {
+  const float *log_mean, *log_logvar, *prior_log_mean, *prior_log_logvar;
+  const float *eps_theta, *gtheta, *g2, *gkd, *seeds;
+  int32_t S, C, D1, map_est;
+} vargp_hyper_grad_desc;
+int vargp_elbo_t0_hyper_desc(const vargp_elbo_t0_desc* d, const float* seeds, vargp_hyper_grad_desc* out);
+int vargp_elbo_tn_hyper_desc(const vargp_elbo_tn_desc* d, const float* seeds, vargp_hyper_grad_desc* out);
+/* vargp_yogi_step_multi with the gradients of tensors idx_mean (log_mean) and idx_logvar (log_logvar; -1 under map_est)
+ * computed on the fly from h (and stored to g[idx_*] as well): the step of experiments/vargp.py:35-37 with one launch less. */
+int vargp_yogi_step_multi_hyper(int ntensors, float* const* p, float* const* g, float* const* m, float* const* v,
+                                const int64_t* n, float lr, float beta1, float beta2, float eps, const float* step,
+                                int step_mode, const vargp_hyper_grad_desc* h, int idx_mean, int idx_logvar,
+                                vargp_stream_t stream);
 
 /* Same update for up to 8 tensors in one launch.  `step` (device float) = the step count t.
  * step_mode 0: use t as is.  1: use t + 1 (the caller advances the stored count elsewhere, e.g. through the `bump`

@@ -38,6 +38,15 @@ class ElboT0Desc(Structure):
         ('ws', c_void_p), ('ws_bytes', c_size_t),
         ('bump', c_void_p),
         ('rng_seed', ctypes.c_uint64), ('rng_counter', c_void_p), ('rng_sample_offset', c_int32),
+        ('defer_hyper', c_int32),
+    ]
+
+
+class HyperGradDesc(Structure):
+    _fields_ = [
+        ('log_mean', c_void_p), ('log_logvar', c_void_p), ('prior_log_mean', c_void_p), ('prior_log_logvar', c_void_p),
+        ('eps_theta', c_void_p), ('gtheta', c_void_p), ('g2', c_void_p), ('gkd', c_void_p), ('seeds', c_void_p),
+        ('S', c_int32), ('C', c_int32), ('D1', c_int32), ('map_est', c_int32),
     ]
 
 
@@ -54,7 +63,7 @@ class ElboTnDesc(Structure):
         ('ws', c_void_p), ('ws_bytes', c_size_t),
         ('bump', c_void_p),
         ('rng_seed', ctypes.c_uint64), ('rng_counter', c_void_p), ('rng_sample_offset', c_int32),
-        ('forward_only', c_int32),
+        ('forward_only', c_int32), ('defer_hyper', c_int32),
     ]
 
 
@@ -86,6 +95,10 @@ _SIGNATURES = {
     'vargp_softmax_nll_bwd': (c_int, [_P] * 7 + [c_int, c_int, c_int, c_int, _P]),
     'vargp_softmax_predict': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     'vargp_yogi_step_multi': (c_int, [c_int, _P, _P, _P, _P, _P] + [c_float] * 4 + [_P, c_int, _P]),
+    'vargp_yogi_step_multi_hyper': (c_int, [c_int, _P, _P, _P, _P, _P] + [c_float] * 4 + [_P, c_int, POINTER(HyperGradDesc), c_int,
+                                            c_int, _P]),
+    'vargp_elbo_t0_hyper_desc': (c_int, [POINTER(ElboT0Desc), _P, POINTER(HyperGradDesc)]),
+    'vargp_elbo_tn_hyper_desc': (c_int, [POINTER(ElboTnDesc), _P, POINTER(HyperGradDesc)]),
     'vargp_hyper_sample_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
     'vargp_hyper_sample_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P]),
     'vargp_hyper_kl_fwd': (c_int, [_P, _P, _P, _P, _P, c_int, _P]),

@@ -92,9 +92,40 @@ struct YogiPack {
   int blk_end[8];   // exclusive prefix of the blocks assigned to each tensor (kYogiPerBlock elements per block)
 };
 constexpr int kYogiPerBlock = 1024;   // 256 threads x 4 elements
+struct YogiHyper { vargp_hyper_grad_desc h; int idx_mean, idx_logvar; };     // idx_mean < 0: off
+// gradients of log_mean[d] and log_logvar[d]: the arithmetic of t0_hyper_bwd_kernel (elbo_shared.h).  tm / tv: the block's
+// sums over (s, c) of the gamma^2 terms (only added at d = D)
+__device__ __forceinline__ void yogi_hyper_grad(const vargp_hyper_grad_desc& h, int d, float tm, float tv, float& gm, float& gv) {
+  const int D1 = h.D1, D = D1 - 1;
+  const int dc = d < D1 ? d : D1 - 1;
+  const float hs = h.map_est ? 0.f : 0.5f * expf(0.5f * h.log_logvar[dc]);
+  gm = 0.f; gv = 0.f;
+  for (int s0 = 0; s0 < h.S; s0 += 8) {          // eight samples per batch, loads first
+    float gt[8], ev[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int s = min(s0 + u, h.S - 1);
+      gt[u] = h.gtheta[s * D1 + dc];
+      ev[u] = h.map_est ? 0.f : h.eps_theta[s * D1 + dc];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (s0 + u < h.S) {
+        gm += gt[u];
+        if (!h.map_est) gv = fmaf(gt[u] * hs, ev[u], gv);
+      }
+    }
+  }
+  if (d == D) { gm += tm; gv += tv; }
+  if (!h.map_est) {
+    const float g = h.seeds[0];
+    gm += g * (h.log_mean[dc] - h.prior_log_mean[dc]) * expf(-h.prior_log_logvar[dc]);
+    gv += g * 0.5f * (expf(h.log_logvar[dc] - h.prior_log_logvar[dc]) - 1.f);
+  }
+}
 // step_mode 0: t = step[0].  1: t = step[0] + 1 (the caller advances the stored count some other way).
 __global__ __launch_bounds__(256) void yogi_multi_kernel(YogiPack pk, int ntensors, float lr, float b1, float b2, float eps,
-                                                         const float* __restrict__ step, int step_mode) {
+                                                         const float* __restrict__ step, int step_mode, const YogiHyper yh) {
   int t = 0;
   while (t + 1 < ntensors && (int)blockIdx.x >= pk.blk_end[t]) ++t;
   const int blk = (int)blockIdx.x - (t ? pk.blk_end[t - 1] : 0);
@@ -103,6 +134,47 @@ __global__ __launch_bounds__(256) void yogi_multi_kernel(YogiPack pk, int ntenso
   const float* __restrict__ g = pk.g[t];
   float* __restrict__ m = pk.m[t];
   float* __restrict__ v = pk.v[t];
+  if (yh.idx_mean >= 0 && (t == yh.idx_mean || t == yh.idx_logvar)) {
+    // the variational hyper-parameters: their gradient is finished here (deferred by the ELBO program's backward).
+    // The whole block shares out the S C gamma^2 terms of the predictive variance (theta_D) when it holds d = D.
+    __shared__ float red[4];
+    const vargp_hyper_grad_desc& h = yh.h;
+    const int D = h.D1 - 1;
+    const float tt = step[0] + (step_mode ? 1.f : 0.f);
+    const float bias1 = 1.f - powf(b1, tt), sb2 = sqrtf(1.f - powf(b2, tt));
+    float tm = 0.f, tv = 0.f;
+    if (blk == D / 256) {                     // (uniform)
+      const float hsD = h.map_est ? 0.f : 0.5f * expf(0.5f * h.log_logvar[D]);
+      float am = 0.f, av = 0.f;
+      for (int e = threadIdx.x; e < h.S * h.C; e += 256) {
+        const int s = e / h.C;
+        const float tq = 2.f * h.g2[s] * h.gkd[e];
+        am += tq;
+        if (!h.map_est) av = fmaf(tq * hsD, h.eps_theta[s * h.D1 + D], av);
+      }
+      tm = block_sum<256>(am, red);
+      __syncthreads();
+      tv = block_sum<256>(av, red);
+    }
+    const bool lv = t == yh.idx_logvar;
+    {     // ONE element per thread (these two tensors get a block per 256 elements): the gradient is a chain of dependent loads
+      const int64_t i = (int64_t)blk * 256 + threadIdx.x;
+      float gm, gv;
+      yogi_hyper_grad(h, (int)min(i, n - 1), tm, tv, gm, gv);
+      if (i < n) {
+        const float gi = lv ? gv : gm;
+        const_cast<float*>(g)[i] = gi;
+        float pi = p[i], mi = m[i], vi = v[i];
+        const float g2 = gi * gi;
+        mi = b1 * mi + (1.f - b1) * gi;
+        const float df = vi - g2;
+        vi -= (1.f - b2) * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * g2;
+        pi -= (lr / bias1) * mi / (sqrtf(vi) / sb2 + eps);
+        p[i] = pi; m[i] = mi; v[i] = vi;
+      }
+    }
+    return;
+  }
   const float tt = step[0] + (step_mode ? 1.f : 0.f);
   const float bias1 = 1.f - powf(b1, tt), sb2 = sqrtf(1.f - powf(b2, tt));
   auto upd = [&](float& pi, float gi, float& mi, float& vi) {
@@ -230,7 +302,37 @@ extern "C" int vargp_yogi_step_multi(int ntensors, float* const* p, const float*
     pk.blk_end[i] = nblk;
   }
   if (nblk == 0) return VARGP_OK;
+  YogiHyper yh{};
+  yh.idx_mean = -1; yh.idx_logvar = -1;
   hipLaunchKernelGGL(yogi_multi_kernel, dim3(nblk), dim3(256), 0, as_stream(stream), pk, ntensors, lr, beta1, beta2, eps,
-                     step, step_mode);
+                     step, step_mode, yh);
   return check_launch("yogi_step_multi");
+}
+
+extern "C" int vargp_yogi_step_multi_hyper(int ntensors, float* const* p, float* const* g, float* const* m, float* const* v,
+                                           const int64_t* n, float lr, float beta1, float beta2, float eps, const float* step,
+                                           int step_mode, const vargp_hyper_grad_desc* h, int idx_mean, int idx_logvar,
+                                           vargp_stream_t stream) {
+  VARGP_REQUIRE(ntensors > 0 && ntensors <= 8 && p && g && m && v && n && step && h, "yogi_step_multi_hyper: bad arguments");
+  VARGP_REQUIRE(step_mode == 0 || step_mode == 1, "yogi_step_multi_hyper: bad step_mode");
+  VARGP_REQUIRE(idx_mean >= 0 && idx_mean < ntensors && idx_logvar < ntensors && n[idx_mean] == h->D1 &&
+                    (idx_logvar < 0 || n[idx_logvar] == h->D1) && (idx_logvar >= 0 || h->map_est),
+                "yogi_step_multi_hyper: tensor indices / sizes do not match the hyper-parameter descriptor");
+  VARGP_REQUIRE(h->S > 0 && h->C > 0, "yogi_step_multi_hyper: bad dims");
+  VARGP_REQUIRE(h->log_mean && h->gtheta && h->g2 && h->gkd && h->seeds &&
+                    (h->map_est || (h->log_logvar && h->prior_log_mean && h->prior_log_logvar && h->eps_theta)),
+                "yogi_step_multi_hyper: null pointer in the hyper-parameter descriptor");
+  YogiPack pk{};
+  int nblk = 0;
+  for (int i = 0; i < ntensors; ++i) {
+    pk.p[i] = p[i]; pk.g[i] = g[i]; pk.m[i] = m[i]; pk.v[i] = v[i]; pk.n[i] = n[i];
+    nblk += cdiv(n[i], (i == idx_mean || i == idx_logvar) ? 256 : kYogiPerBlock);
+    pk.blk_end[i] = nblk;
+  }
+  if (nblk == 0) return VARGP_OK;
+  YogiHyper yh{};
+  yh.h = *h; yh.idx_mean = idx_mean; yh.idx_logvar = idx_logvar;
+  hipLaunchKernelGGL(yogi_multi_kernel, dim3(nblk), dim3(256), 0, as_stream(stream), pk, ntensors, lr, beta1, beta2, eps,
+                     step, step_mode, yh);
+  return check_launch("yogi_step_multi_hyper");
 }

@@ -395,10 +395,15 @@ __global__ __launch_bounds__(256) void t0_fwd_fused_kernel(const float* __restri
   float* sa = sK + kFusedK * kFusedKS;            // [128]       a = Lz^-1 m
   float* red = sa + 128;                          // [3][64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-  const int64_t b = blockIdx.y;
+  // 1-D grid, XCD-aware (as t0_bwd_mid_kernel): XCD x works through the matrices b = x, x + 8, ..., all tiles of one before the
+  // next, so that the tiles of an (s, c) find its T and G in ONE L2 (grid = 8 ceil(SC / 8) ntile; the surplus exits)
+  const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
+  const int64_t b = (int64_t)(idx / ntile) * 8 + xcd;
   const int64_t MM = (int64_t)M * M, MLD = (int64_t)M * LD;
-  if (rng_counter && blockIdx.x == 0 && b == 0 && tid == 0) rng_counter[0] += 1u;   // this step's noise has been drawn
-  const int n0 = (int)blockIdx.x * 64;
+  if (rng_counter && blockIdx.x == 0 && tid == 0) rng_counter[0] += 1u;   // this step's noise has been drawn
+  if (b >= (int64_t)S * C) return;
+  const int tile_x = idx % ntile;
+  const int n0 = tile_x * 64;
   // ---- stage T, G, the K_uf tile and a (zero-padded: rows / inner indices >= M, columns >= B) ----------------------------
   const float* Tb = TT + b * MM;
   const float* Qb = QP + b * MLD;
@@ -409,7 +414,7 @@ __global__ __launch_bounds__(256) void t0_fwd_fused_kernel(const float* __restri
   float kl_acc = 0.f;
   {
     const int c = b % C;
-    const int per = (M + ntile - 1) / ntile, i0 = (int)blockIdx.x * per, i1 = min(M, i0 + per);
+    const int per = (M + ntile - 1) / ntile, i0 = tile_x * per, i1 = min(M, i0 + per);
     for (int e = tid; e < (i1 - i0) * M; e += 256) {      // branch-free: upper entries are stored zeros
       const int i = i0 + e / M, j = e % M;
       const float v = Qb[(int64_t)i * LD + 4 + M + j];
@@ -899,7 +904,7 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
     static std::atomic<unsigned> attr_set_mask[2] = {};      // 64 device ordinals
     rc = ensure_dynamic_lds(reinterpret_cast<const void*>(t0_fwd_fused_kernel), kFusedLdsBytes, attr_set_mask, "elbo_t0_fwd");
     if (rc) return rc;
-    hipLaunchKernelGGL(t0_fwd_fused_kernel, dim3(ntile, SC), dim3(256), kFusedLdsBytes, st, o.TT, o.QP, o.RK, o.W, o.kd, o.LL,
+    hipLaunchKernelGGL(t0_fwd_fused_kernel, dim3(8 * cdiv(SC, 8) * ntile), dim3(256), kFusedLdsBytes, st, o.TT, o.QP, o.RK, o.W, o.kd, o.LL,
                        o.Lu, o.mu, o.var, d->scalars + 1, S, C, M, B, NR, LD, ntile, native ? d->rng_counter : nullptr);
   } else {
     {  // QP = T RK
@@ -933,7 +938,8 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
                                  float* g_z, float* g_u_mean, float* g_u_tril_vec, vargp_stream_t stream) {
   int rc = check_desc(d, "elbo_t0_bwd");
   if (rc) return rc;
-  VARGP_REQUIRE(seeds && g_log_mean && g_log_logvar && g_z && g_u_mean && g_u_tril_vec, "elbo_t0_bwd: null pointer");
+  VARGP_REQUIRE(seeds && g_z && g_u_mean && g_u_tril_vec && (d->defer_hyper || (g_log_mean && g_log_logvar)),
+                "elbo_t0_bwd: null pointer");
   hipStream_t st = as_stream(stream);
   const int S = d->S, C = d->C, M = d->M, D = d->D, B = d->B, F = d->F, SC = S * C;
   const T0Ws o = carve_t0(d->ws, S, C, M, D, B, F);
@@ -974,7 +980,7 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
     if (rc) return rc;
     {
       ProfScope prof("t0_bwd_mid", st);
-      hipLaunchKernelGGL(t0_bwd_mid_kernel, dim3(ntile, SC), dim3(256), kBwdMidLdsBytes, st, o.TT, o.QP, o.W, o.RK, o.gmu, o.gvar,
+      hipLaunchKernelGGL(t0_bwd_mid_kernel, dim3(8 * cdiv(SC, 8) * ntile), dim3(256), kBwdMidLdsBytes, st, o.TT, o.QP, o.W, o.RK, o.gmu, o.gvar,
                          fused_softmax ? seeds + 2 : nullptr, o.gQP, o.gTT, o.gRK, o.gkd, o.r_uf, o.c_uf, o.gtheta, S, C, M, B, D,
                          NR, LD, ntile);
     }
@@ -1072,8 +1078,22 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
     hipLaunchKernelGGL(t0_final_kernel, dim3(gx, nzy + nxy + ngy), dim3(256), 0, st, d->z, d->x, o.r_uu, o.r_uf, o.c_uf,
                        o.Puu, o.Puf, o.w, g_z, o.gtheta, zrows, (int64_t)B, D, o.Dp, S, nzy, gv);
   }
-  hipLaunchKernelGGL(t0_hyper_bwd_kernel, dim3(cdiv(D + 1, 256)), dim3(256), 0, st, d->log_mean, d->log_logvar,
-                     d->prior_log_mean, d->prior_log_logvar, eps_theta, o.gtheta, o.g2, o.gkd, seeds, g_log_mean,
-                     g_log_logvar, S, C, D + 1, d->map_est);
+  if (!d->defer_hyper)
+    hipLaunchKernelGGL(t0_hyper_bwd_kernel, dim3(cdiv(D + 1, 256)), dim3(256), 0, st, d->log_mean, d->log_logvar,
+                       d->prior_log_mean, d->prior_log_logvar, eps_theta, o.gtheta, o.g2, o.gkd, seeds, g_log_mean,
+                       g_log_logvar, S, C, D + 1, d->map_est);
   return check_launch("elbo_t0_bwd");
+}
+
+extern "C" int vargp_elbo_t0_hyper_desc(const vargp_elbo_t0_desc* d, const float* seeds, vargp_hyper_grad_desc* out) {
+  int rc = check_desc(d, "elbo_t0_hyper_desc");
+  if (rc) return rc;
+  VARGP_REQUIRE(seeds && out, "elbo_t0_hyper_desc: null pointer");
+  const T0Ws o = carve_t0(d->ws, d->S, d->C, d->M, d->D, d->B, d->F);
+  out->log_mean = d->log_mean; out->log_logvar = d->log_logvar;
+  out->prior_log_mean = d->prior_log_mean; out->prior_log_logvar = d->prior_log_logvar;
+  out->eps_theta = d->eps_f == nullptr ? o.eps_theta : d->eps_theta;
+  out->gtheta = o.gtheta; out->g2 = o.g2; out->gkd = o.gkd; out->seeds = seeds;
+  out->S = d->S; out->C = d->C; out->D1 = d->D + 1; out->map_est = d->map_est;
+  return VARGP_OK;
 }

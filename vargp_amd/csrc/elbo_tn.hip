@@ -632,7 +632,8 @@ extern "C" int vargp_elbo_tn_bwd(const vargp_elbo_tn_desc* d, const float* seeds
                                  float* g_z, float* g_u_mean, float* g_u_tril_vec, vargp_stream_t stream) {
   int rc = check_tn(d, "elbo_tn_bwd");
   if (rc) return rc;
-  VARGP_REQUIRE(seeds && g_log_mean && g_log_logvar && g_z && g_u_mean && g_u_tril_vec && d->y, "elbo_tn_bwd: null pointer");
+  VARGP_REQUIRE(seeds && g_z && g_u_mean && g_u_tril_vec && d->y && (d->defer_hyper || (g_log_mean && g_log_logvar)),
+                "elbo_tn_bwd: null pointer");
   VARGP_REQUIRE(!d->forward_only, "elbo_tn_bwd: the program was carved forward_only");
   hipStream_t st = as_stream(stream);
   const int S = d->S, C = d->C, M = d->M, D = d->D, B = d->B, F = d->F, nblk = d->nblk, SC = S * C;
@@ -794,10 +795,24 @@ extern "C" int vargp_elbo_tn_bwd(const vargp_elbo_tn_desc* d, const float* seeds
                        d->rk_all + (int64_t)(nblk - 1) * M * NRs, seeds, o.gz_all, g_u_mean, g_u_tril_vec, g_z, S, C, M, Mt, D,
                        NRs, nblk, nun);
   }
-  hipLaunchKernelGGL(t0_hyper_bwd_kernel, dim3(cdiv(D + 1, 256)), dim3(256), 0, st, d->log_mean, d->log_logvar,
-                     d->prior_log_mean, d->prior_log_logvar, eps_theta, o.gtheta, o.g2, o.gkd, seeds, g_log_mean,
-                     g_log_logvar, S, C, D + 1, d->map_est);
+  if (!d->defer_hyper)
+    hipLaunchKernelGGL(t0_hyper_bwd_kernel, dim3(cdiv(D + 1, 256)), dim3(256), 0, st, d->log_mean, d->log_logvar,
+                       d->prior_log_mean, d->prior_log_logvar, eps_theta, o.gtheta, o.g2, o.gkd, seeds, g_log_mean,
+                       g_log_logvar, S, C, D + 1, d->map_est);
   return check_launch("elbo_tn_bwd");
+}
+
+extern "C" int vargp_elbo_tn_hyper_desc(const vargp_elbo_tn_desc* d, const float* seeds, vargp_hyper_grad_desc* out) {
+  int rc = check_tn(d, "elbo_tn_hyper_desc");
+  if (rc) return rc;
+  VARGP_REQUIRE(seeds && out && !d->forward_only, "elbo_tn_hyper_desc: bad arguments");
+  const TnWs o = carve_tn(d->ws, d->S, d->C, d->M, d->D, d->B, d->F, d->nblk);
+  out->log_mean = d->log_mean; out->log_logvar = d->log_logvar;
+  out->prior_log_mean = d->prior_log_mean; out->prior_log_logvar = d->prior_log_logvar;
+  out->eps_theta = d->eps_f == nullptr ? o.eps_theta : d->eps_theta;
+  out->gtheta = o.gtheta; out->g2 = o.g2; out->gkd = o.gkd; out->seeds = seeds;
+  out->S = d->S; out->C = d->C; out->D1 = d->D + 1; out->map_est = d->map_est;
+  return VARGP_OK;
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -177,7 +177,7 @@ __device__ __forceinline__ void bm_tail_atomics(const bm_f32x16 (&acc)[3], float
 #ifdef BM_STAMPS   // per-phase cycle accounting (workgroup (0, 0), thread 0), tuning builds only: tests/native/bm_stamps.py
 __device__ unsigned long long g_bm_stamps[16];
 extern "C" void vargp_debug_bm_stamps(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bm_stamps), 128); }
-#define BM_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_bm_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define BM_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_bm_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define BM_STAMP(i) do { } while (0)
 #endif
@@ -240,8 +240,13 @@ __global__ __launch_bounds__(256) void t0_bwd_mid_kernel(const float* __restrict
   float* sgv = sgm + 64;                            // [64]       seed * gvar
   float* scs = sgv + 64;                            // [64]       column sums of W_uf
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-  const int64_t b = blockIdx.y;
-  const int n0 = (int)blockIdx.x * 64;
+  // 1-D grid, XCD-aware: workgroups go to the 8 XCDs round-robin by linear id, and the tiles of one (s, c) share G and T -- with
+  // (tile, b) = (id % ntile, id / ntile) the 8 tiles of a matrix sat on 8 different L2s.  Here XCD x works through the
+  // matrices b = x, x + 8, ..., all tiles of one before the next (grid = 8 ceil(SC / 8) ntile; the surplus exits).
+  const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
+  const int64_t b = (int64_t)(idx / ntile) * 8 + xcd;
+  if (b >= (int64_t)S * C) return;
+  const int n0 = (idx % ntile) * 64;
   const int64_t MM = (int64_t)M * M, MLD = (int64_t)M * LD;
   const float* Qb = QP + b * MLD;
   const float* Tb = TT + b * MM;
@@ -428,7 +433,6 @@ __global__ __launch_bounds__(256) void t0_bwd_mid_kernel(const float* __restrict
     }
   }
   BM_STAMP(12);
-  (void)S; (void)ntile;
 }
 
 }  // namespace vargp

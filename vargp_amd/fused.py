@@ -21,7 +21,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from . import ops
-from ._lib import ElboT0Desc, ElboTnDesc, check, lib, ptr, require_device, stream_ptr, workspace
+from ._lib import ElboT0Desc, ElboTnDesc, HyperGradDesc, check, lib, ptr, require_device, stream_ptr, workspace
 from .ops import JITTER
 
 
@@ -103,14 +103,24 @@ class T0Program:
         ops._note_chol_errors(self.info)
         return self.scalars
 
-    def backward(self, seeds, g_log_mean, g_log_logvar, g_z, g_u_mean, g_u_tril_vec):
-        """seeds (3,) device = d total / d (kl_hypers, kl_u, nll); overwrites the five gradient buffers."""
+    def backward(self, seeds, g_log_mean, g_log_logvar, g_z, g_u_mean, g_u_tril_vec, defer_hyper=False):
+        """seeds (3,) device = d total / d (kl_hypers, kl_u, nll); overwrites the five gradient buffers.
+        defer_hyper: the last kernel (theta-gradient -> log_mean / log_logvar) is left to the optimiser's launch
+        (`hyper_desc()` -> optim.Yogi.step(hyper=...)); g_log_mean / g_log_logvar are then written by that launch."""
         require_device(seeds, g_log_mean, g_log_logvar, g_z, g_u_mean, g_u_tril_vec)
         assert self._keep is not None, 'T0Program.backward without a forward'
         for g in (g_log_mean, g_log_logvar, g_z, g_u_mean, g_u_tril_vec):
             assert g.is_contiguous() and g.dtype == torch.float32
+        self.desc.defer_hyper = int(bool(defer_hyper))
+        self._seeds = seeds
         check(lib().vargp_elbo_t0_bwd(ctypes.byref(self.desc), ptr(seeds), ptr(g_log_mean), ptr(g_log_logvar), ptr(g_z),
                                       ptr(g_u_mean), ptr(g_u_tril_vec), stream_ptr()), 'vargp_elbo_t0_bwd')
+
+    def hyper_desc(self):
+        """What the deferred last step of `backward(defer_hyper=True)` needs (pointers into this program's workspace)."""
+        h = HyperGradDesc()
+        check(lib().vargp_elbo_t0_hyper_desc(ctypes.byref(self.desc), ptr(self._seeds), ctypes.byref(h)), 'vargp_elbo_t0_hyper_desc')
+        return h
 
     def theta(self):
         """The hyper-parameter samples of the last forward, (S, D+1) (view into the workspace)."""
@@ -293,13 +303,21 @@ class TnProgram:
         ops._note_chol_errors(self.info)
         return self.scalars if y is not None else None
 
-    def backward(self, seeds, g_log_mean, g_log_logvar, g_z, g_u_mean, g_u_tril_vec):
+    def backward(self, seeds, g_log_mean, g_log_logvar, g_z, g_u_mean, g_u_tril_vec, defer_hyper=False):
+        """As T0Program.backward."""
         require_device(seeds, g_log_mean, g_log_logvar, g_z, g_u_mean, g_u_tril_vec)
         assert self._keep is not None, 'TnProgram.backward without a forward'
         for g in (g_log_mean, g_log_logvar, g_z, g_u_mean, g_u_tril_vec):
             assert g.is_contiguous() and g.dtype == torch.float32
+        self.desc.defer_hyper = int(bool(defer_hyper))
+        self._seeds = seeds
         check(lib().vargp_elbo_tn_bwd(ctypes.byref(self.desc), ptr(seeds), ptr(g_log_mean), ptr(g_log_logvar), ptr(g_z),
                                       ptr(g_u_mean), ptr(g_u_tril_vec), stream_ptr()), 'vargp_elbo_tn_bwd')
+
+    def hyper_desc(self):
+        h = HyperGradDesc()
+        check(lib().vargp_elbo_tn_hyper_desc(ctypes.byref(self.desc), ptr(self._seeds), ctypes.byref(h)), 'vargp_elbo_tn_hyper_desc')
+        return h
 
 
     # -- N-tiled ELBO: loss and gradient over a data set swept in minibatch tiles (vargp_elbo_tn_begin / _tile / _end) ----

@@ -28,10 +28,12 @@ class Yogi(torch.optim.Optimizer):
         return group['step']
 
     @torch.no_grad()
-    def step(self):
+    def step(self, hyper=None):
         """One fused launch for all parameter tensors of a group (<= 8).  The step count lives on the
         device (bias corrections are computed inside the kernel), so the whole step can sit inside a
-        captured hipGraph."""
+        captured hipGraph.
+        hyper = (HyperGradDesc, log_mean, log_logvar): the gradients of those two parameters are finished inside this
+        launch (an ELBO program's backward ran with defer_hyper=True) and stored into their .grad as well."""
         for group in self.param_groups:
             b1, b2 = group['betas']
             ps = [p for p in group['params'] if p.grad is not None]
@@ -53,6 +55,16 @@ class Yogi(torch.optim.Optimizer):
                 grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in chunk]
                 arr = lambda ts: (ctypes.c_void_p * k)(*[t.data_ptr() for t in ts])
                 sizes = (ctypes.c_int64 * k)(*[p.numel() for p in chunk])
+                ids = [id(p) for p in chunk]
+                if hyper is not None and id(hyper[1]) in ids:
+                    h, p_mean, p_logvar = hyper
+                    i_lv = ids.index(id(p_logvar)) if (p_logvar is not None and id(p_logvar) in ids) else -1
+                    check(lib().vargp_yogi_step_multi_hyper(
+                        k, arr(chunk), arr(grads), arr([self.state[p]['exp_avg'] for p in chunk]),
+                        arr([self.state[p]['exp_avg_sq'] for p in chunk]), sizes, group['lr'], b1, b2, group['eps'],
+                        ptr(group['step']), 0, ctypes.byref(h), ids.index(id(p_mean)), i_lv, stream_ptr()),
+                        'vargp_yogi_step_multi_hyper')
+                    continue
                 check(lib().vargp_yogi_step_multi(k, arr(chunk), arr(grads), arr([self.state[p]['exp_avg'] for p in chunk]),
                                                   arr([self.state[p]['exp_avg_sq'] for p in chunk]), sizes,
                                                   group['lr'], b1, b2, group['eps'], ptr(group['step']), 0,

@@ -191,8 +191,15 @@ class ElboTrainer:
                 self._own_grads = [torch.empty_like(p) for p in self.params]
             for p, g in zip(self.params, self._own_grads):
                 p.grad = g
-            scal = self._t0_fwd_bwd(x, y, scale, 1.0)
-            self.optim.step()
+            # one GPU, our Yogi over one parameter group: the program's last kernel (theta-gradient -> log_mean / log_logvar)
+            # is finished inside the optimiser's launch
+            defer = self._defer_hyper()
+            scal = self._t0_fwd_bwd(x, y, scale, 1.0, defer_hyper=defer)
+            if defer:
+                k = self.gp.kernel
+                self.optim.step(hyper=(self._prog.hyper_desc(), k.log_mean, k.log_logvar))
+            else:
+                self.optim.step()
             return scal[0], scal[1], scal[2]
         if not self.multi:
             # single GPU: let autograd hand the gradients over (no zero-fill, no accumulate kernels)
@@ -207,7 +214,13 @@ class ElboTrainer:
         self.optim.step()
         return out
 
-    def _t0_fwd_bwd(self, x, y, scale, w):
+    def _defer_hyper(self):
+        k = self.gp.kernel
+        return (isinstance(self.optim, Yogi) and len(self.optim.param_groups) == 1 and len(self.params) <= 8
+                and any(p is k.log_mean for p in self.params)
+                and os.environ.get('VARGP_DEFER_HYPER', '1') != '0')
+
+    def _t0_fwd_bwd(self, x, y, scale, w, defer_hyper=False):
         """Native first-task program: scalars (kl_hypers, kl_u, nll) of this rank's samples, and the gradient of
         w * (beta kl_hypers + kl_u + scale nll) written into every p.grad."""
         from .fused import T0Program, TnProgram
@@ -237,7 +250,7 @@ class ElboTrainer:
                                   kern.prior_log_logvar, gp.z.detach(), gp.u_mean.detach(), gp.u_tril_vec.detach(), *packed,
                                   x, y, eps_theta, eps_f, bump=self._bump)
         self._prog.backward(self._seeds[key], kern.log_mean.grad, kern.log_logvar.grad, gp.z.grad, gp.u_mean.grad,
-                            gp.u_tril_vec.grad)
+                            gp.u_tril_vec.grad, defer_hyper=defer_hyper)
         return scal
 
     def _local_part(self, x, y):
