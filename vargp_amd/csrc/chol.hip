@@ -16,6 +16,7 @@ extern "C" void vargp_debug_chol_stamps(unsigned long long* out) { (void)hipMemc
 #define STAMP(i) do { } while (0)
 #endif
 #include <math.h>
+#include <functional>
 #include <type_traits>
 #include <stdlib.h>
 #include "chol_small3.h"
@@ -36,6 +37,21 @@ constexpr int kNbMax = 100;     // widest panel of the blocked algorithm (multip
 static int panel_width() {
   static const int v = [] { const char* e = getenv("VARGP_CHOL_PANEL"); const int x = e ? atoi(e) : kNbMax; return (x >= 32 && x <= kNbMax && x % 4 == 0) ? x : kNbMax; }();
   return v;
+}
+
+// Outer panel of the two-level blocked factorisation (multiple of the inner width nb): 2 nb from n = 12 nb on, else one level.
+// Measured at n = 2048 (MI355X, tests/native/chol_err.py; fp32 LAPACK: L 4.8e-6, T 1.35e-5 relative to fp64):
+//   one level      L 7.0e-6  T 2.0e-5   factorisation + inverse of 10 matrices 0.168 of the f32 MFMA peak, Permuted-MNIST t=9 18.8 steps/s
+//   outer 2 nb     L 9.6e-6  T 2.8e-5   0.187, 19.6
+//   outer 4 nb     L 1.24e-5 T 3.6e-5   0.201, 20.0
+// The longer the K of the trailing update, the longer the sequential fp32 accumulation inside the MFMA (K = 100 chunks added
+// into the matrix act as a blocked summation): 4 nb is past the "within 2x of fp32 LAPACK" bar the tests hold, 2 nb is inside.
+// VARGP_CHOL_PANEL2 (tuning aid): 0 = one level, otherwise the outer width in units of nb.
+static int outer_panel_width(int n, int nb) {
+  static const int v = [] { const char* e = getenv("VARGP_CHOL_PANEL2"); return e ? atoi(e) : -1; }();
+  if (v == 0) return nb;
+  if (v > 0) return v * nb < n ? v * nb : nb;
+  return n >= 12 * nb ? 2 * nb : nb;
 }
 
 template <typename F> __device__ __forceinline__ F rcp_of(F d);
@@ -284,7 +300,8 @@ extern "C" size_t vargp_chol_workspace_bytes(int nbatch, int n, int backward) {
   const size_t nn = (size_t)nbatch * n * n * sizeof(float);
   if (backward) return 2 * nn + 256;
   if (n <= kSmallMax) return 256;
-  return nn + (size_t)nbatch * n * kNbMax * sizeof(float) + 256;
+  const int wide = n < 4 * kNbMax ? n : 4 * kNbMax;                                       // widest (outer) panel any setting uses
+  return nn + 2 * (size_t)nbatch * n * wide * sizeof(float) + 256;                        // W + two scratch strips (n x widest panel)
 }
 
 extern "C" int vargp_chol_inv_fwd(const float* A, float eps, float* L, float* T, float* logdet, int32_t* info,
@@ -319,91 +336,120 @@ int vargp::chol_inv_fwd_impl(const float* A, float eps, float* L, float* T, floa
   float* W = reinterpret_cast<float*>(ws);
   float* tmp = W + (int64_t)nbatch * nn;
   const int kNbSmall = panel_width();
-  const int64_t stmp = (int64_t)n * kNbSmall;
+  const int NB2 = outer_panel_width(n, kNbSmall);       // == kNbSmall: one level
+  const int64_t stmp = (int64_t)n * NB2;
   float* Tout = T;
   hipLaunchKernelGGL(chol_prep_kernel, dim3(cdiv(nn, 256), nbatch), dim3(256), 0, st, A, W, L, Tout, n, eps, kNbSmall);
-  int rc;
-  for (int k0 = 0; k0 < n; k0 += kNbSmall) {
-    const int kb = (n - k0 < kNbSmall) ? n - k0 : kNbSmall;
-    const int k1 = k0 + kb, rem = n - k1;
-    const int64_t dkk = (int64_t)k0 * n + k0;
-    // diagonal block: L_kk, T_kk.  The panel solve needs T_kk even when the caller skips T: park
-    // it in tmp's head in that case.
-    float* Tkk = Tout ? Tout + dkk : tmp;
-    const int ldt = Tout ? n : kb;
-    const int64_t sT = Tout ? nn : stmp;
-    const int kpanel = k0 / kNbSmall;
-    if (kpanel < nco && Tout && !logdet && info && chol_rbf_gemm_applicable(kb, co[kpanel]) &&
-        co_gemm_is_comparable(co[kpanel], co_nbatch)) {
-      // (chol3_body reports a failing pivot as info_base + j + 1; the merged kernel has no info_base: only the first
-      // panel's index is exact, later panels report the index within the panel -- non-zero is what callers test)
-      rc = launch_chol_rbf_gemm_ld(W + dkk, n, nn, 0.f, L + dkk, n, nn, Tkk, ldt, sT, info, nbatch, kb, co[kpanel], co_nbatch, st);
-      ++ndone;
-    } else {
-      rc = launch_small(W + dkk, n, nn, 0.f, L + dkk, n, nn, Tkk, ldt, sT, logdet, info, k0, nbatch, kb, k0 > 0, st);
-    }
-    if (rc) return rc;
-    // After the pivot chain of block k two independent pairs of products are due:
-    //   (a) the panel below it,           L_ik = W_ik T_kk^T                      (rem x kb),       then W_22 -= L_ik L_ik^T;
-    //   (b) block row k of T = L^-1,      T[k, :k0] = -T_kk (L[k, :k0] T[:k0, :k0])  (kb x k0)      (from L T = I: everything it
-    //       needs -- the earlier rows of T, row k of L, T_kk -- exists at this point; the column-wise order, which waits
-    //       for ALL chains, cost 2 (nblk - 1) launches of its own).
-    // The first product of (a) shares a launch with the first of (b), the second with the second, when they are mid-size.
-    const bool trow = Tout != nullptr && k0 > 0;
-    auto mk = [&](const float* A_, int lda, const float* B_, int ldb, float* C_, int ldc, const float* D_, float alpha,
-                  float beta, int M_, int N_, int K_, int triA, int triB, int triC) {
-      GemmParams p{};
-      p.A = A_; p.B = B_; p.C = C_; p.D = D_;
-      p.M = M_; p.N = N_; p.K = K_; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldd = ldc;
-      p.nb1 = 1; p.nb2 = 1;
-      p.sA[0] = (A_ == tmp) ? stmp : nn; p.sB[0] = (B_ == tmp) ? stmp : nn;
-      p.sC[0] = (C_ == tmp) ? stmp : nn; p.sD[0] = p.sC[0];
-      p.alpha = alpha; p.beta = D_ ? beta : 0.f;
-      p.triA = triA; p.triB = triB; p.triC = triC;
-      return p;
-    };
-    // strides of T_kk when it is parked in tmp (no T wanted) differ: only (a) runs then, through sq_gemm as before
-    if (!Tout) {
-      if (rem > 0) {
-        rc = sq_gemm(W + (int64_t)k1 * n + k0, n, nn, 0, 0, Tkk, ldt, sT, 1, 2, L + (int64_t)k1 * n + k0, n, nn,
-                     nullptr, 1.f, 0.f, rem, kb, kb, 0, nbatch, st);
-        if (rc) return rc;
-        float* W22 = W + (int64_t)k1 * n + k1;
-        rc = sq_gemm(L + (int64_t)k1 * n + k0, n, nn, 0, 0, L + (int64_t)k1 * n + k0, n, nn, 1, 0, W22, n, nn, W22,
-                     -1.f, 1.f, rem, rem, kb, 2, nbatch, st);
-        if (rc) return rc;
+  int rc = VARGP_OK;
+  // batched product on sub-blocks of the [nbatch, n, n] buffers (ld n, batch stride nn) or of tmp (ld ldtmp, stride stmp)
+  auto mk = [&](const float* A_, int lda, const float* B_, int ldb, float* C_, int ldc, const float* D_, float alpha, float beta,
+                int M_, int N_, int K_, int triA, int triB, int triC) {
+    GemmParams p{};
+    p.A = A_; p.B = B_; p.C = C_; p.D = D_;
+    p.M = M_; p.N = N_; p.K = K_; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldd = ldc;
+    p.nb1 = 1; p.nb2 = 1;
+    p.sA[0] = (A_ == tmp) ? stmp : nn; p.sB[0] = (B_ == tmp) ? stmp : nn;
+    p.sC[0] = (C_ == tmp) ? stmp : nn; p.sD[0] = p.sC[0];
+    p.alpha = alpha; p.beta = D_ ? beta : 0.f;
+    p.triA = triA; p.triB = triB; p.triC = triC;
+    return p;
+  };
+  auto wgs = [&](const GemmParams& p) { return (int64_t)cdiv(p.M, 64) * cdiv(p.N, 64) * nbatch; };
+  static const int trow_pair = [] { const char* e = getenv("VARGP_CHOL_TROW_PAIR"); return e ? atoi(e) : 1; }();   // tuning aid
+  // Right-looking, two levels: outer panels [K0, K1) of width NB2 (200 from n = 1200 on; NB2 == nb: the plain one-level
+  // algorithm), inside them panels [k0, k1) of the register kernel's width nb.  After diagonal block k:
+  //   (a1) the column of L below it, to the BOTTOM of the matrix:  L[k1:n, k] = W[k1:n, k] T_kk^T;
+  //   (a2) the rest of the OUTER PANEL's columns only:            W[k1:n, k1:K1] -= L[k1:n, k] L[k1:K1, k]^T;
+  //   (b)  block row k of T = L^-1 inside the outer block:        T[k, K0:k0] = -T_kk (L[k, K0:k0] T[K0:k0, K0:k0]);
+  // and after the last block of an outer panel
+  //   (A2) the trailing matrix, ONCE per outer panel with K = NB2: W[K1:n, K1:n] -= L[K1:n, K] L[K1:n, K]^T  (lower tiles);
+  //   (B)  block row K of T to the left of the outer block:        T[K, 0:K0] = -T_KK (L[K, 0:K0] T[0:K0, 0:K0]).
+  // Every L entry goes through the same arithmetic as in the one-level algorithm (panel solves against the fp64-accurate
+  // 100 x 100 inverse blocks); what changes is that the trailing matrix -- all the remaining n^2 entries, read and written --
+  // and the growing left part of T are passed over half as often, with K = 200 instead of 100 (which pads to 128 in 64-deep slabs).
+  // Independent products share launches when they are mid-size: (a1 || b1), (a2 || b2), (A2 || B1).
+  auto run_pair = [&](const GemmParams* x, int xA, int xB, const GemmParams* y, int yA, int yB, const char* tag) -> int {
+    if (x && y && trow_pair && wgs(*x) + wgs(*y) <= 4096) return launch_gemm_pair2(*x, xA, xB, nbatch, *y, yA, yB, nbatch, st, tag);
+    if (x) { const int r = launch_gemm(*x, xA, xB, nbatch, false, st, tag); if (r) return r; }
+    if (y) { const int r = launch_gemm(*y, yA, yB, nbatch, false, st, tag); if (r) return r; }
+    return VARGP_OK;
+  };
+  const int NBo = Tout ? NB2 : kNbSmall;
+  for (int K0 = 0; K0 < n; K0 += NBo) {
+    const int K1 = (K0 + NBo < n) ? K0 + NBo : n;
+    for (int k0 = K0; k0 < K1; k0 += kNbSmall) {
+      const int k1 = (k0 + kNbSmall < K1) ? k0 + kNbSmall : K1, kb = k1 - k0;
+      const int rem = n - k1;                      // rows below the block, to the bottom
+      const int ncol = K1 - k1;                    // columns of the outer panel still to come
+      const int64_t dkk = (int64_t)k0 * n + k0;
+      // diagonal block: L_kk, T_kk.  The panel solve needs T_kk even when the caller skips T: park it in tmp's head then.
+      float* Tkk = Tout ? Tout + dkk : tmp;
+      const int ldt = Tout ? n : kb;
+      const int64_t sT = Tout ? nn : stmp;
+      const int kpanel = k0 / kNbSmall;
+      if (kpanel < nco && Tout && !logdet && info && chol_rbf_gemm_applicable(kb, co[kpanel]) &&
+          co_gemm_is_comparable(co[kpanel], co_nbatch)) {
+        // (chol3_body reports a failing pivot as info_base + j + 1; the merged kernel has no info_base: only the first
+        // panel's index is exact, later panels report the index within the panel -- non-zero is what callers test)
+        rc = launch_chol_rbf_gemm_ld(W + dkk, n, nn, 0.f, L + dkk, n, nn, Tkk, ldt, sT, info, nbatch, kb, co[kpanel], co_nbatch, st);
+        ++ndone;
+      } else {
+        rc = launch_small(W + dkk, n, nn, 0.f, L + dkk, n, nn, Tkk, ldt, sT, logdet, info, k0, nbatch, kb, k0 > 0, st);
       }
-      continue;
-    }
-    float* W22 = W + (int64_t)k1 * n + k1;
-    // (a1) L_ik = W_ik T_kk^T (NT, T_kk lower: K clipped per column tile)   (b1) tmp = L[k, :k0] T[:k0, :k0] (NN, T lower)
-    const GemmParams a1 = mk(W + (int64_t)k1 * n + k0, n, Tkk, n, L + (int64_t)k1 * n + k0, n, nullptr, 1.f, 0.f, rem, kb, kb, 0, 2, 0);
-    const GemmParams b1 = mk(L + (int64_t)k0 * n, n, Tout, n, tmp, k0 > 0 ? k0 : 1, nullptr, 1.f, 0.f, kb, k0, k0, 0, 1, 0);
-    // (a2) W_22 -= L_ik L_ik^T (NT, lower tiles only, in place)            (b2) T[k, :k0] = -T_kk tmp (NN, T_kk lower)
-    const GemmParams a2 = mk(L + (int64_t)k1 * n + k0, n, L + (int64_t)k1 * n + k0, n, W22, n, W22, -1.f, 1.f, rem, rem, kb, 0, 0, 2);
-    const GemmParams b2 = mk(Tkk, n, tmp, k0 > 0 ? k0 : 1, Tout + (int64_t)k0 * n, n, nullptr, -1.f, 0.f, kb, k0, kb, 1, 0, 0);
-    auto wgs = [&](const GemmParams& p) { return (int64_t)cdiv(p.M, 64) * cdiv(p.N, 64) * nbatch; };
-    static const int trow_pair = [] { const char* e = getenv("VARGP_CHOL_TROW_PAIR"); return e ? atoi(e) : 1; }();   // tuning aid
-    if (rem > 0 && trow && trow_pair && wgs(a1) + wgs(b1) <= 4096 && wgs(a2) + wgs(b2) <= 4096) {
-      rc = launch_gemm_pair2(a1, 0, 1, nbatch, b1, 0, 0, nbatch, st, "chol_panel");
       if (rc) return rc;
-      rc = launch_gemm_pair2(a2, 0, 1, nbatch, b2, 0, 0, nbatch, st, "chol_panel");
-      if (rc) return rc;
-    } else {
-      if (rem > 0) {
-        rc = launch_gemm(a1, 0, 1, nbatch, false, st);
-        if (rc) return rc;
+      float* W22 = W + (int64_t)k1 * n + k1;
+      if (!Tout) {
+        // no T wanted (one level): only (a) runs, T_kk parked in tmp with its own strides
+        if (rem > 0) {
+          rc = sq_gemm(W + (int64_t)k1 * n + k0, n, nn, 0, 0, tmp, kb, stmp, 1, 2, L + (int64_t)k1 * n + k0, n, nn,
+                       nullptr, 1.f, 0.f, rem, kb, kb, 0, nbatch, st);
+          if (rc) return rc;
+          rc = sq_gemm(L + (int64_t)k1 * n + k0, n, nn, 0, 0, L + (int64_t)k1 * n + k0, n, nn, 1, 0, W22, n, nn, W22,
+                       -1.f, 1.f, rem, rem, kb, 2, nbatch, st);
+          if (rc) return rc;
+        }
+        continue;
       }
-      if (trow) {
-        rc = launch_gemm(b1, 0, 0, nbatch, false, st);
+      const int kl = k0 - K0;                      // columns of the outer block to the left of this one
+      const int ldtmp = kl > 0 ? kl : 1;
+      const GemmParams a1 = mk(W + (int64_t)k1 * n + k0, n, Tkk, n, L + (int64_t)k1 * n + k0, n, nullptr, 1.f, 0.f, rem, kb, kb, 0, 2, 0);
+      const GemmParams b1 = mk(L + (int64_t)k0 * n + K0, n, Tout + (int64_t)K0 * n + K0, n, tmp, ldtmp, nullptr, 1.f, 0.f, kb, kl, kl, 0, 1, 0);
+      const GemmParams a2 = mk(L + (int64_t)k1 * n + k0, n, L + (int64_t)k1 * n + k0, n, W22, n, W22, -1.f, 1.f, rem, ncol, kb, 0, 0, 2);
+      const GemmParams b2 = mk(Tkk, n, tmp, ldtmp, Tout + (int64_t)k0 * n + K0, n, nullptr, -1.f, 0.f, kb, kl, kb, 1, 0, 0);
+      // the outer panel's own pair (A2 || B2) follows its last block; B1, which only needs earlier outer panels, rides with
+      // that block's products (its scratch is the second half of tmp: b1 / b2 of this block use the first)
+      const bool last = k1 == K1;
+      const int KB = K1 - K0, REM = n - K1;
+      const int ldTMP = K0 > 0 ? K0 : 1;
+      float* tmpB = tmp + (int64_t)nbatch * stmp;
+      GemmParams B1 = mk(L + (int64_t)K0 * n, n, Tout, n, tmpB, ldTMP, nullptr, 1.f, 0.f, KB, K0, K0, 0, 1, 0);
+      B1.sC[0] = stmp; B1.sD[0] = stmp;
+      const bool doB = last && K0 > 0;
+      if (kl > 0) {
+        rc = run_pair(rem > 0 ? &a1 : nullptr, 0, 1, &b1, 0, 0, "chol_panel");
         if (rc) return rc;
-      }
-      if (rem > 0) {
-        rc = launch_gemm(a2, 0, 1, nbatch, false, st);
+        rc = run_pair((rem > 0 && ncol > 0) ? &a2 : (doB ? &B1 : nullptr), (rem > 0 && ncol > 0) ? 0 : 0,
+                      (rem > 0 && ncol > 0) ? 1 : 0, &b2, 0, 0, "chol_panel");
         if (rc) return rc;
+        if (doB && rem > 0 && ncol > 0) {            // (cannot happen: the last block has ncol == 0)
+          rc = launch_gemm(B1, 0, 0, nbatch, false, st, "chol_trow");
+          if (rc) return rc;
+        }
+      } else {
+        rc = run_pair(rem > 0 ? &a1 : nullptr, 0, 1, doB ? &B1 : nullptr, 0, 0, "chol_panel");
+        if (rc) return rc;
+        if (rem > 0 && ncol > 0) {
+          rc = launch_gemm(a2, 0, 1, nbatch, false, st, "chol_panel");
+          if (rc) return rc;
+        }
       }
-      if (trow) {
-        rc = launch_gemm(b2, 0, 0, nbatch, false, st);
+      if (last) {
+        float* TKK = Tout + (int64_t)K0 * n + K0;
+        float* W22o = W + (int64_t)K1 * n + K1;
+        const GemmParams A2 = mk(L + (int64_t)K1 * n + K0, n, L + (int64_t)K1 * n + K0, n, W22o, n, W22o, -1.f, 1.f, REM, REM, KB, 0, 0, 2);
+        GemmParams B2 = mk(TKK, n, tmpB, ldTMP, Tout + (int64_t)K0 * n, n, nullptr, -1.f, 0.f, KB, K0, KB, 1, 0, 0);
+        B2.sB[0] = stmp;
+        rc = run_pair(REM > 0 ? &A2 : nullptr, 0, 1, K0 > 0 ? &B2 : nullptr, 0, 0, "chol_trailing");
         if (rc) return rc;
       }
     }
