@@ -1044,6 +1044,8 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
     rc = launch_bwdmat_gemm(ma, 0, SC + C, p1, S, st, "rbf_kuf_bwd_gemm");
     if (rc) return rc;
     // ... then P_uu = W_uu z and the gradient of the packed Cholesky vector of q(u)
+    static const int puu_tile = [] { const char* e = getenv("VARGP_T0_PUU_TILE"); return e ? atoi(e) : 0; }();   // tuning aid
+    p0.tile = puu_tile;
     rc = launch_gemm(p0, 0, 0, SC, false, st, "rbf_kuu_bwd_gemm");
     if (rc) return rc;
   } else {

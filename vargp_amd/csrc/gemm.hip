@@ -26,6 +26,11 @@ namespace vargp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Where the out-of-range lanes of an edge tile's epilogue store: with `if (row < M && col < N) C[..] = v` every element is a
+// branch, and the compiler drains vmcnt before each (one memory round trip per element: 32-64 of them per thread, most of a
+// small product's duration).  A select between the real address and this dump keeps the epilogue straight-line.  Never read.
+__device__ float g_gemm_trash[256];
+
 template <bool KC, int ROWS, int BK>
 struct LdsLayout {
   static constexpr int kStride = KC ? BK : (ROWS + 4);
@@ -596,7 +601,8 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int tile_id
             const int row = m0 + wm0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lh;
             const float d2 = nar[r] + nbc - 2.f * acc[a][c][r];
             const float v = (p.same_xy && row == col) ? g2 : g2 * expf(-0.5f * d2);
-            if (row < p.M && col < p.N) C[(int64_t)row * p.ldc + col] = v;
+            float* dst = (row < p.M && col < p.N) ? &C[(int64_t)row * p.ldc + col] : &g_gemm_trash[tid];
+            *dst = v;
           }
         }
       }
@@ -626,6 +632,37 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int tile_id
               if (D) v += p.beta * dv[j];
               if (p.triC == 1 && col > rbase + j) v = 0.f;
               C[(int64_t)(rbase + j) * p.ldc + col] = v;
+            }
+          }
+        }
+      }
+      return;
+    }
+  }
+  if constexpr (!RBF) {
+    if (p.splitk <= 1) {      // plain product, edge tile: straight-line, clamped D loads, out-of-range lanes store to the dump
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+#pragma unroll
+        for (int c = 0; c < TN; ++c) {
+          const int col = n0 + wn0 + 32 * c + li;
+          const int colc = min(col, p.N - 1);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int rbase = m0 + wm0 + 32 * a + 8 * q + 4 * lh;
+            float dv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (D) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) dv[j] = D[(int64_t)min(rbase + j, p.M - 1) * p.ldd + colc];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int row = rbase + j;
+              float v = p.alpha * acc[a][c][4 * q + j];
+              if (D) v += p.beta * dv[j];
+              if (p.triC == 1 && col > row) v = 0.f;
+              float* dst = (row < p.M && col < p.N) ? &C[(int64_t)row * p.ldc + col] : &g_gemm_trash[tid];
+              *dst = v;
             }
           }
         }
