@@ -86,3 +86,22 @@ def test_driver_cli_defaults_match_reference():
     assert (seen['p-mnist'].epochs, seen['p-mnist'].M, seen['p-mnist'].lr, seen['p-mnist'].beta,
             seen['p-mnist'].n_tasks) == (1000, 100, 3.7e-3, 1.64, 10)
     assert seen['toy'].batch_size == 512 and seen['toy'].ep_var_mean is True
+
+
+def test_toy_dataset_reproduces_the_reference_draw():
+    """ToyDataset under a fixed seed == the reference's ToyDataset under the same seed (fixture written by
+    tests/golden/make_golden.py from var_gp/datasets.py:21-51): same random stream, same class layout."""
+    import numpy as np
+    import torch
+    from conftest import GOLDEN
+    from vargp_amd.datasets import ToyDataset
+    g = np.load(os.path.join(GOLDEN, 'toy_dataset.npz'))
+    for seed in (1, 7):
+        torch.manual_seed(seed)
+        ds = ToyDataset()
+        np.testing.assert_allclose(ds.data.numpy(), g[f'x_seed{seed}'], rtol=0, atol=1e-6)
+        np.testing.assert_array_equal(ds.targets.numpy(), g[f'y_seed{seed}'])
+    torch.manual_seed(3)
+    ds = ToyDataset(N_K=20)
+    np.testing.assert_allclose(ds.data.numpy(), g['x_nk20_seed3'], rtol=0, atol=1e-6)
+    np.testing.assert_array_equal(ds.targets.numpy(), g['y_nk20_seed3'])
