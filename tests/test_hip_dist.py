@@ -15,7 +15,7 @@ S_LOCAL, WORLD, F_, C, M, D, B = 2, 2, 4, 4, 12, 16, 64
 SEED = 31
 
 
-def _model(S):
+def _model(S, dev='cuda:0'):
     from vargp_amd.kernels import RBFKernel
     from vargp_amd.likelihoods import MulticlassSoftmax
     from vargp_amd.synthetic import mnist_like
@@ -23,8 +23,8 @@ def _model(S):
     torch.manual_seed(0)
     xall, yall = mnist_like(1024, D, C, kind='gauss', seed=1)
     z = torch.stack([xall[yall == c][:M] for c in range(C)])
-    gp = VARGP(z, RBFKernel(D), MulticlassSoftmax(n_f=F_), n_var_samples=S).to('cuda:0')
-    return gp, xall[:B].to('cuda:0'), yall[:B].to('cuda:0')
+    gp = VARGP(z, RBFKernel(D), MulticlassSoftmax(n_f=F_), n_var_samples=S).to(dev)
+    return gp, xall[:B].to(dev), yall[:B].to(dev)
 
 
 def _run(gp, x, y, use_graph, steps=3):
@@ -50,14 +50,19 @@ def _run(gp, x, y, use_graph, steps=3):
     return outs, {k: v.detach().cpu().clone() for k, v in gp.state_dict().items()}
 
 
-def _worker(rank, port, use_graph, q):
+def _worker(rank, port, use_graph, q, rccl=False):
+    """rccl: one GPU per rank, the exchange over RCCL (backend 'nccl'); otherwise both ranks share cuda:0 and gloo carries it."""
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD))
-    torch.cuda.set_device(0)
-    dist.init_process_group('gloo', rank=rank, world_size=WORLD)
+    dev = rank if rccl else 0
+    torch.cuda.set_device(dev)
+    if rccl:
+        dist.init_process_group('nccl', rank=rank, world_size=WORLD, device_id=torch.device('cuda', dev))
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=WORLD)
     try:
         from vargp_amd import ops
         ops.set_cholesky_error_mode('defer')
-        gp, x, y = _model(S_LOCAL)
+        gp, x, y = _model(S_LOCAL, f'cuda:{dev}')
         outs, sd = _run(gp, x, y, use_graph)
         if rank == 0:
             q.put((outs, {k: v.numpy() for k, v in sd.items()}))
@@ -66,14 +71,18 @@ def _worker(rank, port, use_graph, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('use_graph', [False, True])
-def test_two_ranks_equal_single_process(use_graph):
+@pytest.mark.parametrize('use_graph,rccl', [(False, False), (True, False),
+                                            pytest.param(False, True, id='rccl-2gpu-eager'),
+                                            pytest.param(True, True, id='rccl-2gpu-graph')])
+def test_two_ranks_equal_single_process(use_graph, rccl):
+    if rccl and torch.cuda.device_count() < 2:
+        pytest.skip('needs two GPUs (the RCCL exchange between two devices; the one-GPU box runs the gloo variants)')
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, port, use_graph, q)) for r in range(WORLD)]
+    procs = [ctx.Process(target=_worker, args=(r, port, use_graph, q, rccl)) for r in range(WORLD)]
     for p in procs:
         p.start()
     outs2, sd2 = q.get(timeout=300)
