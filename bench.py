@@ -354,7 +354,8 @@ def run_workload(name, args, device, world, rank, use_dist, steps, warmup, prima
     # recorded launches -- same kernels, same shapes, the trainer's live buffers -- are re-launched back to back between
     # ONE pair of events (vargp_prof_remember / vargp_prof_replay).
     #   first task: "chol_rbf_gemm" = the longest launch of the step (K_uu / S_u factorisations + the K_uf distance GEMM
-    #   in one launch); "rbf_kuu_bwd_gemm" = the heaviest pure-MFMA launch (both W.Y products of the kernel backward).
+    #   in one launch); "rbf_kuf_bwd_gemm" = the heaviest MFMA launch of the backward (P_uf = W_uf x beside the adjoint
+    #   chains of the factorisations; shapes outside the LDS-resident backward: "rbf_kuu_bwd_gemm", both W.Y products).
     #   later tasks (composed path): "rbf_kuf_gemm" = the K_uf distance GEMM of compute_pf_diag.
     _lib.prof_enable(False)
     _lib.prof_read('')
@@ -369,8 +370,11 @@ def run_workload(name, args, device, world, rank, use_dist, steps, warmup, prima
     if not block_prog:
         candidates = [('chol_rbf_gemm', flops_kuf, 'chol_rbf_gemm_kernel (K_uu/S_u factorisations, fp64, latency-bound, sharing '
                        'one launch with the K_uf = rbf(z, x) distance GEMM; flops counted: the GEMM)'),
-                      ('rbf_kuu_bwd_gemm', 2.0 * S * C * M * D * (B + M), 'gemm_pair_kernel (W.Y products of the kernel-matrix '
-                       'backward: [C*M x B] x [B x D] per sample and [M x M] x [M x D] per (sample, class))'),
+                      ('rbf_kuf_bwd_gemm', 2.0 * S * C * M * B * D, 't0_bwdmat_gemm_kernel (P_uf = W_uf x of the kernel-matrix '
+                       'backward, [C*M x B] x [B x D] per sample, sharing one launch with the per-matrix adjoint chains of '
+                       'the factorisations; flops counted: the product)'),
+                      ('rbf_kuu_bwd_gemm', 2.0 * S * C * M * M * D, 'gemm_kernel P_uu = W_uu z of the kernel-matrix backward '
+                       '([M x M] x [M x D] per (sample, class))'),
                       ('rbf_kuf_gemm', flops_kuf, 'gemm_kernel<RBF> (K_uf = rbf(z, x))'),
                       ('rbf_kuu_gemm', 2.0 * S * C * M * D * (B + M), 'gemm_pair_kernel<RBF> (K_uu = rbf(z, z) and K_uf = rbf(z, x) '
                        'in one launch)')]
@@ -394,8 +398,8 @@ def run_workload(name, args, device, world, rank, use_dist, steps, warmup, prima
             kernels[tag] = (_lib.prof_replay(tag, kern_n), fl, desc)
         except _lib.VargpHipError:
             pass
-    if block_prog and 'rbf_kuu_bwd_gemm' in kernels and 'rbf_kuf_bwd_gemm' not in kernels:
-        # mid-size shapes run both W.Y products in ONE pair launch (recorded under the first tag)
+    if 'rbf_kuu_bwd_gemm' in kernels and 'rbf_kuf_bwd_gemm' not in kernels:
+        # shapes outside the LDS-resident backward run both W.Y products in ONE pair launch (recorded under the first tag)
         us, _, _ = kernels['rbf_kuu_bwd_gemm']
         kernels['rbf_kuu_bwd_gemm'] = (us, 2.0 * S * C * Mt * D * (Mt + B), 'gemm_pair_kernel (both W.Y products of the '
                                        'kernel-matrix backward in one launch)')
@@ -448,13 +452,18 @@ def run_workload(name, args, device, world, rank, use_dist, steps, warmup, prima
             res['roofline_others'] = [dict(kernel=dsc, avg_us=us, achieved=fl / (us * 1e-6) / 1e12,
                                            frac=fl / (us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS)
                                       for t, (us, fl, dsc) in kernels.items() if t != dom and us == us and fl > 0]
-        if N_PREV == 0 and 'rbf_kuu_bwd_gemm' in kernels and dom != 'rbf_kuu_bwd_gemm':
-            us2, fl2, desc2 = kernels['rbf_kuu_bwd_gemm']
+        gtag = next((t for t in ('rbf_kuf_bwd_gemm', 'rbf_kuu_bwd_gemm') if t in kernels), None)
+        if N_PREV == 0 and gtag and dom != gtag:       # the heaviest MFMA launch of the backward
+            us2, fl2, desc2 = kernels[gtag]
             res['roofline_gemm'] = dict(bound='mfma', kernel=desc2, achieved=fl2 / (us2 * 1e-6) / 1e12,
                                         peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
                                         frac=fl2 / (us2 * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, launches=kern_n, avg_us=us2,
-                                        traffic=measured_traffic('rbf_kuu_bwd_gemm') if cfg2 else None,
-                                        mfma_util=measured_mfma_util('rbf_kuu_bwd_gemm') if cfg2 else None)
+                                        traffic=measured_traffic(gtag) if cfg2 else None,
+                                        mfma_util=measured_mfma_util(gtag) if cfg2 else None)
+            if not block_prog:
+                res['roofline_others'] = [dict(kernel=dsc, avg_us=us, achieved=fl / (us * 1e-6) / 1e12,
+                                               frac=fl / (us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS)
+                                          for t, (us, fl, dsc) in kernels.items() if t not in (dom, gtag) and us == us and fl > 0]
         if world == 1 and primary and not args.no_cpu_baseline and cfg2:
             res['cpu_baseline'] = cpu_baseline(p0, x, y)
     # hand the workspaces back before the next workload (12 GB at Permuted-MNIST task 9)

@@ -31,10 +31,16 @@ KERNELS = {
     # factorisations: read K_uu/S_u, write L and T ((S*C + C) matrices); GEMM: read z and x once, write K_uf
     'chol_rbf_gemm': ('void vargp::chol_rbf_gemm_kernel',
                       4 * (3 * (S * C + C) * M * M + C * M * D + B * D + S * C * M * B), 2.0 * S * C * M * B * D),
-    # W.Y products: read W_uf (S*C*M*B), W_uu (S*C*M*M), x, z once; write P_uf, P_uu (S*C*M*D each)
-    'rbf_kuu_bwd_gemm': ('void vargp::gemm_pair_kernel<64, 64, 64, true, false, true, false>',
-                         4 * (S * C * M * B + S * C * M * M + B * D + C * M * D + 2 * S * C * M * D),
-                         2.0 * S * C * M * D * (B + M)),
+    # P_uf = W_uf x: read W_uf (S*C*M*B) and x once, write P_uf (S*C*M*D); adjoint chains in the same launch: per (s, c) read
+    # T, the tile kernel's gT, K_uu and write W_uu (4 M^2); per class read T_s and gG_s of every sample, L_S, T_S, write gS_u
+    'rbf_kuf_bwd_gemm': ('void vargp::t0_bwdmat_gemm_kernel',
+                         4 * (S * C * M * B + B * D + S * C * M * D + 4 * S * C * M * M + (2 * S + 3) * C * M * M),
+                         2.0 * S * C * M * B * D),
+    # tile kernel of the backward: read QP-side operands per (s, c, 64-column tile), write W_uf; everything else is atomics
+    't0_bwd_mid': ('void vargp::t0_bwd_mid_kernel', 4 * (2 * S * C * M * B + 3 * S * C * M * M + 3 * S * C * M * M),
+                   8.0 * S * C * M * M * B),
+    't0_fwd_fused': ('void vargp::t0_fwd_fused_kernel', 4 * (S * C * M * B + 2 * S * C * M * M + 2 * S * C * M * B),
+                     4.0 * S * C * M * M * B),
 }
 SECONDARY = ['smnist_s64', 'smnist_t1', 'smnist_t4', 'pmnist_t0', 'pmnist_t1', 'pmnist_t4', 'pmnist_t9', 'stress']
 # kernels of the N = 1e6 sweep (M = 2048, C = 10, S = 1, tile 8192), counters from the short sweep of collect.sh:
@@ -138,6 +144,11 @@ def main():
         mfma['calibration_gemm_4096'] = dict(dispatches=n, mfma_util=busy / (128.0 * gui),
                                              timing=[l for l in open(os.path.join(G, f'{tag}_sqcal.log')).read().splitlines()
                                                      if l.startswith('gemm4k')])
+    import subprocess
+    sha = subprocess.run(['git', 'rev-parse', 'HEAD'], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+    dirty = bool(subprocess.run(['git', 'status', '--porcelain', '--', 'vargp_amd', 'bench.py'], cwd=ROOT, capture_output=True,
+                                text=True).stdout.strip())
+    traffic['commit'] = mfma['commit'] = sha + ('+dirty' if dirty else '')     # the tree the counters were collected on
     json.dump(traffic, open(os.path.join(OUT, f'{tag}_traffic.json'), 'w'), indent=1)
     json.dump(mfma, open(os.path.join(OUT, f'{tag}_mfma.json'), 'w'), indent=1)
 

@@ -166,7 +166,50 @@ __device__ __forceinline__ void chol3_body(const int64_t b, const float* __restr
 
   const int di = 256 / n, dj = 256 - di * n;   // element e -> e + 256 without a division per element
   double va[KC], vb[KC];
-  if (extra && extra->symmetric_input) {
+  if (extra && extra->part && b < extra->first) {
+    // K-split partial Gram matrices -> kernel matrix on the way in (CholExtra, common.h).  Summation order and formula of
+    // t0_combine_norm_kernel (elbo_t0.hip).  Loads on clamped indices, all of a row's in flight together.
+    const float* part = extra->part + b * (int64_t)n * n;
+    const int nsplit = extra->nsplit;
+    const int64_t sS = extra->sSplit;
+    float* Kout = extra->Kout + b * (int64_t)n * n;
+    if (tid < n) {
+      float g = 0.f, v[kCholPartMax];
+#pragma unroll
+      for (int q = 0; q < kCholPartMax; ++q) v[q] = part[min(q, nsplit - 1) * sS + (int64_t)tid * (n + 1)];
+#pragma unroll
+      for (int q = 0; q < kCholPartMax; ++q) if (q < nsplit) g += v[q];
+      stage[tid] = g;
+    }
+    __syncthreads();
+    const float gam = extra->g2[b / extra->part_C];
+    const int cac = min(ca, n - 1), cbc = min(cb, n - 1);
+    const float gja = stage[cac], gjb = stage[cbc];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+      const int i = 4 * k + w, ic = min(i, n - 1);
+      float pa[kCholPartMax], pb[kCholPartMax];
+#pragma unroll
+      for (int q = 0; q < kCholPartMax; ++q) {
+        const float* pq = part + min(q, nsplit - 1) * sS + (int64_t)ic * n;
+        pa[q] = pq[cac];
+        if (SETS == 2) pb[q] = pq[cbc];
+      }
+      float ga = 0.f, gb = 0.f;
+#pragma unroll
+      for (int q = 0; q < kCholPartMax; ++q)
+        if (q < nsplit) { ga += pa[q]; if (SETS == 2) gb += pb[q]; }
+      const float gii = stage[ic];
+      const float ka = i == ca ? gam : gam * expf(-0.5f * (gii + gja - 2.f * ga));
+      const float kb = i == cb ? gam : gam * expf(-0.5f * (gii + gjb - 2.f * gb));
+      va[k] = 0.0; vb[k] = 0.0;
+      if (i < n) {
+        if (minea) { va[k] = (double)ka + (i == ca ? (double)eps : 0.0); Kout[(int64_t)i * n + ca] = ka; }
+        if (mineb) { vb[k] = (double)kb + (i == cb ? (double)eps : 0.0); Kout[(int64_t)i * n + cb] = kb; }
+      }
+    }
+    __syncthreads();      // `stage` is reused for the results
+  } else if (extra && extra->symmetric_input) {
     // both triangles valid: row i lies across the lanes, coalesced as it is
 #pragma unroll
     for (int k = 0; k < KC; ++k) {

@@ -100,9 +100,16 @@ bool chol_rbf_gemm_applicable(int n, const GemmParams& p);
 // base + (b - first) * stride_b + c * stride_copy, row stride ld (the ELBO program wants L_S inside its RK operand).
 // symmetric_input: both triangles of every input matrix are valid (coalesced direct load instead of the mirrored one).
 // diag_only_before_first: for the batch entries b < first only the diagonal of L is wanted (the rest is written as 0).
+// part != NULL: the matrices b < first arrive as nsplit (<= kCholPartMax) partial Gram matrices G_q at part + q * sSplit + b n^2
+// (the K-split inner products of an RBF kernel matrix over ONE point set); the factorising workgroup forms
+// K_ij = g2[b / part_C] exp(-(G_ii + G_jj - 2 G_ij) / 2), G = sum_q G_q, exactly g2 on the diagonal, as it loads, and stores
+// K to Kout + b n^2 (dense, both triangles).
+constexpr int kCholPartMax = 4;
+constexpr int kProKuuMaxD = 4096;       // launch_pro_kuu: 1/sigma^2 of one hyper-sample staged in LDS by the norm role
 struct CholExtra {
   float* base; int first; int ld; int64_t stride_b, stride_copy; int ncopy;
   int symmetric_input, diag_only_before_first;
+  const float* part; int nsplit; int64_t sSplit; const float* g2; int part_C; float* Kout;
 };
 int launch_chol_rbf_gemm(const float* A, float eps, float* L, float* T, int32_t* info, int nchol, int n,
                          const GemmParams& p, int nbatch, hipStream_t st, const CholExtra* extra = nullptr);

@@ -20,10 +20,12 @@
 #include "common.h"
 #include "elbo_shared.h"
 #include "t0_bwd_mid.h"
+#include "t0_prologue.h"
 
 namespace vargp {
 
-constexpr int kKuuSplit = 4;   // K-splits of the K_uu distance GEMM (few workgroups, long K loop: split to use the chip)
+constexpr int kKuuSplit = 2;   // K-splits of the K_uu distance GEMM (few workgroups, long K loop: split to use the chip;
+                               // 2 / 3 / 4 splits at the BASELINE shape: 4064 / 3989 / 4003 steps/s)
 #ifndef VARGP_KL_ROWS
 #define VARGP_KL_ROWS 8
 #endif
@@ -77,151 +79,10 @@ static T0Ws carve_t0(void* ws, int S, int C, int M, int D, int B, int F) {
 // ---------------------------------------------------------------------------------------------------------------
 // forward kernels
 // ---------------------------------------------------------------------------------------------------------------
-struct ProArgs {
-  const float *mean, *logvar, *pmean, *plogvar, *eps_theta, *vec;
-  float *theta, *w, *g2, *kd, *Lu, *Su, *scalars, *zero_begin, *bump;
-  // when the factorisation writes L_S into RK itself, the prologue writes the other small columns (no pack launch)
-  float* RK;
-  const float* u_mean;
-  int NR, LD;
-  int32_t* info;
-  int64_t zero_count, Dp;
-  int S, C, M, D, ninfo, map_est, nzero_blocks;
-  // native noise (eps_theta == eps_f == NULL in the descriptor): the prologue draws it
-  int native, nrng_blocks;
-  uint64_t seed;
-  const uint32_t* rng_counter;
-  int64_t g0_theta, g0_f, n_f;
-  float *eps_theta_out, *eps_f_out;
-};
-
-// Multi-role prologue, role by block index:
-//   block 0            kl_hypers (kernels.py:70-77) -> scalars[0]; scalars[1..2] = 0 (kl_u, nll accumulate); info = 0;
-//                      *bump += 1 if the caller asked for it
-//   blocks 1..S        theta_s = mean + eps_s exp(logvar/2) (kernels.py:62-68); w_s = exp(-2 theta), g2_s = exp(2 theta_D)
-//   next nzero_blocks  zero-fill of the softmax-gradient accumulators
-//   next nrng_blocks   (native noise only) the likelihood noise eps_f; eps_theta is drawn inline by blocks 1..S
-//   rest               Lu = vec2tril(u_tril_vec) (gp_utils.py:22-49) and S_u = Lu Lu^T straight from the packed vector
+// the prologue roles alone (t0_prologue.h; shapes whose K_uu product does not share the launch)
 __global__ __launch_bounds__(256) void t0_prologue_kernel(const ProArgs a) {
   __shared__ float red[4];
-  const int blk = blockIdx.x, tid = threadIdx.x;
-  const int D1 = a.D + 1;
-  if (blk == 0) {
-    float acc = 0.f;
-    if (!a.map_est)
-      for (int d = tid; d < D1; d += 256) {
-        const float dv = a.logvar[d] - a.plogvar[d], dm = a.mean[d] - a.pmean[d];
-        acc += 0.5f * (expf(dv) + dm * dm * expf(-a.plogvar[d]) - 1.f - dv);
-      }
-    const float t = block_sum<256>(acc, red);
-    if (tid == 0) {
-      a.scalars[0] = t; a.scalars[1] = 0.f; a.scalars[2] = 0.f;
-      if (a.bump) a.bump[0] += 1.f;
-    }
-    for (int i = tid; i < a.ninfo; i += 256) a.info[i] = 0;
-    return;
-  }
-  if (blk <= a.S) {
-    const int s = blk - 1;
-    for (int d = tid; d < D1 || d < a.Dp; d += 256) {
-      float t = 0.f;
-      if (d < D1) {
-        if (a.map_est) {
-          t = a.mean[d];
-        } else {
-          float e;
-          if (a.native) {
-            e = normal1(a.seed, kStreamTheta, (uint64_t)(a.g0_theta + (int64_t)s * D1 + d), a.rng_counter[0]);
-            a.eps_theta_out[s * D1 + d] = e;      // kept for the backward
-          } else {
-            e = a.eps_theta[s * D1 + d];
-          }
-          t = a.mean[d] + e * expf(0.5f * a.logvar[d]);
-        }
-        a.theta[s * D1 + d] = t;
-      }
-      if (d < a.Dp) a.w[s * a.Dp + d] = d < a.D ? expf(-2.f * t) : 0.f;
-      if (d == a.D) {
-        const float g = expf(2.f * t);
-        a.g2[s] = g;
-        for (int c = 0; c < a.C; ++c) a.kd[s * a.C + c] = g;
-      }
-    }
-    return;
-  }
-  if (blk <= a.S + a.nzero_blocks) {
-    for (int64_t i = (int64_t)(blk - a.S - 1) * 256 + tid; i < a.zero_count; i += (int64_t)a.nzero_blocks * 256)
-      a.zero_begin[i] = 0.f;
-    return;
-  }
-  if (blk <= a.S + a.nzero_blocks + a.nrng_blocks) {
-    // likelihood noise: one Philox group (4 normals) per thread, groups aligned to the GLOBAL element index
-    const uint32_t step = a.rng_counter[0];
-    const int64_t gfirst = a.g0_f >> 2, glast = (a.g0_f + a.n_f + 3) >> 2;
-    for (int64_t G = gfirst + (int64_t)(blk - a.S - a.nzero_blocks - 1) * 256 + tid; G < glast;
-         G += (int64_t)a.nrng_blocks * 256) {
-      float v[4];
-      normal4(a.seed, kStreamF, (uint64_t)G, step, v);
-#pragma unroll
-      for (int l = 0; l < 4; ++l) {
-        const int64_t i = 4 * G + l - a.g0_f;
-        if (i >= 0 && i < a.n_f) a.eps_f_out[i] = v[l];
-      }
-    }
-    return;
-  }
-  const int64_t e = (int64_t)(blk - 1 - a.S - a.nzero_blocks - a.nrng_blocks) * 256 + tid;
-  const int M = a.M;
-  if (e >= (int64_t)a.C * M * M) return;
-  const int j = e % M, i = (e / M) % M;
-  const int64_t c = e / ((int64_t)M * M);
-  const float* v = a.vec + c * ((int64_t)M * (M + 1) / 2);
-  const int lo = i < j ? i : j, hi = i < j ? j : i;
-  const float* rh = v + (int64_t)hi * (hi + 1) / 2;
-  const float* rl = v + (int64_t)lo * (lo + 1) / 2;
-  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;   // independent chains: the loads of a group are in flight together
-  int k = 0;
-  for (; k + 4 <= lo; k += 4) {
-    acc0 = fmaf(rh[k], rl[k], acc0); acc1 = fmaf(rh[k + 1], rl[k + 1], acc1);
-    acc2 = fmaf(rh[k + 2], rl[k + 2], acc2); acc3 = fmaf(rh[k + 3], rl[k + 3], acc3);
-  }
-  for (; k < lo; ++k) acc0 = fmaf(rh[k], rl[k], acc0);
-  const float dl = softplus_t0(rl[lo]);
-  const float acc = fmaf(hi == lo ? dl : rh[lo], dl, (acc0 + acc1) + (acc2 + acc3));
-  a.Su[e] = acc;
-  const float lu = j < i ? v[(int64_t)i * (i + 1) / 2 + j] : (j == i ? dl : 0.f);
-  a.Lu[e] = lu;
-  if (a.RK) {   // RK[s, c, i, :] = [ m | 0 0 0 | (L_S: by the factorisation) | Lu | 0.. ]
-    for (int s = 0; s < a.S; ++s) {
-      float* r = a.RK + (((int64_t)s * a.C + c) * M + i) * a.LD;
-      r[4 + M + j] = lu;
-      if (j == 0) {
-        r[0] = a.u_mean[c * M + i];
-        r[1] = 0.f; r[2] = 0.f; r[3] = 0.f;
-        for (int col = 4 + 2 * M; col < a.NR; ++col) r[col] = 0.f;
-      }
-    }
-  }
-}
-
-// sum_d x_d^2 w_d of one row by one wave.  Four 64-wide chunks of loads are issued before the first use (a plain loop
-// keeps one chunk in flight: D / 64 memory round trips in a row), on clamped indices with the overhang masked.
-__device__ __forceinline__ float row_norm_wave(const float* __restrict__ xr, const float* __restrict__ ws, int D, int lane) {
-  float acc0 = 0.f, acc1 = 0.f;
-  for (int d0 = 0; d0 < D; d0 += 256) {
-    float xv[4], wv[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int d = min(d0 + 64 * q + lane, D - 1);
-      xv[q] = xr[d]; wv[q] = ws[d];
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float v = (d0 + 64 * q + lane < D) ? xv[q] : 0.f;
-      if (q & 1) acc1 = fmaf(v * v, wv[q], acc1); else acc0 = fmaf(v * v, wv[q], acc0);
-    }
-  }
-  return wave_sum(acc0 + acc1);
+  t0_prologue_body(a, blockIdx.x, red);
 }
 
 // weighted squared row norms of the inducing points (na) and of the minibatch (nb), one wave per row; grid (rows/4, S)
@@ -796,9 +657,15 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
   // the merged factorisation + K_uf launch also writes L_S into RK; then the prologue writes RK's other small columns
   const bool merge_chol = D > kRbfDirectD && M > 50 && M <= 100 && (D % 4) == 0 && (LD % 4) == 0 &&
                           ((reinterpret_cast<uintptr_t>(d->z) | reinterpret_cast<uintptr_t>(d->x)) & 15) == 0;
+  static const int ksp = [] { const char* e = getenv("VARGP_KUU_SPLIT"); return e ? atoi(e) : kKuuSplit; }();   // tuning aid
+  static const int front_env = [] { const char* e = getenv("VARGP_T0_FRONT"); return e ? atoi(e) : 1; }();    // tuning aid
+  // merged factorisation launch + K-split K_uu product: the norms ride along
+  const bool split_kuu = merge_chol && D >= 256 && (int64_t)ksp * M <= LD && ksp > 1;
+  // ... and then the prologue shares the launch of the split product (every workgroup evaluates the 1/sigma^2 it needs itself),
+  // and the partial products are summed and exponentiated by the factorising workgroups as they load: two launches fewer
+  const bool front = split_kuu && front_env && ksp <= kCholPartMax && D <= kProKuuMaxD;
+  ProArgs a{};
   {
-    ProfScope prof("t0_prologue", st);
-    ProArgs a{};
     if (merge_chol) { a.RK = o.RK; a.u_mean = d->u_mean; a.NR = NR; a.LD = LD; }
     a.mean = d->log_mean; a.logvar = d->log_logvar; a.pmean = d->prior_log_mean; a.plogvar = d->prior_log_logvar;
     a.eps_theta = d->eps_theta; a.vec = d->u_tril_vec;
@@ -815,8 +682,11 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
       a.eps_theta_out = o.eps_theta; a.eps_f_out = o.eps_f;
       a.nrng_blocks = (int)std::min<int64_t>(512, cdiv(a.n_f + 7, 1024));
     }
-    const int grid = 1 + S + a.nzero_blocks + a.nrng_blocks + cdiv((int64_t)C * MM, 256);
-    hipLaunchKernelGGL(t0_prologue_kernel, dim3(grid), dim3(256), 0, st, a);
+  }
+  const int npro = 1 + S + a.nzero_blocks + a.nrng_blocks + cdiv((int64_t)C * MM, 256);
+  if (!front) {
+    ProfScope prof("t0_prologue", st);
+    hipLaunchKernelGGL(t0_prologue_kernel, dim3(npro), dim3(256), 0, st, a);
   }
   // kernel matrices: K_uu -> KS[:SC], K_uf -> the trailing block of RK
   bool merged = false;
@@ -827,9 +697,6 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
     if (rc) return rc;
   } else {
     const int64_t zrows = (int64_t)C * M;
-    static const int ksp = [] { const char* e = getenv("VARGP_KUU_SPLIT"); return e ? atoi(e) : kKuuSplit; }();   // tuning aid
-    // merged factorisation launch + K-split K_uu product: the norms ride in the K_uu epilogue launch
-    const bool split_kuu = merge_chol && D >= 256 && (int64_t)ksp * M <= LD && ksp > 1;
     if (!split_kuu)
       hipLaunchKernelGGL(t0_norm_kernel, dim3(cdiv(zrows + B, 4), S), dim3(256), 0, st, d->z, d->x, o.w, o.na, o.nb, zrows,
                          (int64_t)B, D, o.Dp);
@@ -857,22 +724,31 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
       // the chip builds K_uf, which nothing needs before the factors are done
       if (split_kuu) {
         // 4 SC workgroups with D/64 slabs each would leave half the chip idle for the length of that K loop: split K,
-        // partial inner products to scratch, distance/exp epilogue (+ the row norms) in a second launch
+        // partial inner products to scratch, distance/exp epilogue afterwards
         GemmParams ps = p0;
         ps.splitk = ksp; ps.sSplit = SC * MM; ps.C = o.kpart;
-        rc = launch_gemm(ps, 0, 1, SC, true, st, "rbf_kuu_gemm");
-        if (rc) return rc;
-        const int64_t total = SC * MM;
-        const int ncomb = cdiv(total, 256), nrow4 = cdiv(zrows + B, 4);
-        hipLaunchKernelGGL(t0_combine_norm_kernel, dim3(ncomb + nrow4 * S), dim3(256), 0, st, o.kpart, ksp, SC * MM, o.g2,
-                           o.KS, C, M, total, ncomb, d->z, d->x, o.w, o.na, o.nb, zrows, (int64_t)B, D, o.Dp, nrow4);
+        if (front) {
+          NormArgs nr{d->z, d->x, o.na, o.nb, zrows, (int64_t)B, 16, (int)cdiv(zrows + B, 16)};
+          rc = launch_pro_kuu(a, npro, nr, ps, SC, st);
+          if (rc) return rc;
+        } else {
+          rc = launch_gemm(ps, 0, 1, SC, true, st, "rbf_kuu_gemm");
+          if (rc) return rc;
+          const int64_t total = SC * MM;
+          const int ncomb = cdiv(total, 256), nrow4 = cdiv(zrows + B, 4);
+          hipLaunchKernelGGL(t0_combine_norm_kernel, dim3(ncomb + nrow4 * S), dim3(256), 0, st, o.kpart, ksp, SC * MM, o.g2,
+                             o.KS, C, M, total, ncomb, d->z, d->x, o.w, o.na, o.nb, zrows, (int64_t)B, D, o.Dp, nrow4);
+        }
       } else {
         rc = launch_gemm(p0, 0, 1, SC, true, st, "rbf_kuu_gemm");
         if (rc) return rc;
       }
       // L_S[c] -> RK[s, c, :, 4:4+M] for every s; K_uu and S_u arrive with both triangles; of the K_uu factors only
       // the diagonal of L is ever used (log-determinant, and L^T diag(.) in the backward), everything else goes through T
-      const CholExtra lx{o.RK + 4, SC, LD, MLD, (int64_t)C * MLD, S, 1, 1};
+      CholExtra lx{o.RK + 4, SC, LD, MLD, (int64_t)C * MLD, S, 1, 1};
+      if (front) {   // the matrices b < SC arrive as K-split partial Gram matrices (and leave as K_uu in KS for the backward)
+        lx.part = o.kpart; lx.nsplit = ksp; lx.sSplit = SC * MM; lx.g2 = o.g2; lx.part_C = C; lx.Kout = o.KS;
+      }
       rc = launch_chol_rbf_gemm(o.KS, d->jitter, o.LL, o.TT, d->info, SC + C, M, p1, S, st, &lx);
       if (rc) return rc;
       merged = true;

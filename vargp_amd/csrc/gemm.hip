@@ -17,6 +17,7 @@
 #include "common.h"
 #include "chol_small3.h"
 #include "t0_bwd_mat.h"
+#include "t0_prologue.h"
 #include <atomic>
 #include <stdlib.h>
 #include <string.h>
@@ -842,6 +843,53 @@ static bool gemm_vec_ok(const GemmParams& p) {
   bool vec = aligned16(p.A) && aligned16(p.B) && (p.lda % 4 == 0) && (p.ldb % 4 == 0);
   for (int i = 0; i < 3; ++i) vec = vec && (p.sA[i] % 4 == 0) && (p.sB[i] % 4 == 0);
   return vec;
+}
+
+// One launch, three independent roles at the front of the first-task forward: the K-split inner products of K_uu (64 x 64 x BK
+// tiles: the long pole, dispatched first), the prologue roles (t0_prologue.h) and the row norms of [z; x].  The product and
+// the norms need 1/sigma^2 of their hyper-sample, which the prologue's theta role only writes in this same launch: every
+// workgroup evaluates the entries it needs itself (same expression, so the copies in `w` agree bit for bit).
+template <int BK>
+__global__ __launch_bounds__(256) void t0_pro_kuu_kernel(const ProArgs a, const int npro, const NormArgs nr, const int nnorm,
+                                                         const GemmParams p, const int tiles, const int ngemm) {
+  __shared__ __attribute__((aligned(16))) float lds[gemm_lds_floats<64, 64, BK, true, true>()];
+  int blk = blockIdx.x;
+  if (blk >= ngemm) {      // (the other order -- short roles first -- measured 26.9 us against 20.3 us)
+    blk -= ngemm;
+    if (blk < npro) t0_prologue_body(a, blk, lds);
+    else t0_norm_body(a, nr, blk - npro, lds);
+    return;
+  }
+  const int per = ngemm / p.splitk;            // tiles * nbatch
+  const int split = blk / per, r = blk - split * per;
+  const int batch = r / tiles, tile = r - batch * tiles;
+  {  // this workgroup's K range (gemm_body's rule) of w[s, :], s = first batch index
+    const int s = batch / (p.nb2 * p.nb1);
+    const int nslab = (p.K + BK - 1) / BK, share = (nslab + p.splitk - 1) / p.splitk;
+    const int ks = min(p.K, split * share * BK), ke = min(p.K, (split + 1) * share * BK);
+    for (int k = ks + (int)threadIdx.x; k < ke; k += 256) a.w[s * a.Dp + k] = expf(-2.f * t0_theta_at(a, s, k, false));
+    __threadfence_block();
+    __syncthreads();
+  }
+  gemm_body<64, 64, BK, true, true, true, true, true>(p, tile, batch, split, lds);
+}
+
+int launch_pro_kuu(const ProArgs& a, int npro, const NormArgs& n, const GemmParams& ps, int nbatch, hipStream_t st) {
+  VARGP_REQUIRE(ps.splitk > 1 && ps.kscale == a.w && ps.ks_ld == a.Dp && a.D <= kProKuuMaxD && gemm_vec_ok(ps),
+                "pro_kuu: not applicable");
+  if (prof_remembering()) {
+    const ProArgs ac = a; const NormArgs nc = n; const GemmParams pc = ps;
+    prof_remember("t0_pro_kuu", [=](hipStream_t s) { launch_pro_kuu(ac, npro, nc, pc, nbatch, s); });
+  }
+  ProfScope prof("t0_pro_kuu", st);
+  static const int bk = [] { const char* e = getenv("VARGP_PRO_KUU_BK"); return e ? atoi(e) : 32; }();   // tuning aid
+  GemmParams q = ps;
+  q.xcd_remap = 0; q.group_m = 0;
+  const int tiles = cdiv(q.M, 64) * cdiv(q.N, 64), ngemm = tiles * nbatch * q.splitk, nnorm = n.nrow_blocks * a.S;
+  const dim3 grid(ngemm + npro + nnorm);
+  if (bk == 64) hipLaunchKernelGGL((t0_pro_kuu_kernel<64>), grid, dim3(256), 0, st, a, npro, n, nnorm, q, tiles, ngemm);
+  else hipLaunchKernelGGL((t0_pro_kuu_kernel<32>), grid, dim3(256), 0, st, a, npro, n, nnorm, q, tiles, ngemm);
+  return check_launch("pro_kuu");
 }
 
 // two problems, one launch; falls back to two launches when the pair kernel does not apply
