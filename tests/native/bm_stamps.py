@@ -18,6 +18,18 @@ tr = ElboTrainer(gp, lr=bench.LR, beta=bench.BETA, n_total=bench.N_TOTAL)
 for _ in range(5):
     tr.step(x, y)
 torch.cuda.synchronize()
+if len(sys.argv) > 1 and sys.argv[1] == 'tail':     # t0_puu_final_kernel (a -DTAIL_STAMPS build of elbo_t0.hip)
+    out = (ctypes.c_ulonglong * 16)()
+    fn = _lib.lib().vargp_debug_tail_stamps
+    fn.restype, fn.argtypes = None, [ctypes.c_void_p]
+    fn(out)
+    v = list(out)
+    names = {(0, 1): 'issue loads', (1, 3): 'MFMA s=0', (3, 4): 'epilogue s=0', (4, 5): 'MFMA s=1',
+             (5, 6): 'epilogue s=1', (6, 7): 'MFMA s=2', (7, 8): 'epilogue s=2', (8, 13): 'gz stores'}
+    for (i, j), n in names.items():
+        print('%-32s %8d cycles' % (n, v[j] - v[i]))
+    print('%-32s %8d cycles' % ('total', v[13] - v[0]))
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == 'mat':      # t0_bwd_mat_body (a -DBMAT_STAMPS build of gemm.hip)
     out = (ctypes.c_ulonglong * 24)()
     fn = _lib.lib().vargp_debug_bmat_stamps

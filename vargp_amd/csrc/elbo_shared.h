@@ -322,6 +322,43 @@ static __global__ __launch_bounds__(256) void t0_w_kernel(const float* __restric
   if (threadIdx.x == 0) atomicAdd(&gtheta[(b / C) * (D + 1) + D], t);
 }
 
+// minibatch side of the lengthscale gradient: gtheta[s, d] += w_sd sum_b x_bd^2 c_uf[s, b]; block (bx, by) = 64 columns of D x
+// ROWS rows of x; red: [2][4][64] floats of LDS
+template <int ROWS>
+__device__ __forceinline__ void t0_final_x_body(const float* __restrict__ x, const float* __restrict__ c_uf,
+                                                const float* __restrict__ w, float* __restrict__ gtheta, int64_t rows, int D,
+                                                int64_t Dp, int S, int bx, int by, float (*red)[4][64]) {
+  constexpr int RJ = ROWS / 4;
+  const int dx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int d = bx * 64 + dx;
+  const bool dok = d < D;
+  const int dc = dok ? d : D - 1;
+  const int64_t row0 = (int64_t)by * ROWS;
+  float xa[RJ];
+  int64_t rcl[RJ];
+#pragma unroll
+  for (int j = 0; j < RJ; ++j) {
+    const int64_t row = row0 + ry + 4 * j;
+    rcl[j] = row < rows ? row : rows - 1;
+    xa[j] = x[rcl[j] * D + dc] * ((dok && row < rows) ? 1.f : 0.f);
+  }
+  for (int s = 0; s < S; ++s) {
+    const float wv = dok ? w[s * Dp + dc] : 0.f;
+    float cu[RJ];
+#pragma unroll
+    for (int j = 0; j < RJ; ++j) cu[j] = c_uf[(int64_t)s * rows + rcl[j]];
+    float th = 0.f;
+#pragma unroll
+    for (int j = 0; j < RJ; ++j) th += xa[j] * (cu[j] * xa[j]);
+    red[s & 1][ry][dx] = th;
+    __syncthreads();
+    if (ry == 0 && dok) {
+      const float t = red[s & 1][0][dx] + red[s & 1][1][dx] + red[s & 1][2][dx] + red[s & 1][3][dx];
+      atomicAdd(&gtheta[(int64_t)s * (D + 1) + d], wv * t);
+    }
+  }
+}
+
 // RBF finalisation (rbf.hip), both kernel matrices at once.  grid (ceil(D/64), nzy + nxy), 64 d-columns x 4 row lanes.
 //   y-blocks < nzy  (inducing points):  gz[row,d] = -sum_s w_sd ((r_uu + r_uf) z - (P_uu + P_uf))
 //                                       gtheta[s,d] += w_sd sum_row z ((r_uu z - P_uu) + (r_uf z - 2 P_uf))
@@ -339,15 +376,18 @@ static __global__ __launch_bounds__(256) void t0_final_kernel(const float* __res
                  1, gv.C, gv.M, gv.M, 0);
     return;
   }
+  if ((int)blockIdx.y >= nzy) {
+    t0_final_x_body<kFinRows>(x, c_uf, w, gtheta, xrows, D, Dp, S, (int)blockIdx.x, (int)blockIdx.y - nzy, red);
+    return;
+  }
   constexpr int RJ = kFinRows / 4;
   const int dx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int d = blockIdx.x * 64 + dx;
   const bool dok = d < D;
   const int dc = dok ? d : D - 1;
-  const bool zside = (int)blockIdx.y < nzy;
-  const int64_t rows = zside ? zrows : xrows;
-  const int64_t row0 = (int64_t)(zside ? blockIdx.y : blockIdx.y - nzy) * kFinRows;
-  const float* src = zside ? z : x;
+  const int64_t rows = zrows;
+  const int64_t row0 = (int64_t)blockIdx.y * kFinRows;
+  const float* src = z;
   // Every load is unconditional, on clamped indices, and its value masked afterwards: a load inside a per-row branch is
   // followed by its own `s_waitcnt vmcnt(0)`, i.e. one memory round trip per row and sample (8 x S of them in a row).
   float xa[RJ], ga[RJ], msk[RJ];
@@ -363,7 +403,7 @@ static __global__ __launch_bounds__(256) void t0_final_kernel(const float* __res
     xa[j] = src[rcl[j] * D + dc] * msk[j];
     ga[j] = 0.f;
   }
-  if (zside) {
+  {
     for (int s = 0; s < S; ++s) {
       const float wv = dok ? w[s * Dp + dc] : 0.f;
       float p1[RJ], p2[RJ], r1[RJ], r2[RJ];
@@ -393,22 +433,6 @@ static __global__ __launch_bounds__(256) void t0_final_kernel(const float* __res
       for (int j = 0; j < RJ; ++j) {
         const int64_t row = row0 + ry + 4 * j;
         if (row < rows) gz[row * D + d] = ga[j];
-      }
-    }
-  } else {
-    for (int s = 0; s < S; ++s) {
-      const float wv = dok ? w[s * Dp + dc] : 0.f;
-      float cu[RJ];
-#pragma unroll
-      for (int j = 0; j < RJ; ++j) cu[j] = c_uf[(int64_t)s * rows + rcl[j]];
-      float th = 0.f;
-#pragma unroll
-      for (int j = 0; j < RJ; ++j) th += xa[j] * (cu[j] * xa[j]);
-      red[s & 1][ry][dx] = th;
-      __syncthreads();
-      if (ry == 0 && dok) {
-        const float t = red[s & 1][0][dx] + red[s & 1][1][dx] + red[s & 1][2][dx] + red[s & 1][3][dx];
-        atomicAdd(&gtheta[(int64_t)s * (D + 1) + d], wv * t);
       }
     }
   }

@@ -21,6 +21,7 @@
 #include "elbo_shared.h"
 #include "t0_bwd_mid.h"
 #include "t0_prologue.h"
+#include "t0_bwd_tail.h"
 
 namespace vargp {
 
@@ -896,6 +897,7 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
   if (rc) return rc;
   }
   const int64_t zrows = (int64_t)C * M;
+  bool fused_tail = false;
   GemmParams p0{}, p1{};       // the W.Y products of the kernel-matrix backward: P_uu = W_uu z per (s, c), P_uf = W_uf x per s
   p0.A = o.Wuu; p0.B = d->z; p0.C = o.Puu;
   p0.M = M; p0.N = D; p0.K = M; p0.lda = M; p0.ldb = D; p0.ldc = D;
@@ -919,11 +921,15 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
     // all S C + C matrices next to P_uf = W_uf x (which only needs the tile kernel's W_uf) ...
     rc = launch_bwdmat_gemm(ma, 0, SC + C, p1, S, st, "rbf_kuf_bwd_gemm");
     if (rc) return rc;
-    // ... then P_uu = W_uu z and the gradient of the packed Cholesky vector of q(u)
-    static const int puu_tile = [] { const char* e = getenv("VARGP_T0_PUU_TILE"); return e ? atoi(e) : 0; }();   // tuning aid
-    p0.tile = puu_tile;
-    rc = launch_gemm(p0, 0, 0, SC, false, st, "rbf_kuu_bwd_gemm");
-    if (rc) return rc;
+    // ... then P_uu = W_uu z; with few samples inside the launch that consumes it (t0_bwd_tail.h)
+    static const int tail_env = [] { const char* e = getenv("VARGP_T0_TAIL"); return e ? atoi(e) : 1; }();   // tuning aid
+    fused_tail = tail_env && S <= kTailSMax;
+    if (!fused_tail) {
+      static const int puu_tile = [] { const char* e = getenv("VARGP_T0_PUU_TILE"); return e ? atoi(e) : 0; }();   // tuning aid
+      p0.tile = puu_tile;
+      rc = launch_gemm(p0, 0, 0, SC, false, st, "rbf_kuu_bwd_gemm");
+      if (rc) return rc;
+    }
   } else {
   {
     const int64_t total = (int64_t)C * M * (M + 1);
@@ -953,8 +959,24 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
       gv.gvec = g_u_tril_vec; gv.C = C; gv.M = M; gv.y0 = nzy + nxy;
       ngy = cdiv(cdiv((int64_t)C * MM, 256), gx);
     }
-    hipLaunchKernelGGL(t0_final_kernel, dim3(gx, nzy + nxy + ngy), dim3(256), 0, st, d->z, d->x, o.r_uu, o.r_uf, o.c_uf,
-                       o.Puu, o.Puf, o.w, g_z, o.gtheta, zrows, (int64_t)B, D, o.Dp, S, nzy, gv);
+    if (fused_tail) {
+      ProfScope prof("t0_puu_final", st);
+      TailArgs ta{};
+      ta.z = d->z; ta.x = d->x; ta.Wuu = o.Wuu; ta.Puf = o.Puf; ta.r_uu = o.r_uu; ta.r_uf = o.r_uf; ta.c_uf = o.c_uf; ta.w = o.w;
+      ta.gz = g_z; ta.gtheta = o.gtheta; ta.S = S; ta.C = C; ta.M = M; ta.D = D; ta.B = B; ta.Dp = o.Dp;
+      ta.nrb = cdiv(M, 32); ta.ncb = cdiv(D, 32); ta.nz = cdiv(C * ta.nrb * ta.ncb, 4); ta.nx = gx * cdiv(B, kTailXRows); ta.gx = gx;
+      const int ngv = cdiv((int64_t)C * MM, 256);
+      const dim3 grid(ta.nz + ta.nx + ngv);
+      switch (S) {
+        case 1: hipLaunchKernelGGL(t0_puu_final_kernel<1>, grid, dim3(256), 0, st, ta, gv); break;
+        case 2: hipLaunchKernelGGL(t0_puu_final_kernel<2>, grid, dim3(256), 0, st, ta, gv); break;
+        case 3: hipLaunchKernelGGL(t0_puu_final_kernel<3>, grid, dim3(256), 0, st, ta, gv); break;
+        default: hipLaunchKernelGGL(t0_puu_final_kernel<4>, grid, dim3(256), 0, st, ta, gv); break;
+      }
+    } else {
+      hipLaunchKernelGGL(t0_final_kernel, dim3(gx, nzy + nxy + ngy), dim3(256), 0, st, d->z, d->x, o.r_uu, o.r_uf, o.c_uf,
+                         o.Puu, o.Puf, o.w, g_z, o.gtheta, zrows, (int64_t)B, D, o.Dp, S, nzy, gv);
+    }
   }
   if (!d->defer_hyper)
     hipLaunchKernelGGL(t0_hyper_bwd_kernel, dim3(cdiv(D + 1, 256)), dim3(256), 0, st, d->log_mean, d->log_logvar,
