@@ -157,6 +157,21 @@ int main(int argc, char** argv) {
     }
     vargp_tune_gemm_tile(0);
   }
+  if (which == "chol2048") {   // the blocked factorisation + inverse at the stress size (10 matrices of 2048 x 2048)
+    const int n = 2048, nb = 10;
+    std::vector<float> h((size_t)nb * n * n);
+    for (int b = 0; b < nb; ++b) for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j)
+      h[((size_t)b * n + i) * n + j] = (i == j ? 1.f : 0.f) + 0.5f * expf(-0.05f * (i - j) * (i - j));
+    float *A, *L, *T; int* info; void* ws;
+    const size_t wsb = vargp_chol_workspace_bytes(nb, n, 0);
+    CK(hipMalloc(&A, h.size() * 4)); CK(hipMalloc(&L, h.size() * 4)); CK(hipMalloc(&T, h.size() * 4)); CK(hipMalloc(&info, nb * 4));
+    CK(hipMalloc(&ws, wsb));
+    CK(hipMemcpy(A, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    double us = time_us([&] { vargp_chol_inv_fwd(A, 1e-4f, L, T, nullptr, info, nb, n, ws, wsb, nullptr); }, iters);
+    const double fl = nb * (2.0 / 3.0) * (double)n * n * n;      // n^3/3 (L) + n^3/3 (T = L^-1), flops = 2 x MACs
+    printf("chol2048 batch %d  L+T %8.1f us -> %.1f TFLOP/s\n", nb, us, fl / us * 1e-6);
+    return 0;
+  }
   if (want("chol")) {
     for (int n : {20, 40, 64, 100}) {
       const int nb = 30;
