@@ -57,12 +57,21 @@ __device__ __forceinline__ double lane_bcast(double v, int lane) {
   return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
 
+// VARGP_CHOL_FLAGSYNC (tuning experiment): no barrier per pivot -- the publishing wave sets an LDS flag after
+// its row, the readers poll it together with the row (LDS serves a wave's instructions in order, so a set flag means the row
+// is there).  Four row buffers: row J + 4 is published by the wave that published row J, after it has read row J + 3, whose
+// publisher had read row J + 2, ... -- by then every wave has read row J.
+#ifndef VARGP_CHOL_FLAGSYNC
+#define VARGP_CHOL_FLAGSYNC 0
+#endif
+constexpr int kCholBufs = VARGP_CHOL_FLAGSYNC ? 4 : 2;
 struct Chol3Ctx {
-  double* prow;   // [2][128]  pivot row p (columns 0..127; the pivot itself stored as 1 + d), double-buffered by parity
-  double* qrow;   // [2][128]  q = -p / d, same layout
-  double* dpiv;   // [2]       the pivot d (<= 0 or NaN: not positive-definite)
+  double* prow;   // [kCholBufs][128]  pivot row p (columns 0..127; the pivot itself stored as 1 + d), buffered by J % kCholBufs
+  double* qrow;   // [kCholBufs][128]  q = -p / d, same layout
+  double* dpiv;   // [kCholBufs]       the pivot d (<= 0 or NaN: not positive-definite)
   double* sd;     // [n]       all pivots, for the final scaling
   int n, lane, w;
+  int* flag;   // [kCholBufs]  FLAGSYNC: J + 1 once row J is in its buffer
 };
 
 // Row J (slot J / 4 of wave J % 4) to LDS, final once step J - 1 has updated it: p, the scaled copy q = -p / d_J and
@@ -72,8 +81,8 @@ template <int KC, int SETS, int J>
 __device__ __forceinline__ void chol3_publish(const Chol3Ctx& cx, const double (&va)[KC], const double (&vb)[KC]) {
   constexpr bool second = J >= 64;
   constexpr int jl = second ? J - 64 : J;
-  double* prow = cx.prow + (J & 1) * 128;
-  double* qrow = cx.qrow + (J & 1) * 128;
+  double* prow = cx.prow + (J % kCholBufs) * 128;
+  double* qrow = cx.qrow + (J % kCholBufs) * 128;
   double pa = va[J / 4], pb = vb[J / 4];
   const double d = lane_bcast(second ? pb : pa, jl);
   const double ndi = -fast_rcp(d);
@@ -84,7 +93,12 @@ __device__ __forceinline__ void chol3_publish(const Chol3Ctx& cx, const double (
     prow[64 + cx.lane] = pb;
     qrow[64 + cx.lane] = pb * ndi;
   }
-  if (cx.lane == 0) { cx.dpiv[J & 1] = d; cx.sd[J] = d; }
+  if (cx.lane == 0) { cx.dpiv[J % kCholBufs] = d; cx.sd[J] = d; }
+#if VARGP_CHOL_FLAGSYNC
+  asm volatile("" ::: "memory");      // (ordering for the compiler; the LDS itself serves a wave's writes in order)
+  if (cx.lane == 0) cx.flag[J % kCholBufs] = J + 1;
+  asm volatile("" ::: "memory");
+#endif
 }
 
 template <int KC, int SETS, int J>
@@ -97,20 +111,36 @@ __device__ __forceinline__ void chol3_steps(const Chol3Ctx& cx, double (&va)[KC]
     if (J >= cx.n || fail) return;                           // uniform
     const int lane = cx.lane, w = cx.w;
     STAMP(0);
+#if !VARGP_CHOL_FLAGSYNC
     __syncthreads();                                         // row J is in LDS
+#endif
     STAMP(2);
     // every LDS read of the step up front: the pivot, this lane's columns of q, and -- same address in every lane --
     // the entries p_i of the rows i = 4k + w this wave still updates (p_i = A_iJ by symmetry: the multiplier of row i)
-    const double d = cx.dpiv[J & 1];
-    const double* qrow = cx.qrow + (J & 1) * 128;
-    const double* pw = cx.prow + (J & 1) * 128 + w;
-    const double qa = qrow[lane];
-    double qb = 0.0;
+    const double* qrow = cx.qrow + (J % kCholBufs) * 128;
+    const double* pw = cx.prow + (J % kCholBufs) * 128 + w;
+    double d, qa, qb = 0.0, pr[KC];
+#if VARGP_CHOL_FLAGSYNC
+    int seen;
+    do {       // the flag first, the row behind it in the same batch of reads; again if the flag was not up yet
+      asm volatile("" ::: "memory");        // compiler barriers only: every round re-reads, the flag read stays first;
+      seen = cx.flag[J % kCholBufs];        // the LDS serves a wave's reads in order, no wait between them
+      asm volatile("" ::: "memory");
+      d = cx.dpiv[J % kCholBufs];
+      qa = qrow[lane];
+      if constexpr (SETS == 2) qb = qrow[64 + lane];
+#pragma unroll
+      for (int k = kj; k < KC; ++k) pr[k] = pw[4 * k];
+      asm volatile("" ::: "memory");
+    } while (__builtin_amdgcn_readfirstlane(seen) != J + 1);
+#else
+    d = cx.dpiv[J % kCholBufs];
+    qa = qrow[lane];
     if constexpr (SETS == 2) qb = qrow[64 + lane];
-    double pr[KC];
 #pragma unroll
     for (int k = kj; k < KC; ++k) pr[k] = pw[4 * k];
     __builtin_amdgcn_sched_group_barrier(0x100, (KC - kj + 1) / 2 + 3, 0);   // DS reads first
+#endif
     if (!(d > 0.0)) { fail = J + 1; return; }                // uniform
     // rows i = 4k + w > J only: slots below kj are finished for every wave, slot kj for the waves w <= wj
     if (w <= wj) pr[kj] = 0.0;
@@ -151,8 +181,9 @@ __device__ __forceinline__ void chol3_body(const int64_t b, const float* __restr
   // `stage` = chol3_stage_floats<KC>() floats of LDS owned by the kernel (the matrix on its way in, L and T on their
   // way out), so that a kernel with other roles can hand over LDS it has anyway
   constexpr int NP = 4 * KC + 4;
-  __shared__ double prow[2][128], qrow[2][128];
-  __shared__ double dpiv[2];
+  __shared__ double prow[kCholBufs][128], qrow[kCholBufs][128];
+  __shared__ double dpiv[kCholBufs];
+  __shared__ int flag[4];
   __shared__ double sd[NP], sq[NP];
   __shared__ float red[4];
   constexpr int LS = 4 * KC + 1;               // odd row stride: column-wise access hits distinct banks too
@@ -250,7 +281,11 @@ __device__ __forceinline__ void chol3_body(const int64_t b, const float* __restr
   }
 
   int fail = 0;
-  const Chol3Ctx cx{&prow[0][0], &qrow[0][0], dpiv, sd, n, lane, w};
+  const Chol3Ctx cx{&prow[0][0], &qrow[0][0], dpiv, sd, n, lane, w, flag};
+#if VARGP_CHOL_FLAGSYNC
+  if (tid < 4) flag[tid] = 0;
+  __syncthreads();
+#endif
   if (w == 0) chol3_publish<KC, SETS, 0>(cx, va, vb);      // row 0 has no predecessor to publish it
 #ifdef VARGP_CHOL_STAMPS
   unsigned long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
