@@ -39,6 +39,7 @@ DOMINANT_TAG = 'rbf_kuf'       # the K_uf distance GEMM incl. its split-K combin
 WORKLOADS = {
     'smnist': dict(S=3, M=100, n_prev=0, desc='BASELINE config 2 (Split-MNIST t=0): S3 F10 C10 M100 D784 B512 ELBO step'),
     'smnist_s64': dict(S=64, M=100, n_prev=0, strong=True, desc='BASELINE config 4 (Split-MNIST t=0, 64 hyper-samples x 10 classes), samples split over the ranks'),
+    'smnist_s8': dict(S=8, M=100, n_prev=0, desc="one rank's share of BASELINE config 4 on 8 GPUs (Split-MNIST t=0, 8 of the 64 hyper-samples), no exchange"),
     'smnist_t1': dict(S=3, M=100, n_prev=1, desc='Split-MNIST task 1 (Mt=200), M=100, S=3 (native block-structured program)'),
     'smnist_t4': dict(S=3, M=100, n_prev=4, desc='Split-MNIST task 4 (Mt=500), M=100, S=3 (native block-structured program)'),
     'pmnist_t0': dict(S=10, M=200, n_prev=0, desc='BASELINE config 3 (Permuted-MNIST), task 0: M=200, S=10'),
@@ -285,7 +286,7 @@ def elbo_check(gp, x, y):
     return max(errs), ('sub-sample S=%d B=%d' % (Sc, Bc)) if big else 'full workload'
 
 
-SECONDARY = ['smnist_s64', 'smnist_t1', 'pmnist_t0', 'pmnist_t1', 'pmnist_t4', 'pmnist_t9']   # + 'stress'
+SECONDARY = ['smnist_s64', 'smnist_s8', 'smnist_t1', 'pmnist_t0', 'pmnist_t1', 'pmnist_t4', 'pmnist_t9']   # + 'stress'
 
 
 def run_workload(name, args, device, world, rank, use_dist, steps, warmup, primary=True, kern_n=100):

@@ -839,8 +839,9 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
   // ... and everything per matrix after it (small columns of gT / gRK, Cholesky adjoint, W_uu) as one LDS-resident workgroup
   // per matrix inside the launches of the two W.Y products (t0_bwd_mat.h)
   static const int mat_bwd_env = [] { const char* e = getenv("VARGP_T0_MAT_BWD"); return e ? atoi(e) : 1; }();   // tuning aid
-  // (the S_u matrices redo T_s^T gG_s for every hyper-sample: worth it for the few samples of the reference's configs)
-  const bool mat_bwd = fused_bwd && mat_bwd_env && (D % 4) == 0 && S <= 4 &&
+  // (the S_u matrices redo T_s^T gG_s for every hyper-sample: worth it for the few samples of the reference's configs and for
+  // the 8 per GPU of BASELINE config 4 on 8 GPUs -- the product the chains hide under grows with S just as they do)
+  const bool mat_bwd = fused_bwd && mat_bwd_env && (D % 4) == 0 && S <= kTailSMax &&
                        ((reinterpret_cast<uintptr_t>(d->z) | reinterpret_cast<uintptr_t>(d->x)) & 15) == 0;
   {
     const int npd = fused_bwd ? 0 : M * SC, nkx = cdiv(M, kKlRows), nkl = nkx * SC;
@@ -971,7 +972,8 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
         case 1: hipLaunchKernelGGL(t0_puu_final_kernel<1>, grid, dim3(256), 0, st, ta, gv); break;
         case 2: hipLaunchKernelGGL(t0_puu_final_kernel<2>, grid, dim3(256), 0, st, ta, gv); break;
         case 3: hipLaunchKernelGGL(t0_puu_final_kernel<3>, grid, dim3(256), 0, st, ta, gv); break;
-        default: hipLaunchKernelGGL(t0_puu_final_kernel<4>, grid, dim3(256), 0, st, ta, gv); break;
+        case 4: hipLaunchKernelGGL(t0_puu_final_kernel<4>, grid, dim3(256), 0, st, ta, gv); break;
+        default: hipLaunchKernelGGL(t0_puu_final_kernel<0>, grid, dim3(256), 0, st, ta, gv); break;      // 5 .. kTailSMax
       }
     } else {
       hipLaunchKernelGGL(t0_final_kernel, dim3(gx, nzy + nxy + ngy), dim3(256), 0, st, d->z, d->x, o.r_uu, o.r_uf, o.c_uf,

@@ -16,7 +16,7 @@
 
 namespace vargp {
 
-constexpr int kTailSMax = 4;
+constexpr int kTailSMax = 8;
 constexpr int kTailXRows = 64;            // minibatch rows per block of the x role
 constexpr int kTailNG = kBmKP / 8;        // k-groups of 8
 
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256, 2) void t0_puu_final_kernel(const TailArgs a, 
   const float* zc = a.z + (int64_t)c * M * D;
   TAIL_STAMP(0);
   // --- r_uu + r_uf of the block's 32 rows, every sample -> LDS (this wave's slice) --------------------------------------------
-  for (int e = lane; e < 32 * S; e += 64) {
+  for (int e = lane; e < 32 * (S == 0 ? a.S : S); e += 64) {
     const int s = e >> 5, row = min(r0 + (e & 31), M - 1);
     const int64_t sr = (int64_t)s * zrows + (int64_t)c * M + row;
     rsl[wave][s][e & 31] = a.r_uu[sr] + a.r_uf[sr];
@@ -104,8 +104,11 @@ __global__ __launch_bounds__(256, 2) void t0_puu_final_kernel(const TailArgs a, 
   }
   TAIL_STAMP(1);
 
-#pragma unroll
-  for (int s = 0; s < S; ++s) {
+  // S == 0: the sample count is a.S and the loop stays a loop (more than four samples: unrolled, the compiler hoists every
+  // sample's addresses and spills)
+  const int ns = S == 0 ? a.S : S;
+#pragma unroll(S == 0 ? 1 : S)
+  for (int s = 0; s < ns; ++s) {
     const float wv = dok ? a.w[s * a.Dp + dc] : 0.f;
     bm_f32x16 acc;
 #pragma unroll
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void t0_puu_final_kernel(const TailArgs a, 
     }
     __builtin_amdgcn_sched_barrier(0);
     TAIL_STAMP(3 + 2 * s);
-    if (s + 1 < S) tail_load_a(wrow + (s + 1) * wstep, lh, M, af);       // next sample's fragments under the epilogue
+    if (s + 1 < ns) tail_load_a(wrow + (s + 1) * wstep, lh, M, af);       // next sample's fragments under the epilogue
     float th = 0.f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void t0_puu_final_kernel(const TailArgs a, 
         th += zr * (t - q2);
       }
     }
-    if (s + 1 < S) {
+    if (s + 1 < ns) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) p2[r] = pufp[((int64_t)(s + 1) * zrows + min(rowof(r), M - 1)) * D];
     }
