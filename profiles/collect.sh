@@ -1,15 +1,15 @@
 #!/bin/bash
 # Raw rocprofv3 inputs of one round's committed profile summaries.  Run on the GPU box from the repo root:
-#     bash profiles/collect.sh r02
+#     bash profiles/collect.sh r03
 # Writes under gpurun_out/<tag>_* (scratch); `python profiles/summarize.py <tag>` then turns them into profiles/<tag>_*.
 # Counter passes are separate runs with --kernel-trace only (FETCH_SIZE and WRITE_SIZE do not fit one pass; no other trace
 # domain next to --pmc).  The program under the profiler is python3 itself (no wrapper process).
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$(pwd)
 OUT=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --no-cpu-baseline"
+B="python3 $R/bench.py --no-cpu-baseline --no-secondary"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_graph -o p -- $B --steps 100 --warmup 10 > $OUT/${TAG}_graph.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_eager -o p -- $B --eager --no-replay --steps 50 --warmup 5 > $OUT/${TAG}_eager.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_replay -o p -- $B --eager --steps 5 --warmup 2 > $OUT/${TAG}_replay.log 2>&1
@@ -23,10 +23,6 @@ BS="python3 $R/bench.py --workload stress --stress-n 65536 --no-cpu-baseline"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_stfetch -o p -- $BS > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_stwrite -o p -- $BS > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_stsq -o p -- $BS > /dev/null 2>&1
-# secondary workloads: bench lines only
-for w in smnist_s64 smnist_t1 smnist_t4 pmnist_t0 pmnist_t1 pmnist_t4 pmnist_t9; do
-  python3 $R/bench.py --workload $w --steps 30 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_line_$w.log 2>&1
-done
-python3 $R/bench.py --workload stress > $OUT/${TAG}_line_stress.log 2>&1
+# the round's bench line: the default command (its `secondary` object carries the other BASELINE configs and the stress case)
 python3 $R/bench.py > $OUT/${TAG}_line_smnist.log 2>&1
 ls $OUT | grep ${TAG}_ | head -40

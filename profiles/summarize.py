@@ -1,7 +1,7 @@
 """Turn the raw rocprofv3 output of one round (under gpurun_out/, scratch: produced by `bash profiles/collect.sh <tag>` on
 the GPU box) into the committed summaries here.
 
-    python profiles/summarize.py r02
+    python profiles/summarize.py r03
 
 Outputs (profiles/<tag>_*):
   bench.json                       the default `python bench.py` line of this round
@@ -88,7 +88,7 @@ def keep(rows, name):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
+    tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
     G = os.path.join(ROOT, 'gpurun_out')
     src = lambda d, f: os.path.join(G, f'{tag}_{d}', f)
     shutil.copy(src('graph', 'p_kernel_stats.csv'), os.path.join(OUT, f'{tag}_bench_graph_kernel_stats.csv'))
@@ -98,6 +98,8 @@ def main():
     json.dump(line, open(os.path.join(OUT, f'{tag}_bench.json'), 'w'), indent=1)
     lines = {w: last_json(os.path.join(G, f'{tag}_line_{w}.log')) for w in SECONDARY
              if os.path.exists(os.path.join(G, f'{tag}_line_{w}.log'))}
+    if not lines:        # from round 3 on the default line carries them itself
+        lines = (line or {}).get('secondary', {})
     json.dump(lines, open(os.path.join(OUT, f'{tag}_lines.json'), 'w'), indent=1)
 
     traffic, mfma = {}, {}
