@@ -39,9 +39,8 @@ KERNELS = {
     # tile kernel of the backward: read QP-side operands per (s, c, 64-column tile), write W_uf; everything else is atomics
     't0_bwd_mid': ('void vargp::t0_bwd_mid_kernel', 4 * (2 * S * C * M * B + 3 * S * C * M * M + 3 * S * C * M * M),
                    8.0 * S * C * M * M * B),
-    # front launch: read z per (s, c, K split), write the partial Gram matrices; prologue + norms: read z, x once more
-    't0_pro_kuu': ('void vargp::t0_pro_kuu_kernel', 4 * (2 * S * C * M * D + 2 * S * C * M * M + S * (C * M + B) * D),
-                   2.0 * S * C * M * M * D),
+    # front launch: read z once for the product and once for the norms, x once; write the two partial Gram matrices per (s, c)
+    't0_pro_kuu': ('void vargp::t0_pro_kuu_kernel', 4 * (2 * C * M * D + B * D + 2 * S * C * M * M), 2.0 * S * C * M * M * D),
     # last launch: read W_uu, P_uf, z; write gz
     't0_puu_final': ('void vargp::t0_puu_final_kernel', 4 * (S * C * M * M + S * C * M * D + 2 * C * M * D + B * D),
                      2.0 * S * C * M * M * D),
@@ -70,7 +69,8 @@ def last_json(path):
 
 
 def pmc_rows(path, prefix):
-    return [r for r in csv.DictReader(open(path)) if r['Kernel_Name'].startswith(prefix)]
+    bare = prefix[5:] if prefix.startswith('void ') else prefix       # non-template kernels are listed without the return type
+    return [r for r in csv.DictReader(open(path)) if r['Kernel_Name'].startswith(prefix) or r['Kernel_Name'].startswith(bare)]
 
 
 def avg(rows, counter):
