@@ -103,6 +103,21 @@ bool chol_rbf_gemm_applicable(int n, const GemmParams& p);
 // part != NULL: the matrices b < first arrive as nsplit (<= kCholPartMax) partial Gram matrices G_q at part + q * sSplit + b n^2
 // (the K-split inner products of an RBF kernel matrix over ONE point set); the factorising workgroup forms
 // K_ij = g2[b / part_C] exp(-(G_ii + G_jj - 2 G_ij) / 2), G = sum_q G_q, exactly g2 on the diagonal, as it loads, and stores
+// Zero-fills that ride in some other launch's spare workgroups: rows x width floats at p, row stride ld (p == NULL: none)
+struct ZeroJob { float* p; int64_t rows, width, ld; };
+constexpr int kZeroJobs = 5;
+struct ZeroJobs { ZeroJob j[kZeroJobs]; };
+#ifdef __HIPCC__
+__device__ __forceinline__ void zero_jobs_role(const ZeroJobs& z, int blk, int nblk) {
+#pragma unroll
+  for (int q = 0; q < kZeroJobs; ++q) {
+    const ZeroJob t = z.j[q];
+    if (!t.p) continue;
+    for (int64_t i = (int64_t)blk * 256 + threadIdx.x; i < t.rows * t.width; i += (int64_t)nblk * 256)
+      t.p[(i / t.width) * t.ld + i % t.width] = 0.f;
+  }
+}
+#endif
 // K to Kout + b n^2 (dense, both triangles).
 constexpr int kCholPartMax = 4;
 constexpr int kProKuuMaxD = 4096;       // launch_pro_kuu: 1/sigma^2 of one hyper-sample staged in LDS by the norm role
@@ -112,7 +127,8 @@ struct CholExtra {
   const float* part; int nsplit; int64_t sSplit; const float* g2; int part_C; float* Kout;
 };
 int launch_chol_rbf_gemm(const float* A, float eps, float* L, float* T, int32_t* info, int nchol, int n,
-                         const GemmParams& p, int nbatch, hipStream_t st, const CholExtra* extra = nullptr);
+                         const GemmParams& p, int nbatch, hipStream_t st, const CholExtra* extra = nullptr,
+                         const ZeroJobs* zero = nullptr);
 // number of K splits launch_gemm will use for an RBF product of this shape (1 = fused epilogue, no partials)
 int rbf_splitk(int M, int N, int K, int nbatch);
 
@@ -147,6 +163,7 @@ int chol_inv_bwd_impl(const float* L, const float* T, const float* gL, const flo
 // on it (gemm.hip: t0_bwdmat_gemm_kernel).  Matrices [first, first + nmat): ids < S C are the K_uu role of (s, c) = id, ids
 // >= S C the S_u role of class id - S C (which reads nothing the K_uu roles write: one launch for all of them).
 struct BwdMatArgs {
+  const float* QP;      // forward small columns [a | . | G | G2]: the KL part of ga and gG2 is g a and g G2 (seed_kl / S)
   const float *TT, *LL, *gQP, *RK, *KS, *seeds;     // TT / LL / KS: [S C + C][M][M]
   const float* gTT;
   float *gKS, *Wuu, *r_uu, *gtheta;

@@ -635,6 +635,26 @@ static int check_desc(const vargp_elbo_t0_desc* d, const char* who) {
   return VARGP_OK;
 }
 
+// which backward the shapes get (the forward needs to know: it clears the accumulators of the LDS-resident one)
+struct T0BwdPaths { bool fused_bwd, mat_bwd; };
+static T0BwdPaths t0_bwd_paths(const vargp_elbo_t0_desc* d, const T0Ws& o) {
+  const int S = d->S, C = d->C, M = d->M, D = d->D, B = d->B, LD = o.LD;
+  // LDS-resident backward middle (t0_bwd_mid.h): same shapes as the forward's fused middle, plus B % 4 == 0 (float4 rows of W)
+  static const int fused_bwd_env = [] { const char* e = getenv("VARGP_T0_FUSED_BWD"); return e ? atoi(e) : 1; }();   // tuning aid
+  const int ntile = cdiv(B, 64);
+  T0BwdPaths r;
+  r.fused_bwd = fused_bwd_env && M <= kBmKP && M >= 4 && (M % 4) == 0 && (LD % 4) == 0 && (B % 4) == 0 &&
+                (int64_t)S * C * ntile <= 2048;
+  // ... and everything per matrix after it (small columns of gT / gRK, Cholesky adjoint, W_uu) as one LDS-resident workgroup
+  // per matrix inside the launch of the P_uf product (t0_bwd_mat.h)
+  static const int mat_bwd_env = [] { const char* e = getenv("VARGP_T0_MAT_BWD"); return e ? atoi(e) : 1; }();   // tuning aid
+  // (the S_u matrices redo T_s^T gG_s for every hyper-sample: worth it for the few samples of the reference's configs and for
+  // the 8 per GPU of BASELINE config 4 on 8 GPUs -- the product the chains hide under grows with S just as they do)
+  r.mat_bwd = r.fused_bwd && mat_bwd_env && (D % 4) == 0 && S <= kTailSMax &&
+              ((reinterpret_cast<uintptr_t>(d->z) | reinterpret_cast<uintptr_t>(d->x)) & 15) == 0;
+  return r;
+}
+
 }  // namespace vargp
 
 using namespace vargp;
@@ -682,6 +702,23 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
       a.n_f = S * per_sample_f;
       a.eps_theta_out = o.eps_theta; a.eps_f_out = o.eps_f;
       a.nrng_blocks = (int)std::min<int64_t>(512, cdiv(a.n_f + 7, 1024));
+    }
+  }
+  ZeroJobs bwd_zero{};
+  const bool clear_bwd = t0_bwd_paths(d, o).mat_bwd;
+  if (clear_bwd) {
+    // accumulators of the LDS-resident backward (atomics of t0_bwd_mid.h / t0_bwd_mat.h / t0_bwd_tail.h), cleared in the forward,
+    // where it costs nothing (spare workgroups under the pivot chains; shapes without that launch: the prologue's zero role):
+    // column 0 (ga) and the G block of gQP, gT, the per-class sums of gLu, gkd, r_uf / c_uf / gtheta
+    bwd_zero.j[0] = ZeroJob{o.gQP, (int64_t)SC * M, 4 + M, LD};
+    bwd_zero.j[1] = ZeroJob{o.gTT, 1, (SC + C) * MM, 0};
+    bwd_zero.j[2] = ZeroJob{o.gLL + SC * MM, 1, C * MM, 0};
+    bwd_zero.j[3] = ZeroJob{o.gkd, 1, SC, 0};
+    bwd_zero.j[4] = ZeroJob{o.r_uf, 1, o.r_uu - o.r_uf, 0};
+    if (!merge_chol) {
+      a.zero = bwd_zero;
+      const int64_t zt = (int64_t)SC * M * (4 + M) + (SC + 2 * C) * MM + (o.r_uu - o.r_uf);
+      a.nzero_blocks = (int)std::min<int64_t>(128, cdiv(a.zero_count + zt, 2048));
     }
   }
   const int npro = 1 + S + a.nzero_blocks + a.nrng_blocks + cdiv((int64_t)C * MM, 256);
@@ -750,7 +787,7 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
       if (front) {   // the matrices b < SC arrive as K-split partial Gram matrices (and leave as K_uu in KS for the backward)
         lx.part = o.kpart; lx.nsplit = ksp; lx.sSplit = SC * MM; lx.g2 = o.g2; lx.part_C = C; lx.Kout = o.KS;
       }
-      rc = launch_chol_rbf_gemm(o.KS, d->jitter, o.LL, o.TT, d->info, SC + C, M, p1, S, st, &lx);
+      rc = launch_chol_rbf_gemm(o.KS, d->jitter, o.LL, o.TT, d->info, SC + C, M, p1, S, st, &lx, clear_bwd ? &bwd_zero : nullptr);
       if (rc) return rc;
       merged = true;
     } else {
@@ -831,18 +868,12 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
     rc = vargp_softmax_nll_bwd(o.mu, o.var, eps_f, d->y, seeds + 2, o.gmu, o.gvar, S, F, C, B, stream);
     if (rc) return rc;
   }
-  // LDS-resident backward middle (t0_bwd_mid.h): same shapes as the forward's fused middle, plus B % 4 == 0 (float4 rows of W)
-  static const int fused_bwd_env = [] { const char* e = getenv("VARGP_T0_FUSED_BWD"); return e ? atoi(e) : 1; }();   // tuning aid
   const int ntile = cdiv(B, 64);
-  const bool fused_bwd = fused_bwd_env && M <= kBmKP && M >= 4 && (M % 4) == 0 && (LD % 4) == 0 && (B % 4) == 0 &&
-                         (int64_t)SC * ntile <= 2048;
-  // ... and everything per matrix after it (small columns of gT / gRK, Cholesky adjoint, W_uu) as one LDS-resident workgroup
-  // per matrix inside the launches of the two W.Y products (t0_bwd_mat.h)
-  static const int mat_bwd_env = [] { const char* e = getenv("VARGP_T0_MAT_BWD"); return e ? atoi(e) : 1; }();   // tuning aid
-  // (the S_u matrices redo T_s^T gG_s for every hyper-sample: worth it for the few samples of the reference's configs and for
-  // the 8 per GPU of BASELINE config 4 on 8 GPUs -- the product the chains hide under grows with S just as they do)
-  const bool mat_bwd = fused_bwd && mat_bwd_env && (D % 4) == 0 && S <= kTailSMax &&
-                       ((reinterpret_cast<uintptr_t>(d->z) | reinterpret_cast<uintptr_t>(d->x)) & 15) == 0;
+  const T0BwdPaths paths = t0_bwd_paths(d, o);
+  const bool fused_bwd = paths.fused_bwd, mat_bwd = paths.mat_bwd;
+  // mat_bwd: no head launch -- the forward's zero role has cleared the accumulators, the seed-dependent KL columns (g a, g G2) are
+  // formed by the chain kernel from QP, g_u_mean is cleared by the tile kernel.  ONE backward per forward on this path.
+  if (!mat_bwd)
   {
     const int npd = fused_bwd ? 0 : M * SC, nkx = cdiv(M, kKlRows), nkl = nkx * SC;
     const int64_t zc = o.r_uu - o.r_uf;
@@ -860,7 +891,7 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
       ProfScope prof("t0_bwd_mid", st);
       hipLaunchKernelGGL(t0_bwd_mid_kernel, dim3(8 * cdiv(SC, 8) * ntile), dim3(256), kBwdMidLdsBytes, st, o.TT, o.QP, o.W, o.RK, o.gmu, o.gvar,
                          fused_softmax ? seeds + 2 : nullptr, o.gQP, o.gTT, o.gRK, o.gkd, o.r_uf, o.c_uf, o.gtheta, S, C, M, B, D,
-                         NR, LD, ntile);
+                         NR, LD, ntile, mat_bwd ? g_u_mean : nullptr, C * M);
     }
     if (!mat_bwd) {
       // what the tiles cannot see: the small columns [a | . | G | G2 | .] of QP = T RK (K = NR):
@@ -915,7 +946,7 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
   p1.alpha = 1.f;
   if (mat_bwd) {
     BwdMatArgs ma{};
-    ma.TT = o.TT; ma.LL = o.LL; ma.gQP = o.gQP; ma.RK = o.RK; ma.KS = o.KS; ma.seeds = seeds; ma.gTT = o.gTT;
+    ma.QP = o.QP; ma.TT = o.TT; ma.LL = o.LL; ma.gQP = o.gQP; ma.RK = o.RK; ma.KS = o.KS; ma.seeds = seeds; ma.gTT = o.gTT;
     ma.gKS = o.gKS; ma.Wuu = o.Wuu; ma.r_uu = o.r_uu; ma.gtheta = o.gtheta;
     ma.g_u_mean = g_u_mean; ma.gLu_acc = o.gLL + SC * MM;        // (the S_u part of gLL is free on this path)
     ma.S = S; ma.C = C; ma.M = M; ma.D = D; ma.NR = NR; ma.LD = LD;

@@ -809,6 +809,8 @@ struct CholArgs {
   float* T; int ldt; int64_t sT;
   int32_t* info; int n; int nchol;
   CholExtra extra;   // base == nullptr: none
+  ZeroJobs zero;     // third role (the last nzero workgroups): zero-fills of the caller, free under the pivot chains
+  int nzero;
 };
 template <int KC, int SETS, int BM, int BK, bool SCALED = true>
 __global__ __launch_bounds__(256) void chol_rbf_gemm_kernel(const CholArgs c, const GemmParams p, const int tiles) {
@@ -819,7 +821,12 @@ __global__ __launch_bounds__(256) void chol_rbf_gemm_kernel(const CholArgs c, co
                          0, lds, c.extra.base ? &c.extra : nullptr);
     return;
   }
-  const int id = xcd_remap((int)blockIdx.x - c.nchol, (int)gridDim.x - c.nchol);
+  const int ngemm = (int)gridDim.x - c.nchol - c.nzero;
+  if ((int)blockIdx.x >= c.nchol + ngemm) {
+    zero_jobs_role(c.zero, (int)blockIdx.x - c.nchol - ngemm, c.nzero);
+    return;
+  }
+  const int id = xcd_remap((int)blockIdx.x - c.nchol, ngemm);
   gemm_body<BM, 64, BK, true, true, true, true, SCALED>(p, id % tiles, id / tiles, 0, lds);
 }
 
@@ -923,24 +930,27 @@ int launch_gemm_pair(const GemmParams& p0, int nbatch0, const GemmParams& p1, in
 // factorisations (n in (50, 100], dense n x n matrices) + one RBF GEMM in one launch; false if the shapes do not
 // qualify (the caller then launches them separately)
 static int launch_chol_rbf_gemm_impl(const float* A, float eps, float* L, float* T, int32_t* info, int nchol, int n,
-                                     const GemmParams& p, int nbatch, hipStream_t st, const CholExtra& extra);
+                                     const GemmParams& p, int nbatch, hipStream_t st, const CholExtra& extra, const ZeroJobs& zero);
 bool chol_rbf_gemm_applicable(int n, const GemmParams& p) { return n > 50 && n <= 100 && gemm_vec_ok(p); }
 int launch_chol_rbf_gemm(const float* A, float eps, float* L, float* T, int32_t* info, int nchol, int n,
-                         const GemmParams& p, int nbatch, hipStream_t st, const CholExtra* extra) {
+                         const GemmParams& p, int nbatch, hipStream_t st, const CholExtra* extra, const ZeroJobs* zero) {
   const CholExtra ex = extra ? *extra : CholExtra{};
+  const ZeroJobs zj = zero ? *zero : ZeroJobs{};
   if (prof_remembering()) {
     const GemmParams pc = p;
     prof_remember("chol_rbf_gemm", [=](hipStream_t s) {
-      launch_chol_rbf_gemm_impl(A, eps, L, T, info, nchol, n, pc, nbatch, s, ex);
+      launch_chol_rbf_gemm_impl(A, eps, L, T, info, nchol, n, pc, nbatch, s, ex, zj);
     });
   }
-  return launch_chol_rbf_gemm_impl(A, eps, L, T, info, nchol, n, p, nbatch, st, ex);
+  return launch_chol_rbf_gemm_impl(A, eps, L, T, info, nchol, n, p, nbatch, st, ex, zj);
 }
 static int launch_chol_rbf_gemm_impl(const float* A, float eps, float* L, float* T, int32_t* info, int nchol, int n,
-                                     const GemmParams& p, int nbatch, hipStream_t st, const CholExtra& extra) {
+                                     const GemmParams& p, int nbatch, hipStream_t st, const CholExtra& extra, const ZeroJobs& zero) {
   ProfScope prof("chol_rbf_gemm", st);
   const int64_t nn = (int64_t)n * n;
-  CholArgs c{A, n, nn, eps, L, n, nn, T, n, nn, info, n, nchol, extra};
+  bool any_zero = false;
+  for (int q = 0; q < kZeroJobs; ++q) any_zero = any_zero || zero.j[q].p != nullptr;
+  CholArgs c{A, n, nn, eps, L, n, nn, T, n, nn, info, n, nchol, extra, zero, any_zero ? 64 : 0};
   GemmParams q = p;
   q.splitk = 1;
   // GEMM tile: 64x64x64 normally; 128x64x32 when that lets the GEMM finish in ONE round on the CUs the
@@ -950,7 +960,7 @@ static int launch_chol_rbf_gemm_impl(const float* A, float eps, float* L, float*
   const int free_cus = 256 - nchol;
   const bool big = tile_force ? tile_force == 2 : (t64 * nbatch > free_cus && t128 * nbatch <= free_cus);
   const int tiles = big ? t128 : t64;
-  const int total = nchol + tiles * nbatch;
+  const int total = nchol + tiles * nbatch + c.nzero;
   // The kernel needs 68 KB of LDS, so two workgroups fit a CU.  While the GEMM is small enough to finish under the
   // factorisations anyway (the BASELINE shapes), reserving unused dynamic LDS keeps every factorising CU to itself --
   // a co-resident GEMM workgroup competes for its issue slots and stretches the pivot chain (68 -> 77 us measured);
@@ -975,7 +985,7 @@ int launch_chol_rbf_gemm_ld(const float* A, int lda, int64_t sA, float eps, floa
     });
   }
   ProfScope prof("chol_rbf_gemm", st);
-  CholArgs c{A, lda, sA, eps, L, ldl, sL, T, ldt, sT, info, n, nchol, CholExtra{}};
+  CholArgs c{A, lda, sA, eps, L, ldl, sL, T, ldt, sT, info, n, nchol, CholExtra{}, ZeroJobs{}, 0};
   GemmParams q = p;
   q.splitk = 1;
   const int t64 = cdiv(p.M, 64) * cdiv(p.N, 64), t128 = cdiv(p.M, 128) * cdiv(p.N, 64);

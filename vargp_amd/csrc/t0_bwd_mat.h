@@ -226,6 +226,7 @@ __device__ __forceinline__ void mat_kuu(const BwdMatArgs& a, int id, float* __re
   const int c = id % a.C;
   const float* Tb = a.TT + b * MM;
   const float* gq = a.gQP + b * MLD;
+  const float* qp = a.QP + b * MLD;
   const float* rk = a.RK + b * MLD;
   const float g = a.seeds[1] / (float)a.S;
   bm_f32x16 acc[4];
@@ -235,13 +236,16 @@ __device__ __forceinline__ void mat_kuu(const BwdMatArgs& a, int id, float* __re
   bm_load_mat(Tb, M, M, tid, r0);
   bm_load_mat(gq + 4, LD, M, tid, r1);
   bm_load_mat(rk + 4, LD, M, tid, r2);
-  const float gav = tid < 128 ? gq[(int64_t)min(tid, M - 1) * LD] : 0.f;
+  // ga = the tiles' sum (atomics of t0_bwd_mid_kernel into a cleared column) + the KL's share g a
+  const float gav = tid < 128 ? gq[(int64_t)min(tid, M - 1) * LD] + g * qp[(int64_t)min(tid, M - 1) * LD] : 0.f;
   const float mvv = tid < 128 ? rk[(int64_t)min(tid, M - 1) * LD] : 0.f;
   mat_store(sT, r0, M, tid);
   mat_store(X1, r1, M, tid);
   mat_store(X2, r2, M, tid);
   if (tid < 128) { sga[tid] = tid < M ? gav : 0.f; smv[tid] = tid < M ? mvv : 0.f; }
-  bm_load_mat(gq + 4 + M, LD, M, tid, r1);             // gG2 = g tril(G2)   (KL)
+  bm_load_mat(qp + 4 + M, LD, M, tid, r1);             // gG2 = g G2   (KL; G2 = T Lu is lower triangular with stored zeros)
+#pragma unroll
+  for (int u = 0; u < kBmNA; ++u) { r1[u].x *= g; r1[u].y *= g; r1[u].z *= g; r1[u].w *= g; }
   bm_load_mat(rk + 4 + M, LD, M, tid, r2);             // Lu
   // the tiles' share of gT (accumulated by t0_bwd_mid_kernel's atomics), read in the accumulator layout: needed after two products
   float gtt[4][16];

@@ -230,8 +230,13 @@ __global__ __launch_bounds__(256) void t0_bwd_mid_kernel(const float* __restrict
                                                          float* __restrict__ gTT, float* __restrict__ gRK,
                                                          float* __restrict__ gkd, float* __restrict__ r_uf,
                                                          float* __restrict__ c_uf, float* __restrict__ gtheta, int S, int C,
-                                                         int M, int B, int D, int NR, int LD, int ntile) {
+                                                         int M, int B, int D, int NR, int LD, int ntile,
+                                                         float* __restrict__ zero_out, int zero_n) {
   extern __shared__ __attribute__((aligned(16))) float bm_lds[];
+  // an output of the backward that the NEXT launch accumulates into (g_u_mean: sums over s by atomics): cleared here, by the
+  // first workgroup, because the forward -- which clears the workspace's accumulators -- does not know the caller's buffer
+  if (blockIdx.x == 0 && zero_out)
+    for (int i = threadIdx.x; i < zero_n; i += 256) zero_out[i] = 0.f;
   float* sA = bm_lds;                               // [KP][SA]   G[m][k] (row-major), later T[k][m] (row-major)
   float* sP = sA + kBmKP * kBmSA;                   // [KP][ST]   P tile [m][n], later gP
   float* sW = sP + kBmKP * kBmST;                   // [KP][ST]   W tile -> gW, later the K_uf tile

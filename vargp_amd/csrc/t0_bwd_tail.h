@@ -107,7 +107,8 @@ __global__ __launch_bounds__(256, 2) void t0_puu_final_kernel(const TailArgs a, 
   // S == 0: the sample count is a.S and the loop stays a loop (more than four samples: unrolled, the compiler hoists every
   // sample's addresses and spills)
   const int ns = S == 0 ? a.S : S;
-#pragma unroll(S == 0 ? 1 : S)
+  constexpr int kUnroll = S == 0 ? 1 : S;
+#pragma unroll kUnroll
   for (int s = 0; s < ns; ++s) {
     const float wv = dok ? a.w[s * a.Dp + dc] : 0.f;
     bm_f32x16 acc;

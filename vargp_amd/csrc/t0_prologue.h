@@ -22,6 +22,9 @@ struct ProArgs {
   const uint32_t* rng_counter;
   int64_t g0_theta, g0_f, n_f;
   float *eps_theta_out, *eps_f_out;
+  // accumulators of the BACKWARD that need no seed to be cleared (elbo_t0.hip: the LDS-resident backward then starts without a
+  // head launch of its own)
+  ZeroJobs zero;
 };
 
 // theta[s, d] = mean_d + eps[s, d] exp(logvar_d / 2) (kernels.py:62-68; MAP: mean_d): a pure function of the parameters and
@@ -85,6 +88,7 @@ __device__ __forceinline__ void t0_prologue_body(const ProArgs& a, const int blk
   if (blk <= a.S + a.nzero_blocks) {
     for (int64_t i = (int64_t)(blk - a.S - 1) * 256 + tid; i < a.zero_count; i += (int64_t)a.nzero_blocks * 256)
       a.zero_begin[i] = 0.f;
+    zero_jobs_role(a.zero, blk - a.S - 1, a.nzero_blocks);
     return;
   }
   if (blk <= a.S + a.nzero_blocks + a.nrng_blocks) {

@@ -100,6 +100,7 @@ class T0Program:
         d.bump = _p(bump)
         self._keep = tensors + (bump,)   # the descriptor holds raw pointers: keep the tensors alive until backward
         check(lib().vargp_elbo_t0_fwd(ctypes.byref(d), stream_ptr()), 'vargp_elbo_t0_fwd')
+        self._bwd_ok = True
         ops._note_chol_errors(self.info)
         return self.scalars
 
@@ -108,7 +109,9 @@ class T0Program:
         defer_hyper: the last kernel (theta-gradient -> log_mean / log_logvar) is left to the optimiser's launch
         (`hyper_desc()` -> optim.Yogi.step(hyper=...)); g_log_mean / g_log_logvar are then written by that launch."""
         require_device(seeds, g_log_mean, g_log_logvar, g_z, g_u_mean, g_u_tril_vec)
-        assert self._keep is not None, 'T0Program.backward without a forward'
+        # (the forward clears the accumulators the backward adds into: include/vargp_hip.h, vargp_elbo_t0_bwd)
+        assert self._keep is not None and getattr(self, '_bwd_ok', False), 'T0Program.backward needs a forward of its own (one backward per forward)'
+        self._bwd_ok = False
         for g in (g_log_mean, g_log_logvar, g_z, g_u_mean, g_u_tril_vec):
             assert g.is_contiguous() and g.dtype == torch.float32
         self.desc.defer_hyper = int(bool(defer_hyper))
