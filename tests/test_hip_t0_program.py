@@ -51,6 +51,38 @@ def test_program_matches_fp64_oracle(shape):
         assert rel_l2(g.cpu(), og[k]) < tol, k
 
 
+def _random_shapes(n, seed):
+    """Shapes drawn inside and around the limits of the LDS-resident kernels (tests/native/t0_random_sweep.py runs more)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        out.append((int(rng.integers(1, 10)), int(rng.integers(1, 4)), int(rng.integers(1, 13)),
+                    int(rng.choice([4, 8, 12, 20, 32, 36, 52, 60, 64, 68, 96, 100, 104, 23, 51, 77, 108])),
+                    int(rng.choice([8, 36, 40, 64, 100, 260, 300, 33, 37])),
+                    int(rng.choice([4, 8, 36, 60, 64, 68, 128, 132, 200, 30, 65]))))
+    return out
+
+
+RANDOM_SHAPES = _random_shapes(14, 7)
+
+
+@pytest.mark.parametrize('shape', RANDOM_SHAPES, ids=[str(s) for s in RANDOM_SHAPES])
+def test_program_random_shapes_vs_fp64_oracle(shape):
+    from vargp_amd import noise
+    from gpu_common import build_gp, grads_of
+    S, F_, C, M, D, B = shape
+    params, prev, x, y, nz = _problem(S, F_, C, M, D, B, seed=77)
+    gp = build_gp(params, prev, S, F_)
+    with noise.inject(**to_dev(nz, DEV)):
+        kl_h, kl_u, nll = gp.loss(x.to(DEV), y.to(DEV))
+        (2.0 * kl_h + kl_u + 7.0 * nll).backward()
+    sc, og = orc.elbo_step(params, prev, x, y, nz, beta=2.0, n_total=7 * B)
+    for k, v in [('kl_hypers', kl_h), ('kl_u', kl_u), ('nll', nll)]:
+        np.testing.assert_allclose(v.item(), sc[k].item(), rtol=RTOL_SCALAR, err_msg=k)
+    for k, g in grads_of(gp).items():
+        assert rel_l2(g.cpu(), og[k]) < REL_L2_GRAD, k
+
+
 def test_program_map_est():
     """map_est: theta = log_mean, no hyper-KL; against the composed per-op path."""
     from vargp_amd import noise
