@@ -40,6 +40,8 @@ WORKLOADS = {
     'smnist': dict(S=3, M=100, n_prev=0, desc='BASELINE config 2 (Split-MNIST t=0): S3 F10 C10 M100 D784 B512 ELBO step'),
     'smnist_s64': dict(S=64, M=100, n_prev=0, strong=True, desc='BASELINE config 4 (Split-MNIST t=0, 64 hyper-samples x 10 classes), samples split over the ranks'),
     'smnist_s8': dict(S=8, M=100, n_prev=0, desc="one rank's share of BASELINE config 4 on 8 GPUs (Split-MNIST t=0, 8 of the 64 hyper-samples), no exchange"),
+    'smnist_s16': dict(S=16, M=100, n_prev=0, desc="one rank's share of BASELINE config 4 on 4 GPUs (16 of the 64 hyper-samples), no exchange"),
+    'smnist_s32': dict(S=32, M=100, n_prev=0, desc="one rank's share of BASELINE config 4 on 2 GPUs (32 of the 64 hyper-samples), no exchange"),
     'smnist_t1': dict(S=3, M=100, n_prev=1, desc='Split-MNIST task 1 (Mt=200), M=100, S=3 (native block-structured program)'),
     'smnist_t4': dict(S=3, M=100, n_prev=4, desc='Split-MNIST task 4 (Mt=500), M=100, S=3 (native block-structured program)'),
     'pmnist_t0': dict(S=10, M=200, n_prev=0, desc='BASELINE config 3 (Permuted-MNIST), task 0: M=200, S=10'),
