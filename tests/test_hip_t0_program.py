@@ -24,10 +24,10 @@ SHAPES = [(2, 3, 3, 33, 40, 50), (3, 2, 4, 20, 64, 37), (2, 2, 18, 12, 36, 24), 
           # M = 64 and M = 65 (the two register-slot layouts of the factorisation kernel), M = 100 with B % 4 != 0
           (1, 1, 1, 3, 33, 2), (2, 2, 2, 64, 40, 33), (2, 2, 2, 65, 40, 32), (1, 2, 2, 100, 36, 50), (1, 2, 3, 51, 36, 8),
           # the LDS-resident backward (t0_bwd_mid.h / t0_bwd_mat.h: M % 4 == 0, M <= 104, B % 4 == 0, D % 4 == 0): ragged last
-          # 64-column tile, M = 104 (no padding left), M = 4, four / five / eight hyper-samples (the S_u chains redo S products), nine
+          # 64-column tile, M = 104 (no padding left), M = 4, four / five / eight / sixteen hyper-samples (the S_u chains redo S products), seventeen
           # (the tile kernel without the per-matrix chains), several full tiles
           (3, 2, 3, 100, 40, 72), (4, 2, 2, 104, 36, 64), (5, 2, 2, 52, 36, 40), (2, 2, 2, 4, 36, 8), (2, 3, 3, 96, 48, 200),
-          (3, 2, 2, 100, 36, 132), (8, 2, 2, 100, 36, 64), (9, 2, 2, 52, 36, 40)]
+          (3, 2, 2, 100, 36, 132), (8, 2, 2, 100, 36, 64), (16, 1, 2, 100, 36, 64), (17, 2, 2, 52, 36, 40)]
 
 
 @pytest.mark.parametrize('shape', SHAPES, ids=[str(s) for s in SHAPES])

@@ -649,7 +649,7 @@ static T0BwdPaths t0_bwd_paths(const vargp_elbo_t0_desc* d, const T0Ws& o) {
   // per matrix inside the launch of the P_uf product (t0_bwd_mat.h)
   static const int mat_bwd_env = [] { const char* e = getenv("VARGP_T0_MAT_BWD"); return e ? atoi(e) : 1; }();   // tuning aid
   // (the S_u matrices redo T_s^T gG_s for every hyper-sample: worth it for the few samples of the reference's configs and for
-  // the 8 per GPU of BASELINE config 4 on 8 GPUs -- the product the chains hide under grows with S just as they do)
+  // the 8 / 16 per GPU of BASELINE config 4 on 8 / 4 GPUs -- the product the chains hide under grows with S just as they do)
   r.mat_bwd = r.fused_bwd && mat_bwd_env && (D % 4) == 0 && S <= kTailSMax &&
               ((reinterpret_cast<uintptr_t>(d->z) | reinterpret_cast<uintptr_t>(d->x)) & 15) == 0;
   return r;
@@ -1004,7 +1004,7 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
         case 2: hipLaunchKernelGGL(t0_puu_final_kernel<2>, grid, dim3(256), 0, st, ta, gv); break;
         case 3: hipLaunchKernelGGL(t0_puu_final_kernel<3>, grid, dim3(256), 0, st, ta, gv); break;
         case 4: hipLaunchKernelGGL(t0_puu_final_kernel<4>, grid, dim3(256), 0, st, ta, gv); break;
-        default: hipLaunchKernelGGL(t0_puu_final_kernel<0>, grid, dim3(256), 0, st, ta, gv); break;      // 5 .. kTailSMax
+        default: hipLaunchKernelGGL(t0_puu_final_kernel<0>, grid, dim3(256), 0, st, ta, gv); break;      // 5 .. kTailSMax: a loop
       }
     } else {
       hipLaunchKernelGGL(t0_final_kernel, dim3(gx, nzy + nxy + ngy), dim3(256), 0, st, d->z, d->x, o.r_uu, o.r_uf, o.c_uf,

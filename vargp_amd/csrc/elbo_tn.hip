@@ -194,7 +194,10 @@ __global__ __launch_bounds__(256) void tn_prologue_kernel(const TnProArgs a) {
 //   mu = sum_m P a,  var = kd - sum P^2 + sum W^2 + eps sum V2^2     (a = column 0 of QPs, one value per row of P).
 // Blocks >= npd: the KL of q(u_t | u_<t) against p(u_t | u_<t) (vargp.py:182-190) from the last block of QPs:
 //   kl[s,c] = sum log diag L_tt - sum log diag Lu_t + 0.5 (|H_t|_F^2 + |a_t|^2 - M),  kl_u = (1/S) sum kl[s,c]  (atomic)
+// COLS = 64 or 32 columns per block ((256 / COLS) row lanes): 32 when 64 would give fewer than two blocks per CU -- every
+// thread then walks half as many rows (Split-MNIST t = 1: 240 blocks of 50 dependent row steps took 22.9 us)
 constexpr int kTnKlRows = 8;
+template <int COLS>
 __global__ __launch_bounds__(256) void tn_pdiag_kl_kernel(const float* __restrict__ P, const float* __restrict__ W,
                                                           const float* __restrict__ V2, const float* __restrict__ QPs,
                                                           const float* __restrict__ kd, const float* __restrict__ L,
@@ -202,11 +205,12 @@ __global__ __launch_bounds__(256) void tn_pdiag_kl_kernel(const float* __restric
                                                           float* __restrict__ var, float* __restrict__ kl_u, float eps,
                                                           int S, int C, int M, int Mt, int nblk, int B, int NRs, int nbx,
                                                           int npd, int nkx, uint32_t* rng_counter) {
-  __shared__ float red[4][4][64];
+  constexpr int RL = 256 / COLS;       // row lanes
+  __shared__ float red[4][RL][COLS];
   if (rng_counter && blockIdx.x == 0 && threadIdx.x == 0) rng_counter[0] += 1u;   // this step's noise has been drawn
   if ((int)blockIdx.x < npd) {
-    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-    const int col = ((int)blockIdx.x % nbx) * 64 + cx;
+    const int cx = threadIdx.x % COLS, ry = threadIdx.x / COLS;
+    const int col = ((int)blockIdx.x % nbx) * COLS + cx;
     const int64_t b = blockIdx.x / nbx;
     float m0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
     if (col < B) {
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(256) void tn_pdiag_kl_kernel(const float* __restric
       const float* v = V2 + b * Mt * B + col;
       const float* q = QPs + b * Mt * NRs;
 #pragma unroll 8
-      for (int m = ry; m < Mt; m += 4) {
+      for (int m = ry; m < Mt; m += RL) {
         const float pv = p[(int64_t)m * B], wv = w[(int64_t)m * B], vv = v[(int64_t)m * B];
         m0 = fmaf(pv, q[(int64_t)m * NRs], m0);
         d1 = fmaf(pv, pv, d1);
@@ -226,10 +230,9 @@ __global__ __launch_bounds__(256) void tn_pdiag_kl_kernel(const float* __restric
     red[0][ry][cx] = m0; red[1][ry][cx] = d1; red[2][ry][cx] = d2; red[3][ry][cx] = d3;
     __syncthreads();
     if (ry == 0 && col < B) {
-      m0 = red[0][0][cx] + red[0][1][cx] + red[0][2][cx] + red[0][3][cx];
-      d1 = red[1][0][cx] + red[1][1][cx] + red[1][2][cx] + red[1][3][cx];
-      d2 = red[2][0][cx] + red[2][1][cx] + red[2][2][cx] + red[2][3][cx];
-      d3 = red[3][0][cx] + red[3][1][cx] + red[3][2][cx] + red[3][3][cx];
+      m0 = d1 = d2 = d3 = 0.f;
+#pragma unroll
+      for (int r = 0; r < RL; ++r) { m0 += red[0][r][cx]; d1 += red[1][r][cx]; d2 += red[2][r][cx]; d3 += red[3][r][cx]; }
       mu[b * B + col] = m0;
       var[b * B + col] = kd[b] - d1 + d2 + eps * d3;
     }
@@ -610,8 +613,9 @@ extern "C" int vargp_elbo_tn_fwd(const vargp_elbo_tn_desc* d, vargp_stream_t str
     }
   }
   {
-    const int nbx = cdiv(B, 64), npd = nbx * SC, nkx = cdiv(M, kTnKlRows);
-    hipLaunchKernelGGL(tn_pdiag_kl_kernel, dim3(npd + (lik ? nkx * SC : 0)), dim3(256), 0, st, o.P, o.W, o.V2, o.QPs, o.kd,
+    const bool narrow = cdiv(B, 64) * SC < 512;
+    const int nbx = cdiv(B, narrow ? 32 : 64), npd = nbx * SC, nkx = cdiv(M, kTnKlRows);
+    hipLaunchKernelGGL(narrow ? tn_pdiag_kl_kernel<32> : tn_pdiag_kl_kernel<64>, dim3(npd + (lik ? nkx * SC : 0)), dim3(256), 0, st, o.P, o.W, o.V2, o.QPs, o.kd,
                        o.LL, d->rk_all, o.mu, o.var, lik ? d->scalars + 1 : nullptr, d->jitter, S, C, M, Mt, nblk, B, NRs,
                        nbx, npd, nkx, native ? d->rng_counter : nullptr);
   }
@@ -890,7 +894,7 @@ extern "C" int vargp_elbo_tn_begin(const vargp_elbo_tn_desc* d, vargp_stream_t s
   }
   {   // the KL (data-independent): the KL role of the moments kernel alone
     const int nkx = cdiv(M, kTnKlRows);
-    hipLaunchKernelGGL(tn_pdiag_kl_kernel, dim3(nkx * SC), dim3(256), 0, st, o.P, o.W, o.V2, o.QPs, o.kd, o.LL, d->rk_all, o.mu,
+    hipLaunchKernelGGL(tn_pdiag_kl_kernel<64>, dim3(nkx * SC), dim3(256), 0, st, o.P, o.W, o.V2, o.QPs, o.kd, o.LL, d->rk_all, o.mu,
                        o.var, d->scalars + 1, d->jitter, S, C, M, Mt, nblk, B, NRs, 1, 0, nkx, (uint32_t*)nullptr);
   }
   return check_launch("elbo_tn_begin");
@@ -954,8 +958,9 @@ extern "C" int vargp_elbo_tn_tile(const vargp_elbo_tn_desc* d, const float* seed
     if (rc) return rc;
   }
   {
-    const int nbx = cdiv(B, 64), npd = nbx * SC;
-    hipLaunchKernelGGL(tn_pdiag_kl_kernel, dim3(npd), dim3(256), 0, st, o.P, o.W, o.V2, o.QPs, o.kd, o.LL, d->rk_all, o.mu, o.var,
+    const bool narrow = cdiv(B, 64) * SC < 512;
+    const int nbx = cdiv(B, narrow ? 32 : 64), npd = nbx * SC;
+    hipLaunchKernelGGL(narrow ? tn_pdiag_kl_kernel<32> : tn_pdiag_kl_kernel<64>, dim3(npd), dim3(256), 0, st, o.P, o.W, o.V2, o.QPs, o.kd, o.LL, d->rk_all, o.mu, o.var,
                        (float*)nullptr, d->jitter, S, C, M, Mt, nblk, B, NRs, nbx, npd, 1,
                        (native && !moments_only) ? d->rng_counter : nullptr);
   }
