@@ -996,9 +996,13 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
       TailArgs ta{};
       ta.z = d->z; ta.x = d->x; ta.Wuu = o.Wuu; ta.Puf = o.Puf; ta.r_uu = o.r_uu; ta.r_uf = o.r_uf; ta.c_uf = o.c_uf; ta.w = o.w;
       ta.gz = g_z; ta.gtheta = o.gtheta; ta.S = S; ta.C = C; ta.M = M; ta.D = D; ta.B = B; ta.Dp = o.Dp;
-      ta.nrb = cdiv(M, 32); ta.ncb = cdiv(D, 32); ta.nz = cdiv(C * ta.nrb * ta.ncb, 4); ta.nx = gx * cdiv(B, kTailXRows); ta.gx = gx;
-      const int ngv = cdiv((int64_t)C * MM, 256);
-      const dim3 grid(ta.nz + ta.nx + ngv);
+      const int rem = M % 32;
+      ta.nrb = (rem > 0 && rem <= 8) ? M / 32 : cdiv(M, 32);       // a short remainder goes to the vector units
+      const int ngr = cdiv(M, 32);
+      ta.ncb = cdiv(D, 32); ta.nz = cdiv(C * ta.nrb * ta.ncb + C * (ngr * (ngr + 1) / 2), 4);      // z + packed-vector wave-blocks
+      ta.nx = gx * cdiv(B, kTailXRows); ta.gx = gx;
+      ta.nrem = (rem > 0 && rem <= 8) ? C * gx * cdiv(rem, 4) : 0;
+      const dim3 grid(ta.nz + ta.nrem + ta.nx);
       switch (S) {
         case 1: hipLaunchKernelGGL(t0_puu_final_kernel<1>, grid, dim3(256), 0, st, ta, gv); break;
         case 2: hipLaunchKernelGGL(t0_puu_final_kernel<2>, grid, dim3(256), 0, st, ta, gv); break;

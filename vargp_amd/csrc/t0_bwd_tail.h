@@ -8,8 +8,11 @@
 //   [0, nz)       four waves, each with its own (class, 32-row block, 32-column block of D): the z fragments (the same for every
 //                 hyper-sample) stay in registers, the W_uu fragments come straight from memory; f32 MFMA 32x32x2 with the
 //                 k-pairing of gemm.hip; the finalisation runs on the accumulators.  No LDS operands, no barriers.
+//   next nrem     the last M % 32 <= 8 rows of every class on the vector units (tail_rem_rows): at M = 100 a quarter of the MFMA
+//                 wave-blocks would hold 4 rows of 32
+//                 The wave-blocks behind them: the gradient of the packed Cholesky vector of q(u), 2 gS_u Lu as lower 32 x 32
+//                 blocks (tail_gvec_block), which only shares the launch.
 //   next nx       the minibatch side of gtheta (t0_final_x_body, elbo_shared.h)
-//   rest          the gradient of the packed Cholesky vector of q(u) (t0_gvec_role), which only shares the launch
 #pragma once
 #include "elbo_shared.h"
 #include "t0_bwd_common.h"
@@ -26,6 +29,7 @@ struct TailArgs {
   int S, C, M, D, B;
   int64_t Dp;
   int nrb, ncb, nz, nx, gx;      // 32 x 32 blocks per class (rows, columns); z-role workgroups; x-role blocks and their grid width
+  int nrem;                      // remainder-row blocks (rows 32 nrb .. M - 1 when M % 32 <= 8: C x gx x chunks of 4 rows)
 };
 
 #ifdef TAIL_STAMPS   // per-phase cycle accounting (workgroup 0, thread 0), tuning builds only: tests/native/bm_stamps.py tail
@@ -41,6 +45,105 @@ __device__ __forceinline__ void tail_load_a(const float* __restrict__ wp, int lh
   for (int g = 0; g < kTailNG; ++g) af[g] = *reinterpret_cast<const float4*>(wp + min(8 * g + 4 * lh, M - 4));
 }
 
+// Gradient of the packed Cholesky vector of q(u) as 32 x 32 MFMA blocks (one lower block (rb >= cb) of one class per wave):
+//   gLu = 2 gS_u Lu + sum_s gRK[Lu block] - seed_kl diag(1 / Lu_ii),   through vec2tril (softplus on the diagonal)
+// -- the same arithmetic as t0_gvec_role (elbo_shared.h), whose 391 light workgroups of 100-long dot products per thread load the
+// memory pipes the z role's waves wait on.  A = gS_u rows (symmetric, K-contiguous) and B = Lu ([k][column]) straight from
+// memory, as in the z role.
+__device__ __forceinline__ void tail_gvec_block(const GvecArgs& gv, int c, int rb, int cb, int li, int lh) {
+  const int M = gv.M;
+  const int64_t MM = (int64_t)M * M;
+  const float* gs = gv.gSu + c * MM;
+  const float* lu = gv.Lu + c * MM;
+  const int arow = min(32 * rb + li, M - 1);
+  const bool arow_ok = 32 * rb + li < M;
+  const int colc = min(32 * cb + li, M - 1);
+  float4 af[kTailNG], bf[kTailNG];
+  tail_load_a(gs + (int64_t)arow * M, lh, M, af);
+#pragma unroll
+  for (int g = 0; g < kTailNG; ++g) {
+    const float* p = lu + (int64_t)min(8 * g + 4 * lh, M - 4) * M + colc;
+    bf[g] = make_float4(p[0], p[M], p[2 * M], p[3 * M]);
+  }
+  const int rbase = 32 * rb + 4 * lh, k = 32 * cb + li;
+  float ga[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) ga[r] = gv.gLu_acc[c * MM + (int64_t)min(rbase + 8 * (r >> 2) + (r & 3), M - 1) * M + colc];
+  bm_f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int g = 0; g < kTailNG; ++g) {
+    const bool ok = arow_ok && 8 * g + 4 * lh < M;         // (Lu[j][k] = 0 for j < k: the groups below 4 cb only add zeros)
+    const float4 av = ok ? af[g] : make_float4(0.f, 0.f, 0.f, 0.f);
+    bm_mfma4(acc, av, bf[g]);
+  }
+  const int64_t vbase = (int64_t)c * ((int64_t)M * (M + 1) / 2);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = rbase + 8 * (r >> 2) + (r & 3);
+    if (i < M && k <= i) {          // (k <= i < M)
+      float g = 2.f * acc[r] + ga[r];
+      const int64_t idx = vbase + (int64_t)i * (i + 1) / 2 + k;
+      if (i == k) {
+        g -= gv.seeds[1] / lu[(int64_t)i * M + i];
+        const float x = gv.vec[idx];
+        g *= (x > 20.f) ? 1.f : sigmoid_t0(x);
+      }
+      gv.gvec[idx] = g;
+    }
+  }
+}
+
+// The last M % 32 <= 8 rows of every class on the vector units, one wave per row and 64 columns of D per block: as a 32 x 32
+// MFMA block they would be a quarter of the z role's wave-blocks at M = 100 (rows 96 .. 99 of 128) doing 1/8 of a block's work,
+// and push it over one workgroup per CU.  The lane's column of z lives in registers (the same for every sample), the row of
+// W_uu is loaded once per sample across the lanes and broadcast by v_readlane.  Same finalisation as the MFMA blocks.
+__device__ __forceinline__ void tail_rem_rows(const TailArgs& a, int blk, float (*red)[4][64]) {
+  const int M = a.M, D = a.D;
+  const int tx = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int nchunk = (M - 32 * a.nrb + 3) / 4;
+  const int dt = blk % a.gx, ch = (blk / a.gx) % nchunk, c = blk / (a.gx * nchunk);
+  const int row = 32 * a.nrb + 4 * ch + wave;
+  const bool rok = row < M;
+  const int rowc = min(row, M - 1);
+  const int d = 64 * dt + tx;
+  const bool ok = rok && d < D;
+  const int dc = min(d, D - 1);
+  const int64_t zrows = (int64_t)a.C * M;
+  const float* zc = a.z + (int64_t)c * M * D + dc;
+  float zk[kBmKP];
+#pragma unroll
+  for (int k = 0; k < kBmKP; ++k) zk[k] = zc[(int64_t)min(k, M - 1) * D];      // (k >= M only ever meets a zero of W_uu)
+  const float zr = ok ? zc[(int64_t)rowc * D] : 0.f;
+  float ga = 0.f;
+  for (int s = 0; s < a.S; ++s) {
+    const int64_t sr = (int64_t)s * zrows + (int64_t)c * M + rowc;
+    const float* wr = a.Wuu + sr * M;
+    const float w0 = tx < M ? wr[min(tx, M - 1)] : 0.f, w1 = 64 + tx < M ? wr[min(64 + tx, M - 1)] : 0.f;
+    const float p2 = ok ? a.Puf[sr * D + dc] : 0.f, rs = a.r_uu[sr] + a.r_uf[sr], wv = d < D ? a.w[s * a.Dp + dc] : 0.f;
+    float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 64; k += 2) {
+      acc0 = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(w0), k)), zk[k], acc0);
+      acc1 = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(w0), k + 1)), zk[k + 1], acc1);
+    }
+#pragma unroll
+    for (int k = 64; k < kBmKP; k += 2) {
+      acc0 = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(w1), k - 64)), zk[k], acc0);
+      acc1 = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(w1), k - 63)), zk[k + 1], acc1);
+    }
+    const float q1 = ok ? acc0 + acc1 : 0.f;
+    const float t = rs * zr - q1 - p2;              // (r_uu z - P_uu) + (r_uf z - P_uf)
+    ga -= wv * t;
+    red[s & 1][wave][tx] = zr * (t - p2);
+    __syncthreads();
+    if (wave == 0 && d < D)
+      atomicAdd(&a.gtheta[(int64_t)s * (D + 1) + d], wv * (red[s & 1][0][tx] + red[s & 1][1][tx] + red[s & 1][2][tx] + red[s & 1][3][tx]));
+  }
+  if (ok) a.gz[((int64_t)c * M + row) * D + d] = ga;
+}
+
 // (S is a template parameter: the sample loop is unrolled, so that the waits on the prefetched loads are exact -- around a
 // runtime loop the compiler waits for every outstanding load before the first MFMA)
 template <int S>
@@ -50,8 +153,9 @@ __global__ __launch_bounds__(256, 2) void t0_puu_final_kernel(const TailArgs a, 
   int blk = blockIdx.x;
   if (blk >= a.nz) {      // (the short roles last: dispatched first they measured the same)
     blk -= a.nz;
-    if (blk < a.nx) t0_final_x_body<kTailXRows>(a.x, a.c_uf, a.w, a.gtheta, (int64_t)a.B, a.D, a.Dp, a.S, blk % a.gx, blk / a.gx, redx);
-    else t0_gvec_role(blk - a.nx, gv.vec, gv.Lu, gv.gSu, gv.gLu_acc, gv.seeds, gv.gvec, 1, gv.C, gv.M, gv.M, 0);
+    if (blk < a.nrem) { tail_rem_rows(a, blk, redx); return; }
+    blk -= a.nrem;
+    t0_final_x_body<kTailXRows>(a.x, a.c_uf, a.w, a.gtheta, (int64_t)a.B, a.D, a.Dp, a.S, blk % a.gx, blk / a.gx, redx);
     return;
   }
   // one 32 x 32 block of one class per WAVE (flat index: C * ceil(M / 32) * ceil(D / 32) = 1000 blocks = 250 workgroups at the
@@ -60,7 +164,15 @@ __global__ __launch_bounds__(256, 2) void t0_puu_final_kernel(const TailArgs a, 
   const int li = lane & 31, lh = lane >> 5;
   const int M = a.M, D = a.D;
   const int id = __builtin_amdgcn_readfirstlane(blk * 4 + wave);
-  if (id >= a.C * a.nrb * a.ncb) return;
+  const int nzb = a.C * a.nrb * a.ncb;
+  if (id >= nzb) {      // the wave-blocks behind the z role's: lower blocks of the packed-vector gradient, class by class
+    const int ngr = (gv.M + 31) / 32, nlow = ngr * (ngr + 1) / 2, e = id - nzb;
+    if (e >= gv.C * nlow) return;
+    int q = e % nlow, rbg = 0;
+    while (q > rbg) { q -= rbg + 1; ++rbg; }             // q-th lower block: row block rbg, column block q
+    tail_gvec_block(gv, e / nlow, rbg, q, li, lh);
+    return;
+  }
   const int cb = id % a.ncb, rb = (id / a.ncb) % a.nrb, c = id / (a.ncb * a.nrb);
   const int d0 = 32 * cb, r0 = 32 * rb;
   const int64_t zrows = (int64_t)a.C * M;
