@@ -1,9 +1,15 @@
 #!/usr/bin/env python
 """ELBO steps/s of the VAR-GP hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W]          (N > 1 without a launcher: starts its own N ranks, see below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+
+`python bench.py --gpus N` with N > 1 and no RANK / WORLD_SIZE in the environment starts
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>` as a
+CHILD process (before any GPU call; never an exec), forwards rank 0's one JSON line and exits with the child's code.
+`--dry-run` stops after the process group is up (ranks all-gathered, no model, no oracle): rc 0 = the launch path works.
+`--comm allreduce|rsag` selects how the flat [grads | kl_u | nll] buffer is summed over the ranks.
 
 N=1 (default line): BASELINE config 2 (BASELINE.json configs[1]) — Split-MNIST task 0 shape, S=3 hyper-samples, F=10, C=10,
 M=100, D=784, B=512, synthetic data resident in HBM.  One step = zero_grad + VARGP.loss + combine + backward
@@ -312,7 +318,7 @@ def run_workload(name, args, device, world, rank, use_dist, steps, warmup, prima
     p0 = snapshot(gp) if rank == 0 and primary else None     # the CPU baseline runs the same (initial) model
     trainer = ElboTrainer(gp, lr=LR, beta=BETA, n_total=N_TOTAL,
                           sample_counts=(counts if counts is not None else [S] * world) if use_dist else None,
-                          force_exchange=use_dist)
+                          force_exchange=use_dist, comm=args.comm)
 
     def sync():
         if use_dist:
@@ -354,6 +360,27 @@ def run_workload(name, args, device, world, rank, use_dist, steps, warmup, prima
     median_ms = per_step[len(per_step) // 2]
     final_loss = [v.item() for v in out]     # read now: the re-launches below include the kernel that resets the accumulators
     finite = all(v == v and abs(v) != float('inf') for v in final_loss)
+    # The exchange, measured two ways (outside the timed region): in place -- hipEvents around the collective of `n_comm` more
+    # steps (includes waiting for the slowest rank) -- and isolated -- the same collective back to back after a barrier.
+    comm_us = comm_iso_us = None
+    seen = ranks_seen(world, rank, device) if use_dist else [0]
+    if use_dist:
+        n_comm = max(5, min(steps, 50))
+        trainer.comm_events = []
+        for _ in range(n_comm):
+            run()
+        sync()
+        comm_us = sum(a.elapsed_time(b) for a, b in trainer.comm_events) / len(trainer.comm_events) * 1e3
+        trainer.comm_events = []
+        trainer.flat.zero_()                      # repeated sums of zeros stay finite; the next step overwrites the buffer
+        for _ in range(n_comm):
+            trainer.exchange()
+        sync()
+        comm_iso_us = sorted(a.elapsed_time(b) for a, b in trainer.comm_events)[len(trainer.comm_events) // 2] * 1e3
+        trainer.comm_events = None
+        t = torch.tensor([comm_us, comm_iso_us], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        comm_us, comm_iso_us = t.tolist()
     # Dominant kernels: hipEvents cannot bracket a node of a replayed graph, and an event pair around a single launch
     # also times the dispatch gap (+10 us here).  So one more (eager) step is run with launch recording on, and the
     # recorded launches -- same kernels, same shapes, the trainer's live buffers -- are re-launched back to back between
@@ -445,6 +472,9 @@ def run_workload(name, args, device, world, rank, use_dist, steps, warmup, prima
                                launch=('hipGraph replay' + (' (2 graphs around the all-reduce)' if use_dist else '')) if use_graph
                                else 'eager'),
                    elbo_rtol_vs_cpu=rtol, elbo_rtol_checked_on=rtol_on, finite=bool(finite), cholesky_failures=errs,
+                   ranks_seen=seen, comm=args.comm if use_dist else None,
+                   allreduce_us=comm_us, allreduce_us_isolated=comm_iso_us,
+                   allreduce_bytes=trainer.flat.numel() * 4 if use_dist else None,
                    final_loss=dict(kl_hypers=final_loss[0], kl_u=final_loss[1], nll=final_loss[2]),
                    roofline=dict(bound='mfma', kernel=dominant_desc,
                                  achieved=achieved, peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
@@ -497,6 +527,75 @@ def secondary_summary(res):
     return out
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` outside a launcher: run the N ranks under torch.distributed.run as a child process and
+    forward its output (rank 0 prints the one JSON line) and exit code.  Nothing here touches the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL between processes needs it on this image
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // n)))
+    print('[bench] --gpus %d without a launcher: starting %s' % (n, ' '.join(cmd)), file=sys.stderr)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    js = [ln for ln in lines if ln.lstrip().startswith('{')]
+    for ln in lines:
+        if not js or ln is not js[-1]:
+            print(ln, file=sys.stderr)                     # anything that is not THE line goes to stderr
+    if js:
+        print(js[-1])
+    sys.stdout.flush()
+    sys.exit(proc.returncode if proc.returncode != 0 or js else 1)
+
+
+def ranks_seen(world, rank, device):
+    """All-gather of the rank ids: what the line reports as `ranks_seen` (every rank really took part)."""
+    if world == 1 or not dist.is_initialized():
+        return [rank]
+    mine = torch.tensor([rank], dtype=torch.int64, device=device)
+    got = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(got, mine)
+    return [int(t.item()) for t in got]
+
+
+def dry_run(args, world, rank, local):
+    """Bring the process group up exactly as a real run would (RCCL when every rank has its own GPU, gloo otherwise),
+    all-gather the rank ids, print the line and leave: no model, no oracle, no kernel."""
+    n_dev = torch.cuda.device_count()          # does not initialise the GPU
+    backend = 'nccl' if n_dev >= world and n_dev > 0 else 'gloo'
+    device = torch.device('cpu')
+    if backend == 'nccl':
+        torch.cuda.set_device(local)
+        device = torch.device('cuda', local)
+    if world > 1:
+        dist.init_process_group(backend, **(dict(device_id=device) if backend == 'nccl' else {}))
+    seen = ranks_seen(world, rank, device)
+    if world > 1:
+        buf = torch.ones(world * 3 + 1, device=device)          # one exchange of each kind on a toy buffer
+        dist.all_reduce(buf)
+        ok = bool((buf == world).all().item())
+        pad = torch.ones(world * 4, device=device)
+        shard = torch.zeros(4, device=device)
+        dist.reduce_scatter_tensor(shard, pad)
+        dist.all_gather_into_tensor(pad, shard)
+        ok = ok and bool((pad == world).all().item())
+        dist.barrier()
+    else:
+        ok = True
+    if rank == 0:
+        print(json.dumps(dict(dry_run=True, ok=ok, n_gpus=world, ranks_seen=seen, backend=backend, comm=args.comm,
+                              workload=args.workload or ('smnist' if world == 1 or args.scaling == 'weak' else 'smnist_s64'),
+                              devices_visible=n_dev)))
+    if world > 1:
+        dist.destroy_process_group()
+    sys.exit(0 if ok and sorted(seen) == list(range(world)) else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -516,11 +615,22 @@ def main():
     ap.add_argument('--stress-n', type=int, default=1000000)
     ap.add_argument('--no-replay', action='store_true',
                     help='skip the back-to-back re-launches that time the dominant kernels (keeps a rocprof trace clean)')
+    ap.add_argument('--comm', default='allreduce', choices=['allreduce', 'rsag'],
+                    help='several GPUs: sum the flat [grads | kl_u | nll] buffer with one all-reduce, or with a reduce-scatter + '
+                         'all-gather of the same buffer (every shard over its own xGMI link)')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='start the ranks, create the process group, all-gather the rank ids, print a line and exit')
     args = ap.parse_args()
+    if args.gpus > 1 and 'RANK' not in os.environ and 'WORLD_SIZE' not in os.environ:
+        self_launch(args.gpus)                   # does not return
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+    if world != args.gpus:
+        sys.exit(f'--gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus {args.gpus}` (it launches its '
+                 f'own ranks) or under torch.distributed.run with --nproc-per-node {args.gpus}')
+    if args.dry_run:
+        dry_run(args, world, rank, local)        # does not return
     default_line = args.workload is None
     if args.workload is None:
         args.workload = 'smnist' if (world == 1 or args.scaling == 'weak') else 'smnist_s64'

@@ -27,7 +27,7 @@ def _problem(n_prev):
     return orc.make_problem(S_LOCAL * WORLD, F_, C, M, D, B, n_prev=n_prev, seed=9, kind='toy')
 
 
-def _worker(rank, port, n_prev, out, counts=None):
+def _worker(rank, port, n_prev, out, counts=None, comm='allreduce'):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD))
     dist.init_process_group('gloo', rank=rank, world_size=WORLD)
     try:
@@ -50,7 +50,7 @@ def _worker(rank, port, n_prev, out, counts=None):
             return orc.loss(full, prev, xb, yb, nz)
 
         tr = ElboTrainer(None, beta=2.0, n_total=64, noise_seed=SEED, params=[leaves[k] for k in names],
-                         loss_fn=loss_fn, optimizer=lambda ps: torch.optim.SGD(ps, lr=0.0), sample_counts=counts)
+                         loss_fn=loss_fn, optimizer=lambda ps: torch.optim.SGD(ps, lr=0.0), sample_counts=counts, comm=comm)
         assert tr.world == WORLD and tr.rank == rank
         kl_h, kl_u, nll = tr.step(x, y)
         if rank == 0:
@@ -61,13 +61,16 @@ def _worker(rank, port, n_prev, out, counts=None):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('n_prev,counts', [(0, None), (1, None), (0, [2, 1]), (1, [1, 2])])
-def test_sample_parallel_matches_single_process(n_prev, counts):
-    """counts: a sample total that the ranks cannot divide evenly (3 samples over 2 ranks): uneven shards, weights S_r / S."""
+@pytest.mark.parametrize('n_prev,counts,comm', [(0, None, 'allreduce'), (1, None, 'allreduce'), (0, [2, 1], 'allreduce'),
+                                                (1, [1, 2], 'allreduce'), (0, None, 'rsag'), (1, [1, 2], 'rsag')])
+def test_sample_parallel_matches_single_process(n_prev, counts, comm):
+    """counts: a sample total that the ranks cannot divide evenly (3 samples over 2 ranks): uneven shards, weights S_r / S.
+    comm: one all-reduce, or reduce-scatter + all-gather of the same (padded) flat buffer -- the parameter count of the
+    problem (odd: 2 scalars + an odd number of gradient entries is not required; the buffer is padded either way)."""
     ctx = mp.get_context('spawn')
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, port, n_prev, out, counts)) for r in range(WORLD)]
+    procs = [ctx.Process(target=_worker, args=(r, port, n_prev, out, counts, comm)) for r in range(WORLD)]
     for p in procs:
         p.start()
     got = out.get(timeout=120)
@@ -122,3 +125,26 @@ def test_noise_shards_tile_the_global_draw():
         assert torch.equal(torch.cat([p[1] for p in parts]), b)
     finally:
         noise.clear_shard()
+
+
+def test_bench_self_launch_dry_run():
+    """`python bench.py --gpus 2` without a launcher starts its own two ranks under torch.distributed.run (a child
+    process), brings the process group up (gloo here: no GPU), all-gathers the rank ids and exits 0 with one JSON line --
+    the command form the driver uses for the scaling curve, up to (not including) the model build."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run', '--comm', 'rsag'],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line['dry_run'] and line['ok'] and line['n_gpus'] == 2 and line['ranks_seen'] == [0, 1]
+    assert line['comm'] == 'rsag' and line['workload'] == 'smnist_s64'
+    # a WORLD_SIZE that contradicts --gpus is an error message and a non-zero exit code, not an assertion trace
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run'],
+                       env=dict(env, RANK='0', WORLD_SIZE='1'), capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and 'launches its own ranks' in r.stderr

@@ -8,10 +8,11 @@ linearly with the weights w_r = S_r / S, so   total = beta*kl_hypers + sum_r w_r
 The S_r need not be equal (S not divisible by the number of ranks: `split_samples` hands the remainder to the first
 ranks, at most one sample of imbalance), which is how a fixed sample count -- BASELINE config 4: 64 samples over 8 GPUs --
 is divided without any exchange inside the step.
-Each rank back-propagates its share times w_r and ONE all-reduce(sum) over a flat
+Each rank back-propagates its share times w_r and ONE exchange (sum) over a flat
 fp32 buffer [grad(z) | grad(u_mean) | grad(u_tril_vec) | grad(log_mean) | grad(log_logvar) | kl_u | nll]
 yields identical gradients on every rank.  Gradients are views into that flat buffer, so there is no
-pack/unpack copy.
+pack/unpack copy.  The exchange is either one all-reduce (`comm='allreduce'`) or a reduce-scatter + all-gather of
+the same buffer (`comm='rsag'`); both are RCCL collectives on the GPU (gloo in the CPU tests).
 """
 import os
 
@@ -33,7 +34,7 @@ class ElboTrainer:
     replaced by any `loss_fn(x, y) -> (kl_hypers, kl_u, nll)` over an explicit `params` list."""
 
     def __init__(self, gp=None, lr=1e-2, beta=1.0, n_total=None, group=None, noise_seed=1234, optimizer=None,
-                 params=None, loss_fn=None, native_noise=True, sample_counts=None, force_exchange=False):
+                 params=None, loss_fn=None, native_noise=True, sample_counts=None, force_exchange=False, comm='allreduce'):
         self.gp = gp
         self.loss_fn = loss_fn if loss_fn is not None else gp.loss
         self.beta = float(beta)
@@ -47,7 +48,17 @@ class ElboTrainer:
         self.params = list(params) if params is not None else [p for p in gp.parameters() if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
-        self.flat = torch.zeros(n + 2, dtype=torch.float32, device=dev)
+        # comm: how the flat buffer is summed over the ranks -- 'allreduce' (one all-reduce) or 'rsag' (reduce-scatter of
+        # the buffer cut into `world` shards + all-gather of the reduced shards: on 8 fully connected GPUs every shard
+        # travels over its own xGMI link).  The buffer is padded to a multiple of the world size for that.
+        assert comm in ('allreduce', 'rsag'), comm
+        self.comm = comm
+        pad = -(n + 2) % max(self.world, 1)
+        self._flat_store = torch.zeros(n + 2 + pad, dtype=torch.float32, device=dev)
+        self.flat = self._flat_store[:n + 2]
+        self._shard = (torch.zeros(self._flat_store.numel() // self.world, dtype=torch.float32, device=dev)
+                       if comm == 'rsag' else None)
+        self.comm_events = None            # list -> exchange() appends one (start, end) event pair per call (bench.py)
         off = 0
         for p in self.params:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
@@ -172,6 +183,21 @@ class ElboTrainer:
                         if not torch.is_tensor(v):
                             st[k] = v
 
+    def exchange(self):
+        """Sum the flat buffer [grads | kl_u | nll] over the ranks (in place, identical result on every rank)."""
+        ev = None
+        if self.comm_events is not None and self.flat.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        if self.comm == 'rsag':
+            dist.reduce_scatter_tensor(self._shard, self._flat_store, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_gather_into_tensor(self._flat_store, self._shard, group=self.group)
+        else:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        if ev is not None:
+            ev[1].record()
+            self.comm_events.append(ev)
+
     def step_graph(self, x=None, y=None):
         """Replay the captured step (optionally on a new minibatch of the captured shape)."""
         if x is not None:
@@ -179,7 +205,7 @@ class ElboTrainer:
             self._sy.copy_(y, non_blocking=True)
         self.graph.replay()
         if self.multi:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            self.exchange()
             self.graph_opt.replay()
         return self._sout
 
@@ -210,14 +236,19 @@ class ElboTrainer:
             self.optim.step()
             return kl_h.detach(), kl_u.detach(), nll.detach()
         out = self._local_part(x, y)
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        self.exchange()
         self.optim.step()
         return out
 
     def _defer_hyper(self):
+        """Finish the hyper-parameter backward inside the optimiser's launch?  Only when that launch updates BOTH
+        variational hyper-parameter tensors (vargp_yogi_step_multi_hyper rejects a missing log_logvar unless the kernel is
+        a MAP estimate, where log_logvar receives no gradient at all).  NOTE: with deferral the .grad of log_mean /
+        log_logvar is only valid after optim.step()."""
         k = self.gp.kernel
+        has = lambda t: any(p is t for p in self.params)
         return (isinstance(self.optim, Yogi) and len(self.optim.param_groups) == 1 and len(self.params) <= 8
-                and any(p is k.log_mean for p in self.params)
+                and has(k.log_mean) and (bool(k.map_est) or has(k.log_logvar))
                 and os.environ.get('VARGP_DEFER_HYPER', '1') != '0')
 
     def _t0_fwd_bwd(self, x, y, scale, w, defer_hyper=False):
