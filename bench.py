@@ -294,6 +294,57 @@ def elbo_check(gp, x, y):
     return max(errs), ('sub-sample S=%d B=%d' % (Sc, Bc)) if big else 'full workload'
 
 
+def dropin_workload(args, device, steps=300, warmup=30):
+    """BASELINE config 2 on the DROP-IN route: the reference's own loop shape (experiments/vargp.py:29-37) written against the
+    `var_gp` alias package -- `optim.zero_grad(); gp.loss(x, y); combine; loss.backward(); optim.step()`, eager, no trainer, no
+    hipGraph, noise drawn by torch -- with this repo's Yogi standing in for torch_optimizer.Yogi.  Timed in the default
+    Cholesky error mode ('raise': a host sync per loss call, which is what torch.cholesky's error check costs the reference
+    too) and in 'defer' mode (no sync inside the step).  -> dict for the `secondary` object."""
+    global S, M, N_PREV
+    from var_gp.vargp import VARGP            # noqa: F401  (the alias package: what "import lines only" gives a maintainer)
+    from vargp_amd import ops
+    from vargp_amd.optim import Yogi
+    S, M, N_PREV = 3, 100, 0
+    out = dict(workload='BASELINE config 2 through the var_gp alias in the reference loop shape (eager, autograd node, '
+                        'torch-drawn noise, vargp_amd.optim.Yogi)', steps=steps, warmup=warmup)
+    for mode in ('raise', 'defer'):
+        ops.set_cholesky_error_mode(mode)
+        ops.reset_linalg_errors()
+        gp, x, y = make_model(device)
+        assert isinstance(gp, VARGP)
+        optim = Yogi(gp.parameters(), lr=LR)
+        N = N_TOTAL
+
+        def step():
+            optim.zero_grad()
+            kl_hypers, kl_u, lik = gp.loss(x, y)
+            loss = BETA * kl_hypers + kl_u + (N / x.size(0)) * lik
+            loss.backward()
+            optim.step()
+            return kl_hypers, kl_u, lik
+
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            last = step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        fin = all(bool(torch.isfinite(v)) for v in last)
+        out['value' if mode == 'raise' else 'value_defer'] = steps / dt
+        out['ms_per_step' if mode == 'raise' else 'ms_per_step_defer'] = 1e3 * dt / steps
+        out['finite'] = bool(out.get('finite', True) and fin)
+        out['programs_cached'] = len(gp._t0_progs)
+        gp.release_programs()
+        del gp, optim
+    ops.set_cholesky_error_mode('defer')
+    out['unit'] = 'ELBO steps/s (Cfg2 step, drop-in caller loop)'
+    out['cholesky_failures'] = ops.linalg_error_count()
+    torch.cuda.empty_cache()
+    return out
+
+
 SECONDARY = ['smnist_s64', 'smnist_s8', 'smnist_t1', 'pmnist_t0', 'pmnist_t1', 'pmnist_t4', 'pmnist_t9']   # + 'stress'
 
 
@@ -650,11 +701,16 @@ def main():
         # short, driver-timed runs of the other BASELINE configs in the same line (their own step counts are stated)
         t_start = time.perf_counter()
         sec = {}
-        for name in SECONDARY + ['stress']:
+        for name in ['smnist_dropin'] + SECONDARY + ['stress']:
             if time.perf_counter() - t_start > args.secondary_budget:
                 sec[name] = dict(skipped='secondary budget of %.0f s used up' % args.secondary_budget)
                 continue
             try:
+                if name == 'smnist_dropin':
+                    sec[name] = dropin_workload(args, device)
+                    sec[name]['vs_trainer'] = sec[name]['value'] / res['value']
+                    sec[name]['vs_trainer_defer'] = sec[name]['value_defer'] / res['value']
+                    continue
                 if name == 'stress':
                     r = stress(args, device, cpu=False)
                 else:
@@ -667,6 +723,10 @@ def main():
                 torch.cuda.empty_cache()
         res['secondary'] = sec
         res['secondary_seconds'] = time.perf_counter() - t_start
+        # a failing secondary workload never costs the headline line (exit code stays 0), but it is counted at the top level
+        bad = [n for n, r in sec.items() if 'error' in r or r.get('finite') is False or (r.get('cholesky_failures') or 0) > 0]
+        res['secondary_failed'] = len(bad)
+        res['secondary_failed_names'] = bad
     if rank == 0:
         print(json.dumps(res))
     if use_dist:

@@ -217,7 +217,9 @@ typedef struct vargp_elbo_t0_desc {
 size_t vargp_elbo_t0_workspace_bytes(int S, int C, int M, int D, int B, int F);
 int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t stream);
 /* ONE vargp_elbo_t0_bwd per vargp_elbo_t0_fwd: for the shapes of the LDS-resident backward (M <= 104, M % 4 == 0, B % 4 == 0,
- * D % 4 == 0, S <= 16) the forward clears the accumulators the backward adds into -- there is no clearing launch in bwd. */
+ * D % 4 == 0, S <= 16) the forward clears the accumulators the backward adds into -- there is no clearing launch in bwd.
+ * Enforced by the library (host-side state per workspace, checked when the call is issued): a second bwd on one fwd, or a bwd
+ * whose z / x alignment differs from its forward's, returns VARGP_EINVAL with a message instead of accumulating into stale sums. */
 int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds, float* g_log_mean, float* g_log_logvar, float* g_z,
                       float* g_u_mean, float* g_u_tril_vec, vargp_stream_t stream);
 

@@ -397,6 +397,35 @@ def make_problem(S, F_, C, M, D, B, n_prev=0, seed=0, kind='gauss', dtype=torch.
     return params, prev, x, y, noise
 
 
+def step_noise(S, F_, C, M, D, B, n_prev, seed, k, dtype=torch.float32):
+    """Noise tensors of step k of a multi-step trajectory (closed form, as make_problem's: what the reference's training
+    loop, experiments/vargp.py:29-37, draws anew on every loss() call)."""
+    sd = seed + 10007 * (k + 1)
+    noise = dict(eps_theta=hash_normal((S, D + 1), sd + 29).to(dtype), eps_f=hash_normal((S, F_, C, B), sd + 31).to(dtype))
+    if n_prev:
+        noise['eps_u'] = hash_normal((S, S, C, n_prev * M), sd + 37).to(dtype)
+    return noise
+
+
+def adam_trajectory(params, prev, x, y, noise_of, steps, lr, beta, n_total, names=('z', 'u_mean', 'u_tril_vec', 'log_mean',
+                                                                                  'log_logvar')):
+    """The reference's training loop (experiments/vargp.py:29-37: zero_grad, loss, combine, backward, step) with torch's Adam
+    (the optimiser the reference keeps commented out at :22; its Yogi is not installed) on this restatement.
+    -> (triples (steps, 3), final parameters)."""
+    leaf = dict(params)
+    for k in names:
+        leaf[k] = params[k].detach().clone().requires_grad_(True)
+    opt = torch.optim.Adam([leaf[k] for k in names], lr=lr)
+    triples = []
+    for i in range(steps):
+        opt.zero_grad()
+        kl_h, kl_u, nll = loss(leaf, prev, x, y, noise_of(i))
+        (beta * kl_h + kl_u + (n_total / x.shape[0]) * nll).backward()
+        opt.step()
+        triples.append([kl_h.item(), kl_u.item(), nll.item()])
+    return torch.tensor(triples, dtype=torch.float64), {k: leaf[k].detach() for k in names}
+
+
 # ----------------------------------------------------------------------------------------------
 # VARGPRetrain  (reference: var_gp/vargp_retrain.py:119-233) -- the variant that re-optimises the inducing
 # parameters of the earlier tasks and adds an importance-ratio term for the frozen copies

@@ -153,3 +153,26 @@ def test_deep_kernel_loss_and_grads(name):
             continue
         assert rel_l2(v.grad, g[f'grad_phi_{k}']) < REL_L2_GRAD, k
     np.testing.assert_allclose(probs.numpy(), g['probs'], atol=ATOL_PROBS)
+
+
+TRAJ = ['traj_wtoy_t0', 'traj_wtoy_t1', 'traj_mid_t0']
+
+
+def load_trajectory(name):
+    """-> (g, params, prev, x, y, noise_of(k), steps, lr, beta, n_total) of a trajectory fixture (inputs regenerated)."""
+    g = np.load(f'{GOLDEN}/{name}.npz')
+    S, F_, C, M, D, B, n_prev, seed = [int(v) for v in g['meta']]
+    params, prev, x, y, _ = orc.make_problem(S, F_, C, M, D, B, n_prev=n_prev, seed=seed, kind=str(g['kind']))
+    noise_of = lambda k: orc.step_noise(S, F_, C, M, D, B, n_prev, seed, k)
+    return g, params, prev, x, y, noise_of, len(g['triples']), float(g['lr']), float(g['beta']), float(g['n_total'])
+
+
+@pytest.mark.parametrize('name', TRAJ)
+def test_adam_trajectory_matches_reference(name):
+    """Multi-step fixture: the reference's loop (zero_grad, loss, combine, backward, Adam step) with fresh
+    injected noise per step; the oracle in the same loop reproduces every step's loss triple and the final parameters."""
+    g, params, prev, x, y, noise_of, steps, lr, beta, n_total = load_trajectory(name)
+    triples, final = orc.adam_trajectory(params, prev, x, y, noise_of, steps, lr, beta, n_total)
+    np.testing.assert_allclose(triples.numpy(), g['triples'], rtol=5e-5)
+    for k, v in final.items():
+        assert rel_l2(v, g[f'final_{k}']) < 1e-4, k

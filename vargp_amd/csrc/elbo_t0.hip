@@ -16,6 +16,8 @@
 //     gradient, KL reductions, gradient unpacking) into a handful of multi-role kernels.
 // About 30 launches per step instead of about 85; numerics are those of the per-op path (same kernels and formulas).
 #include <atomic>
+#include <mutex>
+#include <unordered_map>
 
 #include "common.h"
 #include "elbo_shared.h"
@@ -655,6 +657,24 @@ static T0BwdPaths t0_bwd_paths(const vargp_elbo_t0_desc* d, const T0Ws& o) {
   return r;
 }
 
+// One backward per forward on the LDS-resident path (the forward clears what the backward adds into).  The C ABI enforces it
+// itself: host-side state per workspace, updated when a call is ISSUED (which is also when a hipGraph capture records it, so a
+// captured fwd -> bwd sequence is checked once and replays as recorded).  kT0Cleared: a forward has cleared the accumulators
+// and no backward has consumed them yet.
+enum { kT0NoClear = 0, kT0Cleared = 1, kT0Consumed = 2 };
+static std::mutex g_t0_state_mu;
+static std::unordered_map<const void*, int> g_t0_state;
+static void t0_state_set(const void* ws, int v) {
+  std::lock_guard<std::mutex> lock(g_t0_state_mu);
+  if (g_t0_state.size() > 4096) g_t0_state.clear();      // workspaces come and go; the map only has to know the live ones
+  g_t0_state[ws] = v;
+}
+static int t0_state_get(const void* ws) {
+  std::lock_guard<std::mutex> lock(g_t0_state_mu);
+  auto it = g_t0_state.find(ws);
+  return it == g_t0_state.end() ? -1 : it->second;
+}
+
 }  // namespace vargp
 
 using namespace vargp;
@@ -706,6 +726,7 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
   }
   ZeroJobs bwd_zero{};
   const bool clear_bwd = t0_bwd_paths(d, o).mat_bwd;
+  t0_state_set(d->ws, clear_bwd ? kT0Cleared : kT0NoClear);
   if (clear_bwd) {
     // accumulators of the LDS-resident backward (atomics of t0_bwd_mid.h / t0_bwd_mat.h / t0_bwd_tail.h), cleared in the forward,
     // where it costs nothing (spare workgroups under the pivot chains; shapes without that launch: the prologue's zero role):
@@ -871,6 +892,17 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
   const int ntile = cdiv(B, 64);
   const T0BwdPaths paths = t0_bwd_paths(d, o);
   const bool fused_bwd = paths.fused_bwd, mat_bwd = paths.mat_bwd;
+  if (mat_bwd) {
+    // the accumulators must have been cleared by a forward on THIS workspace that took the same decision (the decision
+    // depends on the alignment of d->z / d->x and on tuning variables) and must not have been consumed by a backward yet
+    const int state = t0_state_get(d->ws);
+    VARGP_REQUIRE(state == kT0Cleared,
+                  "elbo_t0_bwd: %s -- this path allows ONE vargp_elbo_t0_bwd per vargp_elbo_t0_fwd (the forward clears the "
+                  "accumulators the backward adds into); run the forward again",
+                  state == kT0Consumed ? "second backward on one forward"
+                                       : "no forward on this workspace with the same z / x alignment");
+    t0_state_set(d->ws, kT0Consumed);
+  }
   // mat_bwd: no head launch -- the forward's zero role has cleared the accumulators, the seed-dependent KL columns (g a, g G2) are
   // formed by the chain kernel from QP, g_u_mean is cleared by the tile kernel.  ONE backward per forward on this path.
   if (!mat_bwd)

@@ -45,6 +45,10 @@ class T0Program:
                                ws_bytes=self.ws.numel() * 4)
         self._keep = None
         self._rng = None
+        # busy / _gen: as TnProgram -- a forward recorded by autograd owns the workspace until its backward has run or the
+        # graph node has died (VARGP._t0_program then hands out a spare of the same shape)
+        self.busy = False
+        self._gen = 0
 
     def set_rng(self, seed, counter, sample_offset=0):
         """Native noise: `forward(eps_theta=None, eps_f=None)` then draws both noise tensors inside the program from a
@@ -110,7 +114,10 @@ class T0Program:
         (`hyper_desc()` -> optim.Yogi.step(hyper=...)); g_log_mean / g_log_logvar are then written by that launch."""
         require_device(seeds, g_log_mean, g_log_logvar, g_z, g_u_mean, g_u_tril_vec)
         # (the forward clears the accumulators the backward adds into: include/vargp_hip.h, vargp_elbo_t0_bwd)
-        assert self._keep is not None and getattr(self, '_bwd_ok', False), 'T0Program.backward needs a forward of its own (one backward per forward)'
+        if self._keep is None or not getattr(self, '_bwd_ok', False):
+            raise RuntimeError('T0Program.backward: one backward per forward (the forward clears the accumulators the backward '
+                               'adds into; a second loss.backward(retain_graph=True) on the same loss is not supported -- '
+                               'call loss() again)')
         self._bwd_ok = False
         for g in (g_log_mean, g_log_logvar, g_z, g_u_mean, g_u_tril_vec):
             assert g.is_contiguous() and g.dtype == torch.float32
@@ -130,16 +137,27 @@ class T0Program:
         return self._view(0, (self.shape[0], self.shape[3] + 1))
 
 
+def _release(prog, gen):
+    if prog._gen == gen:
+        prog.busy = False
+
+
 class _ElboT0(Function):
     @staticmethod
     def forward(ctx, log_mean, log_logvar, z, u_mean, u_tril_vec, x, y, eps_theta, eps_f, prior_log_mean,
-                prior_log_logvar, map_est):
+                prior_log_logvar, map_est, prog):
         args = [t.contiguous() if t is not None else None
                 for t in (log_mean, log_logvar, prior_log_mean, prior_log_logvar, z, u_mean, u_tril_vec, x, y, eps_theta,
                           eps_f)]
-        S = 1 if map_est else eps_theta.shape[0]
-        prog = T0Program(*T0Program.shape_of(S, z, x, eps_f.shape[1]), z.device, map_est)   # fresh workspace per graph node
-        scal = prog.forward(*args)
+        if prog is None:         # no cached program handed in: a workspace of this node's own
+            S = 1 if map_est else eps_theta.shape[0]
+            prog = T0Program(*T0Program.shape_of(S, z, x, eps_f.shape[1]), z.device, map_est)
+        scal = prog.forward(*args).clone()          # the program's scalars are overwritten by its next forward
+        # the workspace belongs to this node until its backward has run or the node has died (see _ElboTn.forward)
+        prog._gen += 1
+        prog.busy = True
+        weakref.finalize(ctx, _release, prog, prog._gen)
+        ctx.gen = prog._gen
         ctx.prog = prog
         ctx.map_est = map_est
         ctx.shapes = (log_mean.shape, z.shape, u_mean.shape, u_tril_vec.shape)
@@ -149,21 +167,27 @@ class _ElboT0(Function):
     @once_differentiable
     def backward(ctx, g_klh, g_klu, g_nll):
         prog = ctx.prog
+        if prog is None or prog._gen != ctx.gen or not getattr(prog, '_bwd_ok', False):
+            raise RuntimeError('VARGP.loss: one backward per forward on the native first-task program (its forward clears the '
+                               'accumulators the backward adds into, and the workspace is handed on once the backward has '
+                               'run); backward(retain_graph=True) followed by a second backward is not supported -- call '
+                               'loss() again')
         seeds = torch.stack([g_klh.reshape(()), g_klu.reshape(()), g_nll.reshape(())]).float()
         sh_mean, sh_z, sh_um, sh_uv = ctx.shapes
         dev = seeds.device
         g_mean, g_logvar = torch.empty(sh_mean, device=dev), torch.empty(sh_mean, device=dev)
         g_z, g_um, g_uv = torch.empty(sh_z, device=dev), torch.empty(sh_um, device=dev), torch.empty(sh_uv, device=dev)
         prog.backward(seeds, g_mean, g_logvar, g_z, g_um, g_uv)
+        _release(prog, ctx.gen)
         ctx.prog = None
-        return (g_mean, None if ctx.map_est else g_logvar, g_z, g_um, g_uv, None, None, None, None, None, None, None)
+        return (g_mean, None if ctx.map_est else g_logvar, g_z, g_um, g_uv, None, None, None, None, None, None, None, None)
 
 
-def elbo_t0(kernel, z, u_mean, u_tril_vec, x, y, eps_theta, eps_f):
+def elbo_t0(kernel, z, u_mean, u_tril_vec, x, y, eps_theta, eps_f, prog=None):
     """-> (kl_hypers, kl_u, nll) of VARGP.loss for a model with no previous tasks; `kernel` is the RBFKernel
-    module (variational hyper-parameters and their prior)."""
+    module (variational hyper-parameters and their prior).  `prog`: the (cached, not busy) T0Program of this shape."""
     return _ElboT0.apply(kernel.log_mean, kernel.log_logvar, z, u_mean, u_tril_vec, x, y, eps_theta, eps_f,
-                         kernel.prior_log_mean, kernel.prior_log_logvar, bool(kernel.map_est))
+                         kernel.prior_log_mean, kernel.prior_log_logvar, bool(kernel.map_est), prog)
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -356,11 +380,6 @@ class TnProgram:
         check(lib().vargp_elbo_tn_end(ctypes.byref(d), ptr(seeds), *(ptr(g) for g in grads), st), 'vargp_elbo_tn_end')
         ops._note_chol_errors(self.info)
         return self.scalars
-
-
-def _release(prog, gen):
-    if prog._gen == gen:
-        prog.busy = False
 
 
 class _ElboTn(Function):

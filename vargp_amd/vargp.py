@@ -35,6 +35,7 @@ class VARGP(nn.Module):
         # native block programs: training programs per shape (+ spares while one is owned by a pending backward), ONE
         # forward-only program (moments only, no gradient buffers) sized for the widest batch seen, serving narrower ones
         self._tn_ops, self._tn_progs, self._tn_spares, self._tn_eval = None, {}, {}, None
+        self._t0_progs, self._t0_spares = {}, {}       # first-task programs (csrc/elbo_t0.hip) of the autograd route, per shape
         # frozen earlier tasks: plain dicts, not buffers (same as the reference, vargp.py:17-20);
         # u_tril is materialised lazily on first use because that needs the device the params live on
         self.prev_params = [dict(z=p['z'], u_mean=p['u_mean'], u_tril_vec=p['u_tril_vec'])
@@ -159,6 +160,24 @@ class VARGP(nn.Module):
                 spares.append(prog)
         return prog
 
+    def _t0_program(self, B):
+        """The (cached) first-task program of this shape for `loss` as an autograd node: descriptor + ~120 MB workspace are
+        built once per shape, not per call; a spare while a loss whose backward has not run yet owns the first one."""
+        S = 1 if self.kernel.map_est else self.n_v
+        shape = (S, self.z.size(0), self.M, self.z.size(-1), B, self.likelihood.n_f)
+        prog = self._t0_progs.get(shape)
+        if prog is not None and prog.ws.device != self.z.device:
+            prog = None
+        if prog is None:
+            prog = self._t0_progs[shape] = fused.T0Program(*shape, self.z.device, self.kernel.map_est)
+        elif prog.busy:
+            spares = self._t0_spares.setdefault(shape, [])
+            prog = next((q for q in spares if not q.busy and q.ws.device == self.z.device), None)
+            if prog is None:
+                prog = fused.T0Program(*shape, self.z.device, self.kernel.map_est)
+                spares.append(prog)
+        return prog
+
     def _tn_eval_program(self, B, exact=False):
         """The forward-only program (predictive moments, no gradient buffers): one per model, carved for the widest batch
         asked for so far; narrower batches (the ragged last one of a sweep) run on it through the tile calls."""
@@ -174,6 +193,7 @@ class VARGP(nn.Module):
     def release_programs(self):
         """Drop every cached native program (workspaces of several GB at Mt ~ 2000); they are re-created on demand."""
         self._tn_progs, self._tn_spares, self._tn_eval = {}, {}, None
+        self._t0_progs, self._t0_spares = {}, {}
 
     def _tn_args(self):
         k = self.kernel
@@ -260,7 +280,8 @@ class VARGP(nn.Module):
         block = self._use_block_program()
         if not self.prev_params and self.fused_first_task and type(self.kernel) is RBFKernel and not block:
             # first task: the native program (csrc/elbo_t0.hip) as one autograd node
-            return fused.elbo_t0(self.kernel, self.z, self.u_mean, self.u_tril_vec, x, y, *self.draw_t0_noise(x))
+            return fused.elbo_t0(self.kernel, self.z, self.u_mean, self.u_tril_vec, x, y, *self.draw_t0_noise(x),
+                                 prog=self._t0_program(x.size(0)))
         if block:
             # later tasks: the block-structured program (csrc/elbo_tn.hip) as one autograd node
             eps_theta, eps_f = self.draw_t0_noise(x)
