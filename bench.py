@@ -258,9 +258,21 @@ def cpu_baseline(p, x, y, budget_s=15.0, max_steps=30):
             break
     times = sorted(times[1:]) if len(times) > 1 else times
     med = times[len(times) // 2]
-    return dict(value=1.0 / med, unit='ELBO steps/s', cores=threads, kind='port',
-                sample=f'{len(times)} steps (loss + backward + Yogi) of the same Cfg2 workload (S{S} F{F_} C{C} M{M} D{D} B{B}), '
-                       f'median; {threads} torch threads (more run slower on this host)')
+    out = dict(value=1.0 / med, unit='ELBO steps/s', cores=threads, kind='port',
+               sample=f'{len(times)} steps (loss + backward + Yogi) of the same Cfg2 workload (S{S} F{F_} C{C} M{M} D{D} B{B}), '
+                      f'median; {threads} torch threads (more run slower on this host)')
+    # speed calibration of the port against the reference itself (tests/golden/calibrate_cpu.py, run in the build container on
+    # identical inputs, where the reference can be imported): port steps/s / reference steps/s
+    try:
+        with open(os.path.join(ROOT, 'tests', 'golden', 'cpu_calibration.json')) as f:
+            cal = json.load(f)
+        out['port_vs_reference'] = cal['port_vs_reference']
+        out['value_reference_equivalent'] = out['value'] / cal['port_vs_reference']
+        out['calibration'] = ('tests/golden/cpu_calibration.json: reference %.2f vs port %.2f steps/s on %d threads of the build '
+                              'container (loss + backward)' % (cal['reference_steps_per_s'], cal['port_steps_per_s'], cal['threads']))
+    except Exception:
+        out['port_vs_reference'] = None
+    return out
 
 
 def elbo_check(gp, x, y):

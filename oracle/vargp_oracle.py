@@ -340,10 +340,12 @@ def hash_normal(shape, seed):
     return (-2.0 * u1.log()).sqrt() * (2.0 * math.pi * u2).cos()
 
 
-def make_problem(S, F_, C, M, D, B, n_prev=0, seed=0, kind='gauss', dtype=torch.float32, n_v=None):
+def make_problem(S, F_, C, M, D, B, n_prev=0, seed=0, kind='gauss', dtype=torch.float32, n_v=None, ell=0.5):
     """Synthetic problem of the named shape.  kind='gauss': x ~ N(0, 0.25/D) so that
     K_uf is O(1); kind='mnist': 19 %-dense U[0,1] pixels; kind='toy': clustered 2-D normals (ill-conditioned at t>0);
-    kind='wtoy': well-separated 2-D grid points.  Inducing points are data-like rows.
+    kind='wtoy': well-separated 2-D grid points.  Inducing points are data-like rows.  `ell`: centre of the initial
+    lengthscales (reference default 0.5, kernels.py:14; on the 'mnist' data that makes K_uf underflow to exactly 0 --
+    ell = 2.5 puts it at O(1e-3), where the distance expansion cancels hardest).
     Returns (params, prev, x, y, noise)."""
     n_v = S if n_v is None else n_v
 
@@ -381,6 +383,8 @@ def make_problem(S, F_, C, M, D, B, n_prev=0, seed=0, kind='gauss', dtype=torch.
     prev = [task_params(seed + 1000 * (t + 1), t) for t in range(n_prev)]
     params = task_params(seed + 11, n_prev)
     log_init = math.log(0.5) + 0.05 * hash_normal((D + 1,), seed + 13)
+    if ell != 0.5:
+        log_init[:D] += math.log(ell / 0.5)           # the lengthscales only; log gamma stays at log 0.5
     params.update(
         log_mean=log_init.to(dtype),
         log_logvar=(-2.0 * torch.ones(D + 1, dtype=torch.float64) + 0.1 * hash_normal((D + 1,), seed + 17)).to(dtype),

@@ -40,8 +40,8 @@ def load_case(name):
         noise = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('n_')}
         x, y = torch.from_numpy(g['x']), torch.from_numpy(g['y'])
     else:
-        params, prev, x, y, noise = orc.make_problem(S, F_, C, M, D, B, n_prev=n_prev, seed=seed,
-                                                     kind=str(g['kind']))
+        params, prev, x, y, noise = orc.make_problem(S, F_, C, M, D, B, n_prev=n_prev, seed=seed, kind=str(g['kind']),
+                                                     ell=float(g['ell']) if 'ell' in g.files else 0.5)
     return g, params, prev, x, y, noise
 
 

@@ -79,6 +79,41 @@ def test_full_size_cfg2_vs_reference_golden_and_oracle():
         assert rel_l2(grads[k].cpu(), og[k]) < REL_L2_GRAD, k
 
 
+@pytest.mark.parametrize('name', ['smnist_full_t0_mnist', 'smnist_full_t0_mnist_l25'])
+def test_full_size_cfg2_mnist_like_data_vs_reference_golden_and_oracle(name):
+    """BASELINE config 2 in the MNIST-like data regime BASELINE.md quotes (19 %-dense U[0,1] pixels, |x/sigma|^2 ~ 200 at the
+    reference's initial lengthscale 0.5): K_uf underflows to exactly 0 and K_uu = gamma^2 I in the reference (kernels.py:54-56
+    has no clamp), so the z-gradient is exactly 0 there; `_l25` has lengthscale 2.5, where K_uf is O(1e-3) and the expansion
+    |a|^2 + |b|^2 - 2ab cancels hardest.  Against the reference's outputs and, tensor by tensor, the oracle."""
+    g, (params, prev, x, y, nz), sc, grads, pmu, pvar, probs = _run(name)
+    for k in ['kl_hypers', 'kl_u', 'nll', 'total']:
+        np.testing.assert_allclose(sc[k], float(g[k]), rtol=RTOL_SCALAR, err_msg=k)
+    _, og = orc.elbo_step(params, prev, x, y, nz, beta=float(g['beta']), n_total=float(g['n_total']))
+    for k in GRAD_KEYS:
+        ref_norm = float(g[f'gradnorm_{k}'])
+        got = grads[k].cpu()
+        assert torch.isfinite(got).all(), k
+        if ref_norm == 0.0:      # underflow regime: nothing may leak into a gradient the reference has at exactly zero
+            assert got.double().norm().item() <= 1e-6 * float(g['gradnorm_u_mean']), (k, got.double().norm().item())
+        else:
+            np.testing.assert_allclose(got.double().norm().item(), ref_norm, rtol=1e-3, err_msg=k)
+            assert rel_l2(got, og[k]) < REL_L2_GRAD, k
+    assert rel_l2(grads['log_mean'].cpu(), g['grad_log_mean']) < REL_L2_GRAD
+    assert rel_l2(grads['u_mean'].cpu(), g['grad_u_mean']) < REL_L2_GRAD
+    np.testing.assert_allclose(pmu.numpy(), g['pred_mu'], rtol=RTOL_PRED, atol=ATOL_PRED)
+    np.testing.assert_allclose(pvar.numpy(), g['pred_var'], rtol=RTOL_PRED, atol=ATOL_PRED)
+    np.testing.assert_allclose(probs.numpy(), g['probs'], atol=ATOL_PROBS)
+    if name.endswith('_l25'):
+        # the small kernel values themselves, relative: K_uf of the HIP kernel-matrix GEMM against the oracle's fp64 distances
+        from vargp_amd import ops
+        theta = orc.sample_hypers(params['log_mean'], params['log_logvar'], nz['eps_theta'])
+        K = ops.rbf_gram(theta.to('cuda:0'), params['z'].to('cuda:0'), x.to('cuda:0'), True).cpu()
+        K64 = orc.rbf_gram(theta.double(), params['z'].double(), x.double().expand(params['z'].shape[0], -1, -1))
+        big = K64 > 1e-6
+        rel = ((K.double() - K64).abs() / K64)[big]
+        assert big.float().mean() > 0.5 and rel.max().item() < 2e-4, (big.float().mean().item(), rel.max().item())
+
+
 def test_ep_var_mean_false_matches_oracle():
     """ep_var_mean=False exercises the u_<t sampling + gp_cond mean path (reference vargp.py:137-152)."""
     g, (params, prev, x, y, nz), sc, grads, *_ = _run('toy_t1', ep_var_mean=False)

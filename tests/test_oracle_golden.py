@@ -77,10 +77,13 @@ def test_e2e_loss_grads_predict(name):
     np.testing.assert_allclose(orc.predict(params, prev, x, noise).numpy(), g['probs'], atol=ATOL_PROBS)
 
 
-@pytest.mark.parametrize('name', ['smnist_full_t0', 'pmnist_full_t0', 'pmnist_red_t1', 'pmnist_red_t2', 'smnist_s64_t0'])
+@pytest.mark.parametrize('name', ['smnist_full_t0', 'pmnist_full_t0', 'pmnist_red_t1', 'pmnist_red_t2', 'smnist_s64_t0',
+                                  'smnist_full_t0_mnist', 'smnist_full_t0_mnist_l25'])
 def test_e2e_full_size(name):
     """Outputs-only fixtures (inputs regenerated from the seed, outputs from the reference): Cfg2 (S3 F10 C10 M100 D784
-    B512), Cfg3 task 0 at full size (S10 M200) and tasks 1, 2 (Mt = 400, 600) at reduced D/B, Cfg4's S = 64 unsharded."""
+    B512), Cfg3 task 0 at full size (S10 M200) and tasks 1, 2 (Mt = 400, 600) at reduced D/B, Cfg4's S = 64 unsharded;
+    Cfg2 on MNIST-like data (19 %-dense U[0,1] pixels) at the initial lengthscale 0.5 (K_uf underflows to 0: the z-gradient
+    is exactly 0) and at lengthscale 2.5 (K_uf ~ 1e-3)."""
     g, params, prev, x, y, noise = load_case(name)
     sc, grads = orc.elbo_step(params, prev, x, y, noise, beta=float(g['beta']), n_total=float(g['n_total']))
     for k in ['kl_hypers', 'kl_u', 'nll', 'total']:
