@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _run(args, tmp_path):
+    os.makedirs(tmp_path, exist_ok=True)
     log = tmp_path / 'run'
     cmd = [sys.executable, os.path.join(ROOT, 'experiments', 'vargp.py')] + args + ['--log_dir', str(log)]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
@@ -70,3 +71,49 @@ def test_permuted_mnist_ten_task_loop_at_config_size(tmp_path):
     assert tuple(sd9['z'].shape) == (10, 200, 784) and tuple(sd9['u_tril_vec'].shape) == (10, 200 * 201 // 2)
     sd8 = torch.load(log / 'ckpt8.pt')
     assert torch.allclose(sd9['kernel.prior_log_mean'].cpu(), sd8['kernel.log_mean'].cpu())
+
+
+def test_device_resident_epochs_reach_the_bench_rate(tmp_path):
+    """`experiments/vargp.py s-mnist --synthetic --graph` end to end at BASELINE config 2's shapes (M = 100, S = 3, C = 10,
+    D = 784, batch 512): with the data set resident in HBM, an on-device permutation per epoch and the minibatch gathered
+    into the captured graph's static inputs, the driver's task-0 training rate (steps / wall time of the epochs, ragged last
+    batch of every epoch included) must come within 1.25x of the rate the same trainer reaches on ONE resident minibatch
+    (what bench.py times).  The reference-shaped DataLoader path (--dataloader) is measured beside it and reported."""
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    from vargp_amd import ops
+    from vargp_amd.train import ElboTrainer
+    # -- the bench rate: the trainer replaying its captured step on a resident batch
+    ops.set_cholesky_error_mode('defer')
+    try:
+        gp, x, y = bench.make_model('cuda:0')
+        tr = ElboTrainer(gp, lr=3e-3, beta=10.0, n_total=12000)
+        tr.capture(x, y)
+        for _ in range(50):
+            tr.step_graph()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(400):
+            tr.step_graph()
+        torch.cuda.synchronize()
+        bench_rate = 400 / (time.perf_counter() - t0)
+        del tr
+        gp.release_programs()
+    finally:
+        ops.set_cholesky_error_mode('raise')
+    # -- the driver, device-resident epochs (default) and the reference's DataLoader (--dataloader); only task 0 is compared
+    common = ['s-mnist', '--synthetic', '--n_synth', '36000', '--eval_interval', '100000', '--M', '100', '--graph', '--seed', '4']
+    _, sc = _run(common + ['--epochs', '30'], tmp_path / 'dev')
+    e2e = next(v for (k, _), v in sc.items() if k == 'task0/train/steps_per_s')
+    _, sc2 = _run(common + ['--epochs', '3', '--dataloader'], tmp_path / 'dl')
+    e2e_loader = next(v for (k, _), v in sc2.items() if k == 'task0/train/steps_per_s')
+    report = dict(bench_steps_per_s=bench_rate, driver_device_resident_steps_per_s=e2e, driver_dataloader_steps_per_s=e2e_loader,
+                  ratio=bench_rate / e2e)
+    print('device-resident epochs:', json.dumps(report))
+    out = os.path.join(ROOT, 'gpurun_out')
+    if os.path.isdir(out):
+        with open(os.path.join(out, 'driver_epoch_rate.json'), 'w') as f:
+            json.dump(report, f)
+    assert e2e * 1.25 >= bench_rate, report
+    assert e2e > 3 * e2e_loader, report         # what the device-resident path buys over the host-side loader

@@ -209,6 +209,13 @@ class ElboTrainer:
             self.graph_opt.replay()
         return self._sout
 
+    def step_graph_gather(self, data, targets, idx):
+        """Replay the captured step on the minibatch data[idx], targets[idx] (device-resident data set, idx a device index
+        tensor of the captured batch size): gathered straight into the graph's static inputs, no host copy."""
+        torch.index_select(data, 0, idx, out=self._sx)
+        torch.index_select(targets, 0, idx, out=self._sy)
+        return self.step_graph()
+
     def step(self, x, y):
         """-> (kl_hypers, kl_u, nll) as 0-dim device tensors (global values on every rank)."""
         scale = (self.n_total if self.n_total is not None else x.size(0)) / x.size(0)

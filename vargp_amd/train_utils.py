@@ -15,13 +15,49 @@ def set_seeds(seed=None):
         torch.cuda.manual_seed_all(seed)
 
 
+def materialize(dataset, device=None):
+    """The whole data set as two tensors (x (N, D), y (N)) on `device`: every data set of var_gp/datasets.py is
+    tensor-indexable (VARGP.create_clf relies on that, vargp.py:207-209); a ConcatDataset is the concatenation of its parts."""
+    from torch.utils.data import ConcatDataset
+    if isinstance(dataset, ConcatDataset):
+        xs, ys = zip(*[materialize(d, device) for d in dataset.datasets])
+        return torch.cat(xs), torch.cat(ys)
+    x, y = dataset[torch.arange(len(dataset))]
+    return x.to(device).contiguous(), y.to(device).contiguous()
+
+
+class DeviceBatches:
+    """Device-resident replacement of `DataLoader(train_set, batch_size, shuffle=True)` (experiments/vargp.py:26): data and
+    targets live in HBM, every epoch draws ONE on-device permutation, a minibatch is its index slice -- gathered by the
+    consumer with index_select (one small kernel per tensor), no host copy and no host sync anywhere in the epoch.
+    Iterating yields index tensors; `take(idx)` gathers (x, y)."""
+
+    def __init__(self, dataset, batch_size, device, shuffle=True):
+        self.data, self.targets = materialize(dataset, device)
+        self.batch_size, self.shuffle = int(batch_size), shuffle
+        self.n = self.targets.size(0)
+
+    def __len__(self):
+        return (self.n + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        order = (torch.randperm(self.n, device=self.data.device) if self.shuffle
+                 else torch.arange(self.n, device=self.data.device))
+        for i in range(0, self.n, self.batch_size):
+            yield order[i:i + self.batch_size]
+
+    def take(self, idx):
+        return self.data.index_select(0, idx), self.targets.index_select(0, idx)
+
+
 def _sweep(dataset, gp, batch_size, device, shared_hypers):
     """Class probabilities of `gp` over `dataset`, one (probs, labels) pair per chunk, everything left on the device.
     shared_hypers: the whole set goes through ONE predict(x, tile=batch_size) call -- one hyper-parameter draw and one
     factorisation of K(z_<=t) for the sweep instead of one per batch (the reference, train_utils.py:25-27, re-draws per
     batch; every batch's prediction has the same distribution either way)."""
     loader = DataLoader(dataset, batch_size=batch_size)
-    if shared_hypers:
+    import inspect
+    if shared_hypers and 'tile' in inspect.signature(gp.predict).parameters:
         xs, ys = zip(*[(x, y) for x, y in loader])
         yield gp.predict(torch.cat(xs).to(device), tile=batch_size), torch.cat(ys).to(device)
         return

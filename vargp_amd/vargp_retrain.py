@@ -168,8 +168,11 @@ class VARGPRetrain(nn.Module):
             kl_u = kl.sum(dim=-1).mean(dim=0).mean(dim=0)
         return self.kernel.kl_hypers(), kl_u, nll
 
-    def predict(self, x):
-        """Class probabilities (B, C)  (vargp_retrain.py:235-237)."""
+    def predict(self, x, tile=None):
+        """Class probabilities (B, C)  (vargp_retrain.py:235-237).  `tile`: a large x in chunks of `tile` points (same
+        signature as VARGP.predict; every chunk draws its own hyper-parameter sample, as one call per batch would)."""
+        if tile is not None and x.size(0) > tile:
+            return torch.cat([self.predict(x[i:i + tile]) for i in range(0, x.size(0), tile)], dim=0)
         pred_mu, pred_var = self(x)
         return self.likelihood.predict(pred_mu, pred_var)
 
