@@ -199,7 +199,7 @@ __global__ __launch_bounds__(512) void chol_inv_small_kernel(const float* __rest
 }
 
 // stand-alone launch of chol3_body (chol_small3.h): columns across waves, rows across lanes
-template <int KC, int SETS>
+template <int KC, int SETS, class R = double>
 __global__ __launch_bounds__(256) void chol_inv_small3_kernel(const float* __restrict__ A, int lda, int64_t strideA,
                                                               float eps, float* __restrict__ L, int ldl,
                                                               int64_t strideL, float* __restrict__ T, int ldt,
@@ -207,8 +207,8 @@ __global__ __launch_bounds__(256) void chol_inv_small3_kernel(const float* __res
                                                               int32_t* __restrict__ info, int info_base, int n,
                                                               int logdet_accumulate) {
   __shared__ float stage[chol3_stage_floats<KC>()];
-  chol3_body<KC, SETS>(blockIdx.x, A, lda, strideA, eps, L, ldl, strideL, T, ldt, strideT, logdet, info, info_base, n,
-                       logdet_accumulate, stage);
+  chol3_body<KC, SETS, R>(blockIdx.x, A, lda, strideA, eps, L, ldl, strideL, T, ldt, strideT, logdet, info, info_base, n,
+                          logdet_accumulate, stage);
 }
 
 static int launch_small(const float* A, int lda, int64_t sA, float eps, float* L, int ldl, int64_t sL, float* T,
@@ -219,9 +219,17 @@ static int launch_small(const float* A, int lda, int64_t sA, float eps, float* L
 #define VARGP_CHOL_LAUNCH(K)                                                                                     \
   hipLaunchKernelGGL((chol_inv_small_kernel<double, K>), dim3(nbatch), dim3(nt), 0, st, A, lda, sA, eps, L, ldl, sL, \
                      T, ldt, sT, logdet, info, info_base, n, ld_acc)
-#define VARGP_CHOL3_LAUNCH(KC, SETS)                                                                                   \
-  hipLaunchKernelGGL((chol_inv_small3_kernel<KC, SETS>), dim3(nbatch), dim3(256), 0, st, A, lda, sA, eps, L, ldl, sL, T, \
-                     ldt, sT, logdet, info, info_base, n, ld_acc)
+  // VARGP_CHOL_F32_ALONE=1 (tuning / measurement only): the stand-alone launch in the fp32 arithmetic of chol_small3.h
+  static const int f32_alone = [] { const char* e = getenv("VARGP_CHOL_F32_ALONE"); return e ? atoi(e) : 0; }();
+#define VARGP_CHOL3_LAUNCH(KC, SETS)                                                                                          \
+  do {                                                                                                                          \
+    if (f32_alone)                                                                                                              \
+      hipLaunchKernelGGL((chol_inv_small3_kernel<KC, SETS, float>), dim3(nbatch), dim3(256), 0, st, A, lda, sA, eps, L, ldl, sL, T, \
+                         ldt, sT, logdet, info, info_base, n, ld_acc);                                                            \
+    else                                                                                                                        \
+      hipLaunchKernelGGL((chol_inv_small3_kernel<KC, SETS, double>), dim3(nbatch), dim3(256), 0, st, A, lda, sA, eps, L, ldl, sL, T, \
+                         ldt, sT, logdet, info, info_base, n, ld_acc);                                                            \
+  } while (0)
   // measured (batch 30, MI355X): rows-across-threads kernel 10 / 22 us at n = 20 / 40; columns-across-waves kernel
   // 48 / 65 us at n = 64 / 100
   if (n <= 20) VARGP_CHOL_LAUNCH(4);

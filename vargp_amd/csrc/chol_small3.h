@@ -48,6 +48,11 @@ __device__ __forceinline__ double fast_rcp(double d) {
   x = fma(x, fma(-d, x, 1.0), x);
   return x;
 }
+// fp32 chain (R = float, see chol3_body): v_rcp_f32 (1 ulp) + one Newton step
+__device__ __forceinline__ float fast_rcp(float d) {
+  float x = __builtin_amdgcn_rcpf(d);
+  return fmaf(x, fmaf(-d, x, 1.0f), x);
+}
 
 // value of `v` in lane `lane` (compile-time or wave-uniform index) broadcast to the whole wave
 __device__ __forceinline__ double lane_bcast(double v, int lane) {
@@ -55,6 +60,9 @@ __device__ __forceinline__ double lane_bcast(double v, int lane) {
   const unsigned lo = __builtin_amdgcn_readlane((int)(u & 0xffffffffu), lane);
   const unsigned hi = __builtin_amdgcn_readlane((int)(u >> 32), lane);
   return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ float lane_bcast(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
 // VARGP_CHOL_FLAGSYNC (tuning experiment): no barrier per pivot -- the publishing wave sets an LDS flag after
@@ -65,10 +73,11 @@ __device__ __forceinline__ double lane_bcast(double v, int lane) {
 #define VARGP_CHOL_FLAGSYNC 0
 #endif
 constexpr int kCholBufs = VARGP_CHOL_FLAGSYNC ? 4 : 2;
+template <class R>
 struct Chol3Ctx {
-  double* prow;   // [kCholBufs][128]  pivot row p (columns 0..127; the pivot itself stored as 1 + d), buffered by J % kCholBufs
-  double* qrow;   // [kCholBufs][128]  q = -p / d, same layout
-  double* dpiv;   // [kCholBufs]       the pivot d (<= 0 or NaN: not positive-definite)
+  R* prow;        // [kCholBufs][128]  pivot row p (columns 0..127; the pivot itself stored as 1 + d), buffered by J % kCholBufs
+  R* qrow;        // [kCholBufs][128]  q = -p / d, same layout
+  R* dpiv;        // [kCholBufs]       the pivot d (<= 0 or NaN: not positive-definite)
   double* sd;     // [n]       all pivots, for the final scaling
   int n, lane, w;
   int* flag;   // [kCholBufs]  FLAGSYNC: J + 1 once row J is in its buffer
@@ -77,23 +86,23 @@ struct Chol3Ctx {
 // Row J (slot J / 4 of wave J % 4) to LDS, final once step J - 1 has updated it: p, the scaled copy q = -p / d_J and
 // d_J.  Column J counts as 1 + d_J in both, so that the update below leaves m_i = -p_i / d_J in entry (i, J):
 // A_iJ + p_i q_J = p_i - p_i (1 + d) / d = -p_i / d   (A_iJ = p_i by symmetry, to rounding).
-template <int KC, int SETS, int J>
-__device__ __forceinline__ void chol3_publish(const Chol3Ctx& cx, const double (&va)[KC], const double (&vb)[KC]) {
+template <class R, int KC, int SETS, int J>
+__device__ __forceinline__ void chol3_publish(const Chol3Ctx<R>& cx, const R (&va)[KC], const R (&vb)[KC]) {
   constexpr bool second = J >= 64;
   constexpr int jl = second ? J - 64 : J;
-  double* prow = cx.prow + (J % kCholBufs) * 128;
-  double* qrow = cx.qrow + (J % kCholBufs) * 128;
-  double pa = va[J / 4], pb = vb[J / 4];
-  const double d = lane_bcast(second ? pb : pa, jl);
-  const double ndi = -fast_rcp(d);
-  if constexpr (second) { if (cx.lane == jl) pb = 1.0 + d; } else { if (cx.lane == jl) pa = 1.0 + d; }
+  R* prow = cx.prow + (J % kCholBufs) * 128;
+  R* qrow = cx.qrow + (J % kCholBufs) * 128;
+  R pa = va[J / 4], pb = vb[J / 4];
+  const R d = lane_bcast(second ? pb : pa, jl);
+  const R ndi = -fast_rcp(d);
+  if constexpr (second) { if (cx.lane == jl) pb = R(1) + d; } else { if (cx.lane == jl) pa = R(1) + d; }
   prow[cx.lane] = pa;
   qrow[cx.lane] = pa * ndi;
   if constexpr (SETS == 2) {
     prow[64 + cx.lane] = pb;
     qrow[64 + cx.lane] = pb * ndi;
   }
-  if (cx.lane == 0) { cx.dpiv[J % kCholBufs] = d; cx.sd[J] = d; }
+  if (cx.lane == 0) { cx.dpiv[J % kCholBufs] = d; cx.sd[J] = (double)d; }
 #if VARGP_CHOL_FLAGSYNC
   asm volatile("" ::: "memory");      // (ordering for the compiler; the LDS itself serves a wave's writes in order)
   if (cx.lane == 0) cx.flag[J % kCholBufs] = J + 1;
@@ -101,8 +110,8 @@ __device__ __forceinline__ void chol3_publish(const Chol3Ctx& cx, const double (
 #endif
 }
 
-template <int KC, int SETS, int J>
-__device__ __forceinline__ void chol3_steps(const Chol3Ctx& cx, double (&va)[KC], double (&vb)[KC],
+template <class R, int KC, int SETS, int J>
+__device__ __forceinline__ void chol3_steps(const Chol3Ctx<R>& cx, R (&va)[KC], R (&vb)[KC],
                                             int& fail VARGP_STAMP_PARAMS) {
   if constexpr (J < 4 * KC && J < 64 * SETS) {
     constexpr int kj = J / 4, wj = J % 4;                    // slot / wave of the pivot row
@@ -117,9 +126,9 @@ __device__ __forceinline__ void chol3_steps(const Chol3Ctx& cx, double (&va)[KC]
     STAMP(2);
     // every LDS read of the step up front: the pivot, this lane's columns of q, and -- same address in every lane --
     // the entries p_i of the rows i = 4k + w this wave still updates (p_i = A_iJ by symmetry: the multiplier of row i)
-    const double* qrow = cx.qrow + (J % kCholBufs) * 128;
-    const double* pw = cx.prow + (J % kCholBufs) * 128 + w;
-    double d, qa, qb = 0.0, pr[KC];
+    const R* qrow = cx.qrow + (J % kCholBufs) * 128;
+    const R* pw = cx.prow + (J % kCholBufs) * 128 + w;
+    R d, qa, qb = R(0), pr[KC];
 #if VARGP_CHOL_FLAGSYNC
     int seen;
     do {       // the flag first, the row behind it in the same batch of reads; again if the flag was not up yet
@@ -141,9 +150,9 @@ __device__ __forceinline__ void chol3_steps(const Chol3Ctx& cx, double (&va)[KC]
     for (int k = kj; k < KC; ++k) pr[k] = pw[4 * k];
     __builtin_amdgcn_sched_group_barrier(0x100, (KC - kj + 1) / 2 + 3, 0);   // DS reads first
 #endif
-    if (!(d > 0.0)) { fail = J + 1; return; }                // uniform
+    if (!(d > R(0))) { fail = J + 1; return; }               // uniform
     // rows i = 4k + w > J only: slots below kj are finished for every wave, slot kj for the waves w <= wj
-    if (w <= wj) pr[kj] = 0.0;
+    if (w <= wj) pr[kj] = R(0);
     STAMP(3);
 #define VARGP_CHOL3_UPDATE(k)                                                \
     do {                                                                       \
@@ -153,7 +162,7 @@ __device__ __forceinline__ void chol3_steps(const Chol3Ctx& cx, double (&va)[KC]
     // look-ahead: the next pivot row first, published at once
     if constexpr (has_next) {
       VARGP_CHOL3_UPDATE(k1);
-      if (w == w1 && J + 1 < cx.n) chol3_publish<KC, SETS, J + 1>(cx, va, vb);
+      if (w == w1 && J + 1 < cx.n) chol3_publish<R, KC, SETS, J + 1>(cx, va, vb);
     }
     STAMP(1);
 #pragma unroll
@@ -165,14 +174,17 @@ __device__ __forceinline__ void chol3_steps(const Chol3Ctx& cx, double (&va)[KC]
     asm volatile("" ::"v"(va[KC - 1]), "v"(vb[KC - 1]));
     STAMP(4);
 #endif
-    chol3_steps<KC, SETS, J + 1>(cx, va, vb, fail VARGP_STAMP_ARGS);
+    chol3_steps<R, KC, SETS, J + 1>(cx, va, vb, fail VARGP_STAMP_ARGS);
   }
 }
 
 template <int KC> constexpr int chol3_stage_floats() { return 4 * KC * (4 * KC + 1); }
 
 // One matrix (index b of the batch).  n <= 64: SETS = 1 (columns = lanes); n <= 128 and n <= 4 KC: SETS = 2.
-template <int KC, int SETS>
+// R = the arithmetic of the elimination: double (default; more accurate than the reference's fp32 LAPACK path on
+// ill-conditioned matrices) or float (the reference's own arithmetic, gp_utils.py:5-11 is torch.cholesky in fp32: half the LDS
+// bytes per broadcast, a one-instruction reciprocal, full-rate FMAs -- selected per launch, see launch_chol_rbf_gemm_impl).
+template <int KC, int SETS, class R = double>
 __device__ __forceinline__ void chol3_body(const int64_t b, const float* __restrict__ A, int lda, int64_t strideA, float eps,
                                            float* __restrict__ L, int ldl, int64_t strideL, float* __restrict__ T, int ldt,
                                            int64_t strideT, float* __restrict__ logdet, int32_t* __restrict__ info,
@@ -181,8 +193,8 @@ __device__ __forceinline__ void chol3_body(const int64_t b, const float* __restr
   // `stage` = chol3_stage_floats<KC>() floats of LDS owned by the kernel (the matrix on its way in, L and T on their
   // way out), so that a kernel with other roles can hand over LDS it has anyway
   constexpr int NP = 4 * KC + 4;
-  __shared__ double prow[kCholBufs][128], qrow[kCholBufs][128];
-  __shared__ double dpiv[kCholBufs];
+  __shared__ R prow[kCholBufs][128], qrow[kCholBufs][128];
+  __shared__ R dpiv[kCholBufs];
   __shared__ int flag[4];
   __shared__ double sd[NP], sq[NP];
   __shared__ float red[4];
@@ -196,7 +208,7 @@ __device__ __forceinline__ void chol3_body(const int64_t b, const float* __restr
   if (T) T += b * strideT;
 
   const int di = 256 / n, dj = 256 - di * n;   // element e -> e + 256 without a division per element
-  double va[KC], vb[KC];
+  R va[KC], vb[KC];
   if (extra && extra->part && b < extra->first) {
     // K-split partial Gram matrices -> kernel matrix on the way in (CholExtra, common.h).  Summation order and formula of
     // t0_combine_norm_kernel (elbo_t0.hip).  Loads on clamped indices, all of a row's in flight together.
@@ -233,10 +245,10 @@ __device__ __forceinline__ void chol3_body(const int64_t b, const float* __restr
       const float gii = stage[ic];
       const float ka = i == ca ? gam : gam * expf(-0.5f * (gii + gja - 2.f * ga));
       const float kb = i == cb ? gam : gam * expf(-0.5f * (gii + gjb - 2.f * gb));
-      va[k] = 0.0; vb[k] = 0.0;
+      va[k] = R(0); vb[k] = R(0);
       if (i < n) {
-        if (minea) { va[k] = (double)ka + (i == ca ? (double)eps : 0.0); Kout[(int64_t)i * n + ca] = ka; }
-        if (mineb) { vb[k] = (double)kb + (i == cb ? (double)eps : 0.0); Kout[(int64_t)i * n + cb] = kb; }
+        if (minea) { va[k] = (R)ka + (i == ca ? (R)eps : R(0)); Kout[(int64_t)i * n + ca] = ka; }
+        if (mineb) { vb[k] = (R)kb + (i == cb ? (R)eps : R(0)); Kout[(int64_t)i * n + cb] = kb; }
       }
     }
     __syncthreads();      // `stage` is reused for the results
@@ -245,10 +257,10 @@ __device__ __forceinline__ void chol3_body(const int64_t b, const float* __restr
 #pragma unroll
     for (int k = 0; k < KC; ++k) {
       const int i = 4 * k + w;
-      va[k] = 0.0; vb[k] = 0.0;
+      va[k] = R(0); vb[k] = R(0);
       if (i < n) {
-        if (minea) va[k] = (double)A[(int64_t)i * lda + ca] + (i == ca ? (double)eps : 0.0);
-        if (mineb) vb[k] = (double)A[(int64_t)i * lda + cb] + (i == cb ? (double)eps : 0.0);
+        if (minea) va[k] = (R)A[(int64_t)i * lda + ca] + (i == ca ? (R)eps : R(0));
+        if (mineb) vb[k] = (R)A[(int64_t)i * lda + cb] + (i == cb ? (R)eps : R(0));
       }
     }
   } else {
@@ -266,31 +278,31 @@ __device__ __forceinline__ void chol3_body(const int64_t b, const float* __restr
 #pragma unroll
     for (int k = 0; k < KC; ++k) {
       const int i = 4 * k + w;
-      va[k] = 0.0; vb[k] = 0.0;
+      va[k] = R(0); vb[k] = R(0);
       if (i < n) {
         if (minea) {
           const int hi = i > ca ? i : ca, lo = i > ca ? ca : i;
-          va[k] = (double)stage[hi * LS + lo] + (i == ca ? (double)eps : 0.0);
+          va[k] = (R)stage[hi * LS + lo] + (i == ca ? (R)eps : R(0));
         }
         if (mineb) {
           const int hi = i > cb ? i : cb, lo = i > cb ? cb : i;
-          vb[k] = (double)stage[hi * LS + lo] + (i == cb ? (double)eps : 0.0);
+          vb[k] = (R)stage[hi * LS + lo] + (i == cb ? (R)eps : R(0));
         }
       }
     }
   }
 
   int fail = 0;
-  const Chol3Ctx cx{&prow[0][0], &qrow[0][0], dpiv, sd, n, lane, w, flag};
+  const Chol3Ctx<R> cx{&prow[0][0], &qrow[0][0], dpiv, sd, n, lane, w, flag};
 #if VARGP_CHOL_FLAGSYNC
   if (tid < 4) flag[tid] = 0;
   __syncthreads();
 #endif
-  if (w == 0) chol3_publish<KC, SETS, 0>(cx, va, vb);      // row 0 has no predecessor to publish it
+  if (w == 0) chol3_publish<R, KC, SETS, 0>(cx, va, vb);   // row 0 has no predecessor to publish it
 #ifdef VARGP_CHOL_STAMPS
   unsigned long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
 #endif
-  chol3_steps<KC, SETS, 0>(cx, va, vb, fail VARGP_STAMP_ARGS);
+  chol3_steps<R, KC, SETS, 0>(cx, va, vb, fail VARGP_STAMP_ARGS);
   __syncthreads();
 #ifdef VARGP_CHOL_STAMPS
   if (tid == 0 && b == 0) for (int i = 0; i < 8; ++i) g_chol_stamps[i] = acc_[i];
@@ -320,8 +332,8 @@ __device__ __forceinline__ void chol3_body(const int64_t b, const float* __restr
       const int i = 4 * k + w;
       if (i < n) {
         const double isi = sd[i];
-        if (minea) T[(int64_t)i * ldt + ca] = ca < i ? (float)(va[k] * isi) : (ca == i ? (float)isi : 0.f);
-        if (mineb) T[(int64_t)i * ldt + cb] = cb < i ? (float)(vb[k] * isi) : (cb == i ? (float)isi : 0.f);
+        if (minea) T[(int64_t)i * ldt + ca] = ca < i ? (float)((double)va[k] * isi) : (ca == i ? (float)isi : 0.f);
+        if (mineb) T[(int64_t)i * ldt + cb] = cb < i ? (float)((double)vb[k] * isi) : (cb == i ? (float)isi : 0.f);
       }
     }
   }
@@ -349,7 +361,7 @@ __device__ __forceinline__ void chol3_body(const int64_t b, const float* __restr
       for (int half = 0; half < SETS; ++half) {
         const int e = half ? cb : ca;
         if (half ? mineb : minea) {
-          const double v = half ? vb[k] : va[k];
+          const double v = (double)(half ? vb[k] : va[k]);
           if (e > i) { stage[e * LS + i] = (float)(v * isi); stage[i * LS + e] = 0.f; }
           else if (e == i) stage[i * LS + i] = (float)si;
         }

@@ -120,6 +120,8 @@ __device__ __forceinline__ void zero_jobs_role(const ZeroJobs& z, int blk, int n
 #endif
 // K to Kout + b n^2 (dense, both triangles).
 constexpr int kCholPartMax = 4;
+// arithmetic of the pivot chains inside the merged first-task launch (chol_small3.h: R): 0 = fp64, 1 = the reference's fp32
+constexpr int kCholF32Default = 0;
 constexpr int kProKuuMaxD = 4096;       // launch_pro_kuu: 1/sigma^2 of one hyper-sample staged in LDS by the norm role
 struct CholExtra {
   float* base; int first; int ld; int64_t stride_b, stride_copy; int ncopy;

@@ -277,7 +277,7 @@ static __global__ __launch_bounds__(256) void t0_w_kernel(const float* __restric
   // before its stores
   constexpr int RW = kUuRows / 4;
   const int wv = threadIdx.x >> 6;
-  float acc[RW];
+  float acc[RW], dsum = 0.f;
 #pragma unroll
   for (int r = 0; r < RW; ++r) acc[r] = 0.f;
   for (int j0 = 0; j0 < M; j0 += 128) {
@@ -302,8 +302,11 @@ static __global__ __launch_bounds__(256) void t0_w_kernel(const float* __restric
         if (i < i1 && j < M) {
           // sym_guu: gK_uu is symmetric (it comes out of the Cholesky backward), so W + W^T = 2 W: no transposed reads
           const float v = sym_guu ? 2.f * kv[r][h] * gv[r][h] : kv[r][h] * gv[r][h] + kt[r][h] * gt[r][h];
-          Wuu[b * M * M + (int64_t)i * M + j] = v;
-          acc[r] += v;
+          // the diagonal counts for gamma only (K_ii = gamma^2: see rbf_w_self_kernel, rbf.hip)
+          const bool dg = i == j;
+          Wuu[b * M * M + (int64_t)i * M + j] = dg ? 0.f : v;
+          acc[r] += dg ? 0.f : v;
+          dsum += dg ? v : 0.f;
         }
       }
     }
@@ -317,6 +320,7 @@ static __global__ __launch_bounds__(256) void t0_w_kernel(const float* __restric
       tot += a;
     }
   }
+  tot += wave_sum(dsum);
   // every lane of a wave holds the wave's total: count it once
   const float t = block_sum<256>(lane == 0 ? tot : 0.f, red);
   if (threadIdx.x == 0) atomicAdd(&gtheta[(b / C) * (D + 1) + D], t);

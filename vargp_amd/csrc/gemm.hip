@@ -812,13 +812,13 @@ struct CholArgs {
   ZeroJobs zero;     // third role (the last nzero workgroups): zero-fills of the caller, free under the pivot chains
   int nzero;
 };
-template <int KC, int SETS, int BM, int BK, bool SCALED = true>
+template <int KC, int SETS, int BM, int BK, bool SCALED = true, class R = double>
 __global__ __launch_bounds__(256) void chol_rbf_gemm_kernel(const CholArgs c, const GemmParams p, const int tiles) {
   // one LDS array for both roles (the factorisation stages its matrix through 40 KB of it): 2 workgroups per CU
   __shared__ __attribute__((aligned(16))) float lds[cmax(gemm_lds_floats<BM, 64, BK, true, true>(), chol3_stage_floats<KC>())];
   if ((int)blockIdx.x < c.nchol) {
-    chol3_body<KC, SETS>(blockIdx.x, c.A, c.lda, c.sA, c.eps, c.L, c.ldl, c.sL, c.T, c.ldt, c.sT, nullptr, c.info, 0, c.n,
-                         0, lds, c.extra.base ? &c.extra : nullptr);
+    chol3_body<KC, SETS, R>(blockIdx.x, c.A, c.lda, c.sA, c.eps, c.L, c.ldl, c.sL, c.T, c.ldt, c.sT, nullptr, c.info, 0, c.n,
+                            0, lds, c.extra.base ? &c.extra : nullptr);
     return;
   }
   const int ngemm = (int)gridDim.x - c.nchol - c.nzero;
@@ -966,12 +966,15 @@ static int launch_chol_rbf_gemm_impl(const float* A, float eps, float* L, float*
   // a co-resident GEMM workgroup competes for its issue slots and stretches the pivot chain (68 -> 77 us measured);
   // with many samples the GEMM dominates and wants both slots (S = 64: 950 -> 676 us).
   const unsigned pad = tiles * nbatch <= 1024 ? (big ? 40u : 24u) * 1024u : 0u;
-#define VARGP_MERGED(KC, SETS)                                                                                        \
-  do {                                                                                                                  \
-    if (big) hipLaunchKernelGGL((chol_rbf_gemm_kernel<KC, SETS, 128, 32>), dim3(total), dim3(256), pad, st, c, q, tiles); \
-    else hipLaunchKernelGGL((chol_rbf_gemm_kernel<KC, SETS, 64, 64>), dim3(total), dim3(256), pad, st, c, q, tiles);    \
+  // arithmetic of the pivot chains: fp64 (default) or the reference's own fp32 (VARGP_CHOL_F32=1; chol_small3.h)
+  static const int f32_env = [] { const char* e = getenv("VARGP_CHOL_F32"); return e ? atoi(e) : kCholF32Default; }();
+#define VARGP_MERGED(KC, SETS, R)                                                                                                  \
+  do {                                                                                                                               \
+    if (big) hipLaunchKernelGGL((chol_rbf_gemm_kernel<KC, SETS, 128, 32, true, R>), dim3(total), dim3(256), pad, st, c, q, tiles);    \
+    else hipLaunchKernelGGL((chol_rbf_gemm_kernel<KC, SETS, 64, 64, true, R>), dim3(total), dim3(256), pad, st, c, q, tiles);       \
   } while (0)
-  if (n <= 64) VARGP_MERGED(16, 1); else VARGP_MERGED(25, 2);
+  if (f32_env) { if (n <= 64) VARGP_MERGED(16, 1, float); else VARGP_MERGED(25, 2, float); }
+  else { if (n <= 64) VARGP_MERGED(16, 1, double); else VARGP_MERGED(25, 2, double); }
 #undef VARGP_MERGED
   return check_launch("chol_rbf_gemm");
 }

@@ -177,20 +177,27 @@ __global__ __launch_bounds__(256) void rbf_w_self_kernel(const float* __restrict
   const int i0 = ((int)blockIdx.x % nchunk) * kSelfRows, i1 = min(M, i0 + kSelfRows);
   const float* Kb = K + b * M * M;
   const float* gKb = gK + b * M * M;
-  float tot = 0.f;
+  float tot = 0.f, dsum = 0.f;
   for (int i = i0 + (threadIdx.x >> 6); i < i1; i += 4) {
     float acc = 0.f;
     for (int j = lane; j < M; j += 64) {
       // sym: gK is symmetric (K always is), so W = gK o K is too and W + W^T = 2 W: no transposed (uncoalesced) reads
       const float v = sym ? 2.f * Kb[(int64_t)i * M + j] * gKb[(int64_t)i * M + j]
                           : Kb[(int64_t)i * M + j] * gKb[(int64_t)i * M + j] + Kb[(int64_t)j * M + i] * gKb[(int64_t)j * M + i];
-      Ws[b * M * M + (int64_t)i * M + j] = v;
-      acc += v;
+      // The diagonal: K_ii = gamma^2 does not depend on x_i or the lengthscales (the reference's autograd cancels it
+      // exactly: -2 g + g + g on the entry (i, i) of its Gram, kernels.py:44-54), so it must not reach P = Ws x and r, whose
+      // difference would otherwise leave rounding noise of order eps W_ii x_i where the reference has an exact zero (with
+      // underflowing off-diagonals -- MNIST pixels at the initial lengthscale -- the whole gradient).  It only counts for gamma.
+      const bool dg = i == j;
+      Ws[b * M * M + (int64_t)i * M + j] = dg ? 0.f : v;
+      acc += dg ? 0.f : v;
+      dsum += dg ? v : 0.f;
     }
     acc = wave_sum(acc);
     if (lane == 0) r[b * M + i] = acc;
     tot += acc;
   }
+  tot += wave_sum(dsum);
   const float t = block_sum<256>(lane == 0 ? tot : 0.f, red);   // every lane of a wave holds the wave's total
   if (threadIdx.x == 0) atomicAdd(&gtheta[(b / Cb) * (D + 1) + D], t);
 }

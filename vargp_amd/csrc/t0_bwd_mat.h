@@ -178,6 +178,7 @@ __device__ __forceinline__ void mat_tail(float* __restrict__ sT, float* __restri
   __syncthreads();
   BMAT_STAMP(15);
   // rows out (coalesced float4); row sums: thread (i, h) = (tid / 2, tid % 2) sums half a row
+  float dsum = 0.f;
 #pragma unroll
   for (int u = 0; u < kBmNA; ++u) {
     const int e = tid + 256 * u;
@@ -186,6 +187,12 @@ __device__ __forceinline__ void mat_tail(float* __restrict__ sT, float* __restri
       float4 v = *reinterpret_cast<const float4*>(&X2[i * kMatS + j]);
       if (kmul) {
         v.x *= 2.f * kr[u].x; v.y *= 2.f * kr[u].y; v.z *= 2.f * kr[u].z; v.w *= 2.f * kr[u].w;
+        // the diagonal of W_uu counts for gamma only (K_ii = gamma^2: see rbf_w_self_kernel, rbf.hip): out of W_uu and r_uu
+        if (i >= j && i < j + 4) {
+          const int q = i - j;
+          dsum += q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w;
+          if (q == 0) v.x = 0.f; else if (q == 1) v.y = 0.f; else if (q == 2) v.z = 0.f; else v.w = 0.f;
+        }
         *reinterpret_cast<float4*>(&X2[i * kMatS + j]) = v;       // (for the row sums below; each thread its own elements)
       }
       *reinterpret_cast<float4*>(&out[(int64_t)i * M + j]) = v;
@@ -204,7 +211,7 @@ __device__ __forceinline__ void mat_tail(float* __restrict__ sT, float* __restri
     float t = a0 + a1;
     t += __shfl_xor(t, 1, 64);
     if (h == 0 && i < M) rsum_out[(int64_t)id * M + i] = t;
-    float tot = (h == 0 && i < M) ? t : 0.f;
+    float tot = ((h == 0 && i < M) ? t : 0.f) + dsum;
     tot = wave_sum(tot);
     if (lane == 0) atomicAdd(tot_out, tot);
   }
