@@ -71,7 +71,7 @@ def train(task_id, train_set, val_set, test_set, ep_var_mean=True, map_est_hyper
     # host work per 512-sample batch against a 0.24 ms device step.
     loader = DataLoader(train_set, batch_size=batch_size, shuffle=True) if dataloader else \
         DeviceBatches(train_set, batch_size, device, shuffle=True)
-    captured_for = None
+    captured = set()         # minibatch sizes with a captured step: the full batch and the ragged last one of an epoch
     n_steps, t_train = 0, 0.0
 
     for e in range(epochs):
@@ -83,14 +83,14 @@ def train(task_id, train_set, val_set, test_set, ep_var_mean=True, map_est_hyper
                 nb = x.size(0)
             else:
                 nb = item.numel()
-            if graph and nb == min(batch_size, N):
-                if captured_for != nb:
+            if graph:
+                if nb not in captured:
                     torch.cuda.synchronize()
                     t_cap = time.perf_counter()
                     trainer.capture(*(loader.take(item) if not dataloader else (x, y)))
                     torch.cuda.synchronize()
                     t_train -= time.perf_counter() - t_cap        # the one-off capture is not part of the training rate
-                    captured_for = nb
+                    captured.add(nb)
                 if dataloader:
                     kl_hypers, kl_u, lik = trainer.step_graph(x, y)
                 else:

@@ -134,7 +134,7 @@ def _spd(nb, n, seed):
     return ((A @ A.mT) / (n + 8) + 0.05 * torch.eye(n, dtype=torch.float64)).float()
 
 
-@pytest.mark.parametrize('n', [1, 2, 20, 64, 100, 128, 129, 200, 300])
+@pytest.mark.parametrize('n', [1, 2, 20, 51, 63, 64, 65, 77, 98, 100, 128, 129, 200, 300])
 def test_chol_inv_fwd_bwd(ops, n):
     nb = 3
     A = _spd(nb, n, 20 + n)
@@ -156,8 +156,11 @@ def test_chol_inv_fwd_bwd(ops, n):
     assert rel_l2(L2.cpu(), L64.detach()) < 1e-5
 
 
-def test_chol_not_positive_definite(ops):
-    A = _spd(3, 20, 5)
+@pytest.mark.parametrize('n', [20, 64, 100])
+def test_chol_not_positive_definite(ops, n):
+    """n = 20: rows-across-threads kernel; 64 / 100: the register-resident blocked elimination (chol_small3.h) -- a pivot
+    that is not positive in the middle of a four-pivot block, in the last block, and a NaN entry."""
+    A = _spd(4, n, 5)
     A[1] = -A[1]
     ops.set_cholesky_error_mode('raise')
     with pytest.raises(torch.linalg.LinAlgError):
@@ -167,8 +170,19 @@ def test_chol_not_positive_definite(ops):
         L = ops.chol(A.to(DEV), 1e-4)
         assert torch.isnan(L[1]).all() and not torch.isnan(L[0]).any() and not torch.isnan(L[2]).any()
         assert ops.linalg_error_count() >= 1
+        ops.reset_linalg_errors()
+        # indefinite from the leading minor of order n - 2 on (inside the last block), and a NaN in the matrix
+        B = _spd(4, n, 6)
+        B[2, n - 3, n - 3] = -5.0
+        B[3, n // 2, n // 2 - 1] = float('nan')
+        B[3, n // 2 - 1, n // 2] = float('nan')
+        L, T = ops.chol_inv(B.to(DEV), 1e-4)
+        assert torch.isnan(L[2]).all() and torch.isnan(T[2]).all() and torch.isnan(L[3]).all()
+        assert not torch.isnan(L[0]).any() and not torch.isnan(L[1]).any() and not torch.isnan(T[1]).any()
+        assert ops.linalg_error_count() == 2
     finally:
         ops.set_cholesky_error_mode('raise')
+        ops.reset_linalg_errors()
 
 
 # ---------------------------------------------------------------------------------------------

@@ -144,5 +144,33 @@ def test_program_rejects_bad_arguments():
     with pytest.raises(VargpHipError):        # CPU tensor: no CPU path
         prog.forward(torch.zeros(5), torch.zeros(5), torch.zeros(5), torch.zeros(5), z, z[..., :1], z[..., :1],
                      torch.zeros(8, 4), torch.zeros(8, dtype=torch.int64), torch.zeros(1, 5), torch.zeros(1, 2, 2, 8))
-    with pytest.raises(AssertionError):       # backward before forward
+    with pytest.raises(RuntimeError, match='one backward per forward'):       # backward before forward
         prog.backward(*([torch.zeros(3, device=DEV)] * 6))
+
+
+def test_c_abi_enforces_one_backward_per_forward():
+    """include/vargp_hip.h: on the LDS-resident backward path the forward clears the accumulators the backward adds into; the
+    library itself (not only the Python wrapper) refuses a second vargp_elbo_t0_bwd on one forward."""
+    import ctypes
+    from vargp_amd import noise
+    from vargp_amd._lib import VargpHipError, check, lib, ptr, stream_ptr
+    from vargp_amd.fused import T0Program
+    S, F_, C, M, D, B = 2, 3, 3, 56, 40, 64                 # M <= 104, M % 4 == 0, B % 4 == 0, D % 4 == 0: that path
+    params, prev, x, y, nz = orc.make_problem(S, F_, C, M, D, B, seed=5, kind='gauss')
+    p = {k: v.to(DEV).contiguous() for k, v in params.items()}
+    prog = T0Program(S, C, M, D, B, F_, DEV)
+    seeds = torch.ones(3, device=DEV)
+    grads = [torch.empty_like(p[k]) for k in ('log_mean', 'log_logvar', 'z', 'u_mean', 'u_tril_vec')]
+    args = (p['log_mean'], p['log_logvar'], p['prior_log_mean'], p['prior_log_logvar'], p['z'], p['u_mean'], p['u_tril_vec'],
+            x.to(DEV), y.to(DEV), nz['eps_theta'].to(DEV), nz['eps_f'].to(DEV))
+    prog.forward(*args)
+    prog.backward(seeds, *grads)
+    g1 = [g.clone() for g in grads]
+    call = lambda: check(lib().vargp_elbo_t0_bwd(ctypes.byref(prog.desc), ptr(seeds), *(ptr(g) for g in grads), stream_ptr()),
+                         'vargp_elbo_t0_bwd')
+    with pytest.raises(VargpHipError, match='ONE vargp_elbo_t0_bwd per vargp_elbo_t0_fwd'):
+        call()                                            # straight through the C ABI, past the wrapper's own check
+    prog.forward(*args)                                   # a new forward re-arms it, and the result is the same
+    call()
+    for a, b in zip(grads, g1):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)

@@ -27,6 +27,7 @@
 #pragma once
 #include "common.h"
 #include <math.h>
+#include <type_traits>
 #ifndef STAMP
 #define STAMP(i) do { } while (0)
 #endif
@@ -39,6 +40,30 @@
 #endif
 
 namespace vargp {
+
+#ifdef VARGP_CHOL_PHASES   // tuning builds: wall-clock (100 MHz) stamps of the phases of chol3_body, matrix 0 and the last one
+__device__ unsigned long long g_chol_phase[64];
+__device__ int g_chol_phase_last;
+#define CHOL_PHASE(i) do { if (threadIdx.x == 0 && (b == 0 || b == phase_last_)) g_chol_phase[(b == 0 ? 0 : 16) + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define CHOL_PHASE(i) do { } while (0)
+#endif
+
+// compile-time loop: f(integral_constant<int, I>) for I in [B, E)
+template <int B, int E, class F>
+__device__ __forceinline__ void bm_chol_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    bm_chol_for<B + 1, E>(f);
+  }
+}
+
+// entry (i, c) of the padding beyond the n x n matrix: an identity block (rows i >= n pivot on 1 and touch nothing)
+template <class R> __device__ __forceinline__ R chol_pad(int i, int c, int n) { return (i >= n && i == c) ? R(1) : R(0); }
+
+// a row's two column sets (columns l and l + 64 of lane l) as ONE 2-vector: in fp32 the update of both is a single
+// v_pk_fma_f32 (register pair, the multiplier broadcast by op_sel)
+template <class R> using chol_v2 = R __attribute__((ext_vector_type(2)));
 
 // 1/d for a pivot in the normal range: hardware estimate + two Newton steps (full fp64 accuracy; the IEEE division
 // sequence with its scaling / fix-up steps is three times longer and sits on the critical path of every pivot)
@@ -72,6 +97,10 @@ __device__ __forceinline__ float lane_bcast(float v, int lane) {
 #ifndef VARGP_CHOL_FLAGSYNC
 #define VARGP_CHOL_FLAGSYNC 0
 #endif
+// 1: four pivots per barrier (chol4_steps, below); 0: the rank-1 version (one pivot per barrier)
+#ifndef VARGP_CHOL_BLOCK4
+#define VARGP_CHOL_BLOCK4 1
+#endif
 constexpr int kCholBufs = VARGP_CHOL_FLAGSYNC ? 4 : 2;
 template <class R>
 struct Chol3Ctx {
@@ -87,12 +116,12 @@ struct Chol3Ctx {
 // d_J.  Column J counts as 1 + d_J in both, so that the update below leaves m_i = -p_i / d_J in entry (i, J):
 // A_iJ + p_i q_J = p_i - p_i (1 + d) / d = -p_i / d   (A_iJ = p_i by symmetry, to rounding).
 template <class R, int KC, int SETS, int J>
-__device__ __forceinline__ void chol3_publish(const Chol3Ctx<R>& cx, const R (&va)[KC], const R (&vb)[KC]) {
+__device__ __forceinline__ void chol3_publish(const Chol3Ctx<R>& cx, const chol_v2<R> (&v)[KC]) {
   constexpr bool second = J >= 64;
   constexpr int jl = second ? J - 64 : J;
   R* prow = cx.prow + (J % kCholBufs) * 128;
   R* qrow = cx.qrow + (J % kCholBufs) * 128;
-  R pa = va[J / 4], pb = vb[J / 4];
+  R pa = v[J / 4].x, pb = v[J / 4].y;
   const R d = lane_bcast(second ? pb : pa, jl);
   const R ndi = -fast_rcp(d);
   if constexpr (second) { if (cx.lane == jl) pb = R(1) + d; } else { if (cx.lane == jl) pa = R(1) + d; }
@@ -111,8 +140,7 @@ __device__ __forceinline__ void chol3_publish(const Chol3Ctx<R>& cx, const R (&v
 }
 
 template <class R, int KC, int SETS, int J>
-__device__ __forceinline__ void chol3_steps(const Chol3Ctx<R>& cx, R (&va)[KC], R (&vb)[KC],
-                                            int& fail VARGP_STAMP_PARAMS) {
+__device__ __forceinline__ void chol3_steps(const Chol3Ctx<R>& cx, chol_v2<R> (&v)[KC], int& fail VARGP_STAMP_PARAMS) {
   if constexpr (J < 4 * KC && J < 64 * SETS) {
     constexpr int kj = J / 4, wj = J % 4;                    // slot / wave of the pivot row
     constexpr int k1 = (J + 1) / 4, w1 = (J + 1) % 4;        // ... of the next one
@@ -154,15 +182,20 @@ __device__ __forceinline__ void chol3_steps(const Chol3Ctx<R>& cx, R (&va)[KC], 
     // rows i = 4k + w > J only: slots below kj are finished for every wave, slot kj for the waves w <= wj
     if (w <= wj) pr[kj] = R(0);
     STAMP(3);
+    const chol_v2<R> q2 = {qa, qb};
 #define VARGP_CHOL3_UPDATE(k)                                                \
     do {                                                                       \
-      va[k] = fma(pr[k], qa, va[k]);                                           \
-      if constexpr (SETS == 2) vb[k] = fma(pr[k], qb, vb[k]);                  \
+      if constexpr (SETS == 2) {                                               \
+        const chol_v2<R> p2_ = {pr[k], pr[k]};                                 \
+        v[k] = __builtin_elementwise_fma(p2_, q2, v[k]);                       \
+      } else {                                                                 \
+        v[k].x = fma(pr[k], qa, v[k].x);                                       \
+      }                                                                        \
     } while (0)
     // look-ahead: the next pivot row first, published at once
     if constexpr (has_next) {
       VARGP_CHOL3_UPDATE(k1);
-      if (w == w1 && J + 1 < cx.n) chol3_publish<R, KC, SETS, J + 1>(cx, va, vb);
+      if (w == w1 && J + 1 < cx.n) chol3_publish<R, KC, SETS, J + 1>(cx, v);
     }
     STAMP(1);
 #pragma unroll
@@ -171,10 +204,119 @@ __device__ __forceinline__ void chol3_steps(const Chol3Ctx<R>& cx, R (&va)[KC], 
     }
 #undef VARGP_CHOL3_UPDATE
 #ifdef VARGP_CHOL_STAMPS
-    asm volatile("" ::"v"(va[KC - 1]), "v"(vb[KC - 1]));
+    asm volatile("" ::"v"(v[KC - 1].x), "v"(v[KC - 1].y));
     STAMP(4);
 #endif
-    chol3_steps<R, KC, SETS, J + 1>(cx, va, vb, fail VARGP_STAMP_ARGS);
+    chol3_steps<R, KC, SETS, J + 1>(cx, v, fail VARGP_STAMP_ARGS);
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Blocked variant of the elimination (round 4): FOUR pivots per barrier.  The rows 4K .. 4K+3 of block K are slot K of the
+// four waves.  Each wave publishes its row of the block to LDS (2 values per lane); after ONE barrier every wave reads all
+// four rows at its own columns and runs the 4 x 4 in-block elimination redundantly (the uniform entries it needs -- the
+// pivots and the in-block multipliers -- are lanes 4K .. 4K+3 of those rows: v_readlane with compile-time lane numbers).  Every
+// wave then owns the four ELIMINATED pivot rows p_a and their scaled copies q_a = -p_a / d_a across its lanes, and the
+// rank-4 update of its live rows i = 4k + w (k > K) needs nothing from LDS any more: the multiplier of row i for pivot a is
+// p_a[i] (symmetry of the Schur complement, as in the rank-1 version), which is lane i of the wave's own copy of p_a -- one
+// v_readlane into an SGPR and one FMA (fp32: one v_pk_fma_f32 for both column sets) per row and pivot.  Against the rank-1
+// version per four pivots: 1 barrier instead of 4, 16 LDS reads per wave instead of ~50 contended broadcast reads, one
+// LDS round trip instead of four.  Look-ahead as before: the rows of block K + 1 are updated and published first.
+// ------------------------------------------------------------------------------------------------------------------------------
+template <class R>
+struct Chol4Ctx {
+  R* rows;        // [2][4][128]  the four rows of block K (as published, before the in-block elimination), buffer K % 2
+  int n, lane, w;
+};
+
+template <class R, int KC, int SETS, int K>
+__device__ __forceinline__ void chol4_publish(const Chol4Ctx<R>& cx, const chol_v2<R> (&v)[KC]) {
+  R* dst = cx.rows + ((K & 1) * 4 + cx.w) * 128;
+  dst[cx.lane] = v[K].x;
+  if constexpr (SETS == 2) dst[64 + cx.lane] = v[K].y;
+}
+
+// value of lane `lane` (wave-uniform, in an SGPR) of `v`
+__device__ __forceinline__ float lane_pick(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ double lane_pick(double v, int lane) { return lane_bcast(v, lane); }
+
+template <class R, int KC, int SETS, int K0>
+__device__ __forceinline__ void chol4_steps(const Chol4Ctx<R>& cx, chol_v2<R> (&v)[KC], int& fail) {
+  if constexpr (K0 < KC && 4 * K0 < 64 * SETS) {
+    constexpr int j0 = 4 * K0;
+    if (j0 >= cx.n || fail) return;                          // uniform
+    const int lane = cx.lane;
+    const int w = __builtin_amdgcn_readfirstlane(cx.w);
+    __syncthreads();                                         // the four rows of block K0 are in LDS
+    const R* src = cx.rows + (K0 & 1) * 4 * 128;
+    chol_v2<R> p[4], q[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      p[a].x = src[a * 128 + lane];
+      p[a].y = SETS == 2 ? src[a * 128 + 64 + lane] : R(0);
+    }
+    // ---- in-block elimination: p[a] becomes the final pivot row j0 + a, q[a] = -p[a] / d_a with column j0 + a counted as
+    //      1 + d_a (the inverse's entry (i, j) then restarts as m_i = -A_ij / d_j, see the rank-1 version) ----------------------
+    // (rows / columns beyond n carry an identity block -- see the loads in chol3_body -- so every pivot of a block is a real
+    // one: d = 1, no multipliers; a non-positive pivot is recorded and the block finished on garbage: one exit per block)
+    bm_chol_for<0, 4>([&](auto ai) {
+      constexpr int a = decltype(ai)::value;
+      constexpr int j = j0 + a;
+      constexpr bool second = j >= 64;
+      constexpr int jl = second ? j - 64 : j;
+      const R d = lane_bcast(second ? p[a].y : p[a].x, jl);
+      fail = (fail == 0 && !(d > R(0))) ? j + 1 : fail;      // uniform (every wave computes the same d)
+      const R ndi = -fast_rcp(d);
+      const R qd = ndi * (R(1) + d);
+      q[a].x = p[a].x * ndi;
+      q[a].y = p[a].y * ndi;
+      if constexpr (second) q[a].y = lane == jl ? qd : q[a].y; else q[a].x = lane == jl ? qd : q[a].x;
+      bm_chol_for<a + 1, 4>([&](auto bi) {
+        constexpr int b = decltype(bi)::value;
+        const R c = lane_bcast(second ? p[b].y : p[b].x, jl);         // A_{j0+b, j}: the multiplier of block row b
+        if constexpr (SETS == 2) {
+          const chol_v2<R> c2 = {c, c};
+          p[b] = __builtin_elementwise_fma(c2, q[a], p[b]);
+        } else {
+          p[b].x = fma(c, q[a].x, p[b].x);
+        }
+      });
+    });
+    if (fail) return;                                        // uniform
+    // the owner of row j0 + w keeps the eliminated row (finished: inverse entries | d | column of the unscaled factor)
+    v[K0] = w == 0 ? p[0] : (w == 1 ? p[1] : (w == 2 ? p[2] : p[3]));
+    // ---- rank-4 update of the live rows: slot k > K0 of every wave; multiplier of row i = 4k + w for pivot a: p[a][i] ------
+    // (all four multipliers into SGPRs first, then the FMAs: a VALU read of an SGPR right behind the v_readlane that wrote
+    // it costs wait states)
+#define VARGP_CHOL4_UPDATE(k)                                                                       \
+    do {                                                                                              \
+      const int li_ = 4 * ((k) & 15) + w;                                                             \
+      R c_[4];                                                                                        \
+      _Pragma("unroll") for (int a = 0; a < 4; ++a) c_[a] = lane_pick(4 * (k) >= 64 ? p[a].y : p[a].x, li_); \
+      _Pragma("unroll") for (int a = 0; a < 4; ++a) {                                                 \
+        if constexpr (SETS == 2) {                                                                    \
+          const chol_v2<R> c2_ = {c_[a], c_[a]};                                                      \
+          v[k] = __builtin_elementwise_fma(c2_, q[a], v[k]);                                          \
+        } else {                                                                                      \
+          v[k].x = fma(c_[a], q[a].x, v[k].x);                                                        \
+        }                                                                                             \
+      }                                                                                               \
+    } while (0)
+    constexpr int k1 = K0 + 1;
+    constexpr bool has_next = k1 < KC && 4 * k1 < 64 * SETS;
+    if constexpr (has_next) {                                // look-ahead: the next block's rows first, published at once
+      VARGP_CHOL4_UPDATE(k1);
+      if (4 * k1 < cx.n) chol4_publish<R, KC, SETS, k1>(cx, v);
+    }
+#if !defined(VARGP_CHOL_EXP) || VARGP_CHOL_EXP != 2      // (tuning builds: 2 = no bulk update -- timing only, wrong results)
+#pragma unroll
+    for (int k = K0 + 2; k < KC; ++k) VARGP_CHOL4_UPDATE(k);
+#endif
+#undef VARGP_CHOL4_UPDATE
+    chol4_steps<R, KC, SETS, K0 + 1>(cx, v, fail);
   }
 }
 
@@ -193,9 +335,13 @@ __device__ __forceinline__ void chol3_body(const int64_t b, const float* __restr
   // `stage` = chol3_stage_floats<KC>() floats of LDS owned by the kernel (the matrix on its way in, L and T on their
   // way out), so that a kernel with other roles can hand over LDS it has anyway
   constexpr int NP = 4 * KC + 4;
+#if VARGP_CHOL_BLOCK4
+  __shared__ R rows4[2][4][128];               // the four rows of a pivot block, double-buffered
+#else
   __shared__ R prow[kCholBufs][128], qrow[kCholBufs][128];
   __shared__ R dpiv[kCholBufs];
   __shared__ int flag[4];
+#endif
   __shared__ double sd[NP], sq[NP];
   __shared__ float red[4];
   constexpr int LS = 4 * KC + 1;               // odd row stride: column-wise access hits distinct banks too
@@ -208,7 +354,11 @@ __device__ __forceinline__ void chol3_body(const int64_t b, const float* __restr
   if (T) T += b * strideT;
 
   const int di = 256 / n, dj = 256 - di * n;   // element e -> e + 256 without a division per element
-  R va[KC], vb[KC];
+  chol_v2<R> v[KC];
+#ifdef VARGP_CHOL_PHASES
+  const int64_t phase_last_ = (int64_t)gridDim.x < 0 ? 0 : g_chol_phase_last;
+#endif
+  CHOL_PHASE(0);
   if (extra && extra->part && b < extra->first) {
     // K-split partial Gram matrices -> kernel matrix on the way in (CholExtra, common.h).  Summation order and formula of
     // t0_combine_norm_kernel (elbo_t0.hip).  Loads on clamped indices, all of a row's in flight together.
@@ -225,9 +375,85 @@ __device__ __forceinline__ void chol3_body(const int64_t b, const float* __restr
       stage[tid] = g;
     }
     __syncthreads();
+    CHOL_PHASE(5);
     const float gam = extra->g2[b / extra->part_C];
+    if ((n & 3) == 0 && (sS & 3) == 0 && (reinterpret_cast<uintptr_t>(part) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(Kout) & 15) == 0) {
+      // Wide path: the whole matrix as float4 (16 KC^2 / 1024 per thread and split, all in flight together: a wave has at most
+      // 64 memory operations outstanding, so 200 dword loads per thread are more than three full round trips), kernel values
+      // on the float4 elements, K out as float4 rows, and into LDS, from where every thread picks its (row, column) entries.
+      constexpr int NQ = (4 * KC * KC + 255) / 256;
+      const int n4 = n >> 2, tot4 = n * n4;
+      const int di4 = 256 / n4, dj4 = 256 - di4 * n4;
+      float4 acc[NQ];
+      int qi[NQ], qj[NQ];
+      {
+        int i = tid / n4, j = tid - i * n4;
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+          const bool ok = tid + 256 * u < tot4;
+          qi[u] = ok ? i : -1; qj[u] = j << 2;
+          const int64_t off = ok ? (int64_t)i * n + (j << 2) : 0;
+          float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int q = 0; q < kCholPartMax; ++q) {
+            // (the unused splits are loaded too -- split 0 again -- and multiplied away: a load the compiler can move into
+            // a branch on `use` is followed by s_waitcnt vmcnt(0), i.e. every load becomes its own round trip)
+            const bool use = q < nsplit;
+            const float m = use ? 1.f : 0.f;
+            const float4 t4 = *reinterpret_cast<const float4*>(part + (use ? q : 0) * sS + off);
+            a4.x = fmaf(t4.x, m, a4.x); a4.y = fmaf(t4.y, m, a4.y); a4.z = fmaf(t4.z, m, a4.z); a4.w = fmaf(t4.w, m, a4.w);
+          }
+          acc[u] = a4;
+          i += di4; j += dj4;
+          if (j >= n4) { j -= n4; ++i; }
+        }
+      }
+#ifdef VARGP_CHOL_PHASES
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      CHOL_PHASE(6);
+#endif
+      // the norms move out of the staging area (the matrix goes there): each thread keeps the ones its elements need
+      float gi_[NQ];
+      float4 gj_[NQ];
+#pragma unroll
+      for (int u = 0; u < NQ; ++u) {
+        const int i = max(qi[u], 0), j = qj[u];
+        gi_[u] = stage[i];
+        gj_[u] = make_float4(stage[j], stage[j + 1], stage[j + 2], stage[j + 3]);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < NQ; ++u) {
+        const int i = qi[u], j = qj[u];
+        if (i >= 0) {
+          float4 k4;
+          k4.x = i == j ? gam : gam * expf(-0.5f * (gi_[u] + gj_[u].x - 2.f * acc[u].x));
+          k4.y = i == j + 1 ? gam : gam * expf(-0.5f * (gi_[u] + gj_[u].y - 2.f * acc[u].y));
+          k4.z = i == j + 2 ? gam : gam * expf(-0.5f * (gi_[u] + gj_[u].z - 2.f * acc[u].z));
+          k4.w = i == j + 3 ? gam : gam * expf(-0.5f * (gi_[u] + gj_[u].w - 2.f * acc[u].w));
+          *reinterpret_cast<float4*>(Kout + (int64_t)i * n + j) = k4;
+          float* sp = stage + i * LS + j;
+          sp[0] = k4.x; sp[1] = k4.y; sp[2] = k4.z; sp[3] = k4.w;
+        }
+      }
+      CHOL_PHASE(8);
+      __syncthreads();
+      CHOL_PHASE(9);
+#pragma unroll
+      for (int k = 0; k < KC; ++k) {
+        const int i = 4 * k + w;
+        const int ic = min(i, n - 1);
+        const float sa = stage[ic * LS + min(ca, n - 1)], sb = stage[ic * LS + min(cb, n - 1)];   // unconditional reads
+        v[k].x = (i < n && minea) ? (R)sa + (i == ca ? (R)eps : R(0)) : chol_pad<R>(i, ca, n);
+        v[k].y = (i < n && mineb) ? (R)sb + (i == cb ? (R)eps : R(0)) : chol_pad<R>(i, cb, n);
+      }
+    } else {
     const int cac = min(ca, n - 1), cbc = min(cb, n - 1);
     const float gja = stage[cac], gjb = stage[cbc];
+    // all partial sums of the thread's rows in flight first (the stores to Kout below would otherwise fence every row's
+    // loads behind the previous row's stores: KC dependent round trips), then the kernel values
+    float ga_[KC], gb_[KC];
 #pragma unroll
     for (int k = 0; k < KC; ++k) {
       const int i = 4 * k + w, ic = min(i, n - 1);
@@ -242,71 +468,135 @@ __device__ __forceinline__ void chol3_body(const int64_t b, const float* __restr
 #pragma unroll
       for (int q = 0; q < kCholPartMax; ++q)
         if (q < nsplit) { ga += pa[q]; if (SETS == 2) gb += pb[q]; }
+      ga_[k] = ga; gb_[k] = gb;
+    }
+#ifdef VARGP_CHOL_PHASES
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CHOL_PHASE(6);
+#endif
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+      const int i = 4 * k + w, ic = min(i, n - 1);
+      const float ga = ga_[k], gb = gb_[k];
       const float gii = stage[ic];
       const float ka = i == ca ? gam : gam * expf(-0.5f * (gii + gja - 2.f * ga));
       const float kb = i == cb ? gam : gam * expf(-0.5f * (gii + gjb - 2.f * gb));
-      va[k] = R(0); vb[k] = R(0);
+      v[k].x = chol_pad<R>(i, ca, n); v[k].y = chol_pad<R>(i, cb, n);
       if (i < n) {
-        if (minea) { va[k] = (R)ka + (i == ca ? (R)eps : R(0)); Kout[(int64_t)i * n + ca] = ka; }
-        if (mineb) { vb[k] = (R)kb + (i == cb ? (R)eps : R(0)); Kout[(int64_t)i * n + cb] = kb; }
+        if (minea) { v[k].x = (R)ka + (i == ca ? (R)eps : R(0)); Kout[(int64_t)i * n + ca] = ka; }
+        if (mineb) { v[k].y = (R)kb + (i == cb ? (R)eps : R(0)); Kout[(int64_t)i * n + cb] = kb; }
       }
     }
+    }
+    CHOL_PHASE(7);
     __syncthreads();      // `stage` is reused for the results
   } else if (extra && extra->symmetric_input) {
-    // both triangles valid: row i lies across the lanes, coalesced as it is
+    // both triangles valid: row i lies across the lanes, coalesced as it is.  Unconditional loads on clamped indices, all in
+    // flight together, then selects (a load inside a bounds branch is its own round trip: 2 KC of them)
+    float ra[KC], rb[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+      const int64_t ro = (int64_t)min(4 * k + w, n - 1) * lda;
+      ra[k] = A[ro + min(ca, n - 1)];
+      rb[k] = SETS == 2 ? A[ro + min(cb, n - 1)] : 0.f;
+    }
 #pragma unroll
     for (int k = 0; k < KC; ++k) {
       const int i = 4 * k + w;
-      va[k] = R(0); vb[k] = R(0);
-      if (i < n) {
-        if (minea) va[k] = (R)A[(int64_t)i * lda + ca] + (i == ca ? (R)eps : R(0));
-        if (mineb) vb[k] = (R)A[(int64_t)i * lda + cb] + (i == cb ? (R)eps : R(0));
-      }
+      v[k].x = (i < n && minea) ? (R)ra[k] + (i == ca ? (R)eps : R(0)) : chol_pad<R>(i, ca, n);
+      v[k].y = (i < n && mineb) ? (R)rb[k] + (i == cb ? (R)eps : R(0)) : chol_pad<R>(i, cb, n);
     }
   } else {
     // only the lower triangle is trusted: the matrix comes in through LDS (coalesced global reads), then every
     // thread picks its entries (rows 4k + w) mirrored
-    {
+    if ((n & 3) == 0 && (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0) {
+      constexpr int NQ = (4 * KC * KC + 255) / 256;      // float4 loads, all in flight before the first LDS store
+      const int n4 = n >> 2, tot4 = n * n4;
+      const int di4 = 256 / n4, dj4 = 256 - di4 * n4;
+      float4 tv[NQ];
+      int to[NQ];
+      int i = tid / n4, j = tid - i * n4;
+#pragma unroll
+      for (int u = 0; u < NQ; ++u) {
+        const bool ok = tid + 256 * u < tot4;
+        tv[u] = *reinterpret_cast<const float4*>(A + (ok ? (int64_t)i * lda + (j << 2) : 0));
+        to[u] = ok ? i * LS + (j << 2) : -1;
+        i += di4; j += dj4;
+        if (j >= n4) { j -= n4; ++i; }
+      }
+#pragma unroll
+      for (int u = 0; u < NQ; ++u)
+        if (to[u] >= 0) { float* sp = stage + to[u]; sp[0] = tv[u].x; sp[1] = tv[u].y; sp[2] = tv[u].z; sp[3] = tv[u].w; }
+    } else {
+      // every global load of the thread in flight before the first LDS store (a load behind a store waits for it; one
+      // round trip per element was 40 round trips): clamped indices, the out-of-range elements dropped at the store
+      constexpr int NL = (16 * KC * KC + 255) / 256;
+      float tv[NL];
+      int to[NL];
       int i = tid / n, j = tid - i * n;
-      for (int e = tid; e < n * n; e += 256) {
-        stage[i * LS + j] = A[(int64_t)i * lda + j];
+#pragma unroll
+      for (int u = 0; u < NL; ++u) {
+        const bool ok = i < n;
+        tv[u] = A[(int64_t)(ok ? i : n - 1) * lda + (ok ? j : 0)];
+        to[u] = ok ? i * LS + j : -1;
         i += di; j += dj;
         if (j >= n) { j -= n; ++i; }
       }
+#ifdef VARGP_CHOL_PHASES
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      CHOL_PHASE(5);
+#endif
+#pragma unroll
+      for (int u = 0; u < NL; ++u)
+        if (to[u] >= 0) stage[to[u]] = tv[u];
     }
     __syncthreads();
+    CHOL_PHASE(6);
 #pragma unroll
     for (int k = 0; k < KC; ++k) {
       const int i = 4 * k + w;
-      va[k] = R(0); vb[k] = R(0);
-      if (i < n) {
-        if (minea) {
-          const int hi = i > ca ? i : ca, lo = i > ca ? ca : i;
-          va[k] = (R)stage[hi * LS + lo] + (i == ca ? (R)eps : R(0));
-        }
-        if (mineb) {
-          const int hi = i > cb ? i : cb, lo = i > cb ? cb : i;
-          vb[k] = (R)stage[hi * LS + lo] + (i == cb ? (R)eps : R(0));
-        }
-      }
+      const int ic = min(i, n - 1), cac = min(ca, n - 1), cbc = min(cb, n - 1);
+      const float sa = stage[max(ic, cac) * LS + min(ic, cac)], sb = stage[max(ic, cbc) * LS + min(ic, cbc)];   // unconditional
+      v[k].x = (i < n && minea) ? (R)sa + (i == ca ? (R)eps : R(0)) : chol_pad<R>(i, ca, n);
+      v[k].y = (i < n && mineb) ? (R)sb + (i == cb ? (R)eps : R(0)) : chol_pad<R>(i, cb, n);
     }
   }
 
+  CHOL_PHASE(1);
   int fail = 0;
+#if VARGP_CHOL_BLOCK4
+  {
+    // four pivots per barrier (chol4_steps); the LDS of the rank-1 version's row buffers holds the block's four rows
+    const Chol4Ctx<R> c4{&rows4[0][0][0], n, lane, w};
+    chol4_publish<R, KC, SETS, 0>(c4, v);
+#if !defined(VARGP_CHOL_EXP) || VARGP_CHOL_EXP != 1      // (tuning builds: 1 = no elimination at all -- load / store time only)
+    chol4_steps<R, KC, SETS, 0>(c4, v, fail);
+#endif
+    // the pivots d_i, for the final scaling: entry (i, i) of the finished rows, each in one lane of its owner
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+      const int i = 4 * k + w;
+      if (lane == (i & 63) && i < n) sd[i] = (double)(4 * k >= 64 ? v[k].y : v[k].x);
+    }
+    __syncthreads();
+  }
+#else
   const Chol3Ctx<R> cx{&prow[0][0], &qrow[0][0], dpiv, sd, n, lane, w, flag};
 #if VARGP_CHOL_FLAGSYNC
   if (tid < 4) flag[tid] = 0;
   __syncthreads();
 #endif
-  if (w == 0) chol3_publish<R, KC, SETS, 0>(cx, va, vb);   // row 0 has no predecessor to publish it
+  if (w == 0) chol3_publish<R, KC, SETS, 0>(cx, v);   // row 0 has no predecessor to publish it
 #ifdef VARGP_CHOL_STAMPS
   unsigned long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
 #endif
-  chol3_steps<R, KC, SETS, 0>(cx, va, vb, fail VARGP_STAMP_ARGS);
+  chol3_steps<R, KC, SETS, 0>(cx, v, fail VARGP_STAMP_ARGS);
   __syncthreads();
+#endif
 #ifdef VARGP_CHOL_STAMPS
   if (tid == 0 && b == 0) for (int i = 0; i < 8; ++i) g_chol_stamps[i] = acc_[i];
 #endif
+  CHOL_PHASE(2);
   if (fail) {
     if (tid == 0 && info) { if (info[b] == 0) info[b] = info_base + fail; }
     const float qnan = __builtin_nanf("");
@@ -318,57 +608,32 @@ __device__ __forceinline__ void chol3_body(const int64_t b, const float* __restr
     if (logdet && tid == 0) logdet[b] = qnan;
     return;
   }
-  if (tid < n) {   // sq = sqrt(d), sd <- 1 / sqrt(d): one square root and one division per pivot, not per entry
-    const double s = sqrt(sd[tid]);
-    sq[tid] = s;
-    sd[tid] = 1.0 / s;
+  if (tid < n) {   // sq = sqrt(d), sd <- 1 / sqrt(d): once per pivot, not per entry; hardware estimate + two Newton steps
+    const double d = sd[tid];                       // (the IEEE sqrt / division sequences are ~10x longer; d > 0 here)
+    double r = __builtin_amdgcn_rsq(d);
+    r = r * fma(-0.5 * d * r, r, 1.5);
+    r = r * fma(-0.5 * d * r, r, 1.5);
+    sq[tid] = d * r;
+    sd[tid] = r;
   }
   __syncthreads();
   // Entry (i, e) of the register file: e < i -> T_ie sqrt(d_i); e == i -> d_i; e > i -> L_ei sqrt(d_i).
-  // T first: its rows lie across the lanes, so the stores are coalesced as they are.
-  if (T) {
-#pragma unroll
-    for (int k = 0; k < KC; ++k) {
-      const int i = 4 * k + w;
-      if (i < n) {
-        const double isi = sd[i];
-        if (minea) T[(int64_t)i * ldt + ca] = ca < i ? (float)((double)va[k] * isi) : (ca == i ? (float)isi : 0.f);
-        if (mineb) T[(int64_t)i * ldt + cb] = cb < i ? (float)((double)vb[k] * isi) : (cb == i ? (float)isi : 0.f);
-      }
-    }
-  }
-  if (extra && extra->diag_only_before_first && b < extra->first) {
-    // only diag(L) is wanted: rows straight from registers, zeros off the diagonal
-#pragma unroll
-    for (int k = 0; k < KC; ++k) {
-      const int i = 4 * k + w;
-      if (i < n) {
-        const float si = (float)sq[i];
-        if (minea) L[(int64_t)i * ldl + ca] = ca == i ? si : 0.f;
-        if (mineb) L[(int64_t)i * ldl + cb] = cb == i ? si : 0.f;
-      }
-    }
-    return;   // (no logdet in this mode: the merged launch never asks for it)
-  }
-  // L is the transpose of the row tails: through LDS (lower entry (e, i) from the tail of row i, zero at (i, e)),
-  // then coalesced rows out
+  // Both factors leave through ONE staging matrix: entry (i, e), e != i, scaled by 1 / sqrt(d_i) goes to stage[e][i] -- for
+  // e > i that is L_ei in the lower triangle, for e < i it is T_ie, kept transposed in the upper triangle; the diagonals are
+  // sq (L) and sd (T).  Rows then go out as float4 (fixed trip counts: a store loop with a run-time bound waits for every
+  // iteration's stores before the next).
 #pragma unroll
   for (int k = 0; k < KC; ++k) {
     const int i = 4 * k + w;
     if (i < n) {
-      const double si = sq[i], isi = sd[i];
-#pragma unroll
-      for (int half = 0; half < SETS; ++half) {
-        const int e = half ? cb : ca;
-        if (half ? mineb : minea) {
-          const double v = (double)(half ? vb[k] : va[k]);
-          if (e > i) { stage[e * LS + i] = (float)(v * isi); stage[i * LS + e] = 0.f; }
-          else if (e == i) stage[i * LS + i] = (float)si;
-        }
-      }
+      const double isi = sd[i];
+      if (minea && ca != i) stage[ca * LS + i] = (float)((double)v[k].x * isi);
+      if (mineb && cb != i) stage[cb * LS + i] = (float)((double)v[k].y * isi);
     }
   }
   __syncthreads();
+  CHOL_PHASE(3);
+  const bool diag_only = extra && extra->diag_only_before_first && b < extra->first;   // only diag(L) is wanted (zeros elsewhere)
   // optional extra destination(s) for L (CholExtra, common.h)
   float* xb = nullptr;
   int ldx = 0, ncopy = 0;
@@ -377,26 +642,66 @@ __device__ __forceinline__ void chol3_body(const int64_t b, const float* __restr
     xb = extra->base + (b - extra->first) * extra->stride_b;
     ldx = extra->ld; ncopy = extra->ncopy; sxc = extra->stride_copy;
   }
+  // (every LDS read below is unconditional -- clamped indices -- and the triangle / diagonal logic is selects: a read the
+  // compiler can move into a branch gets its own s_waitcnt, one LDS round trip per element)
   if ((n & 3) == 0 && (ldl & 3) == 0 && (reinterpret_cast<uintptr_t>(L) & 15) == 0 &&
+      (!T || ((ldt & 3) == 0 && (reinterpret_cast<uintptr_t>(T) & 15) == 0)) &&
       (!xb || ((ldx & 3) == 0 && (sxc & 3) == 0 && (reinterpret_cast<uintptr_t>(xb) & 15) == 0))) {
-    const int n4 = n >> 2;
-    for (int q = tid; q < n * n4; q += 256) {
-      const int i = q / n4, j = (q - i * n4) << 2;
-      const float* sp = stage + i * LS + j;
-      const float4 v4 = make_float4(sp[0], sp[1], sp[2], sp[3]);
-      *reinterpret_cast<float4*>(L + (int64_t)i * ldl + j) = v4;
-      for (int c = 0; c < ncopy; ++c) *reinterpret_cast<float4*>(xb + c * sxc + (int64_t)i * ldx + j) = v4;
+    constexpr int NQ = (4 * KC * KC + 255) / 256;
+    const int n4 = n >> 2, tot4 = n * n4;
+    const int di4 = 256 / n4, dj4 = 256 - di4 * n4;
+    int i = tid / n4, j4 = tid - i * n4;
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+      const bool ok = tid + 256 * u < tot4;
+      const int ii = ok ? i : 0, j = ok ? (j4 << 2) : 0;
+      const float* lr = stage + ii * LS + j;          // L: row ii, columns j .. j+3
+      const float* tc = stage + j * LS + ii;          // T (kept transposed): rows j .. j+3 of the staging matrix, column ii
+      const float l0 = lr[0], l1 = lr[1], l2 = lr[2], l3 = lr[3];
+      const float t0 = tc[0], t1 = tc[LS], t2 = tc[2 * LS], t3 = tc[3 * LS];
+      const float dl = (float)sq[ii], dt = (float)sd[ii];
+      float4 l4, t4;
+      l4.x = j < ii ? (diag_only ? 0.f : l0) : (j == ii ? dl : 0.f);
+      l4.y = j + 1 < ii ? (diag_only ? 0.f : l1) : (j + 1 == ii ? dl : 0.f);
+      l4.z = j + 2 < ii ? (diag_only ? 0.f : l2) : (j + 2 == ii ? dl : 0.f);
+      l4.w = j + 3 < ii ? (diag_only ? 0.f : l3) : (j + 3 == ii ? dl : 0.f);
+      t4.x = j < ii ? t0 : (j == ii ? dt : 0.f);
+      t4.y = j + 1 < ii ? t1 : (j + 1 == ii ? dt : 0.f);
+      t4.z = j + 2 < ii ? t2 : (j + 2 == ii ? dt : 0.f);
+      t4.w = j + 3 < ii ? t3 : (j + 3 == ii ? dt : 0.f);
+      if (ok) {
+        *reinterpret_cast<float4*>(L + (int64_t)ii * ldl + j) = l4;
+        if (T) *reinterpret_cast<float4*>(T + (int64_t)ii * ldt + j) = t4;
+        // (a store loop with a run-time trip count waits for each round's stores: the first copies are straight-line code)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (c < ncopy) *reinterpret_cast<float4*>(xb + c * sxc + (int64_t)ii * ldx + j) = l4;
+        for (int c = 4; c < ncopy; ++c) *reinterpret_cast<float4*>(xb + c * sxc + (int64_t)ii * ldx + j) = l4;
+      }
+      i += di4; j4 += dj4;
+      if (j4 >= n4) { j4 -= n4; ++i; }
     }
   } else {
+    constexpr int NL = (16 * KC * KC + 255) / 256;
     int i = tid / n, j = tid - i * n;
-    for (int e = tid; e < n * n; e += 256) {
-      const float v = stage[i * LS + j];
-      L[(int64_t)i * ldl + j] = v;
-      for (int c = 0; c < ncopy; ++c) xb[c * sxc + (int64_t)i * ldx + j] = v;
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+      const bool ok = i < n;
+      const int ii = ok ? i : 0, jj = ok ? j : 0;
+      const float lraw = stage[ii * LS + jj], traw = stage[jj * LS + ii];
+      const float lv = jj < ii ? (diag_only ? 0.f : lraw) : (jj == ii ? (float)sq[ii] : 0.f);
+      const float tv = jj < ii ? traw : (jj == ii ? (float)sd[ii] : 0.f);
+      if (ok) {
+        L[(int64_t)ii * ldl + jj] = lv;
+        if (T) T[(int64_t)ii * ldt + jj] = tv;
+        for (int c = 0; c < ncopy; ++c) xb[c * sxc + (int64_t)ii * ldx + jj] = lv;
+      }
       i += di; j += dj;
       if (j >= n) { j -= n; ++i; }
     }
   }
+  if (diag_only) return;   // (no logdet in this mode: the merged launch never asks for it)
+  CHOL_PHASE(4);
   if (logdet) {   // sum_j log L_jj
     float acc = 0.f;
     for (int j = tid; j < n; j += 256) acc += (float)log(sq[j]);

@@ -827,8 +827,22 @@ __global__ __launch_bounds__(256) void chol_rbf_gemm_kernel(const CholArgs c, co
     return;
   }
   const int id = xcd_remap((int)blockIdx.x - c.nchol, ngemm);
+#ifdef VARGP_CHOL_PHASES
+  if (threadIdx.x == 0 && ((int)blockIdx.x == c.nchol || (int)blockIdx.x == c.nchol + ngemm - 1))
+    g_chol_phase[((int)blockIdx.x == c.nchol ? 32 : 40)] = __builtin_amdgcn_s_memrealtime();
+#endif
   gemm_body<BM, 64, BK, true, true, true, true, SCALED>(p, id % tiles, id / tiles, 0, lds);
+#ifdef VARGP_CHOL_PHASES
+  if (threadIdx.x == 0 && ((int)blockIdx.x == c.nchol || (int)blockIdx.x == c.nchol + ngemm - 1))
+    g_chol_phase[((int)blockIdx.x == c.nchol ? 32 : 40) + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
+#ifdef VARGP_CHOL_PHASES
+extern "C" void vargp_debug_chol_phases(unsigned long long* out, int last) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chol_phase), 64 * 8);
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_chol_phase_last), &last, sizeof(int));
+}
+#endif
 
 // One launch, two independent roles (like chol_rbf_gemm_kernel in the forward): workgroups [0, nmat) walk the chain of
 // M x M products of one matrix of the first-task backward (t0_bwd_mat.h: ~20 us on nmat CUs), the others are 64 x 64 tiles of a
@@ -946,6 +960,7 @@ int launch_chol_rbf_gemm(const float* A, float eps, float* L, float* T, int32_t*
 }
 static int launch_chol_rbf_gemm_impl(const float* A, float eps, float* L, float* T, int32_t* info, int nchol, int n,
                                      const GemmParams& p, int nbatch, hipStream_t st, const CholExtra& extra, const ZeroJobs& zero) {
+  // (nchol / nbatch are modified by the timing experiments below)
   ProfScope prof("chol_rbf_gemm", st);
   const int64_t nn = (int64_t)n * n;
   bool any_zero = false;
@@ -960,12 +975,17 @@ static int launch_chol_rbf_gemm_impl(const float* A, float eps, float* L, float*
   const int free_cus = 256 - nchol;
   const bool big = tile_force ? tile_force == 2 : (t64 * nbatch > free_cus && t128 * nbatch <= free_cus);
   const int tiles = big ? t128 : t64;
+  // VARGP_EXP_MERGED (timing only, wrong results): 1 = the factorisations alone (no GEMM tiles), 2 = the GEMM tiles alone
+  static const int exp_role = [] { const char* e = getenv("VARGP_EXP_MERGED"); return e ? atoi(e) : 0; }();
+  if (exp_role == 2) { c.nchol = 0; nchol = 0; }
+  if (exp_role == 1) nbatch = 0;
   const int total = nchol + tiles * nbatch + c.nzero;
   // The kernel needs 68 KB of LDS, so two workgroups fit a CU.  While the GEMM is small enough to finish under the
   // factorisations anyway (the BASELINE shapes), reserving unused dynamic LDS keeps every factorising CU to itself --
   // a co-resident GEMM workgroup competes for its issue slots and stretches the pivot chain (68 -> 77 us measured);
   // with many samples the GEMM dominates and wants both slots (S = 64: 950 -> 676 us).
-  const unsigned pad = tiles * nbatch <= 1024 ? (big ? 40u : 24u) * 1024u : 0u;
+  static const int pad_force = [] { const char* e = getenv("VARGP_MERGED_PAD"); return e ? atoi(e) : -1; }();   // tuning aid (KB)
+  const unsigned pad = pad_force >= 0 ? (unsigned)pad_force * 1024u : (tiles * nbatch <= 1024 ? (big ? 40u : 24u) * 1024u : 0u);
   // arithmetic of the pivot chains: fp64 (default) or the reference's own fp32 (VARGP_CHOL_F32=1; chol_small3.h)
   static const int f32_env = [] { const char* e = getenv("VARGP_CHOL_F32"); return e ? atoi(e) : kCholF32Default; }();
 #define VARGP_MERGED(KC, SETS, R)                                                                                                  \

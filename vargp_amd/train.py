@@ -82,6 +82,7 @@ class ElboTrainer:
 
         self.graph = None
         self.graph_opt = None
+        self._captured = {}
         # models on a native program (fused.T0Program: first task; fused.TnProgram: later tasks, ep_var_mean=True) drive it
         # directly: no autograd graph, gradients written straight into the optimiser's buffers
         is_model = gp is not None and loss_fn is None and params is None and hasattr(gp, 'draw_t0_noise')
@@ -112,6 +113,7 @@ class ElboTrainer:
         from . import ops
         assert ops._chol_mode == 'defer', "set_cholesky_error_mode('defer') before capturing"
         self._sx, self._sy = x.clone(), y.clone()
+        self.graph_opt = None
         # the warm-up steps are real steps: snapshot parameters, optimiser state and the noise stream, restore afterwards,
         # so that the graph-mode trajectory equals the eager one (no extra updates on the first minibatch)
         snap = self._snapshot_state()
@@ -136,7 +138,17 @@ class ElboTrainer:
             self.graph_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_opt, pool=self.graph.pool()):
                 self.optim.step()
+        # one captured step per minibatch size (the ragged last batch of an epoch gets its own: experiments/vargp.py); the
+        # attributes graph / _sx / _sy / _sout always describe the most recent capture
+        self._captured[int(x.size(0))] = (self.graph, self.graph_opt, self._sx, self._sy, self._sout)
         return self
+
+    def captured_sizes(self):
+        return sorted(self._captured)
+
+    def _select_capture(self, nb):
+        if self._sx.size(0) != nb:
+            self.graph, self.graph_opt, self._sx, self._sy, self._sout = self._captured[int(nb)]
 
     def _snapshot_state(self):
         snap = dict(params=[p.detach().clone() for p in self.params], rng=None, gen=None, opt=[])
@@ -201,6 +213,7 @@ class ElboTrainer:
     def step_graph(self, x=None, y=None):
         """Replay the captured step (optionally on a new minibatch of the captured shape)."""
         if x is not None:
+            self._select_capture(x.size(0))
             self._sx.copy_(x, non_blocking=True)
             self._sy.copy_(y, non_blocking=True)
         self.graph.replay()
@@ -212,6 +225,7 @@ class ElboTrainer:
     def step_graph_gather(self, data, targets, idx):
         """Replay the captured step on the minibatch data[idx], targets[idx] (device-resident data set, idx a device index
         tensor of the captured batch size): gathered straight into the graph's static inputs, no host copy."""
+        self._select_capture(idx.numel())
         torch.index_select(data, 0, idx, out=self._sx)
         torch.index_select(targets, 0, idx, out=self._sy)
         return self.step_graph()
