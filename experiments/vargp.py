@@ -100,6 +100,8 @@ def train(task_id, train_set, val_set, test_set, ep_var_mean=True, map_est_hyper
             n_steps += 1
         torch.cuda.synchronize()             # the one host sync of the epoch
         t_train += time.perf_counter() - t_epoch
+        if e == 0 and epochs > 1:            # the first epoch pays the one-off costs (kernel module loads, first allocations,
+            n_steps, t_train = 0, 0.0        # program workspaces): the logged rate is the steady state of the later epochs
         if graph and vargp_amd.linalg_error_count():
             # 'defer' mode never syncs inside a step: failed factorisations are NaN-filled and flagged on the device.
             # The reference raises at once (torch.cholesky, gp_utils.py:10); here the check runs once per epoch.

@@ -213,6 +213,11 @@ typedef struct vargp_elbo_t0_desc {
   /* 1: bwd leaves the gradients of log_mean / log_logvar to vargp_yogi_step_multi_hyper (see vargp_hyper_grad_desc): it does
    * not touch g_log_mean / g_log_logvar (they may be NULL) and launches one kernel less */
   int32_t defer_hyper;
+  /* 1 (only when a vargp_elbo_t0_bwd on this workspace follows before scalars[2] is read): for the shapes of the LDS-resident
+   * backward with C <= 16 and F <= 16 the forward does NOT launch the Monte-Carlo softmax likelihood; the backward's tile kernel
+   * evaluates it (value and gradient) and adds nll into scalars[2], which is therefore valid only after bwd.  Ignored (the
+   * forward evaluates the likelihood as usual) for every other shape. */
+  int32_t defer_softmax;
 } vargp_elbo_t0_desc;
 size_t vargp_elbo_t0_workspace_bytes(int S, int C, int M, int D, int B, int F);
 int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t stream);

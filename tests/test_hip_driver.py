@@ -77,7 +77,7 @@ def test_device_resident_epochs_reach_the_bench_rate(tmp_path):
     """`experiments/vargp.py s-mnist --synthetic --graph` end to end at BASELINE config 2's shapes (M = 100, S = 3, C = 10,
     D = 784, batch 512): with the data set resident in HBM, an on-device permutation per epoch and the minibatch gathered
     into the captured graph's static inputs, the driver's task-0 training rate (steps / wall time of the epochs, ragged last
-    batch of every epoch included) must come within 1.25x of the rate the same trainer reaches on ONE resident minibatch
+    batch of every epoch included; steady state: the first epoch's one-off costs excluded) must come within 1.25x of the rate the same trainer reaches on ONE resident minibatch
     (what bench.py times).  The reference-shaped DataLoader path (--dataloader) is measured beside it and reported."""
     import time
     sys.path.insert(0, ROOT)
@@ -104,9 +104,9 @@ def test_device_resident_epochs_reach_the_bench_rate(tmp_path):
         ops.set_cholesky_error_mode('raise')
     # -- the driver, device-resident epochs (default) and the reference's DataLoader (--dataloader); only task 0 is compared
     common = ['s-mnist', '--synthetic', '--n_synth', '36000', '--eval_interval', '100000', '--M', '100', '--graph', '--seed', '4']
-    _, sc = _run(common + ['--epochs', '30'], tmp_path / 'dev')
+    _, sc = _run(common + ['--epochs', '60'], tmp_path / 'dev')
     e2e = next(v for (k, _), v in sc.items() if k == 'task0/train/steps_per_s')
-    _, sc2 = _run(common + ['--epochs', '3', '--dataloader'], tmp_path / 'dl')
+    _, sc2 = _run(common + ['--epochs', '4', '--dataloader'], tmp_path / 'dl')
     e2e_loader = next(v for (k, _), v in sc2.items() if k == 'task0/train/steps_per_s')
     report = dict(bench_steps_per_s=bench_rate, driver_device_resident_steps_per_s=e2e, driver_dataloader_steps_per_s=e2e_loader,
                   ratio=bench_rate / e2e)

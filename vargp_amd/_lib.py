@@ -38,7 +38,7 @@ class ElboT0Desc(Structure):
         ('ws', c_void_p), ('ws_bytes', c_size_t),
         ('bump', c_void_p),
         ('rng_seed', ctypes.c_uint64), ('rng_counter', c_void_p), ('rng_sample_offset', c_int32),
-        ('defer_hyper', c_int32),
+        ('defer_hyper', c_int32), ('defer_softmax', c_int32),
     ]
 
 

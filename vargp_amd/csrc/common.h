@@ -120,8 +120,10 @@ __device__ __forceinline__ void zero_jobs_role(const ZeroJobs& z, int blk, int n
 #endif
 // K to Kout + b n^2 (dense, both triangles).
 constexpr int kCholPartMax = 4;
-// arithmetic of the pivot chains inside the merged first-task launch (chol_small3.h: R): 0 = fp64, 1 = the reference's fp32
-constexpr int kCholF32Default = 0;
+// arithmetic of the pivot chains inside the merged first-task launch (chol_small3.h: R): 0 = fp64, 1 = the reference's own fp32
+// (torch.cholesky + triangular_solve in float32, gp_utils.py:5-11; measured accuracy = LAPACK fp32's).  Every other
+// factorisation (stand-alone op, n <= 50 kernel, diagonal blocks of the blocked path) stays fp64.
+constexpr int kCholF32Default = 1;
 constexpr int kProKuuMaxD = 4096;       // launch_pro_kuu: 1/sigma^2 of one hyper-sample staged in LDS by the norm role
 struct CholExtra {
   float* base; int first; int ld; int64_t stride_b, stride_copy; int ncopy;

@@ -661,7 +661,7 @@ static T0BwdPaths t0_bwd_paths(const vargp_elbo_t0_desc* d, const T0Ws& o) {
 // itself: host-side state per workspace, updated when a call is ISSUED (which is also when a hipGraph capture records it, so a
 // captured fwd -> bwd sequence is checked once and replays as recorded).  kT0Cleared: a forward has cleared the accumulators
 // and no backward has consumed them yet.
-enum { kT0NoClear = 0, kT0Cleared = 1, kT0Consumed = 2 };
+enum { kT0NoClear = 0, kT0Cleared = 1, kT0Consumed = 2, kT0SoftmaxDeferred = 16 /* flag: the forward left the likelihood to bwd */ };
 static std::mutex g_t0_state_mu;
 static std::unordered_map<const void*, int> g_t0_state;
 static void t0_state_set(const void* ws, int v) {
@@ -725,8 +725,11 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
     }
   }
   ZeroJobs bwd_zero{};
-  const bool clear_bwd = t0_bwd_paths(d, o).mat_bwd;
-  t0_state_set(d->ws, clear_bwd ? kT0Cleared : kT0NoClear);
+  const T0BwdPaths bwd_paths = t0_bwd_paths(d, o);
+  const bool clear_bwd = bwd_paths.mat_bwd;
+  // the likelihood inside the backward's tile kernel (one launch less): only where that kernel runs and its softmax fits
+  const bool defer_softmax = d->defer_softmax && fused_softmax && bwd_paths.fused_bwd && F <= 4 * kBmSmF && C <= kBmSmC;
+  t0_state_set(d->ws, (clear_bwd ? kT0Cleared : kT0NoClear) | (defer_softmax ? kT0SoftmaxDeferred : 0));
   if (clear_bwd) {
     // accumulators of the LDS-resident backward (atomics of t0_bwd_mid.h / t0_bwd_mat.h / t0_bwd_tail.h), cleared in the forward,
     // where it costs nothing (spare workgroups under the pivot chains; shapes without that launch: the prologue's zero role):
@@ -858,7 +861,9 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
     hipLaunchKernelGGL(t0_pdiag_kl_fwd_kernel, dim3(npd + nkx * SC), dim3(256), 0, st, o.QP, o.W, o.kd, o.LL, o.Lu, o.mu,
                        o.var, d->scalars + 1, S, C, M, B, NR, LD, nbx, npd, nkx, native ? d->rng_counter : nullptr);
   }
-  if (fused_softmax) {
+  if (defer_softmax) {
+    // (nothing: t0_bwd_mid_kernel evaluates the likelihood of its tile -- value into scalars[2], gradient straight into its LDS)
+  } else if (fused_softmax) {
     const int64_t total = (int64_t)S * F * B;
     hipLaunchKernelGGL(t0_softmax_kernel<16>, dim3(cdiv(total, 256)), dim3(256), 0, st, o.mu, o.var, eps_f, d->y,
                        d->scalars + 2, o.gmu, o.gvar, S, F, C, B);
@@ -892,16 +897,21 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
   const int ntile = cdiv(B, 64);
   const T0BwdPaths paths = t0_bwd_paths(d, o);
   const bool fused_bwd = paths.fused_bwd, mat_bwd = paths.mat_bwd;
+  const int state_all = t0_state_get(d->ws);
+  const bool softmax_deferred = state_all >= 0 && (state_all & kT0SoftmaxDeferred) != 0;
+  VARGP_REQUIRE(!softmax_deferred || fused_bwd, "elbo_t0_bwd: the forward deferred the likelihood to a backward path this call does not take");
   if (mat_bwd) {
     // the accumulators must have been cleared by a forward on THIS workspace that took the same decision (the decision
     // depends on the alignment of d->z / d->x and on tuning variables) and must not have been consumed by a backward yet
-    const int state = t0_state_get(d->ws);
+    const int state = state_all < 0 ? state_all : (state_all & ~kT0SoftmaxDeferred);
     VARGP_REQUIRE(state == kT0Cleared,
                   "elbo_t0_bwd: %s -- this path allows ONE vargp_elbo_t0_bwd per vargp_elbo_t0_fwd (the forward clears the "
                   "accumulators the backward adds into); run the forward again",
                   state == kT0Consumed ? "second backward on one forward"
                                        : "no forward on this workspace with the same z / x alignment");
     t0_state_set(d->ws, kT0Consumed);
+  } else if (softmax_deferred) {
+    t0_state_set(d->ws, kT0NoClear);           // (the likelihood is added into scalars[2] once)
   }
   // mat_bwd: no head launch -- the forward's zero role has cleared the accumulators, the seed-dependent KL columns (g a, g G2) are
   // formed by the chain kernel from QP, g_u_mean is cleared by the tile kernel.  ONE backward per forward on this path.
@@ -923,7 +933,8 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
       ProfScope prof("t0_bwd_mid", st);
       hipLaunchKernelGGL(t0_bwd_mid_kernel, dim3(8 * cdiv(SC, 8) * ntile), dim3(256), kBwdMidLdsBytes, st, o.TT, o.QP, o.W, o.RK, o.gmu, o.gvar,
                          fused_softmax ? seeds + 2 : nullptr, o.gQP, o.gTT, o.gRK, o.gkd, o.r_uf, o.c_uf, o.gtheta, S, C, M, B, D,
-                         NR, LD, ntile, mat_bwd ? g_u_mean : nullptr, C * M);
+                         NR, LD, ntile, mat_bwd ? g_u_mean : nullptr, C * M,
+                         softmax_deferred ? BmSoftmax{o.mu, o.var, eps_f, d->y, d->scalars + 2, F} : BmSoftmax{});
     }
     if (!mat_bwd) {
       // what the tiles cannot see: the small columns [a | . | G | G2 | .] of QP = T RK (K = NR):

@@ -11,7 +11,16 @@ constexpr int kBmKP = 104;      // padded inner dimension (M <= 104, multiple of
 constexpr int kBmSA = 108;      // row stride of the M x M operand (G, then T): 108 / 4 odd -> conflict-free b128 rows
 constexpr int kBmST = 68;       // row stride of the M x 64 tiles
 constexpr size_t kBwdMidLdsBytes =
-    sizeof(float) * (kBmKP * kBmSA + 2 * kBmKP * kBmST + 128 /*a*/ + 64 + 64 /*gmu, gvar*/ + 64 /*column sums*/ + 8);
+    sizeof(float) * (kBmKP * kBmSA + 2 * kBmKP * kBmST + 128 /*a*/ + 64 + 64 /*gmu, gvar*/ + 64 /*column sums*/ + 8 +
+                     3 * 4 * 64 /*deferred softmax: partial sums of the four f-groups*/);
+// deferred softmax (t0_bwd_mid_kernel evaluates the likelihood of its tile): at most kBmSmC classes, 4 kBmSmF likelihood samples
+constexpr int kBmSmC = 16, kBmSmF = 4;
+struct BmSoftmax {
+  const float *mu, *var, *eps;      // (S, C, B), (S, C, B), (S, F, C, B); eps == NULL: gmu / gvar come from memory
+  const int64_t* y;                 // (B)
+  float* nll;                       // scalar accumulator (cleared by the forward)
+  int F;
+};
 typedef float bm_f32x16 __attribute__((ext_vector_type(16)));
 
 // fragment of a K-contiguous operand ([index][k]): the lane's 4 consecutive k of one row, one ds_read_b128

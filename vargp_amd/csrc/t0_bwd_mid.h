@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void t0_bwd_mid_kernel(const float* __restrict
                                                          float* __restrict__ gkd, float* __restrict__ r_uf,
                                                          float* __restrict__ c_uf, float* __restrict__ gtheta, int S, int C,
                                                          int M, int B, int D, int NR, int LD, int ntile,
-                                                         float* __restrict__ zero_out, int zero_n) {
+                                                         float* __restrict__ zero_out, int zero_n, const BmSoftmax sm) {
   extern __shared__ __attribute__((aligned(16))) float bm_lds[];
   // an output of the backward that the NEXT launch accumulates into (g_u_mean: sums over s by atomics): cleared here, by the
   // first workgroup, because the forward -- which clears the workspace's accumulators -- does not know the caller's buffer
@@ -268,9 +268,78 @@ __global__ __launch_bounds__(256) void t0_bwd_mid_kernel(const float* __restrict
   bm_load_tile(Wb, B, M, n0, B, tid, rw);
   const float av = tid < 128 ? Qb[(int64_t)min(tid, M - 1) * LD] : 0.f;
   const int ncl = min(n0 + (tid & 63), B - 1);
-  const float gmv = gmu[b * B + ncl], gvv = gvar[b * B + ncl];
+  float gmv = 0.f, gvv = 0.f;
+  // sm.eps != NULL (the forward ran with defer_softmax): the Monte-Carlo softmax likelihood of this tile's columns is evaluated
+  // HERE -- every (s, c, tile) workgroup redoes the softmax over all classes of its 64 columns (C-fold redundant, F C 64 exps)
+  // and keeps the gradient of its own class; the class-0 workgroups also add the tile's share of nll.  One launch less on the
+  // critical path of the step.  Thread (column, f-group) = (tid & 63, tid >> 6) takes the likelihood samples f = fg, fg + 4, ...
+  float smu[kBmSmC], ssd[kBmSmC], sev[kBmSmF][kBmSmC];
+  int syb = 0;
+  if (sm.eps) {
+    const int s = (int)(b / C), fg = tid >> 6;
+#pragma unroll
+    for (int c = 0; c < kBmSmC; ++c) {              // all loads first, unconditional on clamped indices
+      const int cc = min(c, C - 1);
+      const int64_t i = ((int64_t)s * C + cc) * B + ncl;
+      smu[c] = sm.mu[i];
+      ssd[c] = sm.var[i];
+#pragma unroll
+      for (int q = 0; q < kBmSmF; ++q)
+        sev[q][c] = sm.eps[(((int64_t)s * sm.F + min(fg + 4 * q, sm.F - 1)) * C + cc) * B + ncl];
+    }
+    syb = (int)sm.y[ncl];
+  } else {
+    gmv = gmu[b * B + ncl]; gvv = gvar[b * B + ncl];
+  }
   bm_load_mat(Tb, M, M, tid, rt);
   bm_load_tile(Kb, LD, M, n0, B, tid, rk);
+  if (sm.eps) {
+    const int cme = (int)(b % C), fg = tid >> 6;
+    const float sc1 = 1.f / (float)(S * sm.F);
+    float pm = 0.f, pv = 0.f, contrib = 0.f;
+#pragma unroll
+    for (int c = 0; c < kBmSmC; ++c) ssd[c] = c < C ? sqrtf(ssd[c]) : 1.f;
+#pragma unroll
+    for (int q = 0; q < kBmSmF; ++q) {
+      const bool live = fg + 4 * q < sm.F && n0 + (tid & 63) < B;
+      float v[kBmSmC], mx = -INFINITY, fy = 0.f, eme = 0.f;
+#pragma unroll
+      for (int c = 0; c < kBmSmC; ++c) {
+        v[c] = c < C ? fmaf(ssd[c], sev[q][c], smu[c]) : -INFINITY;
+        mx = fmaxf(mx, v[c]);
+        if (c == syb) fy = v[c];
+        if (c == cme) eme = sev[q][c];
+      }
+      float se = 0.f, vme = 0.f;
+#pragma unroll
+      for (int c = 0; c < kBmSmC; ++c) {
+        const float e = c < C ? expf(v[c] - mx) : 0.f;
+        se += e;
+        if (c == cme) vme = e;
+      }
+      const float pc = vme * (sc1 / se) - (cme == syb ? sc1 : 0.f);
+      if (live) { pm += pc; pv += pc * eme; contrib -= (fy - (mx + logf(se))) * sc1; }
+    }
+    float sdme = 1.f;
+#pragma unroll
+    for (int c = 0; c < kBmSmC; ++c) if (c == cme) sdme = ssd[c];
+    pv *= 0.5f / sdme;
+    // the four f-groups of a column meet in LDS
+    float* sred = scs + 64 + 8;                       // [3][4][64]
+    sred[(0 * 4 + fg) * 64 + (tid & 63)] = pm;
+    sred[(1 * 4 + fg) * 64 + (tid & 63)] = pv;
+    sred[(2 * 4 + fg) * 64 + (tid & 63)] = contrib;
+    __syncthreads();
+    if (tid < 64) {
+      gmv = sred[tid] + sred[64 + tid] + sred[128 + tid] + sred[192 + tid];
+      gvv = sred[256 + tid] + sred[320 + tid] + sred[384 + tid] + sred[448 + tid];
+      if (cme == 0) {
+        float t = sred[512 + tid] + sred[576 + tid] + sred[640 + tid] + sred[704 + tid];
+        t = wave_sum(t);
+        if (tid == 0) atomicAdd(sm.nll, t);
+      }
+    }
+  }
 
   BM_STAMP(1);
   // ---- phase 0: G, P, W, a, gmu, gvar into LDS ------------------------------------------------------------------------------

@@ -81,8 +81,10 @@ class T0Program:
         return (n_v, z.shape[0], z.shape[1], z.shape[2], x.shape[0], n_f)
 
     def forward(self, log_mean, log_logvar, prior_log_mean, prior_log_logvar, z, u_mean, u_tril_vec, x, y, eps_theta,
-                eps_f, bump=None):
+                eps_f, bump=None, defer_softmax=False):
         """-> scalars (3,) = (kl_hypers, kl_u, nll).  All tensors contiguous fp32 on the ROCm device (y int64).
+        defer_softmax: the caller runs `backward` right behind this forward and reads nll only afterwards (ElboTrainer): the
+        likelihood is then evaluated inside the backward's tile kernel where the shapes allow (include/vargp_hip.h).
         eps_theta = eps_f = None: the program draws the noise itself (see set_rng).  `bump`: optional device float that the forward increments by one (an optimiser's step counter)."""
         tensors = (log_mean, log_logvar, prior_log_mean, prior_log_logvar, z, u_mean, u_tril_vec, x, y, eps_theta, eps_f)
         require_device(*tensors)
@@ -102,6 +104,7 @@ class T0Program:
         d.z, d.u_mean, d.u_tril_vec, d.x, d.y = _p(z), _p(u_mean), _p(u_tril_vec), _p(x), _p(y)
         d.eps_theta, d.eps_f = _p(eps_theta), _p(eps_f)
         d.bump = _p(bump)
+        d.defer_softmax = int(bool(defer_softmax))
         self._keep = tensors + (bump,)   # the descriptor holds raw pointers: keep the tensors alive until backward
         check(lib().vargp_elbo_t0_fwd(ctypes.byref(d), stream_ptr()), 'vargp_elbo_t0_fwd')
         self._bwd_ok = True

@@ -30,8 +30,16 @@ def reset_linalg_errors():
 
 
 def linalg_error_count():
-    """'defer' mode: number of failed factorisations among the most recent calls (syncs)."""
-    return sum(int((t != 0).sum().item()) for t in _info_ring)
+    """'defer' mode: number of failed factorisations among the most recent calls.  ONE host sync: the ring usually holds the
+    same few info tensors many times over (a program's info buffer is appended on every eager call), so they are counted
+    once each, and the counts are summed on the device before the single read-back."""
+    uniq = {}
+    for t in _info_ring:
+        uniq[(t.data_ptr(), t.numel())] = t
+    if not uniq:
+        return 0
+    counts = [torch.count_nonzero(t) for t in uniq.values()]
+    return int(torch.stack(counts).sum().item()) if len(counts) > 1 else int(counts[0].item())
 
 
 # ------------------------------------------------------------------------------------------------

@@ -298,9 +298,12 @@ class ElboTrainer:
         if key not in self._seeds:
             self._seeds[key] = torch.tensor([self.beta * w, w, scale * w], dtype=torch.float32, device=x.device)
         packed = gp._tn_operands() if self._tn else ()
+        # (first-task program: forward and backward are issued back to back here and nll is read after both, so the
+        # likelihood may be left to the backward's tile kernel -- one launch less)
+        extra = {} if self._tn else dict(defer_softmax=os.environ.get('VARGP_DEFER_SOFTMAX', '1') != '0')
         scal = self._prog.forward(kern.log_mean.detach(), kern.log_logvar.detach(), kern.prior_log_mean,
                                   kern.prior_log_logvar, gp.z.detach(), gp.u_mean.detach(), gp.u_tril_vec.detach(), *packed,
-                                  x, y, eps_theta, eps_f, bump=self._bump)
+                                  x, y, eps_theta, eps_f, bump=self._bump, **extra)
         self._prog.backward(self._seeds[key], kern.log_mean.grad, kern.log_logvar.grad, gp.z.grad, gp.u_mean.grad,
                             gp.u_tril_vec.grad, defer_hyper=defer_hyper)
         return scal
