@@ -162,3 +162,55 @@ def test_graph_survives_ragged_eager_step_and_capture_keeps_state():
             assert rel_l2(res[1][1][k], res[0][1][k]) < 1e-5, k
     finally:
         ops.set_cholesky_error_mode('raise')
+
+
+@pytest.mark.parametrize('shape,map_est', [((3, 3, 4, 56, 784, 64), False), ((2, 3, 3, 24, 40, 32), False),
+                                          ((1, 3, 3, 56, 300, 64), True)])
+def test_deferred_hyper_backward_equals_its_own_launch(shape, map_est, monkeypatch):
+    """The trainer finishes the hyper-parameter backward inside the optimiser's launch (vargp_yogi_step_multi_hyper); with
+    VARGP_DEFER_HYPER=0 the program's own last kernel (t0_hyper_bwd_kernel) does it before a plain Yogi step.  Same
+    gradients of log_mean / log_logvar and the same parameters after three steps -- D + 1 = 785 > 256 (several blocks of
+    the hyper role), a small D, and a MAP estimate of the hyper-parameters (log_logvar receives no gradient)."""
+    from vargp_amd import noise
+    from vargp_amd.train import ElboTrainer
+    from gpu_common import build_gp
+    S, F_, C, M, D, B = shape
+    params, prev, x, y, nz = orc.make_problem(S, F_, C, M, D, B, seed=21, kind='gauss')
+    xd, yd = x.to(DEV), y.to(DEV)
+    res = []
+    for defer in ('1', '0'):
+        monkeypatch.setenv('VARGP_DEFER_HYPER', defer)
+        gp = build_gp(params, prev, S, F_)
+        gp.kernel.map_est = map_est
+        tr = ElboTrainer(gp, lr=3e-3, beta=2.0, n_total=10 * B)
+        assert tr._t0 and tr._defer_hyper() == (defer == '1')
+        for it in range(3):
+            inj = dict(eps_f=(nz['eps_f'] + 0.1 * it).to(DEV))
+            if not map_est:
+                inj['eps_theta'] = (nz['eps_theta'] - 0.05 * it).to(DEV)
+            with noise.inject(**inj):
+                tr.step(xd, yd)
+        k = gp.kernel
+        res.append(dict(g_mean=k.log_mean.grad.clone().cpu(), g_logvar=None if map_est else k.log_logvar.grad.clone().cpu(),
+                        params={n: p.detach().clone().cpu() for n, p in gp.named_parameters()}))
+    a, b = res
+    assert rel_l2(a['g_mean'], b['g_mean']) < 1e-5
+    if not map_est:
+        assert rel_l2(a['g_logvar'], b['g_logvar']) < 1e-5
+    for n in a['params']:
+        assert rel_l2(a['params'][n], b['params'][n]) < 1e-5, n
+
+
+def test_defer_hyper_needs_both_hyper_tensors_in_the_optimiser():
+    """with log_logvar frozen (not among the optimiser's parameters) and no MAP estimate, the deferred launch
+    would be handed idx_logvar = -1 and reject it; _defer_hyper() must say no and the step must run."""
+    from vargp_amd.train import ElboTrainer
+    from gpu_common import build_gp
+    S, F_, C, M, D, B = 2, 3, 3, 24, 40, 32
+    params, prev, x, y, nz = orc.make_problem(S, F_, C, M, D, B, seed=22, kind='gauss')
+    gp = build_gp(params, prev, S, F_)
+    gp.kernel.log_logvar.requires_grad_(False)
+    tr = ElboTrainer(gp, lr=3e-3, beta=1.0, n_total=B)
+    assert not tr._defer_hyper()
+    out = tr.step(x.to(DEV), y.to(DEV))
+    assert all(torch.isfinite(v) for v in out)

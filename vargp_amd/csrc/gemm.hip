@@ -30,7 +30,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // Where the out-of-range lanes of an edge tile's epilogue store: with `if (row < M && col < N) C[..] = v` every element is a
 // branch, and the compiler drains vmcnt before each (one memory round trip per element: 32-64 of them per thread, most of a
 // small product's duration).  A select between the real address and this dump keeps the epilogue straight-line.  Never read.
-__device__ float g_gemm_trash[256];
+__device__ float g_gemm_trash[512];
 
 template <bool KC, int ROWS, int BK>
 struct LdsLayout {
@@ -46,15 +46,15 @@ struct LdsLayout {
 
 // Global -> registers for one ROWS x BK slab.  Element (r,k) lives at base[(r0+r)*ld + k] (KC) or
 // base[k*ld + r0 + r] (!KC).  Out-of-range elements (r >= rmax, k >= ke) read as zero.
-template <bool KC, int ROWS, int BK, bool VEC>
+template <bool KC, int ROWS, int BK, bool VEC, int NT = 256>
 __device__ __forceinline__ void load_slab(const float* __restrict__ base, int ld, int r0, int rmax, int k0,
-                                          int ke, float (&reg)[ROWS * BK / 256]) {
-  constexpr int NPT = ROWS * BK / 256;
+                                          int ke, float (&reg)[ROWS * BK / NT]) {
+  constexpr int NPT = ROWS * BK / NT;
   const int tid = threadIdx.x;
   if constexpr (VEC) {
 #pragma unroll
     for (int c = 0; c < NPT / 4; ++c) {
-      const int q = tid + 256 * c;
+      const int q = tid + NT * c;
       int r, k;
       if constexpr (KC) { r = q / (BK / 4); k = (q % (BK / 4)) * 4; } else { k = q / (ROWS / 4); r = (q % (ROWS / 4)) * 4; }
       const int gr = r0 + r, gk = k0 + k;
@@ -85,7 +85,7 @@ __device__ __forceinline__ void load_slab(const float* __restrict__ base, int ld
   } else {
 #pragma unroll
     for (int c = 0; c < NPT; ++c) {
-      const int e = tid + 256 * c;
+      const int e = tid + NT * c;
       int r, k;
       if constexpr (KC) { r = e / BK; k = e % BK; } else { k = e / ROWS; r = e % ROWS; }
       const int gr = r0 + r, gk = k0 + k;
@@ -115,16 +115,16 @@ __device__ __forceinline__ void load_scale(const float* __restrict__ kscale, int
 }
 
 // registers -> LDS (same element <-> thread map as load_slab); optional per-k scale (KC only)
-template <bool KC, int ROWS, int BK, bool VEC, bool SCALE>
-__device__ __forceinline__ void store_slab(float* __restrict__ lds, const float (&reg)[ROWS * BK / 256],
+template <bool KC, int ROWS, int BK, bool VEC, bool SCALE, int NT = 256>
+__device__ __forceinline__ void store_slab(float* __restrict__ lds, const float (&reg)[ROWS * BK / NT],
                                            const float (&rs)[4]) {
-  constexpr int NPT = ROWS * BK / 256;
+  constexpr int NPT = ROWS * BK / NT;
   using L = LdsLayout<KC, ROWS, BK>;
   const int tid = threadIdx.x;
   if constexpr (VEC) {
 #pragma unroll
     for (int c = 0; c < NPT / 4; ++c) {
-      const int q = tid + 256 * c;
+      const int q = tid + NT * c;
       if constexpr (KC) {
         const int r = q / (BK / 4), k = (q % (BK / 4)) * 4;
         float4 v = make_float4(reg[4 * c], reg[4 * c + 1], reg[4 * c + 2], reg[4 * c + 3]);
@@ -139,7 +139,7 @@ __device__ __forceinline__ void store_slab(float* __restrict__ lds, const float 
   } else {
 #pragma unroll
     for (int c = 0; c < NPT; ++c) {
-      const int e = tid + 256 * c;
+      const int e = tid + NT * c;
       int r, k;
       if constexpr (KC) { r = e / BK; k = e % BK; } else { k = e / ROWS; r = e % ROWS; }
       float v = reg[c];
@@ -151,15 +151,15 @@ __device__ __forceinline__ void store_slab(float* __restrict__ lds, const float 
 
 // ---- the same staging, one piece at a time (a piece = one float4 chunk with VEC, one float without),
 // so that the main loop can drop pieces into the shadow of individual MFMAs ----------------------------
-template <bool KC, int ROWS, int BK, bool VEC>
-struct Pieces { static constexpr int kCount = VEC ? ROWS * BK / 256 / 4 : ROWS * BK / 256; };
+template <bool KC, int ROWS, int BK, bool VEC, int NT = 256>
+struct Pieces { static constexpr int kCount = VEC ? ROWS * BK / NT / 4 : ROWS * BK / NT; };
 
-template <bool KC, int ROWS, int BK, bool VEC>
+template <bool KC, int ROWS, int BK, bool VEC, int NT = 256>
 __device__ __forceinline__ void load_piece(const float* __restrict__ base, int ld, int r0, int rmax, int k0, int ke,
-                                           int c, float (&reg)[ROWS * BK / 256]) {
+                                           int c, float (&reg)[ROWS * BK / NT]) {
   const int tid = threadIdx.x;
   if constexpr (VEC) {
-    const int q = tid + 256 * c;
+    const int q = tid + NT * c;
     int r, k;
     if constexpr (KC) { r = q / (BK / 4); k = (q % (BK / 4)) * 4; } else { k = q / (ROWS / 4); r = (q % (ROWS / 4)) * 4; }
     const int gr = r0 + r, gk = k0 + k;
@@ -179,7 +179,7 @@ __device__ __forceinline__ void load_piece(const float* __restrict__ base, int l
     }
     reg[4 * c + 0] = v.x; reg[4 * c + 1] = v.y; reg[4 * c + 2] = v.z; reg[4 * c + 3] = v.w;
   } else {
-    const int e = tid + 256 * c;
+    const int e = tid + NT * c;
     int r, k;
     if constexpr (KC) { r = e / BK; k = e % BK; } else { k = e / ROWS; r = e % ROWS; }
     const int gr = r0 + r, gk = k0 + k;
@@ -192,9 +192,9 @@ __device__ __forceinline__ void load_piece(const float* __restrict__ base, int l
 // Loop-invariant element offset of a VEC piece's float4 relative to the slab origin, with the row index
 // clamped into the operand.  A clamped (duplicated) row/column only feeds output rows/columns >= M/N,
 // which are never stored, so the fast path needs no masks and no zero-fill.
-template <bool KC, int ROWS, int BK>
+template <bool KC, int ROWS, int BK, int NT = 256>
 __device__ __forceinline__ int piece_offset(int ld, int r0, int rmax, int c) {
-  const int q = threadIdx.x + 256 * c;
+  const int q = threadIdx.x + NT * c;
   if constexpr (KC) {
     const int r = q / (BK / 4), k = (q % (BK / 4)) * 4;
     return min(r0 + r, rmax - 1) * ld + k;
@@ -220,19 +220,19 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* base, int bytes) {
   r.w = 0x00020000;
   return r;
 }
-template <int ROWS, int BK>
-__device__ __forceinline__ void load_piece_fast(i32x4 rsrc, int voff, int soff, int c, float (&reg)[ROWS * BK / 256]) {
+template <int ROWS, int BK, int NT = 256>
+__device__ __forceinline__ void load_piece_fast(i32x4 rsrc, int voff, int soff, int c, float (&reg)[ROWS * BK / NT]) {
   const f32x4 v = llvm_amdgcn_raw_buffer_load_f32x4(rsrc, voff, soff, 0);
   reg[4 * c + 0] = v.x; reg[4 * c + 1] = v.y; reg[4 * c + 2] = v.z; reg[4 * c + 3] = v.w;
 }
 
-template <bool KC, int ROWS, int BK, bool VEC, bool SCALE>
-__device__ __forceinline__ void store_piece(float* __restrict__ lds, const float (&reg)[ROWS * BK / 256],
+template <bool KC, int ROWS, int BK, bool VEC, bool SCALE, int NT = 256>
+__device__ __forceinline__ void store_piece(float* __restrict__ lds, const float (&reg)[ROWS * BK / NT],
                                             const float (&rs)[4], int c) {
   using L = LdsLayout<KC, ROWS, BK>;
   const int tid = threadIdx.x;
   if constexpr (VEC) {
-    const int q = tid + 256 * c;
+    const int q = tid + NT * c;
     if constexpr (KC) {
       const int r = q / (BK / 4), k = (q % (BK / 4)) * 4;
       float4 v = make_float4(reg[4 * c], reg[4 * c + 1], reg[4 * c + 2], reg[4 * c + 3]);
@@ -244,7 +244,7 @@ __device__ __forceinline__ void store_piece(float* __restrict__ lds, const float
           make_float4(reg[4 * c], reg[4 * c + 1], reg[4 * c + 2], reg[4 * c + 3]);
     }
   } else {
-    const int e = tid + 256 * c;
+    const int e = tid + NT * c;
     int r, k;
     if constexpr (KC) { r = e / BK; k = e % BK; } else { k = e / ROWS; r = e % ROWS; }
     float v = reg[c];
@@ -264,7 +264,7 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 // hand over a pre-scaled B operand (x o w, written once per hyper-sample by the norm pass) pass kscale = NULL and get the
 // unscaled instantiation: the scale loads and multiplies sit in the main loop, where nothing overlaps them with the MFMAs
 // (stress K_uf tile [20480 x 784] x [8192 x 784]^T: 93 TFLOP/s scaled in the loop, 133 as a plain product).
-template <int BM, int BN, int BK, bool AKC, bool BKC, bool VEC, bool RBF, bool SCALED = true>
+template <int BM, int BN, int BK, bool AKC, bool BKC, bool VEC, bool RBF, bool SCALED = true, int NT = 256>
 __device__ __forceinline__ void gemm_body(const GemmParams& p, const int tile_id_, const int batch_id_, const int split_id_,
                                           float* __restrict__ lds) {
   // The workgroup's tile / batch / split indices are wave-uniform, but they come out of integer divisions that the
@@ -274,7 +274,12 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int tile_id
   const int tile_id = __builtin_amdgcn_readfirstlane(tile_id_);
   const int batch_id = __builtin_amdgcn_readfirstlane(batch_id_);
   const int split_id = __builtin_amdgcn_readfirstlane(split_id_);
-  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+  // NT threads = NT / 64 waves in a (NT / 128) x 2 grid over the tile: 256 threads 2 x 2 (the default), 512 threads 4 x 2 --
+  // the same tile and LDS with two waves per SIMD, for launches that are limited to one workgroup per CU by their LDS
+  static_assert(NT == 256 || NT == 512, "gemm_body: 4 or 8 waves");
+  constexpr int WROWS = NT / 128;
+  constexpr int WM = BM / WROWS, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+  static_assert(TM >= 1 && TN >= 1, "gemm_body: tile too small for the wave grid");
   using LA = LdsLayout<AKC, BM, BK>;
   using LB = LdsLayout<BKC, BN, BK>;
   // two LDS stages: slab s is consumed from stage s&1 while slab s+1 is written to the other one,
@@ -315,7 +320,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int tile_id
   // tiles strictly above the diagonal of a lower-triangular result
   if (p.triC != 0 && n0 >= m0 + BM) {
     if (p.triC == 1) {
-      for (int e = tid; e < BM * BN; e += 256) {
+      for (int e = tid; e < BM * BN; e += NT) {
         const int r = m0 + e / BN, c = n0 + e % BN;
         if (r < p.M && c < p.N) C[(int64_t)r * p.ldc + c] = 0.f;
       }
@@ -348,7 +353,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int tile_id
   constexpr bool SC = RBF && SCALED;
   const float* kscale = SC ? p.kscale + i0 * p.ks_ld : nullptr;
 
-  float ra[BM * BK / 256], rb[BN * BK / 256], rs[4] = {1.f, 1.f, 1.f, 1.f};
+  float ra[BM * BK / NT], rb[BN * BK / NT], rs[4] = {1.f, 1.f, 1.f, 1.f};
   float* const stage0 = lds;
   constexpr int kBoff = (LA::kSize + 3) & ~3;
   constexpr int NG = BK / 8;      // groups of 8 k: per group one float4 per lane and operand feeds 4 x TM*TN MFMAs
@@ -412,15 +417,15 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int tile_id
       // ---- pipelined main loop over the full slabs: NO control flow around the loads/stores (a branch there
       // makes the compiler drain vmcnt before every load).  Loads past the last full slab re-read that slab and
       // the matching stores go to the idle LDS stage, where nobody reads them.
-      constexpr int NPA = Pieces<AKC, BM, BK, true>::kCount, NPB = Pieces<BKC, BN, BK, true>::kCount, NP = NPA + NPB;
+      constexpr int NPA = Pieces<AKC, BM, BK, true, NT>::kCount, NPB = Pieces<BKC, BN, BK, true, NT>::kCount, NP = NPA + NPB;
       constexpr int HALF = (NG >= 2) ? NG / 2 : 1;         // groups [0, HALF): global loads, [HALF, NG): LDS stores
       constexpr int PERL = (NP + HALF - 1) / HALF;          // pieces loaded per group
       constexpr int PERS = (NP + (NG - HALF > 0 ? NG - HALF : 1) - 1) / (NG - HALF > 0 ? NG - HALF : 1);
       int offA[NPA], offB[NPB];
 #pragma unroll
-      for (int c = 0; c < NPA; ++c) offA[c] = piece_offset<AKC, BM, BK>(p.lda, m0, p.M, c);
+      for (int c = 0; c < NPA; ++c) offA[c] = piece_offset<AKC, BM, BK, NT>(p.lda, m0, p.M, c);
 #pragma unroll
-      for (int c = 0; c < NPB; ++c) offB[c] = piece_offset<BKC, BN, BK>(p.ldb, n0, p.N, c);
+      for (int c = 0; c < NPB; ++c) offB[c] = piece_offset<BKC, BN, BK, NT>(p.ldb, n0, p.N, c);
       const int stepA = 4 * (AKC ? BK : BK * p.lda), stepB = 4 * (BKC ? BK : BK * p.ldb);     // bytes per slab
       const i32x4 rsA = make_rsrc(A + (AKC ? ks : (int64_t)ks * p.lda), (int)(4 * extA));
       const i32x4 rsB = make_rsrc(B + (BKC ? ks : (int64_t)ks * p.ldb), (int)(4 * extB));
@@ -431,23 +436,23 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int tile_id
       // Two register sets: while slab sl is multiplied out of LDS, slab sl+1 goes registers(set X) -> idle LDS
       // stage and slab sl+2 goes global -> registers(set Y).  A load therefore has more than a whole slab of
       // MFMAs before its data is needed (one wave per SIMD cannot hide a global-load latency any other way).
-      float ra2[BM * BK / 256], rb2[BN * BK / 256], rs2[4] = {1.f, 1.f, 1.f, 1.f};
-      auto load_set = [&](int slab, float (&xa)[BM * BK / 256], float (&xb)[BN * BK / 256], float (&xs)[4]) {
+      float ra2[BM * BK / NT], rb2[BN * BK / NT], rs2[4] = {1.f, 1.f, 1.f, 1.f};
+      auto load_set = [&](int slab, float (&xa)[BM * BK / NT], float (&xb)[BN * BK / NT], float (&xs)[4]) {
 #pragma unroll
-        for (int c = 0; c < NPA; ++c) load_piece_fast<BM, BK>(rsA, offA[c], slab * stepA, c, xa);
+        for (int c = 0; c < NPA; ++c) load_piece_fast<BM, BK, NT>(rsA, offA[c], slab * stepA, c, xa);
 #pragma unroll
-        for (int c = 0; c < NPB; ++c) load_piece_fast<BN, BK>(rsB, offB[c], slab * stepB, c, xb);
+        for (int c = 0; c < NPB; ++c) load_piece_fast<BN, BK, NT>(rsB, offB[c], slab * stepB, c, xb);
         if constexpr (SC) load_scale<BK, true>(kscale, ks + slab * BK, ke, xs);
       };
       load_set(0, ra, rb, rs);
-      store_slab<AKC, BM, BK, true, SC>(stage0, ra, rs);
-      store_slab<BKC, BN, BK, true, false>(stage0 + kBoff, rb, rs);
+      store_slab<AKC, BM, BK, true, SC, NT>(stage0, ra, rs);
+      store_slab<BKC, BN, BK, true, false, NT>(stage0 + kBoff, rb, rs);
       load_set(min(1, nfull - 1), ra, rb, rs);              // slab 1 -> set X
       __syncthreads();
       // The loop is unrolled by two, so the LDS stage each half works on is a compile-time constant and every LDS
       // address is a loop-invariant register plus an immediate.
-      auto iteration = [&](auto stage_c, int sl, float (&xa)[BM * BK / 256], float (&xb)[BN * BK / 256], float (&xs)[4],
-                           float (&ya)[BM * BK / 256], float (&yb)[BN * BK / 256], float (&ys)[4]) {
+      auto iteration = [&](auto stage_c, int sl, float (&xa)[BM * BK / NT], float (&xb)[BN * BK / NT], float (&xs)[4],
+                           float (&ya)[BM * BK / NT], float (&yb)[BN * BK / NT], float (&ys)[4]) {
         constexpr int stage = decltype(stage_c)::value;
         const float* As = lds + stage * kStage;
         float* An = lds + (stage ^ 1) * kStage;
@@ -458,8 +463,8 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int tile_id
 #pragma unroll
             for (int u = 0; u < PERL; ++u) {
               const int pc = g * PERL + u;
-              if (pc < NPA) load_piece_fast<BM, BK>(rsA, offA[pc], soA, pc, ya);
-              else if (pc < NP) load_piece_fast<BN, BK>(rsB, offB[pc - NPA], soB, pc - NPA, yb);
+              if (pc < NPA) load_piece_fast<BM, BK, NT>(rsA, offA[pc], soA, pc, ya);
+              else if (pc < NP) load_piece_fast<BN, BK, NT>(rsB, offB[pc - NPA], soB, pc - NPA, yb);
             }
             if constexpr (SC) { if (g == HALF - 1) load_scale<BK, true>(kscale, ks + nxt * BK, ke, ys); }
           }
@@ -467,8 +472,8 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int tile_id
 #pragma unroll
             for (int u = 0; u < PERS; ++u) {
               const int pc = (g - HALF) * PERS + u;
-              if (pc < NPA) store_piece<AKC, BM, BK, true, SC>(An, xa, xs, pc);
-              else if (pc < NP) store_piece<BKC, BN, BK, true, false>(An + kBoff, xb, xs, pc - NPA);
+              if (pc < NPA) store_piece<AKC, BM, BK, true, SC, NT>(An, xa, xs, pc);
+              else if (pc < NP) store_piece<BKC, BN, BK, true, false, NT>(An + kBoff, xb, xs, pc - NPA);
             }
           }
         });
@@ -483,12 +488,12 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int tile_id
   }
   // ---- generic guarded slabs: everything when the fast path does not apply, otherwise only the K tail
   for (int k0 = kdone; k0 < ke; k0 += BK) {
-    load_slab<AKC, BM, BK, VEC>(A, p.lda, m0, p.M, k0, ke, ra);
-    load_slab<BKC, BN, BK, VEC>(B, p.ldb, n0, p.N, k0, ke, rb);
+    load_slab<AKC, BM, BK, VEC, NT>(A, p.lda, m0, p.M, k0, ke, ra);
+    load_slab<BKC, BN, BK, VEC, NT>(B, p.ldb, n0, p.N, k0, ke, rb);
     if constexpr (SC) load_scale<BK, VEC>(kscale, k0, ke, rs);
     __syncthreads();                                        // previous slab fully consumed
-    store_slab<AKC, BM, BK, VEC, SC>(stage0, ra, rs);
-    store_slab<BKC, BN, BK, VEC, false>(stage0 + kBoff, rb, rs);
+    store_slab<AKC, BM, BK, VEC, SC, NT>(stage0, ra, rs);
+    store_slab<BKC, BN, BK, VEC, false, NT>(stage0 + kBoff, rb, rs);
     __syncthreads();
     slab_mfma(stage0, stage0 + kBoff, [](int) {});
   }
@@ -812,17 +817,22 @@ struct CholArgs {
   ZeroJobs zero;     // third role (the last nzero workgroups): zero-fills of the caller, free under the pivot chains
   int nzero;
 };
-template <int KC, int SETS, int BM, int BK, bool SCALED = true, class R = double>
-__global__ __launch_bounds__(256) void chol_rbf_gemm_kernel(const CholArgs c, const GemmParams p, const int tiles) {
+// NT = 512 (round 4): the launch is held to one workgroup per CU by its LDS reservation, so the GEMM role runs one wave per
+// SIMD at 256 threads; with 512 threads the same 128 x 64 tile is worked by 8 waves (two per SIMD); the factorisation and
+// zero-fill roles use the first four waves (the others leave at once: a finished wave no longer counts at s_barrier).
+template <int KC, int SETS, int BM, int BK, bool SCALED = true, class R = double, int NT = 256>
+__global__ __launch_bounds__(NT) void chol_rbf_gemm_kernel(const CholArgs c, const GemmParams p, const int tiles) {
   // one LDS array for both roles (the factorisation stages its matrix through 40 KB of it): 2 workgroups per CU
   __shared__ __attribute__((aligned(16))) float lds[cmax(gemm_lds_floats<BM, 64, BK, true, true>(), chol3_stage_floats<KC>())];
   if ((int)blockIdx.x < c.nchol) {
+    if (NT > 256 && threadIdx.x >= 256) return;
     chol3_body<KC, SETS, R>(blockIdx.x, c.A, c.lda, c.sA, c.eps, c.L, c.ldl, c.sL, c.T, c.ldt, c.sT, nullptr, c.info, 0, c.n,
                             0, lds, c.extra.base ? &c.extra : nullptr);
     return;
   }
   const int ngemm = (int)gridDim.x - c.nchol - c.nzero;
   if ((int)blockIdx.x >= c.nchol + ngemm) {
+    if (NT > 256 && threadIdx.x >= 256) return;
     zero_jobs_role(c.zero, (int)blockIdx.x - c.nchol - ngemm, c.nzero);
     return;
   }
@@ -831,7 +841,7 @@ __global__ __launch_bounds__(256) void chol_rbf_gemm_kernel(const CholArgs c, co
   if (threadIdx.x == 0 && ((int)blockIdx.x == c.nchol || (int)blockIdx.x == c.nchol + ngemm - 1))
     g_chol_phase[((int)blockIdx.x == c.nchol ? 32 : 40)] = __builtin_amdgcn_s_memrealtime();
 #endif
-  gemm_body<BM, 64, BK, true, true, true, true, SCALED>(p, id % tiles, id / tiles, 0, lds);
+  gemm_body<BM, 64, BK, true, true, true, true, SCALED, NT>(p, id % tiles, id / tiles, 0, lds);
 #ifdef VARGP_CHOL_PHASES
   if (threadIdx.x == 0 && ((int)blockIdx.x == c.nchol || (int)blockIdx.x == c.nchol + ngemm - 1))
     g_chol_phase[((int)blockIdx.x == c.nchol ? 32 : 40) + 1] = __builtin_amdgcn_s_memrealtime();
@@ -993,6 +1003,8 @@ static int launch_chol_rbf_gemm_impl(const float* A, float eps, float* L, float*
     if (big) hipLaunchKernelGGL((chol_rbf_gemm_kernel<KC, SETS, 128, 32, true, R>), dim3(total), dim3(256), pad, st, c, q, tiles);    \
     else hipLaunchKernelGGL((chol_rbf_gemm_kernel<KC, SETS, 64, 64, true, R>), dim3(total), dim3(256), pad, st, c, q, tiles);       \
   } while (0)
+  // (an 8-wave GEMM role -- chol_rbf_gemm_kernel<..., NT = 512>, gemm_body<..., NT = 512>: the same 128 x 64 tile on two waves
+  // per SIMD -- measured 37.7 us against 39.1 us for the K_uf product alone and nothing for the launch: not instantiated)
   if (f32_env) { if (n <= 64) VARGP_MERGED(16, 1, float); else VARGP_MERGED(25, 2, float); }
   else { if (n <= 64) VARGP_MERGED(16, 1, double); else VARGP_MERGED(25, 2, double); }
 #undef VARGP_MERGED

@@ -34,7 +34,7 @@ class VARGP(nn.Module):
         self.fused_tasks = True          # ... and of a model with previous tasks as the block-structured program
         # native block programs: training programs per shape (+ spares while one is owned by a pending backward), ONE
         # forward-only program (moments only, no gradient buffers) sized for the widest batch seen, serving narrower ones
-        self._tn_ops, self._tn_progs, self._tn_spares, self._tn_eval = None, {}, {}, None
+        self._tn_ops, self._tn_progs, self._tn_spares, self._tn_eval, self._tn_eval_exact = None, {}, {}, None, {}
         self._t0_progs, self._t0_spares = {}, {}       # first-task programs (csrc/elbo_t0.hip) of the autograd route, per shape
         # frozen earlier tasks: plain dicts, not buffers (same as the reference, vargp.py:17-20);
         # u_tril is materialised lazily on first use because that needs the device the params live on
@@ -106,7 +106,7 @@ class VARGP(nn.Module):
         return linear_marginal_diag(mu_leq_t, S_leq_t, Kzz, Kzx, Kxx_diag, cache=cache)
 
     # -- the block-structured native program (csrc/elbo_tn.hip) ------------------------------------------------------
-    def first_task_as_block(self):
+    def first_task_as_block(self, B=None):
         """First-task models outside the range of the LDS-resident forward middle of csrc/elbo_t0.hip (M <= 104 and at most
         2048 (sample, class, 64-column) tiles, i.e. S C <= 256 at B = 512) run faster as the one-block case of the block
         program (csrc/elbo_tn.hip: symmetric K_uu tiles, the factorisation's pivot chains beside the K_uf row slices, paired
@@ -118,13 +118,17 @@ class VARGP(nn.Module):
         if env is not None:
             return env == '1'
         n_v = 1 if self.kernel.map_est else self.n_v
-        return self.M > 104 or n_v * self.z.size(0) > 256
+        # the LDS-resident middles of csrc/elbo_t0.hip take at most 2048 (sample, class, 64-column) tiles: S C <= 256 at the
+        # reference's batch of 512, <= 64 at B = 2048, <= 1024 at B = 128.  B unknown (the trainer decides its program before
+        # it has seen a batch): the reference's 512.
+        ntile = (int(B if B is not None else 512) + 63) // 64
+        return self.M > 104 or n_v * self.z.size(0) * ntile > 2048
 
     def _tn_applicable(self):
         return (self.fused_tasks and type(self.kernel) is RBFKernel and self.z.is_cuda
                 and all(p['z'].shape[-2] == self.M for p in self.prev_params))
 
-    def _use_block_program(self):
+    def _use_block_program(self, B=None):
         """Does `loss` run on the block program (csrc/elbo_tn.hip)?  Models with previous tasks: ep_var_mean=True only (the
         KL of the ablation depends on a u_<t sample); first-task models: when first_task_as_block() says so -- the mask is
         irrelevant without previous tasks -- and fused_first_task has not been cleared."""
@@ -132,7 +136,7 @@ class VARGP(nn.Module):
             return False
         if self.prev_params:
             return self.var_mean_mask == 1.0
-        return self.fused_first_task and self.first_task_as_block()
+        return self.fused_first_task and self.first_task_as_block(B)
 
     def _tn_operands(self):
         """z_all (C, Mt, D), rk_all (C, nblk, M, NR): earlier tasks packed once, the last block is the program's scratch."""
@@ -181,10 +185,20 @@ class VARGP(nn.Module):
     def _tn_eval_program(self, B, exact=False):
         """The forward-only program (predictive moments, no gradient buffers): one per model, carved for the widest batch
         asked for so far; narrower batches (the ragged last one of a sweep) run on it through the tile calls."""
-        prog = self._tn_eval
         S = 1 if self.kernel.map_est else self.n_v
         key = (S, self.z.size(0), self.M, self.z.size(-1), self.likelihood.n_f, len(self.prev_params) + 1)
-        if (prog is None or prog.shape[4] < B or (exact and prog.shape[4] != B) or (prog.shape[:4] + prog.shape[5:]) != key
+        if exact:
+            # D <= 32 (the direct distance form) has no tile mode: one small program per batch size, kept -- an accuracy sweep
+            # with a ragged last batch would otherwise free and re-carve the single workspace twice per data set
+            prog = self._tn_eval_exact.get(key + (B,))
+            if prog is None or prog.ws.device != self.z.device:
+                if len(self._tn_eval_exact) >= 8:
+                    self._tn_eval_exact.clear()
+                prog = self._tn_eval_exact[key + (B,)] = fused.TnProgram(*key[:4], B, *key[4:], self.z.device,
+                                                                         self.kernel.map_est, forward_only=True)
+            return prog
+        prog = self._tn_eval
+        if (prog is None or prog.shape[4] < B or (prog.shape[:4] + prog.shape[5:]) != key
                 or prog.ws.device != self.z.device):
             self._tn_eval = None          # release the old workspace before carving the wider one
             prog = self._tn_eval = fused.TnProgram(*key[:4], B, *key[4:], self.z.device, self.kernel.map_est, forward_only=True)
@@ -192,7 +206,7 @@ class VARGP(nn.Module):
 
     def release_programs(self):
         """Drop every cached native program (workspaces of several GB at Mt ~ 2000); they are re-created on demand."""
-        self._tn_progs, self._tn_spares, self._tn_eval = {}, {}, None
+        self._tn_progs, self._tn_spares, self._tn_eval, self._tn_eval_exact = {}, {}, None, {}
         self._t0_progs, self._t0_spares = {}, {}
 
     def _tn_args(self):
@@ -277,7 +291,7 @@ class VARGP(nn.Module):
     def loss(self, x, y):
         """(kl_hypers, kl_u, nll); the caller combines beta*kl_hypers + kl_u + (N/B)*nll
         (vargp.py:177-194, experiments/vargp.py:34)."""
-        block = self._use_block_program()
+        block = self._use_block_program(x.size(0))
         if not self.prev_params and self.fused_first_task and type(self.kernel) is RBFKernel and not block:
             # first task: the native program (csrc/elbo_t0.hip) as one autograd node
             return fused.elbo_t0(self.kernel, self.z, self.u_mean, self.u_tril_vec, x, y, *self.draw_t0_noise(x),
