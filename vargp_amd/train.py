@@ -91,7 +91,7 @@ class ElboTrainer:
                         and type(gp.kernel).__name__ == 'RBFKernel') or self._tn                           # csrc/elbo_t0.hip
         # one program (descriptor + workspace) PER SHAPE, never freed: a captured hipGraph holds raw pointers into the
         # program it was captured with, and the ragged last minibatch of an epoch runs eagerly through another shape
-        self._progs, self._prog, self._seeds, self._own_grads = {}, None, {}, None
+        self._progs, self._prog, self._seeds, self._own_grads, self._scratch_grads = {}, None, {}, None, {}
         # with our Yogi (one parameter group) the program's first kernel also advances the optimiser's step count
         self._bump = None
         # native noise: the program draws eps_theta / eps_f itself (Philox keyed by noise_seed, device-side step
@@ -304,8 +304,11 @@ class ElboTrainer:
         scal = self._prog.forward(kern.log_mean.detach(), kern.log_logvar.detach(), kern.prior_log_mean,
                                   kern.prior_log_logvar, gp.z.detach(), gp.u_mean.detach(), gp.u_tril_vec.detach(), *packed,
                                   x, y, eps_theta, eps_f, bump=self._bump, **extra)
-        self._prog.backward(self._seeds[key], kern.log_mean.grad, kern.log_logvar.grad, gp.z.grad, gp.u_mean.grad,
-                            gp.u_tril_vec.grad, defer_hyper=defer_hyper)
+        # (a tensor that is frozen / not among the optimiser's parameters has no .grad: the program still writes all five
+        # gradients, those into scratch)
+        gbuf = lambda t: t.grad if t.grad is not None else self._scratch_grads.setdefault(id(t), torch.empty_like(t))
+        self._prog.backward(self._seeds[key], gbuf(kern.log_mean), gbuf(kern.log_logvar), gbuf(gp.z), gbuf(gp.u_mean),
+                            gbuf(gp.u_tril_vec), defer_hyper=defer_hyper)
         return scal
 
     def _local_part(self, x, y):
