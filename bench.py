@@ -463,8 +463,8 @@ def run_workload(name, args, device, world, rank, use_dist, steps, warmup, prima
     Mt = M * (N_PREV + 1)
     block_prog = N_PREV > 0 or gp.first_task_as_block()      # which native program runs this model (vargp.py)
     if not block_prog:
-        candidates = [('chol_rbf_gemm', flops_kuf, 'chol_rbf_gemm_kernel (K_uu/S_u factorisations, fp64, latency-bound, sharing '
-                       'one launch with the K_uf = rbf(z, x) distance GEMM; flops counted: the GEMM)'),
+        candidates = [('chol_rbf_gemm', flops_kuf, 'chol_rbf_gemm_kernel (K_uu/S_u factorisations -- register-resident pivot chains, four '
+                       'pivots per barrier -- sharing one launch with the K_uf = rbf(z, x) distance GEMM; flops counted: the GEMM)'),
                       ('rbf_kuf_bwd_gemm', 2.0 * S * C * M * B * D, 't0_bwdmat_gemm_kernel (P_uf = W_uf x of the kernel-matrix '
                        'backward, [C*M x B] x [B x D] per sample, sharing one launch with the per-matrix adjoint chains of '
                        'the factorisations; flops counted: the product)'),

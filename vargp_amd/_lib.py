@@ -162,6 +162,10 @@ def require_device(*tensors):
 
 
 def stream_ptr():
+    # (torch.cuda.current_stream() builds a Stream object: ~20 us per call, three calls per training step on the eager route)
+    raw = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+    if raw is not None:
+        return c_void_p(raw(torch.cuda.current_device()))
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
