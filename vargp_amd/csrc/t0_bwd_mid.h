@@ -299,23 +299,36 @@ __global__ __launch_bounds__(256) void t0_bwd_mid_kernel(const float* __restrict
     float pm = 0.f, pv = 0.f, contrib = 0.f;
 #pragma unroll
     for (int c = 0; c < kBmSmC; ++c) ssd[c] = c < C ? sqrtf(ssd[c]) : 1.f;
+    // (padded slots are skipped by wave-uniform branches -- no loads inside them: likelihood samples beyond F per f-group,
+    // classes in groups of four beyond C: at F = 10, C = 10 that is 2.5 x 12 of the 4 x 16 slots)
 #pragma unroll
     for (int q = 0; q < kBmSmF; ++q) {
-      const bool live = fg + 4 * q < sm.F && n0 + (tid & 63) < B;
+      if (fg + 4 * q >= sm.F) continue;                       // uniform: fg is the wave index
+      const bool live = n0 + (tid & 63) < B;
       float v[kBmSmC], mx = -INFINITY, fy = 0.f, eme = 0.f;
 #pragma unroll
-      for (int c = 0; c < kBmSmC; ++c) {
-        v[c] = c < C ? fmaf(ssd[c], sev[q][c], smu[c]) : -INFINITY;
-        mx = fmaxf(mx, v[c]);
-        if (c == syb) fy = v[c];
-        if (c == cme) eme = sev[q][c];
+      for (int c = 0; c < kBmSmC; ++c) v[c] = -INFINITY;
+#pragma unroll
+      for (int cg = 0; cg < kBmSmC / 4; ++cg) {
+        if (4 * cg >= C) continue;                             // uniform
+#pragma unroll
+        for (int c = 4 * cg; c < 4 * cg + 4; ++c) {
+          v[c] = c < C ? fmaf(ssd[c], sev[q][c], smu[c]) : -INFINITY;
+          mx = fmaxf(mx, v[c]);
+          if (c == syb) fy = v[c];
+          if (c == cme) eme = sev[q][c];
+        }
       }
       float se = 0.f, vme = 0.f;
 #pragma unroll
-      for (int c = 0; c < kBmSmC; ++c) {
-        const float e = c < C ? expf(v[c] - mx) : 0.f;
-        se += e;
-        if (c == cme) vme = e;
+      for (int cg = 0; cg < kBmSmC / 4; ++cg) {
+        if (4 * cg >= C) continue;                             // uniform
+#pragma unroll
+        for (int c = 4 * cg; c < 4 * cg + 4; ++c) {
+          const float e = c < C ? expf(v[c] - mx) : 0.f;
+          se += e;
+          if (c == cme) vme = e;
+        }
       }
       const float pc = vme * (sc1 / se) - (cme == syb ? sc1 : 0.f);
       if (live) { pm += pc; pv += pc * eme; contrib -= (fy - (mx + logf(se))) * sc1; }
