@@ -34,6 +34,14 @@ def test_toy_two_tasks_learn_and_checkpoint(tmp_path):
     assert torch.allclose(sd1['kernel.prior_log_mean'].cpu(), sd0['kernel.log_mean'].cpu())
 
 
+def test_toy_retrain_with_shared_hyper_sweeps(tmp_path):
+    """`toy --retrain --eval_shared_hypers` -- the accuracy sweeps call predict(x, tile=...) on a VARGPRetrain model
+    (which had no `tile` parameter): runs through both tasks and evaluates."""
+    log, sc = _run(['toy', '--retrain', '--eval_shared_hypers', '--epochs', '40', '--eval_interval', '20', '--seed', '5'], tmp_path)
+    assert all(v == v for v in sc.values())
+    assert 0.0 <= sc[('task1/test/acc', 40)] <= 1.0 and os.path.exists(log / 'ckpt1.pt')
+
+
 def test_split_mnist_synthetic_graph_mode(tmp_path):
     log, sc = _run(['s-mnist', '--synthetic', '--n_synth', '3000', '--epochs', '4', '--eval_interval', '2', '--M', '20',
                     '--graph', '--seed', '2'], tmp_path)
