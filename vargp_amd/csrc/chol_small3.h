@@ -24,6 +24,14 @@
 //   * look-ahead: the wave holding row j + 1 updates that slot first in step j and publishes it at once (pivot by
 //     v_readlane, reciprocal by rcp + Newton), so the one barrier per pivot rarely waits.
 // 1/d_j by v_rcp_f64 + two Newton steps; matrix I/O staged through LDS (coalesced global access, transposition for L).
+//
+// Round 4 (what runs by default, VARGP_CHOL_BLOCK4 = 1): the elimination takes FOUR pivots per barrier (chol4_steps below: the
+// block's four rows through LDS once, the 4 x 4 in-block elimination redundantly in every wave, multipliers of the rank-4 update
+// by v_readlane from the wave's own copy of the eliminated rows -- no LDS broadcast reads); the arithmetic is a template
+// parameter (fp64, or the reference's fp32 inside the merged first-task launch); a row's two column sets are one 2-vector
+// (v_pk_fma_f32 in fp32); every load of the I/O phases is unconditional on clamped indices and float4 where the rows allow, L
+// and T leave through one staging matrix.  The rank-1 version described above (chol3_publish / chol3_steps) is kept behind
+// VARGP_CHOL_BLOCK4 = 0 as the reference point of DESIGN_HISTORY.md's measurements.
 #pragma once
 #include "common.h"
 #include <math.h>
