@@ -408,6 +408,11 @@ def run_workload(name, args, device, world, rank, use_dist, steps, warmup, prima
         run = trainer.step_graph
     else:
         run = lambda: trainer.step(x, y)
+    # The CPU oracle (ELBO check above, cpu_baseline of the previous workload) leaves its OpenMP workers spinning for ~200 ms
+    # after their last parallel region; on a box whose CPU quota they exhaust, the launching thread is starved and a short timed
+    # region (30 steps = 18 ms) picks up a 20 ms stall (seen as mean = 2 x median on smnist_t1 in the default line only).  Let
+    # them go to sleep before the warm-up.
+    time.sleep(0.3)
     for _ in range(warmup):
         run()
     sync()
