@@ -178,8 +178,14 @@ class _ElboT0(Function):
         seeds = torch.stack([g_klh.reshape(()), g_klu.reshape(()), g_nll.reshape(())]).float()
         sh_mean, sh_z, sh_um, sh_uv = ctx.shapes
         dev = seeds.device
-        g_mean, g_logvar = torch.empty(sh_mean, device=dev), torch.empty(sh_mean, device=dev)
-        g_z, g_um, g_uv = torch.empty(sh_z, device=dev), torch.empty(sh_um, device=dev), torch.empty(sh_uv, device=dev)
+        # the five gradients as views of ONE allocation (each starting on a 256-byte boundary): one allocator call instead of five
+        ns = [sh_mean.numel(), sh_mean.numel(), sh_z.numel(), sh_um.numel(), sh_uv.numel()]
+        offs, tot = [], 0
+        for n in ns:
+            offs.append(tot)
+            tot += (n + 63) // 64 * 64
+        flat = torch.empty(tot, dtype=torch.float32, device=dev)
+        g_mean, g_logvar, g_z, g_um, g_uv = (flat[o:o + n].view(sh) for o, n, sh in zip(offs, ns, (sh_mean, sh_mean, sh_z, sh_um, sh_uv)))
         prog.backward(seeds, g_mean, g_logvar, g_z, g_um, g_uv)
         _release(prog, ctx.gen)
         ctx.prog = None

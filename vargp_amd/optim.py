@@ -19,6 +19,11 @@ class Yogi(torch.optim.Optimizer):
         # True: somebody else advances the device-side step count before step() (ElboTrainer lets the ELBO
         # program's first kernel do it), so step() launches nothing but the update kernel
         self.external_step = False
+        self._chunk_cache = {}
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._chunk_cache = {}                 # the moment buffers are new tensors
 
     def step_counter(self, device):
         """The device-side step count of the (single) parameter group."""
@@ -44,29 +49,38 @@ class Yogi(torch.optim.Optimizer):
             if not self.external_step:
                 group['step'].add_(1.0)
             for p in ps:
-                require_device(p, p.grad)
                 st = self.state[p]
                 if not st:
+                    require_device(p, p.grad)
                     st['exp_avg'] = torch.full_like(p, group['initial_accumulator'])
                     st['exp_avg_sq'] = torch.full_like(p, group['initial_accumulator'])
             for i in range(0, len(ps), 8):
                 chunk = ps[i:i + 8]
                 k = len(chunk)
                 grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in chunk]
+                if not all(g.is_cuda for g in grads):
+                    require_device(*grads)
                 arr = lambda ts: (ctypes.c_void_p * k)(*[t.data_ptr() for t in ts])
-                sizes = (ctypes.c_int64 * k)(*[p.numel() for p in chunk])
-                ids = [id(p) for p in chunk]
+                # parameters and moment buffers keep their addresses from step to step: their pointer arrays are built once
+                # per chunk (the eager drop-in loop is host-bound; this call used to cost ~60 us of Python)
+                key = tuple(id(p) for p in chunk)
+                cached = self._chunk_cache.get(key)
+                if cached is None or cached[0] != tuple(p.data_ptr() for p in chunk):
+                    cached = (tuple(p.data_ptr() for p in chunk), arr(chunk), arr([self.state[p]['exp_avg'] for p in chunk]),
+                              arr([self.state[p]['exp_avg_sq'] for p in chunk]),
+                              (ctypes.c_int64 * k)(*[p.numel() for p in chunk]))
+                    self._chunk_cache[key] = cached
+                _, a_p, a_m, a_v, sizes = cached
+                ids = list(key)
                 if hyper is not None and id(hyper[1]) in ids:
                     h, p_mean, p_logvar = hyper
                     i_lv = ids.index(id(p_logvar)) if (p_logvar is not None and id(p_logvar) in ids) else -1
                     check(lib().vargp_yogi_step_multi_hyper(
-                        k, arr(chunk), arr(grads), arr([self.state[p]['exp_avg'] for p in chunk]),
-                        arr([self.state[p]['exp_avg_sq'] for p in chunk]), sizes, group['lr'], b1, b2, group['eps'],
+                        k, a_p, arr(grads), a_m, a_v, sizes, group['lr'], b1, b2, group['eps'],
                         ptr(group['step']), 0, ctypes.byref(h), ids.index(id(p_mean)), i_lv, stream_ptr()),
                         'vargp_yogi_step_multi_hyper')
                     continue
-                check(lib().vargp_yogi_step_multi(k, arr(chunk), arr(grads), arr([self.state[p]['exp_avg'] for p in chunk]),
-                                                  arr([self.state[p]['exp_avg_sq'] for p in chunk]), sizes,
+                check(lib().vargp_yogi_step_multi(k, a_p, arr(grads), a_m, a_v, sizes,
                                                   group['lr'], b1, b2, group['eps'], ptr(group['step']), 0,
                                                   stream_ptr()),
                       'vargp_yogi_step_multi')
