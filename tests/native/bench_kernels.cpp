@@ -86,6 +86,20 @@ int main(int argc, char** argv) {
     double us = time_us([&] { gemm(W, Y, P, 1000, 784, 512, 0, 0, 3, 1000L * 512, 0, 1000L * 784); }, iters);
     printf("kufbwd [1000x512]x[512x784] b3     %8.1f us  -> %.1f TFLOP/s\n", us, 2.0 * 3 * 1000 * 784 * 512 / us * 1e-6);
   }
+  if (which == "hot") {   // the two big products of the Cfg2 step as plain GEMMs, every tile shape (timing experiments)
+    float* Z = dev_rand((size_t)1000 * 784, 1.f, 4);
+    float* X = dev_rand((size_t)512 * 784, 1.f, 5);
+    float* W = dev_rand((size_t)3 * 1000 * 512, 1.f, 4);
+    float* P; CK(hipMalloc(&P, (size_t)3 * 1000 * 784 * 4));
+    for (int tile = 0; tile <= 3; ++tile) {
+      vargp_tune_gemm_tile(tile);
+      double a = time_us([&] { gemm(Z, X, P, 1000, 512, 784, 0, 1, 3, 0, 0, 1000L * 512); }, iters);
+      double b = time_us([&] { gemm(W, X, P, 1000, 784, 512, 0, 0, 3, 1000L * 512, 0, 1000L * 784); }, iters);
+      printf("hot tile %d   K_uf-shaped NT [1000x784]x[512x784]^T b3 %7.1f us (%.1f TF)   P_uf-shaped NN [1000x512]x[512x784] b3 %7.1f us (%.1f TF)\n",
+             tile, a, 2.408e9 / a * 1e-6, b, 2.408e9 / b * 1e-6);
+    }
+    vargp_tune_gemm_tile(0);
+  }
   if (want("gemm4k")) {
     const int n = 4096;
     float* A = dev_rand((size_t)n * n, 1.f, 6);
