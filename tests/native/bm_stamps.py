@@ -31,31 +31,50 @@ if len(sys.argv) > 1 and sys.argv[1] == 'tail':     # t0_puu_final_kernel (a -DT
     print('%-32s %8d cycles' % ('total', v[13] - v[0]))
     sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == 'mat':      # t0_bwd_mat_body (a -DBMAT_STAMPS build of gemm.hip)
-    out = (ctypes.c_ulonglong * 24)()
+    out = (ctypes.c_ulonglong * 96)()                # [wave][stamp]
     fn = _lib.lib().vargp_debug_bmat_stamps
     fn.restype, fn.argtypes = None, [ctypes.c_void_p]
     fn(out)
-    names = {(0, 1): 'loads + stage T, gG, L_S', (1, 2): 'gG L_S^T', (2, 3): 'T^T ga', (3, 5): 'gTT loads + barrier',
-             (5, 6): 'stage gG2, Lu', (6, 7): 'gG2 Lu^T, T^T gG2 + atomics', (7, 8): 'barrier', (8, 9): 'gT -> X1 + barrier',
+    names = {(0, 1): 'loads + stage gG, L_S', (1, 2): 'gG L_S^T', (2, 3): 'stage T, ga, m + barrier', (3, 5): 'stage gG2, Lu; T^T ga + barrier',
+             (5, 6): 'g_u_mean atomics', (6, 7): 'gG2 Lu^T, T^T gG2 + atomics', (7, 8): 'barrier', (8, 9): 'gT -> X1 + barrier',
              (9, 10): 'w1 = gT T^T', (10, 11): 'S -> X2 + barrier', (11, 12): 'K loads, tmp = T^T S', (12, 13): 'tmp -> X1 + barriers',
              (13, 14): 'gK = tmp T', (14, 15): 'W -> X2 + barrier', (15, 16): 'rows out, row sums'}
-    v = list(out)
+    v = [list(out)[24 * w:24 * w + 24] for w in range(4)]
+    print('%-32s %s' % ('cycles per wave', ''.join('%9s' % ('wave %d' % w) for w in range(4))))
     for (i, j), n in names.items():
-        print('%-32s %8d cycles' % (n, v[j] - v[i]))
-    print('%-32s %8d cycles' % ('total', v[16] - v[0]))
-    sys.exit(0)
-    v = list(out)
-    for i, n in enumerate(names):
-        print('%-32s %8d cycles' % (n, v[i + 1] - v[i]))
-    print('%-32s %8d cycles' % ('total', v[16] - v[0]))
+        print('%-32s %s' % (n, ''.join('%9d' % (v[w][j] - v[w][i]) for w in range(4))))
+    print('%-32s %s' % ('total', ''.join('%9d' % (v[w][16] - v[w][0]) for w in range(4))))
+    # wall-clock spans of the two roles over ONE more step (100 MHz ticks -> us)
+    sp = _lib.lib().vargp_debug_bmat_span
+    sp.restype, sp.argtypes = None, [ctypes.c_void_p, ctypes.c_int]
+    span = (ctypes.c_ulonglong * 8)()
+    tr.capture(x, y)
+    for _ in range(300):                              # steady state (clocks up) before the step that is measured
+        tr.step_graph()
+    torch.cuda.synchronize()
+    sp(span, 1)
+    tr.step_graph()
+    torch.cuda.synchronize()
+    sp(span, 0)
+    t = list(span)
+    t0 = min(t[0], t[4])
+    for r, n in ((0, 'matrix chains'), (1, 'P_uf tiles')):
+        print('%-14s first start %6.2f us, last start %6.2f, last end %6.2f' % (n, (t[4 * r] - t0) / 100., (t[4 * r + 2] - t0) / 100.,
+                                                                                  (t[4 * r + 1] - t0) / 100.))
+    su = v[3][17:22]
+    print('S_u role (first class, wave 0): samples %d, stage gL / T_S / L_S %d, L_S^T gL and S -> X2 %d, tail %d, total %d cycles'
+          % (su[1] - su[0], su[2] - su[1], su[3] - su[2], su[4] - su[3], su[4] - su[0]))
     sys.exit(0)
 out = (ctypes.c_ulonglong * 16)()
 fn = _lib.lib().vargp_debug_bm_stamps
 fn.restype, fn.argtypes = None, [ctypes.c_void_p]
 fn(out)
-names = ['issue loads', 'wait loads + LDS stores', 'barrier', 'phase 1 (gW, ga)', 'tri product 1 + atomics', 'product 2 (gP)',
-         'barrier', 'gP/T/K_uf -> LDS + barrier', 'tri product 3 + atomics', 'product 4 (gK_uf)', 'epilogue W_uf', 'barrier', 'tail']
+names = {(0, 13): 'issue all loads', (13, 14): 'softmax: wait its loads + evaluate', (14, 15): 'f-groups meet in LDS + barrier',
+         (15, 1): 'column sums, nll atomic', (1, 2): 'wait G/P/W, LDS stores + barrier', (2, 3): 'phase 1 (gW, ga) + barrier',
+         (3, 4): 'phase 2: tril(P gW^T) atomics, gP', (4, 6): 'barrier', (6, 7): 'phase 3: gP/T/K_uf -> LDS + barrier',
+         (7, 8): 'phase 4: tril(gP K_uf^T) atomics, gK_uf', (8, 10): 'tail atomics, W_uf -> LDS', (10, 11): 'barrier',
+         (11, 12): 'W_uf rows out, row / column sums'}
 v = list(out)
-for i, n in enumerate(names):
-    print('%-32s %8d cycles' % (n, v[i + 1] - v[i]))
-print('%-32s %8d cycles' % ('total', v[12] - v[0]))
+for (i, j), n in names.items():
+    print('%-44s %8d cycles' % (n, v[j] - v[i]))
+print('%-44s %8d cycles' % ('total', v[12] - v[0]))

@@ -6,6 +6,40 @@
 #include <functional>
 #include "../../include/vargp_hip.h"
 
+// Tuning builds only (-DSTEP_SPANS, tests/native/step_spans.py): wall-clock (100 MHz) of the first workgroup's start and the last
+// workgroup's end of each kernel of the first-task step -- the time line of the step as the GPU sees it, to set against the
+// dispatch-to-completion durations rocprofv3 reports.  One table per translation unit.
+#if defined(STEP_SPANS) && defined(__HIPCC__)
+namespace vargp {
+struct SpanGuard {
+  unsigned long long* p;
+  __device__ __forceinline__ explicit SpanGuard(unsigned long long* q) : p(q) {
+    // (start: the first workgroup's, a plain store -- an atomic with a result from every workgroup serialises them on one address)
+    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) p[0] = wall_clock64();
+  }
+  __device__ __forceinline__ ~SpanGuard() { if (threadIdx.x == 0) atomicMax(&p[1], wall_clock64()); }
+};
+}  // namespace vargp
+#define STEP_SPAN_TABLE(tu)                                                                                      \
+  __device__ unsigned long long g_spans_##tu[12][4];                                                              \
+  extern "C" void vargp_debug_spans_##tu(unsigned long long* out, int reset) {                                   \
+    if (reset) {                                                                                                 \
+      unsigned long long init[12][4];                                                                             \
+      for (int i = 0; i < 12; ++i) { init[i][0] = ~0ull; init[i][1] = init[i][2] = init[i][3] = 0; }              \
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_spans_##tu), init, sizeof(init));                                     \
+    } else {                                                                                                     \
+      (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_spans_##tu), 12 * 4 * sizeof(unsigned long long));              \
+    }                                                                                                            \
+  }
+#define STEP_SPAN(tu, i) vargp::SpanGuard step_span_guard_(g_spans_##tu[i])
+// (the end of one role of a multi-role kernel: slot i holds the last workgroup's end)
+#define STEP_SPAN_MARK(tu, i) do { if (threadIdx.x == 0) atomicMax(&g_spans_##tu[i][1], wall_clock64()); } while (0)
+#else
+#define STEP_SPAN_TABLE(tu)
+#define STEP_SPAN(tu, i) do { } while (0)
+#define STEP_SPAN_MARK(tu, i) do { } while (0)
+#endif
+
 namespace vargp {
 
 constexpr int kWave = 64;
@@ -171,7 +205,7 @@ struct BwdMatArgs {
   const float *TT, *LL, *gQP, *RK, *KS, *seeds;     // TT / LL / KS: [S C + C][M][M]
   const float* gTT;
   float *gKS, *Wuu, *r_uu, *gtheta;
-  float *g_u_mean, *gLu_acc;                        // [C][M], [C][M][M]: sums over s, accumulated with atomics (pre-zeroed)
+  float *g_u_mean, *gLu_part;                       // [C][M]: sum over s, accumulated with atomics (pre-zeroed); [S][C][M][M]: per-sample shares (lower triangles written)
   int S, C, M, D, NR, LD;
 };
 int launch_bwdmat_gemm(const BwdMatArgs& a, int first, int nmat, const GemmParams& p, int nbatch, hipStream_t st,

@@ -5,6 +5,8 @@
 #include <vector>
 #include <string.h>
 
+STEP_SPAN_TABLE(core)
+
 namespace vargp {
 
 static thread_local char g_err[512] = "";
@@ -126,6 +128,7 @@ __device__ __forceinline__ void yogi_hyper_grad(const vargp_hyper_grad_desc& h, 
 // step_mode 0: t = step[0].  1: t = step[0] + 1 (the caller advances the stored count some other way).
 __global__ __launch_bounds__(256) void yogi_multi_kernel(YogiPack pk, int ntensors, float lr, float b1, float b2, float eps,
                                                          const float* __restrict__ step, int step_mode, const YogiHyper yh) {
+  STEP_SPAN(core, 7);
   int t = 0;
   while (t + 1 < ntensors && (int)blockIdx.x >= pk.blk_end[t]) ++t;
   const int blk = (int)blockIdx.x - (t ? pk.blk_end[t - 1] : 0);

@@ -154,7 +154,7 @@ constexpr int kFinRows = VARGP_FIN_ROWS;   // rows per workgroup of the RBF fina
 // gradient of the packed Cholesky vector of q(u):  gLu = sum_s gRK[.., Lu block] - seed_kl diag(1/Lu_ii) + 2 gS_u Lu,
 // through vec2tril (softplus on the diagonal).  One thread per (c, i, k <= i).  (A role of t0_w_kernel.)
 // gRK: [S][C][M][LD] with the Lu block at column 4 + M (summed over s here), or -- S = 1, LD = M, off = 0 -- the per-class sum
-// itself (t0_bwd_mat.h accumulates it with atomics).
+// array's layout (t0_bwd_mat.h: [S][C][M][M], lower triangles).
 __device__ __forceinline__ void t0_gvec_role(int blk, const float* __restrict__ vec, const float* __restrict__ Lu,
                                              const float* __restrict__ gSu, const float* __restrict__ gRK,
                                              const float* __restrict__ seeds, float* __restrict__ gvec, int S, int C,
@@ -198,17 +198,10 @@ __device__ __forceinline__ void t0_gvec_role(int blk, const float* __restrict__ 
 
 // arguments of the packed-Cholesky-vector gradient when it rides in t0_final_kernel's launch (gvec == NULL: off)
 struct GvecArgs {
-  const float *vec, *Lu, *gSu, *gLu_acc, *seeds;
+  const float *vec, *Lu, *gSu, *gLu_part, *seeds;      // gLu_part: [S][C][M][M] (t0_bwd_mat.h)
   float* gvec;
-  int C, M, y0;
+  int S, C, M, y0;
 };
-
-// the packed-Cholesky-vector gradient alone, from the per-class sums of t0_bwd_mat.h
-static __global__ __launch_bounds__(256) void t0_gvec_kernel(const float* __restrict__ vec, const float* __restrict__ Lu,
-                                                      const float* __restrict__ gSu, const float* __restrict__ gLu_acc,
-                                                      const float* __restrict__ seeds, float* __restrict__ gvec, int C, int M) {
-  t0_gvec_role((int)blockIdx.x, vec, Lu, gSu, gLu_acc, seeds, gvec, 1, C, M, M, 0);
-}
 
 // W = gK o K for both kernel matrices (see rbf.hip for the algebra).
 //   blocks < nuf : K_uf, in place on the K_uf block of gRK (row stride LD); row sums r_uf, column sums c_uf (atomics),
@@ -376,8 +369,8 @@ static __global__ __launch_bounds__(256) void t0_final_kernel(const float* __res
                                                        const GvecArgs gv = GvecArgs{}) {
   __shared__ float red[2][4][64];      // double-buffered by sample parity: one barrier per sample
   if (gv.gvec && (int)blockIdx.y >= gv.y0) {      // extra rows of the grid: the packed-Cholesky-vector gradient (only shares the launch)
-    t0_gvec_role(((int)blockIdx.y - gv.y0) * (int)gridDim.x + (int)blockIdx.x, gv.vec, gv.Lu, gv.gSu, gv.gLu_acc, gv.seeds, gv.gvec,
-                 1, gv.C, gv.M, gv.M, 0);
+    t0_gvec_role(((int)blockIdx.y - gv.y0) * (int)gridDim.x + (int)blockIdx.x, gv.vec, gv.Lu, gv.gSu, gv.gLu_part, gv.seeds, gv.gvec,
+                 gv.S, gv.C, gv.M, gv.M, 0);
     return;
   }
   if ((int)blockIdx.y >= nzy) {

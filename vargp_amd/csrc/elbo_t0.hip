@@ -20,6 +20,7 @@
 #include <unordered_map>
 
 #include "common.h"
+STEP_SPAN_TABLE(t0)
 #include "elbo_shared.h"
 #include "t0_bwd_mid.h"
 #include "t0_prologue.h"
@@ -253,6 +254,7 @@ __global__ __launch_bounds__(256) void t0_fwd_fused_kernel(const float* __restri
                                                            float* __restrict__ var, float* __restrict__ kl_u, int S, int C,
                                                            int M, int B, int NR, int LD, int ntile, uint32_t* rng_counter) {
   extern __shared__ __attribute__((aligned(16))) float lds_f[];
+  STEP_SPAN(t0, 3);
   float* sT = lds_f;                              // [128][TS]   T[i][k]
   float* sG = sT + 128 * kFusedTS;                // [K][GS]     G[k][i]
   float* sK = sG + kFusedK * kFusedGS;            // [K][KS]     K_uf tile [k][n], then P[m][n]
@@ -279,10 +281,22 @@ __global__ __launch_bounds__(256) void t0_fwd_fused_kernel(const float* __restri
   {
     const int c = b % C;
     const int per = (M + ntile - 1) / ntile, i0 = tile_x * per, i1 = min(M, i0 + per);
-    for (int e = tid; e < (i1 - i0) * M; e += 256) {      // branch-free: upper entries are stored zeros
-      const int i = i0 + e / M, j = e % M;
-      const float v = Qb[(int64_t)i * LD + 4 + M + j];
-      kl_acc = fmaf(j <= i ? v : 0.f, v, kl_acc);
+    // (eight loads in flight per round on clamped indices: with one load per iteration of a run-time loop every iteration
+    // is a memory round trip of its own -- six of them in front of the staging loads at the reference's shapes)
+    const int nkl = (i1 - i0) * M;
+    for (int e0 = 0; e0 < nkl; e0 += 8 * 256) {
+      float kv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = min(e0 + tid + 256 * u, nkl - 1);
+        kv[u] = Qb[(int64_t)(i0 + e / M) * LD + 4 + M + e % M];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + tid + 256 * u;
+        const int i = i0 + e / M, j = e % M;
+        kl_acc = fmaf((e < nkl && j <= i) ? kv[u] : 0.f, kv[u], kl_acc);      // upper entries are stored zeros
+      }
     }
     for (int i = i0 + tid; i < i1; i += 256) {
       const float a = Qb[(int64_t)i * LD];
@@ -397,16 +411,19 @@ __global__ __launch_bounds__(256) void t0_fwd_fused_kernel(const float* __restri
   float* Pout = QP + b * MLD + NR;
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
+    // a[m] for the block's 16 rows first, unconditionally (sa holds 128 entries, zero beyond M; rows of P beyond M are zero
+    // as well: T is zero-padded) -- an LDS read inside `if (m < M)` is waited for element by element
+    float sav[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sav[r] = sa[32 * rbs[u] + (r & 3) + 8 * (r >> 2) + 4 * lh];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = 32 * rbs[u] + (r & 3) + 8 * (r >> 2) + 4 * lh;
       const float v = accP[u][r];
       if (m < kFusedK) sK[m * kFusedKS + 32 * cb + li] = v;
-      if (m < M) {
-        if (col < B) Pout[(int64_t)m * LD + col] = v;
-        s_mu = fmaf(v, sa[m], s_mu);
-        s_p2 = fmaf(v, v, s_p2);
-      }
+      if (m < M && col < B) Pout[(int64_t)m * LD + col] = v;
+      s_mu = fmaf(v, sav[r], s_mu);
+      s_p2 = fmaf(v, v, s_p2);
     }
   }
   __syncthreads();
@@ -728,15 +745,17 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
   const T0BwdPaths bwd_paths = t0_bwd_paths(d, o);
   const bool clear_bwd = bwd_paths.mat_bwd;
   // the likelihood inside the backward's tile kernel (one launch less): only where that kernel runs and its softmax fits
-  const bool defer_softmax = d->defer_softmax && fused_softmax && bwd_paths.fused_bwd && F <= 4 * kBmSmF && C <= kBmSmC;
+  // (float4 reads of the noise there: a caller's eps_f must sit on a 16-byte boundary, the workspace's own does)
+  const bool defer_softmax = d->defer_softmax && fused_softmax && bwd_paths.fused_bwd && F <= 4 * kBmSmF && C <= kBmSmC &&
+                             reinterpret_cast<uintptr_t>(eps_f) % 16 == 0;
   t0_state_set(d->ws, (clear_bwd ? kT0Cleared : kT0NoClear) | (defer_softmax ? kT0SoftmaxDeferred : 0));
   if (clear_bwd) {
     // accumulators of the LDS-resident backward (atomics of t0_bwd_mid.h / t0_bwd_mat.h / t0_bwd_tail.h), cleared in the forward,
     // where it costs nothing (spare workgroups under the pivot chains; shapes without that launch: the prologue's zero role):
-    // column 0 (ga) and the G block of gQP, gT, the per-class sums of gLu, gkd, r_uf / c_uf / gtheta
+    // column 0 (ga) and the G block of gQP, gT, gkd, r_uf / c_uf / gtheta
     bwd_zero.j[0] = ZeroJob{o.gQP, (int64_t)SC * M, 4 + M, LD};
     bwd_zero.j[1] = ZeroJob{o.gTT, 1, (SC + C) * MM, 0};
-    bwd_zero.j[2] = ZeroJob{o.gLL + SC * MM, 1, C * MM, 0};
+    bwd_zero.j[2] = ZeroJob{nullptr, 0, 0, 0};
     bwd_zero.j[3] = ZeroJob{o.gkd, 1, SC, 0};
     bwd_zero.j[4] = ZeroJob{o.r_uf, 1, o.r_uu - o.r_uf, 0};
     if (!merge_chol) {
@@ -991,7 +1010,7 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
     BwdMatArgs ma{};
     ma.QP = o.QP; ma.TT = o.TT; ma.LL = o.LL; ma.gQP = o.gQP; ma.RK = o.RK; ma.KS = o.KS; ma.seeds = seeds; ma.gTT = o.gTT;
     ma.gKS = o.gKS; ma.Wuu = o.Wuu; ma.r_uu = o.r_uu; ma.gtheta = o.gtheta;
-    ma.g_u_mean = g_u_mean; ma.gLu_acc = o.gLL + SC * MM;        // (the S_u part of gLL is free on this path)
+    ma.g_u_mean = g_u_mean; ma.gLu_part = o.gLL;                 // (gLL is free on this path: no head launch, no Cholesky-adjoint op)
     ma.S = S; ma.C = C; ma.M = M; ma.D = D; ma.NR = NR; ma.LD = LD;
     // all S C + C matrices next to P_uf = W_uf x (which only needs the tile kernel's W_uf) ...
     rc = launch_bwdmat_gemm(ma, 0, SC + C, p1, S, st, "rbf_kuf_bwd_gemm");
@@ -1030,8 +1049,8 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
     GvecArgs gv{};
     int ngy = 0;
     if (mat_bwd) {               // the gradient of the packed Cholesky vector of q(u) from the per-class sums: extra grid rows
-      gv.vec = d->u_tril_vec; gv.Lu = o.Lu; gv.gSu = o.gKS + SC * MM; gv.gLu_acc = o.gLL + SC * MM; gv.seeds = seeds;
-      gv.gvec = g_u_tril_vec; gv.C = C; gv.M = M; gv.y0 = nzy + nxy;
+      gv.vec = d->u_tril_vec; gv.Lu = o.Lu; gv.gSu = o.gKS + SC * MM; gv.gLu_part = o.gLL; gv.seeds = seeds;
+      gv.gvec = g_u_tril_vec; gv.S = S; gv.C = C; gv.M = M; gv.y0 = nzy + nxy;
       ngy = cdiv(cdiv((int64_t)C * MM, 256), gx);
     }
     if (fused_tail) {

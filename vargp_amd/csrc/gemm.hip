@@ -23,6 +23,12 @@
 #include <string.h>
 #include <type_traits>
 
+STEP_SPAN_TABLE(gemm)
+#ifdef STEP_SPANS      // start / end of every matrix chain of the backward's merged launch
+__device__ unsigned long long g_bmat_ends[64][2];
+extern "C" void vargp_debug_bmat_ends(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bmat_ends), sizeof(g_bmat_ends)); }
+#endif
+
 namespace vargp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -711,6 +717,203 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int tile_id
   }
 }
 
+// Persistent variant of gemm_body's fast path for PLAIN products (no RBF epilogue, no D, no split-K, no triangular hints; K a
+// multiple of BK; operands as the fast path wants them -- gemm_persist_ok() on the host).  Workgroup wg of nwg walks a list
+// of tiles and treats the K slabs of ALL of them as one pipelined sequence: while the last slabs of a tile are multiplied
+// the first slabs of the next one are already on their way (global -> registers -> idle LDS stage), and a tile's result is
+// stored between two slabs.  Why: a 64 x 64 x 512 tile of the backward's P_uf product takes 13 us as a workgroup of its own
+// against 6.8 us of MFMAs -- descriptor set-up, the cold round trip of the first two slabs and the epilogue are paid per
+// tile, three times per CU (tests/native/bm_stamps.py mat: last tile starts at 39.5 us, ends at 52.8).
+// Tile order: XCD x (= wg % 8: workgroups go to the XCDs round-robin) works through the contiguous range
+// [x T / 8, (x + 1) T / 8) of the (batch, tile_m, tile_n) order, its workgroups side by side (as xcd_remap does for
+// one-tile workgroups).
+template <int BM, int BN, int BK, bool AKC, bool BKC>
+__device__ __forceinline__ void gemm_persist_body(const GemmParams& p, const int wg_, const int nwg_, const int tiles,
+                                                  const int total, float* __restrict__ lds) {
+  constexpr int NT = 256;
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+  using LA = LdsLayout<AKC, BM, BK>;
+  using LB = LdsLayout<BKC, BN, BK>;
+  constexpr int kBoff = (LA::kSize + 3) & ~3;
+  constexpr int kStage = kBoff + ((LB::kSize + 3) & ~3);
+  constexpr int NG = BK / 8, PF = (NG >= 4) ? 2 : 1;
+  const int wg = __builtin_amdgcn_readfirstlane(wg_), nwg = __builtin_amdgcn_readfirstlane(nwg_);
+  const int x = wg & 7, jx = wg >> 3, nx = (nwg - x + 7) >> 3;
+  const int lo = (int)((int64_t)total * x / 8), hi = (int)((int64_t)total * (x + 1) / 8);
+  const int nloc = (hi - lo - jx + nx - 1) / nx;          // tiles lo + jx + j nx < hi
+  if (hi - lo - jx <= 0) return;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int ns = p.K / BK;                                 // slabs per tile
+  const int ftot = nloc * ns;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+
+  constexpr int NPA = Pieces<AKC, BM, BK, true>::kCount, NPB = Pieces<BKC, BN, BK, true>::kCount, NP = NPA + NPB;
+  constexpr int HALF = (NG >= 2) ? NG / 2 : 1;
+  constexpr int PERL = (NP + HALF - 1) / HALF;
+  constexpr int PERS = (NP + (NG - HALF > 0 ? NG - HALF : 1) - 1) / (NG - HALF > 0 ? NG - HALF : 1);
+  const int64_t extA = AKC ? ((int64_t)(p.M - 1) * p.lda + p.K) : ((int64_t)(p.K - 1) * p.lda + p.M);
+  const int64_t extB = BKC ? ((int64_t)(p.N - 1) * p.ldb + p.K) : ((int64_t)(p.K - 1) * p.ldb + p.N);
+  const int stepA = 4 * (AKC ? BK : BK * p.lda), stepB = 4 * (BKC ? BK : BK * p.ldb);     // bytes per slab
+
+  // a tile of the list: batch indices, origin
+  struct Tile { int m0, n0, i0, i1, i2; };
+  auto locate = [&](int j) {
+    const int id = __builtin_amdgcn_readfirstlane(lo + jx + min(j, nloc - 1) * nx);
+    const int b = id / tiles, t = id - b * tiles;
+    Tile r;
+    r.m0 = (t / tiles_n) * BM; r.n0 = (t % tiles_n) * BN;
+    r.i2 = b % p.nb2; r.i1 = (b / p.nb2) % p.nb1; r.i0 = b / (p.nb2 * p.nb1);
+    return r;
+  };
+  // load cursor: the tile whose slabs are being fetched
+  i32x4 rsA, rsB;
+  int offA[NPA], offB[NPB];
+  auto set_load_tile = [&](int j) {
+    const Tile t = locate(j);
+    rsA = make_rsrc(p.A + t.i0 * p.sA[0] + t.i1 * p.sA[1] + t.i2 * p.sA[2], (int)(4 * extA));
+    rsB = make_rsrc(p.B + t.i0 * p.sB[0] + t.i1 * p.sB[1] + t.i2 * p.sB[2], (int)(4 * extB));
+#pragma unroll
+    for (int c = 0; c < NPA; ++c) offA[c] = 4 * piece_offset<AKC, BM, BK>(p.lda, t.m0, p.M, c);
+#pragma unroll
+    for (int c = 0; c < NPB; ++c) offB[c] = 4 * piece_offset<BKC, BN, BK>(p.ldb, t.n0, p.N, c);
+  };
+  int jL = 0, sL = 0;                                      // local tile and slab of the NEXT load
+  auto advance_load = [&]() {
+    if (jL * ns + sL + 1 < ftot) {                         // past the end: the last slab is fetched again (and never used)
+      if (++sL == ns) { sL = 0; ++jL; set_load_tile(jL); }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int c = 0; c < TN; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+  };
+  zero_acc();
+
+  auto slab_mfma = [&](const float* As, const float* Bs, auto&& between) {
+    float af[NG][TM][4], bf[NG][TN][4];
+    auto frag = [&](int g) {
+      const int k = 8 * g + 4 * lh;
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+        if constexpr (AKC) {
+          const float4 v = *reinterpret_cast<const float4*>(&As[LA::at(wm0 + 32 * a + li, k)]);
+          af[g][a][0] = v.x; af[g][a][1] = v.y; af[g][a][2] = v.z; af[g][a][3] = v.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) af[g][a][j] = As[LA::at(wm0 + 32 * a + li, k + j)];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < TN; ++c) {
+        if constexpr (BKC) {
+          const float4 v = *reinterpret_cast<const float4*>(&Bs[LB::at(wn0 + 32 * c + li, k)]);
+          bf[g][c][0] = v.x; bf[g][c][1] = v.y; bf[g][c][2] = v.z; bf[g][c][3] = v.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bf[g][c][j] = Bs[LB::at(wn0 + 32 * c + li, k + j)];
+        }
+      }
+    };
+#pragma unroll
+    for (int g = 0; g < PF && g < NG; ++g) frag(g);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if (g + PF < NG) frag(g + PF);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int c = 0; c < TN; ++c)
+            acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][a][j], bf[g][c][j], acc[a][c], 0, 0, 0);
+      between(g);
+    }
+  };
+
+  float ra[BM * BK / NT], rb[BN * BK / NT], ra2[BM * BK / NT], rb2[BN * BK / NT];
+  const float one[4] = {1.f, 1.f, 1.f, 1.f};
+  auto load_set = [&](float (&xa)[BM * BK / NT], float (&xb)[BN * BK / NT]) {
+    const int soA = sL * stepA, soB = sL * stepB;
+#pragma unroll
+    for (int c = 0; c < NPA; ++c) load_piece_fast<BM, BK>(rsA, offA[c], soA, c, xa);
+#pragma unroll
+    for (int c = 0; c < NPB; ++c) load_piece_fast<BN, BK>(rsB, offB[c], soB, c, xb);
+  };
+  set_load_tile(0);
+  load_set(ra, rb);
+  advance_load();
+  store_slab<AKC, BM, BK, true, false>(lds, ra, one);
+  store_slab<BKC, BN, BK, true, false>(lds + kBoff, rb, one);
+  load_set(ra, rb);                                        // flat slab 1 -> set X
+  advance_load();
+  __syncthreads();
+
+  int jM = 0, sM = 0;                                      // tile and slab being multiplied
+  // the result of the tile the multiply cursor is on: straight-line stores, lanes outside the matrix write to the dump
+  auto epilogue = [&]() {
+    const Tile t = locate(jM);
+    float* C = p.C + t.i0 * p.sC[0] + t.i1 * p.sC[1] + t.i2 * p.sC[2];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+#pragma unroll
+      for (int c = 0; c < TN; ++c) {
+        const int col = t.n0 + wn0 + 32 * c + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = t.m0 + wm0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          float* dst = (row < p.M && col < p.N) ? &C[(int64_t)row * p.ldc + col] : &g_gemm_trash[tid];
+          *dst = p.alpha * acc[a][c][r];
+        }
+      }
+    }
+  };
+  auto iteration = [&](auto stage_c, float (&xa)[BM * BK / NT], float (&xb)[BN * BK / NT], float (&ya)[BM * BK / NT],
+                       float (&yb)[BN * BK / NT]) {
+    constexpr int stage = decltype(stage_c)::value;
+    const float* As = lds + stage * kStage;
+    float* An = lds + (stage ^ 1) * kStage;
+    const int soA = sL * stepA, soB = sL * stepB;
+    slab_mfma(As, As + kBoff, [&](int g) {
+      if (g < HALF) {                                      // global (flat slab f + 2) -> register set Y
+#pragma unroll
+        for (int u = 0; u < PERL; ++u) {
+          const int pc = g * PERL + u;
+          if (pc < NPA) load_piece_fast<BM, BK>(rsA, offA[pc], soA, pc, ya);
+          else if (pc < NP) load_piece_fast<BN, BK>(rsB, offB[pc - NPA], soB, pc - NPA, yb);
+        }
+      }
+      if (g >= HALF) {                                     // register set X (flat slab f + 1) -> idle LDS stage
+#pragma unroll
+        for (int u = 0; u < PERS; ++u) {
+          const int pc = (g - HALF) * PERS + u;
+          if (pc < NPA) store_piece<AKC, BM, BK, true, false>(An, xa, one, pc);
+          else if (pc < NP) store_piece<BKC, BN, BK, true, false>(An + kBoff, xb, one, pc - NPA);
+        }
+      }
+    });
+    advance_load();
+    if (++sM == ns) {                                      // (uniform) the tile is complete
+      epilogue();
+      zero_acc();
+      sM = 0; ++jM;
+    }
+    __syncthreads();
+  };
+  for (int f = 0; f < ftot; f += 2) {
+    iteration(std::integral_constant<int, 0>{}, ra, rb, ra2, rb2);
+    if (f + 1 < ftot) iteration(std::integral_constant<int, 1>{}, ra2, rb2, ra, rb);
+  }
+}
+
 // Workgroup -> tile map that keeps each XCD on a compact set of tiles.  Workgroups go to the 8 XCDs round-robin by
 // linear id, and each XCD has its own L2: with the plain map the 8 column-tiles that share an A panel land on 8
 // different L2s and every panel is fetched 8 times (measured: 98 MB fetched by the backward pair GEMM against 12 MB of
@@ -726,6 +929,7 @@ __device__ __forceinline__ int xcd_remap(int lin, int total) {
 template <int BM, int BN, int BK, bool AKC, bool BKC, bool VEC, bool RBF, bool SCALED = true>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   __shared__ __attribute__((aligned(16))) float lds[gemm_lds_floats<BM, BN, BK, AKC, BKC>()];
+  STEP_SPAN(gemm, 2);
   const int lin = (int)(blockIdx.y * gridDim.x + blockIdx.x), total = (int)(gridDim.x * gridDim.y);
   const int id = p.xcd_remap ? xcd_remap(lin, total) : lin;
   gemm_body<BM, BN, BK, AKC, BKC, VEC, RBF, SCALED>(p, id % (int)gridDim.x, id / (int)gridDim.x, blockIdx.z, lds);
@@ -824,10 +1028,12 @@ template <int KC, int SETS, int BM, int BK, bool SCALED = true, class R = double
 __global__ __launch_bounds__(NT) void chol_rbf_gemm_kernel(const CholArgs c, const GemmParams p, const int tiles) {
   // one LDS array for both roles (the factorisation stages its matrix through 40 KB of it): 2 workgroups per CU
   __shared__ __attribute__((aligned(16))) float lds[cmax(gemm_lds_floats<BM, 64, BK, true, true>(), chol3_stage_floats<KC>())];
+  STEP_SPAN(gemm, 1);
   if ((int)blockIdx.x < c.nchol) {
     if (NT > 256 && threadIdx.x >= 256) return;
     chol3_body<KC, SETS, R>(blockIdx.x, c.A, c.lda, c.sA, c.eps, c.L, c.ldl, c.sL, c.T, c.ldt, c.sT, nullptr, c.info, 0, c.n,
                             0, lds, c.extra.base ? &c.extra : nullptr);
+    STEP_SPAN_MARK(gemm, 9);
     return;
   }
   const int ngemm = (int)gridDim.x - c.nchol - c.nzero;
@@ -859,14 +1065,33 @@ extern "C" void vargp_debug_chol_phases(unsigned long long* out, int last) {
 // plain NN product the chain does not feed (P_uf = W_uf x next to the K_uu matrices, P_uu = W_uu z next to the S_u ones).
 // Every workgroup is carved the chain's 136 KB of LDS, i.e. one workgroup per CU.
 __global__ __launch_bounds__(256) void t0_bwdmat_gemm_kernel(const BwdMatArgs a, const int first, const int nmat,
-                                                             const GemmParams p, const int tiles) {
+                                                             const GemmParams p, const int tiles, const int npersist,
+                                                             const int total) {
   extern __shared__ __attribute__((aligned(16))) float bmat_lds[];
+  STEP_SPAN(gemm, 5);
+#ifdef STEP_SPANS
+  const unsigned long long t_in_ = wall_clock64();
+#endif
+#ifdef BMAT_STAMPS      // tuning builds: wall-clock span (100 MHz) of each role over all its workgroups, [role][first start, last end, last start]
+  const unsigned long long t_in = wall_clock64();
+  const int role = (int)blockIdx.x < nmat ? 0 : 1;
+  if (threadIdx.x == 0) { atomicMin(&g_bmat_span[role][0], t_in); atomicMax(&g_bmat_span[role][2], t_in); }
+#endif
   if ((int)blockIdx.x < nmat) {
     t0_bwd_mat_body(a, first + (int)blockIdx.x, bmat_lds);
-    return;
+    STEP_SPAN_MARK(gemm, 8);
+#ifdef STEP_SPANS
+    if (threadIdx.x == 0 && blockIdx.x < 64) { g_bmat_ends[blockIdx.x][1] = wall_clock64(); g_bmat_ends[blockIdx.x][0] = t_in_; }
+#endif
+  } else if (npersist > 0) {       // npersist workgroups walk the tiles of the product (gemm_persist_body)
+    gemm_persist_body<64, 64, 64, true, false>(p, (int)blockIdx.x - nmat, npersist, tiles, total, bmat_lds);
+  } else {
+    const int id = xcd_remap((int)blockIdx.x - nmat, (int)gridDim.x - nmat);
+    gemm_body<64, 64, 64, true, false, true, false>(p, id % tiles, id / tiles, 0, bmat_lds);
   }
-  const int id = xcd_remap((int)blockIdx.x - nmat, (int)gridDim.x - nmat);
-  gemm_body<64, 64, 64, true, false, true, false>(p, id % tiles, id / tiles, 0, bmat_lds);
+#ifdef BMAT_STAMPS
+  if (threadIdx.x == 0) atomicMax(&g_bmat_span[role][1], wall_clock64());
+#endif
 }
 
 static bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -884,6 +1109,7 @@ template <int BK>
 __global__ __launch_bounds__(256) void t0_pro_kuu_kernel(const ProArgs a, const int npro, const NormArgs nr, const int nnorm,
                                                          const GemmParams p, const int tiles, const int ngemm) {
   __shared__ __attribute__((aligned(16))) float lds[gemm_lds_floats<64, 64, BK, true, true>()];
+  STEP_SPAN(gemm, 0);
   int blk = blockIdx.x;
   if (blk >= ngemm) {      // (the other order -- short roles first -- measured 26.9 us against 20.3 us)
     blk -= ngemm;
@@ -1079,6 +1305,25 @@ int launch_gemm_pair2(const GemmParams& p0, int tA0, int tB0, int nbatch0, const
   return check_launch("gemm_pair2");
 }
 
+// what gemm_persist_body needs of a plain product (BK-deep slabs, A K-contiguous or not, B likewise)
+static bool gemm_persist_ok(const GemmParams& p, int BK, bool AKC, bool BKC) {
+  const int64_t extA = AKC ? ((int64_t)(p.M - 1) * p.lda + p.K) : ((int64_t)(p.K - 1) * p.lda + p.M);
+  const int64_t extB = BKC ? ((int64_t)(p.N - 1) * p.ldb + p.K) : ((int64_t)(p.K - 1) * p.ldb + p.N);
+  return gemm_vec_ok(p) && p.K >= 2 * BK && p.K % BK == 0 && !p.D && p.triA == 0 && p.triB == 0 && p.triC == 0 && !p.symout &&
+         p.splitk <= 1 && (AKC || (p.M % 4 == 0 && p.M >= 4)) && (BKC || (p.N % 4 == 0 && p.N >= 4)) &&
+         extA < (1ll << 29) && extB < (1ll << 29);
+}
+static int device_cu_count(int dev) {
+  static std::atomic<int> cus[64] = {};
+  int v = cus[dev].load(std::memory_order_acquire);
+  if (v == 0) {
+    hipDeviceProp_t prop;
+    v = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    cus[dev].store(v, std::memory_order_release);
+  }
+  return v;
+}
+
 int launch_bwdmat_gemm(const BwdMatArgs& a, int first, int nmat, const GemmParams& p, int nbatch, hipStream_t st,
                        const char* tag) {
   VARGP_REQUIRE(gemm_vec_ok(p), "bwdmat_gemm: the product's operands must be 16-byte aligned with strides % 4 == 0");
@@ -1107,7 +1352,15 @@ int launch_bwdmat_gemm(const BwdMatArgs& a, int first, int nmat, const GemmParam
   static const int exp_role = [] { const char* e = getenv("VARGP_EXP_BWDMAT"); return e ? atoi(e) : 0; }();
   if (exp_role == 1) nbatch = 0;
   if (exp_role == 2) nmat = 0;
-  hipLaunchKernelGGL(t0_bwdmat_gemm_kernel, dim3(nmat + tiles * nbatch), dim3(256), kBwdMatLdsBytes, st, a, first, nmat, q, tiles);
+  // the product's tiles: one workgroup each, or -- more tiles than free CUs -- one persistent workgroup per free CU walking its
+  // share of them (every workgroup of this launch has a CU to itself: the chain's LDS)
+  static const int persist_env = [] { const char* e = getenv("VARGP_GEMM_PERSIST"); return e ? atoi(e) : 1; }();   // tuning aid
+  const int total = tiles * nbatch;
+  const int free_cus = device_cu_count(dev) - nmat;
+  const bool persist = persist_env && total > free_cus && free_cus >= 8 && gemm_persist_ok(q, 64, true, false);
+  const int ngemm = persist ? free_cus : total;
+  hipLaunchKernelGGL(t0_bwdmat_gemm_kernel, dim3(nmat + ngemm), dim3(256), kBwdMatLdsBytes, st, a, first, nmat, q, tiles,
+                     persist ? ngemm : 0, total);
   return check_launch("bwdmat_gemm");
 }
 

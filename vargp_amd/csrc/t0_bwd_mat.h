@@ -7,7 +7,7 @@
 //
 // K_uu role (matrix id = (s, c); reference: autograd of gp_utils.py:150-191 through torch.cholesky / triangular_solve):
 //   gT   = gT_tiles + tril(ga m^T + gG L_S^T + gG2 Lu^T)                  (small columns of gT = tril(gQP RK^T), QP = T RK)
-//   g_u_mean[c] += T^T ga,   gLu_acc[c] += tril(T^T gG2)                   (small columns of gRK = T^T gQP, summed over s: atomics)
+//   g_u_mean[c] += T^T ga (atomics over s),   gLu_part[s, c] = tril(T^T gG2)  (small columns of gRK = T^T gQP; the consumers sum over s)
 //   w1 = gT T^T,  S = sym(0.5 (g I - tril(w1))),  gK = T^T S T              (Cholesky + inverse adjoint, chol.hip: gL is
 //                                                                            diag(g / L_ii) here, so L^T tril(gL) = g I)
 //   W_uu = 2 gK o K_uu, r_uu = its row sums, gtheta[s, D] += sum W_uu       (the K_uu role of the W = gK o K pass)
@@ -128,22 +128,61 @@ __device__ __forceinline__ void mat_store(float* __restrict__ dst, const float4 
 }
 
 #ifdef BMAT_STAMPS   // tuning builds only: s_memtime of matrix 0, thread 0 after each phase (tests/native/bm_stamps.py mat)
-__device__ unsigned long long g_bmat_stamps[24];
-extern "C" void vargp_debug_bmat_stamps(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bmat_stamps), 192); }
-#define BMAT_STAMP(i) do { if (threadIdx.x == 0 && id == 0) g_bmat_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ unsigned long long g_bmat_stamps[4][24];     // [wave][stamp]
+__device__ unsigned long long g_bmat_span[2][4];        // gemm.hip, t0_bwdmat_gemm_kernel
+extern "C" void vargp_debug_bmat_span(unsigned long long* out, int reset) {
+  if (reset) {
+    const unsigned long long init[2][4] = {{~0ull, 0, 0, 0}, {~0ull, 0, 0, 0}};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bmat_span), init, sizeof(init));
+  } else {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bmat_span), 64);
+  }
+}
+extern "C" void vargp_debug_bmat_stamps(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bmat_stamps), 4 * 192); }
+#define BMAT_STAMP(i) do { if ((threadIdx.x & 63) == 0 && id == 0) g_bmat_stamps[threadIdx.x >> 6][i] = __builtin_amdgcn_s_memtime(); } while (0)
+// the S_u role's own stamps (first class, wave 0) go into slots 17.. of wave 3's row, which the K_uu role leaves free
+#define BSU_STAMP(i) do { if (threadIdx.x == 0 && id == a.S * a.C) g_bmat_stamps[3][17 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define BMAT_STAMP(i) do { } while (0)
+#define BSU_STAMP(i) do { } while (0)
 #endif
 
-// X[i][j] = X[j][i] = scale (diag delta_ij + acc) from the lower blocks of family FAM (rows / columns >= M: zero)
+// X[i][j] = X[j][i] = scale (diag delta_ij + acc) from the lower blocks of family FAM (rows / columns >= M: zero).  The direct
+// write runs along rows (b32, conflict-free); the mirrored one of an off-diagonal block is one b128 per register quad -- the
+// quad's four consecutive i are four consecutive words of row j, and rows are 27 quads apart (odd: conflict-free) -- instead
+// of 16 b32 writes down a column, four lanes to a bank.  Diagonal blocks, where only j <= i counts, stay element by element.
 template <int FAM, int WV>
 __device__ __forceinline__ void mat_write_sym(float* __restrict__ X, const bm_f32x16 (&acc)[4], int M, float scale, float diag,
                                               int li, int lh) {
-  mat_foreach<FAM, WV>(li, lh, [&](int u, int rb, int cb, int r, int i, int j) {
-    if (i < kBmKP && (rb != cb || j <= i)) {
-      const float v = i < M ? scale * ((i == j ? diag : 0.f) + acc[u][r]) : 0.f;
-      X[i * kMatS + j] = v;
-      X[j * kMatS + i] = v;
+  bm_for<0, 4>([&](auto ui) {
+    constexpr int u = decltype(ui)::value;
+    using Bk = MatBlk<FAM, WV, u>;
+    if constexpr (Bk::valid) {
+      const int j = 32 * Bk::cb + li;
+      if constexpr (Bk::rb != Bk::cb) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int i0 = 32 * Bk::rb + 8 * q + 4 * lh;
+          float v[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) v[t] = i0 + t < M ? scale * acc[u][4 * q + t] : 0.f;
+          if (i0 < kBmKP) {                                  // (kBmKP % 4 == 0: the whole quad is inside; j <= 95 here)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) X[(i0 + t) * kMatS + j] = v[t];
+            *reinterpret_cast<float4*>(&X[j * kMatS + i0]) = make_float4(v[0], v[1], v[2], v[3]);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = 32 * Bk::rb + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (i < kBmKP && j <= i) {
+            const float v = i < M ? scale * ((i == j ? diag : 0.f) + acc[u][r]) : 0.f;
+            X[i * kMatS + j] = v;
+            X[j * kMatS + i] = v;
+          }
+        }
+      }
     }
   });
 }
@@ -157,7 +196,7 @@ __device__ __forceinline__ void mat_tail(float* __restrict__ sT, float* __restri
   // the factor the result is multiplied by, row by row (coalesced float4): requested now, used in the last pass
   float4 kr[kBmNA];
   if (kmul) bm_load_mat(kmul, M, M, tid, kr);
-  mat_product<false, false, kFamF, WV>(acc, sT, X2, true, li, lh);                 // tmp = T^T S
+  mat_product<false, true, kFamF, WV>(acc, sT, X2, true, li, lh);                  // tmp = T^T S  (S symmetric: rows of X2 as the K-contiguous operand, one b128 per fragment)
   BMAT_STAMP(12);
   __syncthreads();                                     // (X1 may still be read by a slower wave's previous product)
   mat_foreach<kFamF, WV>(li, lh, [&](int u, int rb, int cb, int r, int i, int j) {
@@ -168,35 +207,35 @@ __device__ __forceinline__ void mat_tail(float* __restrict__ sT, float* __restri
   mat_product<true, false, kFamC, WV>(acc, X1, sT, true, li, lh);                  // gA = tmp T, lower blocks
   BMAT_STAMP(14);
   // (X2 = S was last read by the product before the previous barrier)
-  mat_foreach<kFamC, WV>(li, lh, [&](int u, int rb, int cb, int r, int i, int j) {
-    if (i < kBmKP && (rb != cb || j <= i)) {
-      const float v = i < M ? acc[u][r] : 0.f;
-      X2[i * kMatS + j] = v;
-      X2[j * kMatS + i] = v;
-    }
-  });
+  mat_write_sym<kFamC, WV>(X2, acc, M, 1.f, 0.f, li, lh);
   __syncthreads();
   BMAT_STAMP(15);
-  // rows out (coalesced float4); row sums: thread (i, h) = (tid / 2, tid % 2) sums half a row
+  // rows out (coalesced float4); row sums: thread (i, h) = (tid / 2, tid % 2) sums half a row.  (LDS reads first, on clamped
+  // indices, all in flight: inside the bounds branch each one is waited for.)
   float dsum = 0.f;
+  float4 xv[kBmNA];
+#pragma unroll
+  for (int u = 0; u < kBmNA; ++u) {
+    const int e = min(tid + 256 * u, kBmKP * kBmNQ - 1);
+    const int i = e / kBmNQ, j = (e - i * kBmNQ) * 4;
+    xv[u] = *reinterpret_cast<const float4*>(&X2[i * kMatS + j]);
+  }
 #pragma unroll
   for (int u = 0; u < kBmNA; ++u) {
     const int e = tid + 256 * u;
     const int i = e / kBmNQ, j = (e - i * kBmNQ) * 4;
-    if (e < kBmKP * kBmNQ && i < M && j < M) {
-      float4 v = *reinterpret_cast<const float4*>(&X2[i * kMatS + j]);
-      if (kmul) {
-        v.x *= 2.f * kr[u].x; v.y *= 2.f * kr[u].y; v.z *= 2.f * kr[u].z; v.w *= 2.f * kr[u].w;
-        // the diagonal of W_uu counts for gamma only (K_ii = gamma^2: see rbf_w_self_kernel, rbf.hip): out of W_uu and r_uu
-        if (i >= j && i < j + 4) {
-          const int q = i - j;
-          dsum += q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w;
-          if (q == 0) v.x = 0.f; else if (q == 1) v.y = 0.f; else if (q == 2) v.z = 0.f; else v.w = 0.f;
-        }
-        *reinterpret_cast<float4*>(&X2[i * kMatS + j]) = v;       // (for the row sums below; each thread its own elements)
-      }
-      *reinterpret_cast<float4*>(&out[(int64_t)i * M + j]) = v;
+    float4 v = xv[u];
+    const bool ok = e < kBmKP * kBmNQ && i < M && j < M;
+    if (kmul) {
+      v.x *= 2.f * kr[u].x; v.y *= 2.f * kr[u].y; v.z *= 2.f * kr[u].z; v.w *= 2.f * kr[u].w;
+      // the diagonal of W_uu counts for gamma only (K_ii = gamma^2: see rbf_w_self_kernel, rbf.hip): out of W_uu and r_uu
+      const int q = i - j;
+      const float dv = q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w;
+      dsum += (ok && q >= 0 && q < 4) ? dv : 0.f;
+      v.x = q == 0 ? 0.f : v.x; v.y = q == 1 ? 0.f : v.y; v.z = q == 2 ? 0.f : v.z; v.w = q == 3 ? 0.f : v.w;
+      if (ok) *reinterpret_cast<float4*>(&X2[i * kMatS + j]) = v;       // (for the row sums below; each thread its own elements)
     }
+    if (ok) *reinterpret_cast<float4*>(&out[(int64_t)i * M + j]) = v;
   }
   if (rsum_out) {
     __syncthreads();
@@ -239,20 +278,17 @@ __device__ __forceinline__ void mat_kuu(const BwdMatArgs& a, int id, float* __re
   bm_f32x16 acc[4];
   float4 r0[kBmNA], r1[kBmNA], r2[kBmNA];
   BMAT_STAMP(0);
-  // ---- T, gG, L_S -> LDS; gG2, Lu requested right behind them ------------------------------------------------------------------
-  bm_load_mat(Tb, M, M, tid, r0);
+  // ---- gG, L_S -> LDS for the first product; T is only needed after it and lands while it runs; gG2, Lu (second stage) and the
+  //      tiles' gT are requested right behind
   bm_load_mat(gq + 4, LD, M, tid, r1);
   bm_load_mat(rk + 4, LD, M, tid, r2);
+  bm_load_mat(Tb, M, M, tid, r0);
   // ga = the tiles' sum (atomics of t0_bwd_mid_kernel into a cleared column) + the KL's share g a
   const float gav = tid < 128 ? gq[(int64_t)min(tid, M - 1) * LD] + g * qp[(int64_t)min(tid, M - 1) * LD] : 0.f;
   const float mvv = tid < 128 ? rk[(int64_t)min(tid, M - 1) * LD] : 0.f;
-  mat_store(sT, r0, M, tid);
   mat_store(X1, r1, M, tid);
   mat_store(X2, r2, M, tid);
-  if (tid < 128) { sga[tid] = tid < M ? gav : 0.f; smv[tid] = tid < M ? mvv : 0.f; }
-  bm_load_mat(qp + 4 + M, LD, M, tid, r1);             // gG2 = g G2   (KL; G2 = T Lu is lower triangular with stored zeros)
-#pragma unroll
-  for (int u = 0; u < kBmNA; ++u) { r1[u].x *= g; r1[u].y *= g; r1[u].z *= g; r1[u].w *= g; }
+  bm_load_mat(qp + 4 + M, LD, M, tid, r1);             // G2 (gG2 = g G2: KL; G2 = T Lu is lower triangular with stored zeros)
   bm_load_mat(rk + 4 + M, LD, M, tid, r2);             // Lu
   // the tiles' share of gT (accumulated by t0_bwd_mid_kernel's atomics), read in the accumulator layout: needed after two products
   float gtt[4][16];
@@ -264,44 +300,72 @@ __device__ __forceinline__ void mat_kuu(const BwdMatArgs& a, int id, float* __re
   }
   __syncthreads();
   BMAT_STAMP(1);
-  // ---- gT (small columns), part 1: gG L_S^T;  g_u_mean[c] += T^T ga --------------------------------------------------------------
+  // ---- gT (small columns), part 1: gG L_S^T --------------------------------------------------------------------------------------
   mat_product<true, true, kFamL, WV>(acc, X1, X2, true, li, lh);
   BMAT_STAMP(2);
-  {
-    // (T^T ga)[i] = sum_{k >= i} T[k][i] ga[k]: thread (i, h) takes every second k (consecutive lanes read consecutive words)
-    const int i = tid & 127, h = tid >> 7;
-    float s0 = 0.f;
-    if (i < M)
-      for (int k = i + h; k < M; k += 2) s0 = fmaf(sT[k * kMatS + i], sga[k], s0);
-    srs[tid] = s0;
-  }
+  mat_store(sT, r0, M, tid);
+  if (tid < 128) { sga[tid] = tid < M ? gav : 0.f; smv[tid] = tid < M ? mvv : 0.f; }
+  __syncthreads();                                     // everybody is done with gG and L_S; T, ga, m are in place
   BMAT_STAMP(3);
-  __syncthreads();                                     // everybody is done with gG and L_S
-  BMAT_STAMP(5);
-  if (tid < M) atomicAdd(&a.g_u_mean[(int64_t)c * M + tid], srs[tid] + srs[tid + 128]);
+#pragma unroll
+  for (int u = 0; u < kBmNA; ++u) { r1[u].x *= g; r1[u].y *= g; r1[u].z *= g; r1[u].w *= g; }
   mat_store(X1, r1, M, tid);
   mat_store(X2, r2, M, tid);
+  {
+    // g_u_mean[c] += T^T ga.  (T^T ga)[i] = sum_{k >= i} T[k][i] ga[k]: thread (i, h) takes the k of half h.  Fixed trip count,
+    // every LDS read unconditional and in flight together (a run-time `for k = i..M` waited for each read: 2.3 us for this
+    // mat-vec); rows k >= M of T and of ga are zero
+    const int i = tid & 127, h = tid >> 7, ic = min(i, kBmKP - 1);
+    constexpr int KH = kBmKP / 2;
+    const float* tp = sT + (KH * h) * kMatS + ic;
+    float tv[KH];
+    float4 gk[KH / 4];
+#pragma unroll
+    for (int q = 0; q < KH / 4; ++q) gk[q] = *reinterpret_cast<const float4*>(&sga[KH * h + 4 * q]);
+#pragma unroll
+    for (int k = 0; k < KH; ++k) tv[k] = tp[k * kMatS];
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < KH / 4; ++q) {
+      const int k0 = KH * h + 4 * q;
+      s0 = fmaf(k0 >= i ? tv[4 * q] : 0.f, gk[q].x, s0);
+      s1 = fmaf(k0 + 1 >= i ? tv[4 * q + 1] : 0.f, gk[q].y, s1);
+      s0 = fmaf(k0 + 2 >= i ? tv[4 * q + 2] : 0.f, gk[q].z, s0);
+      s1 = fmaf(k0 + 3 >= i ? tv[4 * q + 3] : 0.f, gk[q].w, s1);
+    }
+    srs[tid] = s0 + s1;
+  }
   __syncthreads();
+  BMAT_STAMP(5);
+  if (tid < M) atomicAdd(&a.g_u_mean[(int64_t)c * M + tid], srs[tid] + srs[tid + 128]);
   BMAT_STAMP(6);
-  // ---- part 2: + gG2 Lu^T;  gLu_acc[c] += tril(T^T gG2) --------------------------------------------------------------------------------
+  // ---- part 2: + gG2 Lu^T;  gLu_part[s, c] = tril(T^T gG2) --------------------------------------------------------------------------------
   mat_product<true, true, kFamL, WV>(acc, X1, X2, false, li, lh);
   {
     bm_f32x16 acr[4];
     mat_product<false, false, kFamR, WV>(acr, sT, X1, true, li, lh);
-    float* gl = a.gLu_acc + (int64_t)c * MM;
+    // this (s, c)'s share, plain stores (lower triangle; lanes run along a row): the consumers add the S shares of a class.
+    // As float atomics into a per-class sum -- 5050 per matrix, three matrices per address -- they drained for 7.5 us AFTER
+    // the last wave had retired (kernel 47.2 -> 39.7 us without them, chains alone)
+    float* gl = a.gLu_part + b * MM;
     mat_foreach<kFamR, WV>(li, lh, [&](int u, int rb, int cb, int r, int i, int j) {
-      if (i < M && (rb != cb || j <= i)) atomicAdd(&gl[(int64_t)i * M + j], acr[u][r]);
+      if (i < M && (rb != cb || j <= i)) gl[(int64_t)i * M + j] = acr[u][r];
     });
   }
   BMAT_STAMP(7);
   __syncthreads();                                     // everybody is done with gG2 and Lu
   BMAT_STAMP(8);
   // ---- gT = tiles + tril(ga m^T + gG L_S^T + gG2 Lu^T) -> X1 (K-contiguous operand of w1 = gT T^T) ------------------------------
+  // (ga and m read first, unconditionally -- i, j < 128 = their padded lengths: a read inside the bounds branch is waited for
+  // element by element)
+  float gai[4][16], mj[4];
   mat_foreach<kFamL, WV>(li, lh, [&](int u, int rb, int cb, int r, int i, int j) {
-    if (i < kBmKP && j < kBmKP) {
-      const float v = acc[u][r] + gtt[u][r] + sga[i] * smv[j];
-      X1[i * kMatS + j] = (i < M && j <= i) ? v : 0.f;
-    }
+    gai[u][r] = sga[i];
+    if (r == 0) mj[u] = smv[j];
+  });
+  mat_foreach<kFamL, WV>(li, lh, [&](int u, int rb, int cb, int r, int i, int j) {
+    const float v = acc[u][r] + gtt[u][r] + gai[u][r] * mj[u];
+    if (i < kBmKP && j < kBmKP) X1[i * kMatS + j] = (i < M && j <= i) ? v : 0.f;
   });
   __syncthreads();
   BMAT_STAMP(9);
@@ -326,20 +390,23 @@ __device__ __forceinline__ void mat_su(const BwdMatArgs& a, int id, float* __res
   const int c = id - SC;
   bm_f32x16 acc[4];
   float4 r0[kBmNA], r1[kBmNA];
-  // gL = sum_s tril(T_s^T gG_s): lower blocks, accumulated over the samples in registers
+  // gL = sum_s tril(T_s^T gG_s): lower blocks, accumulated over the samples in registers.  The next sample's operands (after
+  // the last one: T_S and L_S) are requested before the current product, so that only the first round trip is exposed
+  BSU_STAMP(0);
+  bm_load_mat(a.TT + (int64_t)c * MM, M, M, tid, r0);
+  bm_load_mat(a.gQP + (int64_t)c * MLD + 4, LD, M, tid, r1);
   for (int s = 0; s < a.S; ++s) {
-    const int64_t b = (int64_t)s * a.C + c;
-    bm_load_mat(a.TT + b * MM, M, M, tid, r0);
-    bm_load_mat(a.gQP + b * MLD + 4, LD, M, tid, r1);
     if (s > 0) __syncthreads();                        // everybody is done with the previous sample's operands
     mat_store(sT, r0, M, tid);
     mat_store(X1, r1, M, tid);
     __syncthreads();
+    const bool more = s + 1 < a.S;
+    const int64_t bn = (int64_t)(s + 1) * a.C + c;
+    bm_load_mat(a.TT + (more ? bn : (int64_t)id) * MM, M, M, tid, r0);
+    bm_load_mat(more ? a.gQP + bn * MLD + 4 : a.LL + (int64_t)id * MM, more ? LD : M, M, tid, r1);
     mat_product<false, false, kFamR, WV>(acc, sT, X1, s == 0, li, lh);
   }
-  // T_S, L_S requested while the last product runs out
-  bm_load_mat(a.TT + (int64_t)id * MM, M, M, tid, r0);
-  bm_load_mat(a.LL + (int64_t)id * MM, M, M, tid, r1);
+  BSU_STAMP(1);
   __syncthreads();
   // gL (lower, zeros above the diagonal) -> X2 as the k-major operand of P = tril(L_S^T gL)
   mat_foreach<kFamR, WV>(li, lh, [&](int u, int rb, int cb, int r, int i, int j) {
@@ -348,11 +415,14 @@ __device__ __forceinline__ void mat_su(const BwdMatArgs& a, int id, float* __res
   mat_store(sT, r0, M, tid);
   mat_store(X1, r1, M, tid);
   __syncthreads();
+  BSU_STAMP(2);
   mat_product<false, false, kFamR, WV>(acc, X1, X2, true, li, lh);      // A[i][k] = L_S[k][i] (k >= i), B[k][j] = gL[k][j] (j <= k)
   __syncthreads();                                     // everybody is done with gL before S takes its place
   mat_write_sym<kFamR, WV>(X2, acc, M, 0.5f, 0.f, li, lh);
   __syncthreads();
+  BSU_STAMP(3);
   mat_tail<WV>(sT, X1, X2, nullptr, a.gKS + (int64_t)id * MM, nullptr, nullptr, M, id, tid, lane, li, lh);
+  BSU_STAMP(4);
 }
 
 // matrix id < S C: K_uu role for (s, c) = id;  id >= S C: S_u role for class id - S C

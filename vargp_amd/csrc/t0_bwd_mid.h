@@ -233,6 +233,7 @@ __global__ __launch_bounds__(256) void t0_bwd_mid_kernel(const float* __restrict
                                                          int M, int B, int D, int NR, int LD, int ntile,
                                                          float* __restrict__ zero_out, int zero_n, const BmSoftmax sm) {
   extern __shared__ __attribute__((aligned(16))) float bm_lds[];
+  STEP_SPAN(t0, 4);
   // an output of the backward that the NEXT launch accumulates into (g_u_mean: sums over s by atomics): cleared here, by the
   // first workgroup, because the forward -- which clears the workspace's accumulators -- does not know the caller's buffer
   if (blockIdx.x == 0 && zero_out)
@@ -260,7 +261,30 @@ __global__ __launch_bounds__(256) void t0_bwd_mid_kernel(const float* __restrict
   const float gs = gscale ? gscale[0] : 1.f;
   constexpr int NA_ = kBmNA, NT_ = kBmNT;
   BM_STAMP(0);
-  // ---- every global load of the kernel up front (clamped indices, padding selected in when the value is stored):
+  // ---- every global load of the kernel up front (clamped indices, padding selected in when the value is stored).
+  // sm.eps != NULL (the forward ran with defer_softmax): the Monte-Carlo softmax likelihood of this tile's columns is evaluated
+  // HERE -- every (s, c, tile) workgroup redoes the softmax over all classes of its 64 columns (C-fold redundant, F C 64 exps)
+  // and keeps the gradient of its own class; the class-0 workgroups also add the tile's share of nll.  One launch less on the
+  // critical path of the step.  Its loads go FIRST (vmcnt retires in order: the evaluation then runs under the tile loads) and
+  // wide: thread (column quad, likelihood sample) = (tid & 15, tid >> 4) takes one float4 of eps per class -- 18 loads per
+  // thread (the first version, one column and F / 4 samples per thread, issued 96 scalar loads in front of the tile loads:
+  // 11 us of the kernel's 39 went by before the first LDS store); mu and var are loaded once per workgroup (thread = (class,
+  // quad)) and shared through LDS (in P's place, which is written after the barrier that ends the evaluation).
+  const int q4 = tid & 15, fs = tid >> 4;
+  const int nq = min(n0 + 4 * q4, B - 4);            // B % 4 == 0: a column quad lies wholly inside or outside
+  float4 sev[kBmSmC], mu4 = make_float4(0.f, 0.f, 0.f, 0.f), var4 = mu4;
+  int64_t yq[4] = {0, 0, 0, 0};
+  if (sm.eps) {
+    const int s = (int)(b / C);
+    const int64_t rc = ((int64_t)s * C + min(fs, C - 1)) * B + nq;
+    mu4 = *reinterpret_cast<const float4*>(sm.mu + rc);
+    var4 = *reinterpret_cast<const float4*>(sm.var + rc);
+    const float* ep = sm.eps + ((int64_t)s * sm.F + min(fs, sm.F - 1)) * C * B + nq;
+#pragma unroll
+    for (int c = 0; c < kBmSmC; ++c) sev[c] = *reinterpret_cast<const float4*>(ep + (int64_t)min(c, C - 1) * B);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) yq[j] = sm.y[nq + j];
+  }
   //      G, the P and W tiles now; T and the K_uf tile stay in registers until the first two products are done
   float4 rg[NA_], rp[NT_], rw[NT_], rt[NA_], rk[NT_];
   bm_load_mat(Qb + 4, LD, M, tid, rg);
@@ -269,80 +293,86 @@ __global__ __launch_bounds__(256) void t0_bwd_mid_kernel(const float* __restrict
   const float av = tid < 128 ? Qb[(int64_t)min(tid, M - 1) * LD] : 0.f;
   const int ncl = min(n0 + (tid & 63), B - 1);
   float gmv = 0.f, gvv = 0.f;
-  // sm.eps != NULL (the forward ran with defer_softmax): the Monte-Carlo softmax likelihood of this tile's columns is evaluated
-  // HERE -- every (s, c, tile) workgroup redoes the softmax over all classes of its 64 columns (C-fold redundant, F C 64 exps)
-  // and keeps the gradient of its own class; the class-0 workgroups also add the tile's share of nll.  One launch less on the
-  // critical path of the step.  Thread (column, f-group) = (tid & 63, tid >> 6) takes the likelihood samples f = fg, fg + 4, ...
-  float smu[kBmSmC], ssd[kBmSmC], sev[kBmSmF][kBmSmC];
-  int syb = 0;
-  if (sm.eps) {
-    const int s = (int)(b / C), fg = tid >> 6;
-#pragma unroll
-    for (int c = 0; c < kBmSmC; ++c) {              // all loads first, unconditional on clamped indices
-      const int cc = min(c, C - 1);
-      const int64_t i = ((int64_t)s * C + cc) * B + ncl;
-      smu[c] = sm.mu[i];
-      ssd[c] = sm.var[i];
-#pragma unroll
-      for (int q = 0; q < kBmSmF; ++q)
-        sev[q][c] = sm.eps[(((int64_t)s * sm.F + min(fg + 4 * q, sm.F - 1)) * C + cc) * B + ncl];
-    }
-    syb = (int)sm.y[ncl];
-  } else {
-    gmv = gmu[b * B + ncl]; gvv = gvar[b * B + ncl];
-  }
+  if (!sm.eps) { gmv = gmu[b * B + ncl]; gvv = gvar[b * B + ncl]; }
   bm_load_mat(Tb, M, M, tid, rt);
   bm_load_tile(Kb, LD, M, n0, B, tid, rk);
+  BM_STAMP(13);
   if (sm.eps) {
-    const int cme = (int)(b % C), fg = tid >> 6;
+    const int cme = (int)(b % C);
     const float sc1 = 1.f / (float)(S * sm.F);
-    float pm = 0.f, pv = 0.f, contrib = 0.f;
-#pragma unroll
-    for (int c = 0; c < kBmSmC; ++c) ssd[c] = c < C ? sqrtf(ssd[c]) : 1.f;
-    // (padded slots are skipped by wave-uniform branches -- no loads inside them: likelihood samples beyond F per f-group,
-    // classes in groups of four beyond C: at F = 10, C = 10 that is 2.5 x 12 of the 4 x 16 slots)
-#pragma unroll
-    for (int q = 0; q < kBmSmF; ++q) {
-      if (fg + 4 * q >= sm.F) continue;                       // uniform: fg is the wave index
-      const bool live = n0 + (tid & 63) < B;
-      float v[kBmSmC], mx = -INFINITY, fy = 0.f, eme = 0.f;
-#pragma unroll
-      for (int c = 0; c < kBmSmC; ++c) v[c] = -INFINITY;
-#pragma unroll
-      for (int cg = 0; cg < kBmSmC / 4; ++cg) {
-        if (4 * cg >= C) continue;                             // uniform
-#pragma unroll
-        for (int c = 4 * cg; c < 4 * cg + 4; ++c) {
-          v[c] = c < C ? fmaf(ssd[c], sev[q][c], smu[c]) : -INFINITY;
-          mx = fmaxf(mx, v[c]);
-          if (c == syb) fy = v[c];
-          if (c == cme) eme = sev[q][c];
-        }
-      }
-      float se = 0.f, vme = 0.f;
-#pragma unroll
-      for (int cg = 0; cg < kBmSmC / 4; ++cg) {
-        if (4 * cg >= C) continue;                             // uniform
-#pragma unroll
-        for (int c = 4 * cg; c < 4 * cg + 4; ++c) {
-          const float e = c < C ? expf(v[c] - mx) : 0.f;
-          se += e;
-          if (c == cme) vme = e;
-        }
-      }
-      const float pc = vme * (sc1 / se) - (cme == syb ? sc1 : 0.f);
-      if (live) { pm += pc; pv += pc * eme; contrib -= (fy - (mx + logf(se))) * sc1; }
-    }
-    float sdme = 1.f;
-#pragma unroll
-    for (int c = 0; c < kBmSmC; ++c) if (c == cme) sdme = ssd[c];
-    pv *= 0.5f / sdme;
-    // the four f-groups of a column meet in LDS
-    float* sred = scs + 64 + 8;                       // [3][4][64]
-    sred[(0 * 4 + fg) * 64 + (tid & 63)] = pm;
-    sred[(1 * 4 + fg) * 64 + (tid & 63)] = pv;
-    sred[(2 * 4 + fg) * 64 + (tid & 63)] = contrib;
+    float* smu = sP;                                  // [kBmSmC][64] mu, then [kBmSmC][64] sd = sqrt(var)
+    float* ssd = sP + kBmSmC * 64;
+    *reinterpret_cast<float4*>(&smu[fs * 64 + 4 * q4]) = mu4;
+    *reinterpret_cast<float4*>(&ssd[fs * 64 + 4 * q4]) = make_float4(sqrtf(var4.x), sqrtf(var4.y), sqrtf(var4.z), sqrtf(var4.w));
     __syncthreads();
+    float pm[4] = {0.f, 0.f, 0.f, 0.f}, pv[4] = {0.f, 0.f, 0.f, 0.f}, ct[4] = {0.f, 0.f, 0.f, 0.f};
+    if (4 * wave < sm.F) {                            // uniform: a wave holds four likelihood samples
+      const bool live = n0 + 4 * q4 < B && fs < sm.F;
+      const int yb[4] = {(int)yq[0], (int)yq[1], (int)yq[2], (int)yq[3]};
+      float mx[4], fy[4] = {0.f, 0.f, 0.f, 0.f}, sdme[4] = {1.f, 1.f, 1.f, 1.f};
+      float eme[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mx[j] = -INFINITY;
+      // v = mu + sd eps in place over eps (classes in groups of four, skipped by uniform branches beyond C; no loads inside)
+#pragma unroll
+      for (int cg = 0; cg < kBmSmC / 4; ++cg) {
+        if (4 * cg >= C) continue;
+#pragma unroll
+        for (int c = 4 * cg; c < 4 * cg + 4; ++c) {
+          const float4 m4 = *reinterpret_cast<const float4*>(&smu[c * 64 + 4 * q4]);
+          const float4 s4 = *reinterpret_cast<const float4*>(&ssd[c * 64 + 4 * q4]);
+          const float e[4] = {sev[c].x, sev[c].y, sev[c].z, sev[c].w};
+          const float m_[4] = {m4.x, m4.y, m4.z, m4.w}, s_[4] = {s4.x, s4.y, s4.z, s4.w};
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[j] = c < C ? fmaf(s_[j], e[j], m_[j]) : -INFINITY;
+            mx[j] = fmaxf(mx[j], v[j]);
+            if (c == yb[j]) fy[j] = v[j];
+            if (c == cme) { eme[j] = e[j]; sdme[j] = s_[j]; }
+          }
+          sev[c] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+      float se[4] = {0.f, 0.f, 0.f, 0.f}, vme[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int cg = 0; cg < kBmSmC / 4; ++cg) {
+        if (4 * cg >= C) continue;
+#pragma unroll
+        for (int c = 4 * cg; c < 4 * cg + 4; ++c) {
+          const float v[4] = {sev[c].x, sev[c].y, sev[c].z, sev[c].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float e = c < C ? expf(v[j] - mx[j]) : 0.f;
+            se[j] += e;
+            if (c == cme) vme[j] = e;
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float pc = vme[j] * (sc1 / se[j]) - (cme == yb[j] ? sc1 : 0.f);
+        pm[j] = live ? pc : 0.f;
+        pv[j] = live ? pc * eme[j] * (0.5f / sdme[j]) : 0.f;
+        ct[j] = live ? -(fy[j] - (mx[j] + logf(se[j]))) * sc1 : 0.f;
+      }
+    }
+    // the four samples of a wave meet by shuffles (lane = 16 (f % 4) + quad), the four waves in LDS
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      pm[j] += __shfl_xor(pm[j], 16, 64); pm[j] += __shfl_xor(pm[j], 32, 64);
+      pv[j] += __shfl_xor(pv[j], 16, 64); pv[j] += __shfl_xor(pv[j], 32, 64);
+      ct[j] += __shfl_xor(ct[j], 16, 64); ct[j] += __shfl_xor(ct[j], 32, 64);
+    }
+    BM_STAMP(14);
+    float* sred = scs + 64 + 8;                       // [3][4][64]
+    if (lane < 16) {
+      *reinterpret_cast<float4*>(&sred[(0 * 4 + wave) * 64 + 4 * q4]) = make_float4(pm[0], pm[1], pm[2], pm[3]);
+      *reinterpret_cast<float4*>(&sred[(1 * 4 + wave) * 64 + 4 * q4]) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+      *reinterpret_cast<float4*>(&sred[(2 * 4 + wave) * 64 + 4 * q4]) = make_float4(ct[0], ct[1], ct[2], ct[3]);
+    }
+    __syncthreads();
+    BM_STAMP(15);
     if (tid < 64) {
       gmv = sred[tid] + sred[64 + tid] + sred[128 + tid] + sred[192 + tid];
       gvv = sred[256 + tid] + sred[320 + tid] + sred[384 + tid] + sred[448 + tid];

@@ -66,9 +66,17 @@ __device__ __forceinline__ void tail_gvec_block(const GvecArgs& gv, int c, int r
     bf[g] = make_float4(p[0], p[M], p[2 * M], p[3 * M]);
   }
   const int rbase = 32 * rb + 4 * lh, k = 32 * cb + li;
-  float ga[16];
+  float ga[16];          // sum over the samples' shares (t0_bwd_mat.h writes one lower triangle per (s, c))
 #pragma unroll
-  for (int r = 0; r < 16; ++r) ga[r] = gv.gLu_acc[c * MM + (int64_t)min(rbase + 8 * (r >> 2) + (r & 3), M - 1) * M + colc];
+  for (int r = 0; r < 16; ++r) ga[r] = 0.f;
+  for (int sidx = 0; sidx < gv.S; ++sidx) {
+    const float* gp = gv.gLu_part + ((int64_t)sidx * gv.C + c) * MM + colc;
+    float gs_[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gs_[r] = gp[(int64_t)min(rbase + 8 * (r >> 2) + (r & 3), M - 1) * M];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ga[r] += gs_[r];
+  }
   bm_f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -150,6 +158,7 @@ template <int S>
 __global__ __launch_bounds__(256, 2) void t0_puu_final_kernel(const TailArgs a, const GvecArgs gv) {
   __shared__ __attribute__((aligned(16))) float rsl[4][kTailSMax][32];
   __shared__ float redx[2][4][64];
+  STEP_SPAN(t0, 6);
   int blk = blockIdx.x;
   if (blk >= a.nz) {      // (the short roles last: dispatched first they measured the same)
     blk -= a.nz;
