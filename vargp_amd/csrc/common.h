@@ -208,8 +208,9 @@ struct BwdMatArgs {
   float *g_u_mean, *gLu_part;                       // [C][M]: sum over s, accumulated with atomics (pre-zeroed); [S][C][M][M]: per-sample shares (lower triangles written)
   int S, C, M, D, NR, LD;
 };
+// queue: 8 ints, zero when the launch starts (work queue of the product's tiles: gemm_persist_body), or NULL
 int launch_bwdmat_gemm(const BwdMatArgs& a, int first, int nmat, const GemmParams& p, int nbatch, hipStream_t st,
-                       const char* tag);
+                       const char* tag, int* queue);
 
 // Launch replay (vargp_prof_remember / vargp_prof_replay): while remembering, tagged launch sites store a closure that
 // repeats the launch.

@@ -38,7 +38,8 @@ constexpr int kKlRows = VARGP_KL_ROWS;     // rows of one (s, c) block per KL wo
 
 struct T0Ws {
   // forward results kept for the backward
-  float *theta, *eps_theta, *eps_f, *w, *g2, *kd, *na, *nb, *Lu, *KS, *LL, *TT, *RK, *QP, *W, *mu, *var;
+  float* queue;                    // 8 tile counters of the backward's merged launch (cleared by the forward)
+  float *theta, *eps_theta, *eps_f, *w, *g2, *kd, *na, *nb, *xs, *Lu, *KS, *LL, *TT, *RK, *QP, *W, *mu, *var;
   float *gmu, *gvar;               // accumulators zeroed by the forward prologue (softmax gradient, unscaled)
   float *r_uf, *c_uf, *gtheta;     // accumulators zeroed by the first backward kernel
   float *r_uu, *gW, *gkd, *gQP, *gLL, *gTT, *gRK, *gKS, *Wuu, *Puu, *Puf;
@@ -60,8 +61,9 @@ static T0Ws carve_t0(void* ws, int S, int C, int M, int D, int B, int F) {
   auto take = [&](int64_t n) { float* q = p; p += round_up(n, 64); return q; };
   // theta, eps_theta, eps_f first, in this order (vargp_amd/fused.py exposes them as views)
   o.theta = take(S * D1); o.eps_theta = take(S * D1); o.eps_f = take((int64_t)S * F * C * B);
-  o.w = take(S * o.Dp); o.g2 = take(S); o.kd = take(SC);
+  o.w = take(S * o.Dp); o.g2 = take(S); o.kd = take(SC); o.queue = take(8);
   o.na = take(SC * M); o.nb = take((int64_t)S * B);
+  o.xs = take((int64_t)S * B * D);          // x o 1/sigma_s^2 (written by the norm role of the front launch)
   o.Lu = take(C * MM); o.KS = take((SC + C) * MM); o.LL = take((SC + C) * MM); o.TT = take((SC + C) * MM);
   o.RK = take(SC * M * o.LD); o.QP = take(SC * M * o.LD); o.W = take(SC * M * B);
   o.mu = take(SC * B); o.var = take(SC * B);
@@ -755,7 +757,7 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
     // column 0 (ga) and the G block of gQP, gT, gkd, r_uf / c_uf / gtheta
     bwd_zero.j[0] = ZeroJob{o.gQP, (int64_t)SC * M, 4 + M, LD};
     bwd_zero.j[1] = ZeroJob{o.gTT, 1, (SC + C) * MM, 0};
-    bwd_zero.j[2] = ZeroJob{nullptr, 0, 0, 0};
+    bwd_zero.j[2] = ZeroJob{o.queue, 1, 8, 0};          // work queue of the P_uf tiles (launch_bwdmat_gemm)
     bwd_zero.j[3] = ZeroJob{o.gkd, 1, SC, 0};
     bwd_zero.j[4] = ZeroJob{o.r_uf, 1, o.r_uu - o.r_uf, 0};
     if (!merge_chol) {
@@ -809,9 +811,12 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
         GemmParams ps = p0;
         ps.splitk = ksp; ps.sSplit = SC * MM; ps.C = o.kpart;
         if (front) {
-          NormArgs nr{d->z, d->x, o.na, o.nb, zrows, (int64_t)B, 16, (int)cdiv(zrows + B, 16)};
+          // (the norm role also writes x o 1/sigma_s^2: the K_uf product then runs without scale loads / multiplies in its
+          // main loop -- step 209.5 -> 207.7 us at S = 3, 510 -> 494 us at S = 8)
+          NormArgs nr{d->z, d->x, o.na, o.nb, zrows, (int64_t)B, 16, (int)cdiv(zrows + B, 16), o.xs};
           rc = launch_pro_kuu(a, npro, nr, ps, SC, st);
           if (rc) return rc;
+          p1.B = o.xs; p1.sB[0] = (int64_t)B * D; p1.kscale = nullptr;
         } else {
           rc = launch_gemm(ps, 0, 1, SC, true, st, "rbf_kuu_gemm");
           if (rc) return rc;
@@ -1013,7 +1018,7 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
     ma.g_u_mean = g_u_mean; ma.gLu_part = o.gLL;                 // (gLL is free on this path: no head launch, no Cholesky-adjoint op)
     ma.S = S; ma.C = C; ma.M = M; ma.D = D; ma.NR = NR; ma.LD = LD;
     // all S C + C matrices next to P_uf = W_uf x (which only needs the tile kernel's W_uf) ...
-    rc = launch_bwdmat_gemm(ma, 0, SC + C, p1, S, st, "rbf_kuf_bwd_gemm");
+    rc = launch_bwdmat_gemm(ma, 0, SC + C, p1, S, st, "rbf_kuf_bwd_gemm", reinterpret_cast<int*>(o.queue));
     if (rc) return rc;
     // ... then P_uu = W_uu z; with few samples inside the launch that consumes it (t0_bwd_tail.h)
     static const int tail_env = [] { const char* e = getenv("VARGP_T0_TAIL"); return e ? atoi(e) : 1; }();   // tuning aid

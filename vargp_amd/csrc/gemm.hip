@@ -718,18 +718,21 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int tile_id
 }
 
 // Persistent variant of gemm_body's fast path for PLAIN products (no RBF epilogue, no D, no split-K, no triangular hints; K a
-// multiple of BK; operands as the fast path wants them -- gemm_persist_ok() on the host).  Workgroup wg of nwg walks a list
-// of tiles and treats the K slabs of ALL of them as one pipelined sequence: while the last slabs of a tile are multiplied
-// the first slabs of the next one are already on their way (global -> registers -> idle LDS stage), and a tile's result is
-// stored between two slabs.  Why: a 64 x 64 x 512 tile of the backward's P_uf product takes 13 us as a workgroup of its own
-// against 6.8 us of MFMAs -- descriptor set-up, the cold round trip of the first two slabs and the epilogue are paid per
-// tile, three times per CU (tests/native/bm_stamps.py mat: last tile starts at 39.5 us, ends at 52.8).
-// Tile order: XCD x (= wg % 8: workgroups go to the XCDs round-robin) works through the contiguous range
-// [x T / 8, (x + 1) T / 8) of the (batch, tile_m, tile_n) order, its workgroups side by side (as xcd_remap does for
-// one-tile workgroups).
+// multiple of BK with at least three slabs; operands as the fast path wants them -- gemm_persist_ok() on the host).  A workgroup
+// takes tile after tile from a work queue and treats the K slabs of ALL its tiles as one pipelined sequence: while the last
+// slabs of a tile are multiplied the first slabs of the next one are already on their way (global -> registers -> idle LDS
+// stage), and a tile's result is stored between two slabs.  Why: a 64 x 64 x 512 tile of the backward's P_uf product takes
+// 13 us as a workgroup of its own against 6.8 us of MFMAs -- descriptor set-up, the cold round trip of the first two slabs and
+// the epilogue are paid per tile, three times per CU.
+// Queue: `queue` = 8 counters (zero when the kernel starts), one per XCD (x = blockIdx.x % 8: workgroups go to the XCDs
+// round-robin); XCD x hands out the contiguous range [x T / 8, (x + 1) T / 8) of the (batch, tile_m, tile_n) order, so the
+// tiles in flight on one L2 share their A panels (as xcd_remap does for one-tile workgroups).  Any workgroup of the launch
+// may join at any time -- the matrix-chain workgroups of t0_bwdmat_gemm_kernel do when their chain is finished (with many
+// hyper-samples the chains end long before the product).  The next tile's id is fetched (thread 0, one atomic) during the first
+// slab of the current tile and published through LDS with that slab's barrier.
 template <int BM, int BN, int BK, bool AKC, bool BKC>
-__device__ __forceinline__ void gemm_persist_body(const GemmParams& p, const int wg_, const int nwg_, const int tiles,
-                                                  const int total, float* __restrict__ lds) {
+__device__ __forceinline__ void gemm_persist_body(const GemmParams& p, int* __restrict__ queue, const int tiles, const int total,
+                                                  float* __restrict__ lds) {
   constexpr int NT = 256;
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   using LA = LdsLayout<AKC, BM, BK>;
@@ -737,18 +740,25 @@ __device__ __forceinline__ void gemm_persist_body(const GemmParams& p, const int
   constexpr int kBoff = (LA::kSize + 3) & ~3;
   constexpr int kStage = kBoff + ((LB::kSize + 3) & ~3);
   constexpr int NG = BK / 8, PF = (NG >= 4) ? 2 : 1;
-  const int wg = __builtin_amdgcn_readfirstlane(wg_), nwg = __builtin_amdgcn_readfirstlane(nwg_);
-  const int x = wg & 7, jx = wg >> 3, nx = (nwg - x + 7) >> 3;
+  const int x = (int)blockIdx.x & 7;
   const int lo = (int)((int64_t)total * x / 8), hi = (int)((int64_t)total * (x + 1) / 8);
-  const int nloc = (hi - lo - jx + nx - 1) / nx;          // tiles lo + jx + j nx < hi
-  if (hi - lo - jx <= 0) return;
+  int* const qx = queue + x;
+  int* const slot = reinterpret_cast<int*>(lds + 2 * kStage);          // one word behind the two stages
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int ns = p.K / BK;                                 // slabs per tile
-  const int ftot = nloc * ns;
+  const int ns = p.K / BK;                                 // slabs per tile (>= 3)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+
+  // the first tile: fetched and published before anything else
+  __syncthreads();                                         // (a caller that used the LDS before is done with it)
+  if (tid == 0) { const int t = lo + atomicAdd(qx, 1); *slot = t < hi ? t : -1; }
+  __syncthreads();
+  int idM = __builtin_amdgcn_readfirstlane(*slot);         // tile being multiplied
+  if (idM < 0) return;
+  int idL = idM;                                           // tile whose slabs are being fetched
+  int idN = -2;                                            // the tile after idM: -2 not known yet, -1 none
 
   constexpr int NPA = Pieces<AKC, BM, BK, true>::kCount, NPB = Pieces<BKC, BN, BK, true>::kCount, NP = NPA + NPB;
   constexpr int HALF = (NG >= 2) ? NG / 2 : 1;
@@ -758,21 +768,18 @@ __device__ __forceinline__ void gemm_persist_body(const GemmParams& p, const int
   const int64_t extB = BKC ? ((int64_t)(p.N - 1) * p.ldb + p.K) : ((int64_t)(p.K - 1) * p.ldb + p.N);
   const int stepA = 4 * (AKC ? BK : BK * p.lda), stepB = 4 * (BKC ? BK : BK * p.ldb);     // bytes per slab
 
-  // a tile of the list: batch indices, origin
   struct Tile { int m0, n0, i0, i1, i2; };
-  auto locate = [&](int j) {
-    const int id = __builtin_amdgcn_readfirstlane(lo + jx + min(j, nloc - 1) * nx);
+  auto locate = [&](int id) {
     const int b = id / tiles, t = id - b * tiles;
     Tile r;
     r.m0 = (t / tiles_n) * BM; r.n0 = (t % tiles_n) * BN;
     r.i2 = b % p.nb2; r.i1 = (b / p.nb2) % p.nb1; r.i0 = b / (p.nb2 * p.nb1);
     return r;
   };
-  // load cursor: the tile whose slabs are being fetched
   i32x4 rsA, rsB;
   int offA[NPA], offB[NPB];
-  auto set_load_tile = [&](int j) {
-    const Tile t = locate(j);
+  auto set_load_tile = [&](int id) {
+    const Tile t = locate(id);
     rsA = make_rsrc(p.A + t.i0 * p.sA[0] + t.i1 * p.sA[1] + t.i2 * p.sA[2], (int)(4 * extA));
     rsB = make_rsrc(p.B + t.i0 * p.sB[0] + t.i1 * p.sB[1] + t.i2 * p.sB[2], (int)(4 * extB));
 #pragma unroll
@@ -780,11 +787,12 @@ __device__ __forceinline__ void gemm_persist_body(const GemmParams& p, const int
 #pragma unroll
     for (int c = 0; c < NPB; ++c) offB[c] = 4 * piece_offset<BKC, BN, BK>(p.ldb, t.n0, p.N, c);
   };
-  int jL = 0, sL = 0;                                      // local tile and slab of the NEXT load
+  int sL = 0;                                              // slab of the NEXT load (of tile idL)
   auto advance_load = [&]() {
-    if (jL * ns + sL + 1 < ftot) {                         // past the end: the last slab is fetched again (and never used)
-      if (++sL == ns) { sL = 0; ++jL; set_load_tile(jL); }
-    }
+    if (sL + 1 < ns) { ++sL; return; }
+    // the tile is fetched completely: on to the next one, if the queue had one (idN is known by now: it was published with the
+    // first slab's barrier and ns >= 3); otherwise the last slab is fetched again (and never used)
+    if (idL == idM && idN >= 0) { idL = idN; sL = 0; set_load_tile(idL); }
   };
 
   f32x16 acc[TM][TN];
@@ -848,19 +856,19 @@ __device__ __forceinline__ void gemm_persist_body(const GemmParams& p, const int
 #pragma unroll
     for (int c = 0; c < NPB; ++c) load_piece_fast<BN, BK>(rsB, offB[c], soB, c, xb);
   };
-  set_load_tile(0);
+  set_load_tile(idL);
   load_set(ra, rb);
   advance_load();
   store_slab<AKC, BM, BK, true, false>(lds, ra, one);
   store_slab<BKC, BN, BK, true, false>(lds + kBoff, rb, one);
-  load_set(ra, rb);                                        // flat slab 1 -> set X
+  load_set(ra, rb);                                        // slab 1 -> set X
   advance_load();
   __syncthreads();
 
-  int jM = 0, sM = 0;                                      // tile and slab being multiplied
+  int sM = 0;                                              // slab being multiplied (of tile idM)
   // the result of the tile the multiply cursor is on: straight-line stores, lanes outside the matrix write to the dump
   auto epilogue = [&]() {
-    const Tile t = locate(jM);
+    const Tile t = locate(idM);
     float* C = p.C + t.i0 * p.sC[0] + t.i1 * p.sC[1] + t.i2 * p.sC[2];
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
@@ -876,14 +884,18 @@ __device__ __forceinline__ void gemm_persist_body(const GemmParams& p, const int
       }
     }
   };
+  // one slab; returns false when the last tile of this workgroup is done
   auto iteration = [&](auto stage_c, float (&xa)[BM * BK / NT], float (&xb)[BN * BK / NT], float (&ya)[BM * BK / NT],
-                       float (&yb)[BN * BK / NT]) {
+                       float (&yb)[BN * BK / NT]) -> bool {
     constexpr int stage = decltype(stage_c)::value;
     const float* As = lds + stage * kStage;
     float* An = lds + (stage ^ 1) * kStage;
     const int soA = sL * stepA, soB = sL * stepB;
+    const bool fetch = sM == 0;                            // (uniform) first slab of a tile: ask the queue for the tile after it
+    int fetched = 0;
+    if (fetch && tid == 0) fetched = atomicAdd(qx, 1);
     slab_mfma(As, As + kBoff, [&](int g) {
-      if (g < HALF) {                                      // global (flat slab f + 2) -> register set Y
+      if (g < HALF) {                                      // global (two slabs ahead) -> register set Y
 #pragma unroll
         for (int u = 0; u < PERL; ++u) {
           const int pc = g * PERL + u;
@@ -891,7 +903,7 @@ __device__ __forceinline__ void gemm_persist_body(const GemmParams& p, const int
           else if (pc < NP) load_piece_fast<BN, BK>(rsB, offB[pc - NPA], soB, pc - NPA, yb);
         }
       }
-      if (g >= HALF) {                                     // register set X (flat slab f + 1) -> idle LDS stage
+      if (g >= HALF) {                                     // register set X (one slab ahead) -> idle LDS stage
 #pragma unroll
         for (int u = 0; u < PERS; ++u) {
           const int pc = (g - HALF) * PERS + u;
@@ -900,17 +912,23 @@ __device__ __forceinline__ void gemm_persist_body(const GemmParams& p, const int
         }
       }
     });
+    if (fetch && tid == 0) { const int t = lo + fetched; *slot = t < hi ? t : -1; }
     advance_load();
+    bool more = true;
     if (++sM == ns) {                                      // (uniform) the tile is complete
       epilogue();
       zero_acc();
-      sM = 0; ++jM;
+      sM = 0;
+      more = idN >= 0;
+      idM = idN; idN = -2;
     }
     __syncthreads();
+    if (fetch) idN = __builtin_amdgcn_readfirstlane(*slot);
+    return more;
   };
-  for (int f = 0; f < ftot; f += 2) {
-    iteration(std::integral_constant<int, 0>{}, ra, rb, ra2, rb2);
-    if (f + 1 < ftot) iteration(std::integral_constant<int, 1>{}, ra2, rb2, ra, rb);
+  for (;;) {
+    if (!iteration(std::integral_constant<int, 0>{}, ra, rb, ra2, rb2)) break;
+    if (!iteration(std::integral_constant<int, 1>{}, ra2, rb2, ra, rb)) break;
   }
 }
 
@@ -1065,7 +1083,7 @@ extern "C" void vargp_debug_chol_phases(unsigned long long* out, int last) {
 // plain NN product the chain does not feed (P_uf = W_uf x next to the K_uu matrices, P_uu = W_uu z next to the S_u ones).
 // Every workgroup is carved the chain's 136 KB of LDS, i.e. one workgroup per CU.
 __global__ __launch_bounds__(256) void t0_bwdmat_gemm_kernel(const BwdMatArgs a, const int first, const int nmat,
-                                                             const GemmParams p, const int tiles, const int npersist,
+                                                             const GemmParams p, const int tiles, int* __restrict__ queue,
                                                              const int total) {
   extern __shared__ __attribute__((aligned(16))) float bmat_lds[];
   STEP_SPAN(gemm, 5);
@@ -1083,8 +1101,10 @@ __global__ __launch_bounds__(256) void t0_bwdmat_gemm_kernel(const BwdMatArgs a,
 #ifdef STEP_SPANS
     if (threadIdx.x == 0 && blockIdx.x < 64) { g_bmat_ends[blockIdx.x][1] = wall_clock64(); g_bmat_ends[blockIdx.x][0] = t_in_; }
 #endif
-  } else if (npersist > 0) {       // npersist workgroups walk the tiles of the product (gemm_persist_body)
-    gemm_persist_body<64, 64, 64, true, false>(p, (int)blockIdx.x - nmat, npersist, tiles, total, bmat_lds);
+    // queue != NULL: the product's tiles come from a work queue (gemm_persist_body) -- a finished chain joins in
+    if (queue) gemm_persist_body<64, 64, 64, true, false>(p, queue, tiles, total, bmat_lds);
+  } else if (queue) {
+    gemm_persist_body<64, 64, 64, true, false>(p, queue, tiles, total, bmat_lds);
   } else {
     const int id = xcd_remap((int)blockIdx.x - nmat, (int)gridDim.x - nmat);
     gemm_body<64, 64, 64, true, false, true, false>(p, id % tiles, id / tiles, 0, bmat_lds);
@@ -1224,10 +1244,16 @@ static int launch_chol_rbf_gemm_impl(const float* A, float eps, float* L, float*
   const unsigned pad = pad_force >= 0 ? (unsigned)pad_force * 1024u : (tiles * nbatch <= 1024 ? (big ? 40u : 24u) * 1024u : 0u);
   // arithmetic of the pivot chains: fp64 (default) or the reference's own fp32 (VARGP_CHOL_F32=1; chol_small3.h)
   static const int f32_env = [] { const char* e = getenv("VARGP_CHOL_F32"); return e ? atoi(e) : kCholF32Default; }();
+  // kscale == NULL: the caller's B operand is pre-scaled (x o 1/sigma^2, written once per hyper-sample by the norm role) and the
+  // main loop carries no scale loads and multiplies
+  static const int exp_unscaled = [] { const char* e = getenv("VARGP_EXP_UNSCALED"); return e ? atoi(e) : 0; }();   // timing only
+  const bool scaled = q.kscale != nullptr && !exp_unscaled;
 #define VARGP_MERGED(KC, SETS, R)                                                                                                  \
   do {                                                                                                                               \
-    if (big) hipLaunchKernelGGL((chol_rbf_gemm_kernel<KC, SETS, 128, 32, true, R>), dim3(total), dim3(256), pad, st, c, q, tiles);    \
-    else hipLaunchKernelGGL((chol_rbf_gemm_kernel<KC, SETS, 64, 64, true, R>), dim3(total), dim3(256), pad, st, c, q, tiles);       \
+    if (big && scaled) hipLaunchKernelGGL((chol_rbf_gemm_kernel<KC, SETS, 128, 32, true, R>), dim3(total), dim3(256), pad, st, c, q, tiles);  \
+    else if (big) hipLaunchKernelGGL((chol_rbf_gemm_kernel<KC, SETS, 128, 32, false, R>), dim3(total), dim3(256), pad, st, c, q, tiles);     \
+    else if (scaled) hipLaunchKernelGGL((chol_rbf_gemm_kernel<KC, SETS, 64, 64, true, R>), dim3(total), dim3(256), pad, st, c, q, tiles);    \
+    else hipLaunchKernelGGL((chol_rbf_gemm_kernel<KC, SETS, 64, 64, false, R>), dim3(total), dim3(256), pad, st, c, q, tiles);              \
   } while (0)
   // (an 8-wave GEMM role -- chol_rbf_gemm_kernel<..., NT = 512>, gemm_body<..., NT = 512>: the same 128 x 64 tile on two waves
   // per SIMD -- measured 37.7 us against 39.1 us for the K_uf product alone and nothing for the launch: not instantiated)
@@ -1309,7 +1335,7 @@ int launch_gemm_pair2(const GemmParams& p0, int tA0, int tB0, int nbatch0, const
 static bool gemm_persist_ok(const GemmParams& p, int BK, bool AKC, bool BKC) {
   const int64_t extA = AKC ? ((int64_t)(p.M - 1) * p.lda + p.K) : ((int64_t)(p.K - 1) * p.lda + p.M);
   const int64_t extB = BKC ? ((int64_t)(p.N - 1) * p.ldb + p.K) : ((int64_t)(p.K - 1) * p.ldb + p.N);
-  return gemm_vec_ok(p) && p.K >= 2 * BK && p.K % BK == 0 && !p.D && p.triA == 0 && p.triB == 0 && p.triC == 0 && !p.symout &&
+  return gemm_vec_ok(p) && p.K >= 4 * BK && p.K % BK == 0 && !p.D && p.triA == 0 && p.triB == 0 && p.triC == 0 && !p.symout &&
          p.splitk <= 1 && (AKC || (p.M % 4 == 0 && p.M >= 4)) && (BKC || (p.N % 4 == 0 && p.N >= 4)) &&
          extA < (1ll << 29) && extB < (1ll << 29);
 }
@@ -1325,14 +1351,14 @@ static int device_cu_count(int dev) {
 }
 
 int launch_bwdmat_gemm(const BwdMatArgs& a, int first, int nmat, const GemmParams& p, int nbatch, hipStream_t st,
-                       const char* tag) {
+                       const char* tag, int* queue) {
   VARGP_REQUIRE(gemm_vec_ok(p), "bwdmat_gemm: the product's operands must be 16-byte aligned with strides % 4 == 0");
   VARGP_REQUIRE(a.M <= kBmKP && a.M >= 4 && (a.M % 4) == 0 && (a.LD % 4) == 0, "bwdmat_gemm: M = %d out of range", a.M);
   static_assert(kBwdMatLdsBytes >= sizeof(float) * gemm_lds_floats<64, 64, 64, true, false>(), "LDS of the GEMM role");
   if (prof_remembering() && strcmp(tag, "replay") != 0) {
     const GemmParams pc = p;
     const BwdMatArgs ac = a;
-    prof_remember(tag, [=](hipStream_t s) { launch_bwdmat_gemm(ac, first, nmat, pc, nbatch, s, "replay"); });
+    prof_remember(tag, [=](hipStream_t s) { launch_bwdmat_gemm(ac, first, nmat, pc, nbatch, s, "replay", nullptr); });
   }
   // hipFuncAttributeMaxDynamicSharedMemorySize is per device
   static std::atomic<unsigned> attr_mask[2] = {};
@@ -1352,15 +1378,16 @@ int launch_bwdmat_gemm(const BwdMatArgs& a, int first, int nmat, const GemmParam
   static const int exp_role = [] { const char* e = getenv("VARGP_EXP_BWDMAT"); return e ? atoi(e) : 0; }();
   if (exp_role == 1) nbatch = 0;
   if (exp_role == 2) nmat = 0;
-  // the product's tiles: one workgroup each, or -- more tiles than free CUs -- one persistent workgroup per free CU walking its
-  // share of them (every workgroup of this launch has a CU to itself: the chain's LDS)
+  // the product's tiles: one workgroup each, or -- more tiles than free CUs, and the caller has 8 zeroed counters for us -- one
+  // persistent workgroup per free CU taking tiles from a work queue (every workgroup of this launch has a CU to itself: the
+  // chain's LDS), joined by the chains' workgroups when they are done
   static const int persist_env = [] { const char* e = getenv("VARGP_GEMM_PERSIST"); return e ? atoi(e) : 1; }();   // tuning aid
   const int total = tiles * nbatch;
   const int free_cus = device_cu_count(dev) - nmat;
-  const bool persist = persist_env && total > free_cus && free_cus >= 8 && gemm_persist_ok(q, 64, true, false);
+  const bool persist = persist_env && queue && total > free_cus && free_cus >= 8 && gemm_persist_ok(q, 64, true, false);
   const int ngemm = persist ? free_cus : total;
   hipLaunchKernelGGL(t0_bwdmat_gemm_kernel, dim3(nmat + ngemm), dim3(256), kBwdMatLdsBytes, st, a, first, nmat, q, tiles,
-                     persist ? ngemm : 0, total);
+                     persist ? queue : (int*)nullptr, total);
   return check_launch("bwdmat_gemm");
 }
 

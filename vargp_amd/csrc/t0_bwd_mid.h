@@ -61,7 +61,11 @@ __device__ __forceinline__ void bm_tri_atomic(const bm_f32x16 (&acc)[3], float* 
     const int row = 32 * rb + rl + 4 * lh, col = 32 * cb + li;
     const bool ok = row < M && (rb != cb || col <= row);
 #ifndef BM_EXP_NOATOM
+#ifdef BM_EXP_PLAIN_STORES      // tuning builds (wrong results): what the float atomics of the two triangular products cost
+    if (ok) dst[(int64_t)row * ldd + col] = acc[u][r];
+#else
     if (ok) atomicAdd(&dst[(int64_t)row * ldd + col], acc[u][r]);
+#endif
 #else
     if (ok && acc[u][r] == 12345.f) dst[(int64_t)row * ldd + col] = 0.f;
 #endif

@@ -168,6 +168,7 @@ struct NormArgs {
   float *na, *nb;
   int64_t zrows, xrows;
   int rows_per_block, nrow_blocks;       // blocks per hyper-sample
+  float* xs;                             // (S, xrows, D) or NULL: x o 1/sigma_s^2, the pre-scaled operand of the K_uf distance product
 };
 __device__ __forceinline__ void t0_norm_body(const ProArgs& a, const NormArgs& n, const int id, float* __restrict__ wl) {
   const int s = id / n.nrow_blocks, rb = id - s * n.nrow_blocks;
@@ -186,19 +187,39 @@ __device__ __forceinline__ void t0_norm_body(const ProArgs& a, const NormArgs& n
       xr[q] = rc < n.zrows ? n.z + rc * a.D : n.x + (rc - n.zrows) * a.D;
     }
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    bool xout[4];                                     // (uniform) the row is a row of x whose scaled copy this wave writes
+    float* xo[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      xout[q] = n.xs != nullptr && row[q] >= n.zrows && row[q] < nrows && r0 + 4 * q < n.rows_per_block;
+      xo[q] = n.xs + ((int64_t)s * n.xrows + (xout[q] ? row[q] - n.zrows : 0)) * a.D;
+    }
+    // (the next chunk's loads are issued BEFORE this chunk's stores: a load behind a store waits for the store's
+    // acknowledgement as well -- vmcnt counts both in order)
+    float xv[4][4], xn[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) xv[q][c] = xr[q][min(64 * c + lane, a.D - 1)];
     for (int d0 = 0; d0 < a.D; d0 += 256) {
-      float xv[4][4];
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) xv[q][c] = xr[q][min(d0 + 64 * c + lane, a.D - 1)];
+        for (int c = 0; c < 4; ++c) xn[q][c] = xr[q][min(d0 + 256 + 64 * c + lane, a.D - 1)];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int dd = d0 + 64 * c + lane;
         const float wv = dd < a.D ? wl[dd] : 0.f;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = fmaf(xv[q][c] * xv[q][c], wv, acc[q]);
+        for (int q = 0; q < 4; ++q) {
+          acc[q] = fmaf(xv[q][c] * xv[q][c], wv, acc[q]);
+          if (xout[q] && dd < a.D) xo[q][dd] = xv[q][c] * wv;
+        }
       }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xv[q][c] = xn[q][c];
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
