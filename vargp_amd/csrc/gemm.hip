@@ -718,7 +718,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int tile_id
 }
 
 // Persistent variant of gemm_body's fast path for PLAIN products (no RBF epilogue, no D, no split-K, no triangular hints; K a
-// multiple of BK with at least three slabs; operands as the fast path wants them -- gemm_persist_ok() on the host).  A workgroup
+// multiple of BK with at least four slabs; operands as the fast path wants them -- gemm_persist_ok() on the host).  A workgroup
 // takes tile after tile from a work queue and treats the K slabs of ALL its tiles as one pipelined sequence: while the last
 // slabs of a tile are multiplied the first slabs of the next one are already on their way (global -> registers -> idle LDS
 // stage), and a tile's result is stored between two slabs.  Why: a 64 x 64 x 512 tile of the backward's P_uf product takes
@@ -729,10 +729,17 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int tile_id
 // tiles in flight on one L2 share their A panels (as xcd_remap does for one-tile workgroups).  Any workgroup of the launch
 // may join at any time -- the matrix-chain workgroups of t0_bwdmat_gemm_kernel do when their chain is finished (with many
 // hyper-samples the chains end long before the product).  The next tile's id is fetched (thread 0, one atomic) during the first
-// slab of the current tile and published through LDS with that slab's barrier.
+// slab of the current tile and published through LDS a few slabs later (iteration()).
+// rank >= 0: this workgroup's first tile is number `rank` of its XCD's range (no round trip to the queue before the first
+// load), the queue hands out the tiles from number `nstatic` on (= the number of workgroups that start this way on the XCD);
+// rank < 0: a late joiner, which asks the queue for its first tile too.
+// queue == NULL: no queue -- the workgroup's tiles are rank, rank + nstatic, rank + 2 nstatic, ... of the range.  (The
+// returning atomic costs: the loads issued behind it cannot retire before it does -- vmcnt counts in order -- and a
+// device-scope atomic takes longer than a slab.  P_uf alone at S = 3: 39.4 us static, 44.0 with the queue; with 8+ samples,
+// where the chains' CUs would otherwise idle for most of the launch, the queue wins: S = 8 step 496 -> 476 us.)
 template <int BM, int BN, int BK, bool AKC, bool BKC>
 __device__ __forceinline__ void gemm_persist_body(const GemmParams& p, int* __restrict__ queue, const int tiles, const int total,
-                                                  float* __restrict__ lds) {
+                                                  float* __restrict__ lds, const int rank, const int nstatic) {
   constexpr int NT = 256;
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   using LA = LdsLayout<AKC, BM, BK>;
@@ -745,18 +752,24 @@ __device__ __forceinline__ void gemm_persist_body(const GemmParams& p, int* __re
   int* const qx = queue + x;
   int* const slot = reinterpret_cast<int*>(lds + 2 * kStage);          // one word behind the two stages
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int ns = p.K / BK;                                 // slabs per tile (>= 3)
+  const int ns = p.K / BK;                                 // slabs per tile (>= 4)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
 
-  // the first tile: fetched and published before anything else
-  __syncthreads();                                         // (a caller that used the LDS before is done with it)
-  if (tid == 0) { const int t = lo + atomicAdd(qx, 1); *slot = t < hi ? t : -1; }
-  __syncthreads();
-  int idM = __builtin_amdgcn_readfirstlane(*slot);         // tile being multiplied
+  const int q0 = lo + nstatic;                             // the queue's first tile
+  int idM;                                                 // tile being multiplied
+  if (rank >= 0) {
+    idM = lo + rank < hi ? lo + rank : -1;
+  } else {                                                 // fetched and published before anything else
+    __syncthreads();                                       // (a caller that used the LDS before is done with it)
+    if (tid == 0) { const int t = q0 + atomicAdd(qx, 1); *slot = t < hi ? t : -1; }
+    __syncthreads();
+    idM = __builtin_amdgcn_readfirstlane(*slot);
+  }
   if (idM < 0) return;
+  if (queue == nullptr && rank < 0) return;
   int idL = idM;                                           // tile whose slabs are being fetched
   int idN = -2;                                            // the tile after idM: -2 not known yet, -1 none
 
@@ -790,8 +803,8 @@ __device__ __forceinline__ void gemm_persist_body(const GemmParams& p, int* __re
   int sL = 0;                                              // slab of the NEXT load (of tile idL)
   auto advance_load = [&]() {
     if (sL + 1 < ns) { ++sL; return; }
-    // the tile is fetched completely: on to the next one, if the queue had one (idN is known by now: it was published with the
-    // first slab's barrier and ns >= 3); otherwise the last slab is fetched again (and never used)
+    // the tile is fetched completely (this is the iteration that multiplies its slab ns - 3): on to the next one, if the queue
+    // had one (idN was published with the barrier of slab ns - 4); otherwise the last slab is fetched again (and never used)
     if (idL == idM && idN >= 0) { idL = idN; sL = 0; set_load_tile(idL); }
   };
 
@@ -866,6 +879,7 @@ __device__ __forceinline__ void gemm_persist_body(const GemmParams& p, int* __re
   __syncthreads();
 
   int sM = 0;                                              // slab being multiplied (of tile idM)
+  int fetched = 0;                                         // thread 0: the queue's answer, in flight
   // the result of the tile the multiply cursor is on: straight-line stores, lanes outside the matrix write to the dump
   auto epilogue = [&]() {
     const Tile t = locate(idM);
@@ -891,9 +905,10 @@ __device__ __forceinline__ void gemm_persist_body(const GemmParams& p, int* __re
     const float* As = lds + stage * kStage;
     float* An = lds + (stage ^ 1) * kStage;
     const int soA = sL * stepA, soB = sL * stepB;
-    const bool fetch = sM == 0;                            // (uniform) first slab of a tile: ask the queue for the tile after it
-    int fetched = 0;
-    if (fetch && tid == 0) fetched = atomicAdd(qx, 1);
+    // (uniform) first slab of a tile: thread 0 asks the queue for the tile after it; the answer -- a device-scope atomic takes
+    // longer than a slab -- is published through LDS with the barrier of slab ns - 4, one slab before the load cursor needs it
+    const bool publish = sM == ns - 4;
+    if (queue != nullptr && sM == 0 && tid == 0) fetched = atomicAdd(qx, 1);
     slab_mfma(As, As + kBoff, [&](int g) {
       if (g < HALF) {                                      // global (two slabs ahead) -> register set Y
 #pragma unroll
@@ -912,7 +927,7 @@ __device__ __forceinline__ void gemm_persist_body(const GemmParams& p, int* __re
         }
       }
     });
-    if (fetch && tid == 0) { const int t = lo + fetched; *slot = t < hi ? t : -1; }
+    if (queue != nullptr && publish && tid == 0) { const int t = q0 + fetched; *slot = t < hi ? t : -1; }
     advance_load();
     bool more = true;
     if (++sM == ns) {                                      // (uniform) the tile is complete
@@ -923,7 +938,10 @@ __device__ __forceinline__ void gemm_persist_body(const GemmParams& p, int* __re
       idM = idN; idN = -2;
     }
     __syncthreads();
-    if (fetch) idN = __builtin_amdgcn_readfirstlane(*slot);
+    if (publish) {
+      if (queue != nullptr) idN = __builtin_amdgcn_readfirstlane(*slot);
+      else idN = idM + nstatic < hi ? idM + nstatic : -1;      // static list: every nstatic-th tile of the range
+    }
     return more;
   };
   for (;;) {
@@ -1084,7 +1102,7 @@ extern "C" void vargp_debug_chol_phases(unsigned long long* out, int last) {
 // Every workgroup is carved the chain's 136 KB of LDS, i.e. one workgroup per CU.
 __global__ __launch_bounds__(256) void t0_bwdmat_gemm_kernel(const BwdMatArgs a, const int first, const int nmat,
                                                              const GemmParams p, const int tiles, int* __restrict__ queue,
-                                                             const int total) {
+                                                             const int total, const int persist) {
   extern __shared__ __attribute__((aligned(16))) float bmat_lds[];
   STEP_SPAN(gemm, 5);
 #ifdef STEP_SPANS
@@ -1102,9 +1120,14 @@ __global__ __launch_bounds__(256) void t0_bwdmat_gemm_kernel(const BwdMatArgs a,
     if (threadIdx.x == 0 && blockIdx.x < 64) { g_bmat_ends[blockIdx.x][1] = wall_clock64(); g_bmat_ends[blockIdx.x][0] = t_in_; }
 #endif
     // queue != NULL: the product's tiles come from a work queue (gemm_persist_body) -- a finished chain joins in
-    if (queue) gemm_persist_body<64, 64, 64, true, false>(p, queue, tiles, total, bmat_lds);
-  } else if (queue) {
-    gemm_persist_body<64, 64, 64, true, false>(p, queue, tiles, total, bmat_lds);
+    // (workgroups go to the XCDs round-robin by blockIdx: XCD x holds cx of the chains and nx of the product's workgroups)
+    const int x = (int)blockIdx.x & 7;
+    const int cx = nmat > x ? (nmat - x + 7) >> 3 : 0, nx = (((int)gridDim.x - x + 7) >> 3) - cx;
+    if (queue) gemm_persist_body<64, 64, 64, true, false>(p, queue, tiles, total, bmat_lds, -1, nx);
+  } else if (persist) {
+    const int x = (int)blockIdx.x & 7;
+    const int cx = nmat > x ? (nmat - x + 7) >> 3 : 0, nx = (((int)gridDim.x - x + 7) >> 3) - cx;
+    gemm_persist_body<64, 64, 64, true, false>(p, queue, tiles, total, bmat_lds, ((int)blockIdx.x >> 3) - cx, nx);
   } else {
     const int id = xcd_remap((int)blockIdx.x - nmat, (int)gridDim.x - nmat);
     gemm_body<64, 64, 64, true, false, true, false>(p, id % tiles, id / tiles, 0, bmat_lds);
@@ -1378,16 +1401,19 @@ int launch_bwdmat_gemm(const BwdMatArgs& a, int first, int nmat, const GemmParam
   static const int exp_role = [] { const char* e = getenv("VARGP_EXP_BWDMAT"); return e ? atoi(e) : 0; }();
   if (exp_role == 1) nbatch = 0;
   if (exp_role == 2) nmat = 0;
-  // the product's tiles: one workgroup each, or -- more tiles than free CUs, and the caller has 8 zeroed counters for us -- one
-  // persistent workgroup per free CU taking tiles from a work queue (every workgroup of this launch has a CU to itself: the
-  // chain's LDS), joined by the chains' workgroups when they are done
+  // the product's tiles: one workgroup each, or -- more tiles than free CUs -- one persistent workgroup per free CU (every
+  // workgroup of this launch has a CU to itself: the chain's LDS).  VARGP_GEMM_PERSIST (tuning aid): 0 off, 2 / 3 force the
+  // work queue / the static lists
   static const int persist_env = [] { const char* e = getenv("VARGP_GEMM_PERSIST"); return e ? atoi(e) : 1; }();   // tuning aid
   const int total = tiles * nbatch;
   const int free_cus = device_cu_count(dev) - nmat;
-  const bool persist = persist_env && queue && total > free_cus && free_cus >= 8 && gemm_persist_ok(q, 64, true, false);
+  const bool persist = persist_env && total > free_cus && free_cus >= 8 && gemm_persist_ok(q, 64, true, false);
+  // few tiles per CU (the chains take about as long as the product): static tile lists; many: the work queue, which the chains'
+  // workgroups join when they are done (needs the caller's 8 zeroed counters)
+  const bool use_queue = persist && queue && (persist_env == 2 || (persist_env != 3 && total > 4 * free_cus));
   const int ngemm = persist ? free_cus : total;
   hipLaunchKernelGGL(t0_bwdmat_gemm_kernel, dim3(nmat + ngemm), dim3(256), kBwdMatLdsBytes, st, a, first, nmat, q, tiles,
-                     persist ? queue : (int*)nullptr, total);
+                     use_queue ? queue : (int*)nullptr, total, persist ? 1 : 0);
   return check_launch("bwdmat_gemm");
 }
 

@@ -52,13 +52,18 @@ __host__ __device__ constexpr int bm_min(int a, int b) { return a < b ? a : b; }
 constexpr int kBmNQ = kBmKP / 4;                          // float4 per row of an M x M operand (26)
 constexpr int kBmNA = (kBmKP * kBmNQ + 255) / 256;        // float4 per thread of one M x M operand (11)
 
-// one M x M matrix (row-major, row stride ld in global memory) -> registers (clamped indices)
+// one M x M matrix (row-major, row stride ld in global memory) -> registers (clamped indices).  32-bit BYTE offsets from the
+// (uniform) base: the load then takes its address as SGPR pair + one VGPR, and the address arithmetic stays 32-bit -- with
+// 64-bit element indices every load carried a v_mad_i64 / v_lshl_add_u64 chain (a third of the instructions in front of the
+// first barrier of t0_bwd_mid_kernel).  A matrix spans far less than 4 GB.
 __device__ __forceinline__ void bm_load_mat(const float* __restrict__ base, int ld, int M, int tid, float4 (&dst)[kBmNA]) {
+  const char* bp = reinterpret_cast<const char*>(base);
 #pragma unroll
   for (int u = 0; u < kBmNA; ++u) {
     const int e = min(tid + 256 * u, kBmKP * kBmNQ - 1);
     const int i = e / kBmNQ, j = (e - i * kBmNQ) * 4;
-    dst[u] = *reinterpret_cast<const float4*>(base + (int64_t)min(i, M - 1) * ld + min(j, M - 4));
+    const unsigned off = 4u * (__umul24((unsigned)min(i, M - 1), (unsigned)ld) + (unsigned)min(j, M - 4));
+    dst[u] = *reinterpret_cast<const float4*>(bp + off);
   }
 }
 

@@ -198,11 +198,13 @@ constexpr int kBmNT = (kBmKP * 16 + 255) / 256;     // float4 per thread of one 
 // branch around a load makes the compiler drain vmcnt before the next one: one memory round trip per load)
 __device__ __forceinline__ void bm_load_tile(const float* __restrict__ base, int ld, int M, int n0, int B, int tid,
                                              float4 (&dst)[kBmNT]) {
+  const char* bp = reinterpret_cast<const char*>(base);      // (32-bit byte offsets: see bm_load_mat)
 #pragma unroll
   for (int u = 0; u < kBmNT; ++u) {
     const int e = min(tid + 256 * u, kBmKP * 16 - 1);
     const int m = e >> 4, n = (e & 15) * 4;
-    dst[u] = *reinterpret_cast<const float4*>(base + (int64_t)min(m, M - 1) * ld + min(n0 + n, B - 4));
+    const unsigned off = 4u * (__umul24((unsigned)min(m, M - 1), (unsigned)ld) + (unsigned)min(n0 + n, B - 4));
+    dst[u] = *reinterpret_cast<const float4*>(bp + off);
   }
 }
 // registers -> LDS tile [m][n] (stride kBmST), rows m >= M and columns n0 + n >= B zero
