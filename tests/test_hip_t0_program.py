@@ -27,7 +27,11 @@ SHAPES = [(2, 3, 3, 33, 40, 50), (3, 2, 4, 20, 64, 37), (2, 2, 18, 12, 36, 24), 
           # 64-column tile, M = 104 (no padding left), M = 4, four / five / eight / sixteen hyper-samples (the S_u chains redo S products), seventeen
           # (the tile kernel without the per-matrix chains), several full tiles
           (3, 2, 3, 100, 40, 72), (4, 2, 2, 104, 36, 64), (5, 2, 2, 52, 36, 40), (2, 2, 2, 4, 36, 8), (2, 3, 3, 96, 48, 200),
-          (3, 2, 2, 100, 36, 132), (8, 2, 2, 100, 36, 64), (16, 1, 2, 100, 36, 64), (17, 2, 2, 52, 36, 40)]
+          (3, 2, 2, 100, 36, 132), (8, 2, 2, 100, 36, 64), (16, 1, 2, 100, 36, 64), (17, 2, 2, 52, 36, 40),
+          # the persistent P_uf role of the backward's merged launch (gemm_persist_body: more tiles than free CUs, B % 64 == 0,
+          # B >= 256): static tile lists with four (the minimum) and five slabs per tile, and the work queue that the finished
+          # matrix chains join (many tiles per CU: 8 hyper-samples)
+          (3, 2, 10, 100, 784, 256), (3, 2, 10, 100, 784, 320), (8, 2, 10, 100, 384, 256)]
 
 
 @pytest.mark.parametrize('shape', SHAPES, ids=[str(s) for s in SHAPES])
