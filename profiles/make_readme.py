@@ -22,13 +22,13 @@ def avg(d, sub):
 
 
 ROWS = [('chol_rbf_gemm', 'chol_rbf_gemm_kernel', 'roofline', 2.408e9,
-         '`chol_rbf_gemm_kernel<25,2,128,32,true,float>` — factorisations of K_uu+εI (30, from K-split partial Gram matrices) and '
-         'S_u+εI (10): fp32 chains, four pivots per barrier ‖ K_uf distance GEMM'),
+         '`chol_rbf_gemm_kernel<25,2,128,32,false,float>` — factorisations of K_uu+εI (30, from K-split partial Gram matrices) and '
+         'S_u+εI (10): fp32 chains, four pivots per barrier ‖ K_uf distance GEMM (x pre-scaled by the norm role)'),
         ('rbf_kuf_bwd_gemm', 't0_bwdmat_gemm_kernel', 'roofline_gemm', 2.408e9,
-         '`t0_bwdmat_gemm_kernel` — per-matrix adjoint chains (40 workgroups) ‖ P_uf = W_uf·x'),
+         '`t0_bwdmat_gemm_kernel` — per-matrix adjoint chains (40 workgroups) ‖ P_uf = W_uf·x (216 persistent workgroups, three tiles each)'),
         ('t0_bwd_mid', 't0_bwd_mid_kernel', None, 1.23e9, '`t0_bwd_mid_kernel` — backward middle per (s, c, 64-column tile), incl. the likelihood of the tile'),
         ('t0_fwd_fused', 't0_fwd_fused_kernel', None, 0.61e9, '`t0_fwd_fused_kernel` — forward middle per (s, c, 64-column tile)'),
-        ('t0_pro_kuu', 't0_pro_kuu_kernel', None, 0.47e9, '`t0_pro_kuu_kernel<32>` — prologue ‖ row norms ‖ K-split K_uu inner products'),
+        ('t0_pro_kuu', 't0_pro_kuu_kernel', None, 0.47e9, '`t0_pro_kuu_kernel<32>` — prologue ‖ row norms (+ x∘σ⁻²) ‖ K-split K_uu inner products'),
         ('t0_puu_final', 't0_puu_final_kernel', None, 0.47e9, '`t0_puu_final_kernel<3>` — P_uu = W_uu·z + finalisation (ḡz, ḡθ) + packed-vector gradient')]
 out = f'''# profiles — round {int(tag[1:])} (MI355X, ROCm 7.2)
 

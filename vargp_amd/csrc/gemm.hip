@@ -1266,11 +1266,15 @@ static int launch_chol_rbf_gemm_impl(const float* A, float eps, float* L, float*
   static const int pad_force = [] { const char* e = getenv("VARGP_MERGED_PAD"); return e ? atoi(e) : -1; }();   // tuning aid (KB)
   const unsigned pad = pad_force >= 0 ? (unsigned)pad_force * 1024u : (tiles * nbatch <= 1024 ? (big ? 40u : 24u) * 1024u : 0u);
   // arithmetic of the pivot chains: fp64 (default) or the reference's own fp32 (VARGP_CHOL_F32=1; chol_small3.h)
-  static const int f32_env = [] { const char* e = getenv("VARGP_CHOL_F32"); return e ? atoi(e) : kCholF32Default; }();
   // kscale == NULL: the caller's B operand is pre-scaled (x o 1/sigma^2, written once per hyper-sample by the norm role) and the
   // main loop carries no scale loads and multiplies
   static const int exp_unscaled = [] { const char* e = getenv("VARGP_EXP_UNSCALED"); return e ? atoi(e) : 0; }();   // timing only
   const bool scaled = q.kscale != nullptr && !exp_unscaled;
+  static const int f32_env = [] { const char* e = getenv("VARGP_CHOL_F32"); return e ? atoi(e) : kCholF32Default; }();
+  // 8-wave GEMM role (two waves per SIMD on the same 128 x 64 x 32 tile; the factorising workgroups use their first four waves):
+  // pays since the launch is bound by its GEMM role (the fp32 chains end 6 us before the K_uf tiles)
+  static const int nt_env = [] { const char* e = getenv("VARGP_MERGED_NT"); return e ? atoi(e) : 512; }();   // tuning aid
+  const bool wide = big && !scaled && nt_env == 512 && f32_env && n > 64;
 #define VARGP_MERGED(KC, SETS, R)                                                                                                  \
   do {                                                                                                                               \
     if (big && scaled) hipLaunchKernelGGL((chol_rbf_gemm_kernel<KC, SETS, 128, 32, true, R>), dim3(total), dim3(256), pad, st, c, q, tiles);  \
@@ -1278,9 +1282,8 @@ static int launch_chol_rbf_gemm_impl(const float* A, float eps, float* L, float*
     else if (scaled) hipLaunchKernelGGL((chol_rbf_gemm_kernel<KC, SETS, 64, 64, true, R>), dim3(total), dim3(256), pad, st, c, q, tiles);    \
     else hipLaunchKernelGGL((chol_rbf_gemm_kernel<KC, SETS, 64, 64, false, R>), dim3(total), dim3(256), pad, st, c, q, tiles);              \
   } while (0)
-  // (an 8-wave GEMM role -- chol_rbf_gemm_kernel<..., NT = 512>, gemm_body<..., NT = 512>: the same 128 x 64 tile on two waves
-  // per SIMD -- measured 37.7 us against 39.1 us for the K_uf product alone and nothing for the launch: not instantiated)
-  if (f32_env) { if (n <= 64) VARGP_MERGED(16, 1, float); else VARGP_MERGED(25, 2, float); }
+  if (wide) hipLaunchKernelGGL((chol_rbf_gemm_kernel<25, 2, 128, 32, false, float, 512>), dim3(total), dim3(512), pad, st, c, q, tiles);
+  else if (f32_env) { if (n <= 64) VARGP_MERGED(16, 1, float); else VARGP_MERGED(25, 2, float); }
   else { if (n <= 64) VARGP_MERGED(16, 1, double); else VARGP_MERGED(25, 2, double); }
 #undef VARGP_MERGED
   return check_launch("chol_rbf_gemm");
