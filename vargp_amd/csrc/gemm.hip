@@ -1252,7 +1252,12 @@ static int launch_chol_rbf_gemm_impl(const float* A, float eps, float* L, float*
   static const int tile_force = [] { const char* e = getenv("VARGP_MERGED_TILE"); return e ? atoi(e) : 0; }();   // tuning aid
   const int t64 = cdiv(p.M, 64) * cdiv(p.N, 64), t128 = cdiv(p.M, 128) * cdiv(p.N, 64);
   const int free_cus = 256 - nchol;
-  const bool big = tile_force ? tile_force == 2 : (t64 * nbatch > free_cus && t128 * nbatch <= free_cus);
+  // (with the 8-wave GEMM role below -- pre-scaled operand, fp32 chains, n > 64 -- the 128 x 64 tile is the better one whenever
+  // 64 x 64 tiles need more than one round: S = 16 step 869 -> 831 us, S = 8 477 -> 474, S >= 32 the same)
+  static const int f32_env = [] { const char* e = getenv("VARGP_CHOL_F32"); return e ? atoi(e) : kCholF32Default; }();
+  const bool wide_ok = p.kscale == nullptr && f32_env && n > 64;
+  const bool big = tile_force ? tile_force == 2
+                              : (t64 * nbatch > free_cus && (wide_ok || t128 * nbatch <= free_cus));
   const int tiles = big ? t128 : t64;
   // VARGP_EXP_MERGED (timing only, wrong results): 1 = the factorisations alone (no GEMM tiles), 2 = the GEMM tiles alone
   static const int exp_role = [] { const char* e = getenv("VARGP_EXP_MERGED"); return e ? atoi(e) : 0; }();
@@ -1270,7 +1275,6 @@ static int launch_chol_rbf_gemm_impl(const float* A, float eps, float* L, float*
   // main loop carries no scale loads and multiplies
   static const int exp_unscaled = [] { const char* e = getenv("VARGP_EXP_UNSCALED"); return e ? atoi(e) : 0; }();   // timing only
   const bool scaled = q.kscale != nullptr && !exp_unscaled;
-  static const int f32_env = [] { const char* e = getenv("VARGP_CHOL_F32"); return e ? atoi(e) : kCholF32Default; }();
   // 8-wave GEMM role (two waves per SIMD on the same 128 x 64 x 32 tile; the factorising workgroups use their first four waves):
   // pays since the launch is bound by its GEMM role (the fp32 chains end 6 us before the K_uf tiles)
   static const int nt_env = [] { const char* e = getenv("VARGP_MERGED_NT"); return e ? atoi(e) : 512; }();   // tuning aid
