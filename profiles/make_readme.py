@@ -22,8 +22,8 @@ def avg(d, sub):
 
 
 ROWS = [('chol_rbf_gemm', 'chol_rbf_gemm_kernel', 'roofline', 2.408e9,
-         '`chol_rbf_gemm_kernel<25,2,128,32,false,float>` — factorisations of K_uu+εI (30, from K-split partial Gram matrices) and '
-         'S_u+εI (10): fp32 chains, four pivots per barrier ‖ K_uf distance GEMM (x pre-scaled by the norm role)'),
+         '`chol_rbf_gemm_kernel<25,2,128,32,false,float,512>` — factorisations of K_uu+εI (30, from K-split partial Gram matrices) and '
+         'S_u+εI (10): fp32 chains, four pivots per barrier ‖ K_uf distance GEMM (x pre-scaled by the norm role, eight waves per 128×64 tile)'),
         ('rbf_kuf_bwd_gemm', 't0_bwdmat_gemm_kernel', 'roofline_gemm', 2.408e9,
          '`t0_bwdmat_gemm_kernel` — per-matrix adjoint chains (40 workgroups) ‖ P_uf = W_uf·x (216 persistent workgroups, three tiles each)'),
         ('t0_bwd_mid', 't0_bwd_mid_kernel', None, 1.23e9, '`t0_bwd_mid_kernel` — backward middle per (s, c, 64-column tile), incl. the likelihood of the tile'),
