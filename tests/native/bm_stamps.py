@@ -30,6 +30,20 @@ if len(sys.argv) > 1 and sys.argv[1] == 'tail':     # t0_puu_final_kernel (a -DT
         print('%-32s %8d cycles' % (n, v[j] - v[i]))
     print('%-32s %8d cycles' % ('total', v[13] - v[0]))
     sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == 'ff':       # t0_fwd_fused_kernel (a -DFF_STAMPS build of elbo_t0.hip)
+    out = (ctypes.c_ulonglong * 64)()
+    fn = _lib.lib().vargp_debug_ff_stamps
+    fn.restype, fn.argtypes = None, [ctypes.c_void_p]
+    fn(out)
+    names = {(0, 1): 'KL loads + sums', (1, 2): 'stage T, G, K_uf tile + barrier', (2, 3): 'P = T K_uf', (3, 4): 'barrier',
+             (4, 5): 'P -> LDS, global; column sums + barrier', (5, 6): 'W = G^T P', (6, 7): 'W out, sums', (7, 8): 'column reductions, mu / var',
+             (8, 9): 'KL block sum'}
+    v = [list(out)[16 * w:16 * w + 16] for w in range(4)]
+    print('%-44s %s' % ('cycles per wave', ''.join('%9s' % ('wave %d' % w) for w in range(4))))
+    for (i, j), n in names.items():
+        print('%-44s %s' % (n, ''.join('%9d' % (v[w][j] - v[w][i]) for w in range(4))))
+    print('%-44s %s' % ('total', ''.join('%9d' % (v[w][9] - v[w][0]) for w in range(4))))
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == 'mat':      # t0_bwd_mat_body (a -DBMAT_STAMPS build of gemm.hip)
     out = (ctypes.c_ulonglong * 96)()                # [wave][stamp]
     fn = _lib.lib().vargp_debug_bmat_stamps

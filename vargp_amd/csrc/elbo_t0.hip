@@ -248,6 +248,13 @@ constexpr int kFusedKS = 68;     // row stride of the K_uf / P tile
 constexpr int kFusedK = 104;     // padded inner dimension (M <= 104, multiple of 8)
 constexpr size_t kFusedLdsBytes = sizeof(float) * (128 * kFusedTS + kFusedK * kFusedGS + kFusedK * kFusedKS + 128 + 3 * 64);
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
+#ifdef FF_STAMPS   // tuning builds only: s_memtime of workgroup 0 (lane 0 of each wave) after each phase (tests/native/bm_stamps.py ff)
+__device__ unsigned long long g_ff_stamps[4][16];
+extern "C" void vargp_debug_ff_stamps(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ff_stamps), sizeof(g_ff_stamps)); }
+#define FF_STAMP(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) g_ff_stamps[threadIdx.x >> 6][i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FF_STAMP(i) do { } while (0)
+#endif
 
 __global__ __launch_bounds__(256) void t0_fwd_fused_kernel(const float* __restrict__ TT, float* __restrict__ QP,
                                                            const float* __restrict__ RK, float* __restrict__ W,
@@ -276,74 +283,30 @@ __global__ __launch_bounds__(256) void t0_fwd_fused_kernel(const float* __restri
   const float* Tb = TT + b * MM;
   const float* Qb = QP + b * MLD;
   const float* Kb = RK + b * MLD + NR + n0;
-  // ---- KL of q(u) against p(u) for this (s, c) (vargp.py:182-190), its rows shared out over the tile workgroups:
-  //      kl[s,c] = sum log diag Lz - sum log diag Lu + (|G2|_F^2 + |a|^2 - M) / 2,   kl_u = (1/S) sum kl[s,c]
-  // Evaluated first: its (latency-bound) global loads are in flight together with the staging loads below.
-  float kl_acc = 0.f;
-  {
-    const int c = b % C;
-    const int per = (M + ntile - 1) / ntile, i0 = tile_x * per, i1 = min(M, i0 + per);
-    // (eight loads in flight per round on clamped indices: with one load per iteration of a run-time loop every iteration
-    // is a memory round trip of its own -- six of them in front of the staging loads at the reference's shapes)
-    const int nkl = (i1 - i0) * M;
-    for (int e0 = 0; e0 < nkl; e0 += 8 * 256) {
-      float kv[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int e = min(e0 + tid + 256 * u, nkl - 1);
-        kv[u] = Qb[(int64_t)(i0 + e / M) * LD + 4 + M + e % M];
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int e = e0 + tid + 256 * u;
-        const int i = i0 + e / M, j = e % M;
-        kl_acc = fmaf((e < nkl && j <= i) ? kv[u] : 0.f, kv[u], kl_acc);      // upper entries are stored zeros
-      }
-    }
-    for (int i = i0 + tid; i < i1; i += 256) {
-      const float a = Qb[(int64_t)i * LD];
-      kl_acc = fmaf(a, a, kl_acc);
-      kl_acc += 2.f * (logf(Lz[(b * M + i) * M + i]) - logf(Lu[((int64_t)c * M + i) * M + i])) - 1.f;
-    }
-  }
+  FF_STAMP(0);
+  FF_STAMP(1);      // (the KL's loads are part of the staging phase now)
+  // ---- every global load first: T, G, the K_uf tile, a, and the first round of the KL's operands; then the LDS stores; then
+  //      the KL arithmetic.  (One round trip instead of two, and no faster: 15.5k cycles against 4.3k + 10.7k -- the front of this
+  //      kernel is bound by the 24 MB the 240 workgroups pull from memory, T and G eight times each, not by round trips.)
   // (branch-free: a branch around a load makes the compiler wait for every load before issuing the next; indices are
   //  clamped into the operand and the padding is selected in afterwards, so that each loop issues its loads back to back)
-  {
-    constexpr int NT_ = 128 * (kFusedK / 4) / 256;          // 13 float4 per thread
-    float4 rt[NT_];
+  constexpr int NT_ = 128 * (kFusedK / 4) / 256;          // 13 float4 per thread
+  constexpr int NG_ = kFusedK * 32 / 256;                 // 13
+  constexpr int NK_ = (kFusedK * 16 + 255) / 256;         // 7 (the last one partly out of range)
+  float4 rt[NT_], rg[NG_], rk[NK_];
 #pragma unroll
-    for (int u = 0; u < NT_; ++u) {
-      const int e = tid + 256 * u;
-      const int i = e / (kFusedK / 4), k = (e - i * (kFusedK / 4)) * 4;
-      rt[u] = *reinterpret_cast<const float4*>(Tb + (int64_t)min(i, M - 1) * M + min(k, M - 4));
-    }
+  for (int u = 0; u < NT_; ++u) {
+    const int e = tid + 256 * u;
+    const int i = e / (kFusedK / 4), k = (e - i * (kFusedK / 4)) * 4;
+    rt[u] = *reinterpret_cast<const float4*>(Tb + (int64_t)min(i, M - 1) * M + min(k, M - 4));
+  }
 #pragma unroll
-    for (int u = 0; u < NT_; ++u) {
-      const int e = tid + 256 * u;
-      const int i = e / (kFusedK / 4), k = (e - i * (kFusedK / 4)) * 4;
-      const bool ok = i < M && k < M;
-      *reinterpret_cast<float4*>(&sT[i * kFusedTS + k]) = ok ? rt[u] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+  for (int u = 0; u < NG_; ++u) {
+    const int e = tid + 256 * u;
+    const int k = e >> 5, i = (e & 31) * 4;
+    rg[u] = *reinterpret_cast<const float4*>(Qb + (int64_t)min(k, M - 1) * LD + 4 + min(i, M - 4));
   }
   {
-    constexpr int NG_ = kFusedK * 32 / 256;                 // 13
-    float4 rg[NG_];
-#pragma unroll
-    for (int u = 0; u < NG_; ++u) {
-      const int e = tid + 256 * u;
-      const int k = e >> 5, i = (e & 31) * 4;
-      rg[u] = *reinterpret_cast<const float4*>(Qb + (int64_t)min(k, M - 1) * LD + 4 + min(i, M - 4));
-    }
-#pragma unroll
-    for (int u = 0; u < NG_; ++u) {
-      const int e = tid + 256 * u;
-      const int k = e >> 5, i = (e & 31) * 4;
-      *reinterpret_cast<float4*>(&sG[k * kFusedGS + i]) = (k < M && i < M) ? rg[u] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
-  {
-    constexpr int NK_ = (kFusedK * 16 + 255) / 256;          // 7 (the last one partly out of range)
-    float4 rk[NK_];
     const bool full = n0 + 64 <= B;                         // (uniform) all 64 columns exist: plain float4 loads
 #pragma unroll
     for (int u = 0; u < NK_; ++u) {
@@ -356,18 +319,79 @@ __global__ __launch_bounds__(256) void t0_fwd_fused_kernel(const float* __restri
         rk[u].z = n0 + n + 2 < B ? src[n + 2] : 0.f; rk[u].w = n0 + n + 3 < B ? src[n + 3] : 0.f;
       }
     }
+  }
+  const float av = tid < 128 ? Qb[(int64_t)min(tid, M - 1) * LD] : 0.f;
+  // ---- KL of q(u) against p(u) for this (s, c) (vargp.py:182-190), its rows shared out over the tile workgroups:
+  //      kl[s,c] = sum log diag Lz - sum log diag Lu + (|G2|_F^2 + |a|^2 - M) / 2,   kl_u = (1/S) sum kl[s,c]
+  const int c_kl = b % C;
+  const int per = (M + ntile - 1) / ntile, i0 = tile_x * per, i1 = min(M, i0 + per);
+  const int nkl = max((i1 - i0) * M, 0);
+  float kv[8];                                            // first round of G2 entries (clamped; eight loads in flight per round)
 #pragma unroll
-    for (int u = 0; u < NK_; ++u) {
-      const int e = tid + 256 * u;
-      if (e < kFusedK * 16) {
-        const int k = e >> 4, n = (e & 15) * 4;
-        *reinterpret_cast<float4*>(&sK[k * kFusedKS + n]) = k < M ? rk[u] : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+  for (int u = 0; u < 8; ++u) {
+    const int e = min(tid + 256 * u, max(nkl - 1, 0));
+    kv[u] = Qb[(int64_t)min(i0 + e / M, M - 1) * LD + 4 + M + e % M];
+  }
+  // the diagonal terms: thread t < i1 - i0 takes row i0 + t (rows beyond: clamped loads, masked)
+  const int idg = min(i0 + tid, M - 1);
+  const float dga = Qb[(int64_t)idg * LD], dlz = Lz[(b * M + idg) * M + idg], dlu = Lu[((int64_t)c_kl * M + idg) * M + idg];
+  // ---- LDS stores (zero-padded: rows / inner indices >= M, columns >= B)
+#pragma unroll
+  for (int u = 0; u < NT_; ++u) {
+    const int e = tid + 256 * u;
+    const int i = e / (kFusedK / 4), k = (e - i * (kFusedK / 4)) * 4;
+    const bool ok = i < M && k < M;
+    *reinterpret_cast<float4*>(&sT[i * kFusedTS + k]) = ok ? rt[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int u = 0; u < NG_; ++u) {
+    const int e = tid + 256 * u;
+    const int k = e >> 5, i = (e & 31) * 4;
+    *reinterpret_cast<float4*>(&sG[k * kFusedGS + i]) = (k < M && i < M) ? rg[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int u = 0; u < NK_; ++u) {
+    const int e = tid + 256 * u;
+    if (e < kFusedK * 16) {
+      const int k = e >> 4, n = (e & 15) * 4;
+      *reinterpret_cast<float4*>(&sK[k * kFusedKS + n]) = k < M ? rk[u] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
-  if (tid < 128) sa[tid] = tid < M ? Qb[(int64_t)tid * LD] : 0.f;
+  // ---- KL arithmetic (further rounds of loads only when a workgroup's share exceeds 2048 entries)
+  float kl_acc = 0.f;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int e = tid + 256 * u;
+    const int i = i0 + e / M, j = e % M;
+    kl_acc = fmaf((e < nkl && j <= i) ? kv[u] : 0.f, kv[u], kl_acc);      // upper entries are stored zeros
+  }
+  for (int e0 = 8 * 256; e0 < nkl; e0 += 8 * 256) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = min(e0 + tid + 256 * u, nkl - 1);
+      kv[u] = Qb[(int64_t)(i0 + e / M) * LD + 4 + M + e % M];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + tid + 256 * u;
+      const int i = i0 + e / M, j = e % M;
+      kl_acc = fmaf((e < nkl && j <= i) ? kv[u] : 0.f, kv[u], kl_acc);
+    }
+  }
+  {
+    const bool dok = i0 + tid < i1;
+    float t = fmaf(dga, dga, 2.f * (logf(dlz) - logf(dlu)) - 1.f);
+    kl_acc += dok ? t : 0.f;
+    for (int i = i0 + tid + 256; i < i1; i += 256) {     // (more than 256 rows per workgroup: never at M <= 104)
+      const float a = Qb[(int64_t)i * LD];
+      kl_acc = fmaf(a, a, kl_acc);
+      kl_acc += 2.f * (logf(Lz[(b * M + i) * M + i]) - logf(Lu[((int64_t)c_kl * M + i) * M + i])) - 1.f;
+    }
+  }
+  if (tid < 128) sa[tid] = tid < M ? av : 0.f;
   if (tid < 192) red[tid] = 0.f;
   __syncthreads();
+  FF_STAMP(2);
   const int cb = wave & 1;
   const int rbs[2] = {(wave >> 1) ? 1 : 0, (wave >> 1) ? 2 : 3};
   // ---- P = T K: row block rb needs k < 32 rb + 32.  The wave's two blocks advance together (two independent accumulators:
@@ -406,7 +430,9 @@ __global__ __launch_bounds__(256) void t0_fwd_fused_kernel(const float* __restri
       accP[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b3, accP[1], 0, 0, 0);
     }
   }
+  FF_STAMP(3);
   __syncthreads();                                // everybody is done with the K_uf tile
+  FF_STAMP(4);
   // P into the tile's place (second product's operand) and out to QP; column sums of P a and P^2 on the way
   const int col = n0 + 32 * cb + li;
   float s_mu = 0.f, s_p2 = 0.f, s_w2 = 0.f;
@@ -429,6 +455,7 @@ __global__ __launch_bounds__(256) void t0_fwd_fused_kernel(const float* __restri
     }
   }
   __syncthreads();
+  FF_STAMP(5);
   // ---- W = G^T P: row block rb needs k >= 32 rb (G is lower triangular); rbs[0] < ... the block with the smaller rb starts
   // alone, then both advance together
   float* Wb = W + b * (int64_t)M * B;
@@ -469,6 +496,7 @@ __global__ __launch_bounds__(256) void t0_fwd_fused_kernel(const float* __restri
       accW[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b3, accW[0], 0, 0, 0);
       accW[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(c3, b3, accW[1], 0, 0, 0);
     }
+    FF_STAMP(6);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int rb = u ? rhi : rlo;
@@ -483,6 +511,7 @@ __global__ __launch_bounds__(256) void t0_fwd_fused_kernel(const float* __restri
       }
     }
   }
+  FF_STAMP(7);
   // ---- column reductions: the two half-waves hold different rows of the same column, the waves different row blocks ----------
   s_mu += __shfl_xor(s_mu, 32, 64); s_p2 += __shfl_xor(s_p2, 32, 64); s_w2 += __shfl_xor(s_w2, 32, 64);
   if (lh == 0) {
@@ -493,10 +522,12 @@ __global__ __launch_bounds__(256) void t0_fwd_fused_kernel(const float* __restri
     mu[b * B + n0 + tid] = red[tid];
     var[b * B + n0 + tid] = kd[b] - red[64 + tid] + red[128 + tid];
   }
+  FF_STAMP(8);
   // ---- KL (partial sum from the top of the kernel)
   __syncthreads();
   const float tkl = block_sum<256>(kl_acc, red);
   if (tid == 0) atomicAdd(kl_u, 0.5f * tkl / (float)S);
+  FF_STAMP(9);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
