@@ -256,6 +256,69 @@ extern "C" void vargp_debug_ff_stamps(unsigned long long* out) { (void)hipMemcpy
 #define FF_STAMP(i) do { } while (0)
 #endif
 
+// The two products of t0_fwd_fused_kernel for the wave pair that owns row blocks R0 < R1 ({0, 3} or {1, 2}): every k-group
+// range is a compile-time constant, the loops are fully unrolled and the next group's fragments are requested before the current
+// group's MFMAs (one wave per SIMD: nothing else hides the LDS latency -- as run-time loops the products took 6.1-7.2k cycles
+// for 3.6-4.4k of MFMAs).  The two blocks' MFMAs alternate while both are active (two independent accumulators).
+__device__ __forceinline__ void ff_mfma4x2(f32x16_t& x, f32x16_t& y, const float4 a, const float4 c, const float4 b) {
+  x = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, x, 0, 0, 0);
+  y = __builtin_amdgcn_mfma_f32_32x32x2f32(c.x, b.x, y, 0, 0, 0);
+  x = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, x, 0, 0, 0);
+  y = __builtin_amdgcn_mfma_f32_32x32x2f32(c.y, b.y, y, 0, 0, 0);
+  x = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, x, 0, 0, 0);
+  y = __builtin_amdgcn_mfma_f32_32x32x2f32(c.z, b.z, y, 0, 0, 0);
+  x = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, x, 0, 0, 0);
+  y = __builtin_amdgcn_mfma_f32_32x32x2f32(c.w, b.w, y, 0, 0, 0);
+}
+__device__ __forceinline__ void ff_mfma4(f32x16_t& x, const float4 a, const float4 b) {
+  x = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, x, 0, 0, 0);
+  x = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, x, 0, 0, 0);
+  x = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, x, 0, 0, 0);
+  x = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, x, 0, 0, 0);
+}
+// P = T K: row block rb needs k < 32 rb + 32 (T lower triangular).  acc[0]: block R0, acc[1]: block R1
+template <int R0, int R1>
+__device__ __forceinline__ void ff_product_p(f32x16_t (&acc)[2], const float* __restrict__ sT, const float* __restrict__ sK, int cb,
+                                             int li, int lh) {
+  constexpr int GE = kFusedK / 8, G0 = bm_min(GE, 4 * R0 + 4), G1 = bm_min(GE, 4 * R1 + 4);      // G0 <= G1
+  const float* arow0 = sT + (32 * R0 + li) * kFusedTS + 4 * lh;
+  const float* arow1 = sT + (32 * R1 + li) * kFusedTS + 4 * lh;
+  const float* bcol = sK + (4 * lh) * kFusedKS + 32 * cb + li;
+  float4 a0 = bm_frag_kc(arow0, 0), a1 = bm_frag_kc(arow1, 0), bb = bm_frag_km(bcol, 0, kFusedKS);
+  bm_for<0, G1>([&](auto gi) {
+    constexpr int g = decltype(gi)::value;
+    const float4 c0 = a0, c1 = a1, cbv = bb;
+    if constexpr (g + 1 < G1) {
+      if constexpr (g + 1 < G0) a0 = bm_frag_kc(arow0, 8 * (g + 1));
+      a1 = bm_frag_kc(arow1, 8 * (g + 1));
+      bb = bm_frag_km(bcol, 8 * (g + 1), kFusedKS);
+    }
+    if constexpr (g < G0) ff_mfma4x2(acc[0], acc[1], c0, c1, cbv);
+    else ff_mfma4(acc[1], c1, cbv);
+  });
+}
+// W = G^T P: row block rb needs k >= 32 rb (G lower triangular).  acc[0]: block R0 (starts alone), acc[1]: block R1
+template <int R0, int R1>
+__device__ __forceinline__ void ff_product_w(f32x16_t (&acc)[2], const float* __restrict__ sG, const float* __restrict__ sK, int cb,
+                                             int li, int lh) {
+  constexpr int GE = kFusedK / 8, S0 = 4 * R0, S1 = 4 * R1;                                         // S0 < S1 < GE
+  const float* acol0 = sG + (4 * lh) * kFusedGS + 32 * R0 + li;
+  const float* acol1 = sG + (4 * lh) * kFusedGS + 32 * R1 + li;
+  const float* bcol = sK + (4 * lh) * kFusedKS + 32 * cb + li;
+  float4 a0 = bm_frag_km(acol0, 8 * S0, kFusedGS), a1 = a0, bb = bm_frag_km(bcol, 8 * S0, kFusedKS);
+  bm_for<S0, GE>([&](auto gi) {
+    constexpr int g = decltype(gi)::value;
+    const float4 c0 = a0, c1 = a1, cbv = bb;
+    if constexpr (g + 1 < GE) {
+      a0 = bm_frag_km(acol0, 8 * (g + 1), kFusedGS);
+      if constexpr (g + 1 >= S1) a1 = bm_frag_km(acol1, 8 * (g + 1), kFusedGS);
+      bb = bm_frag_km(bcol, 8 * (g + 1), kFusedKS);
+    }
+    if constexpr (g >= S1) ff_mfma4x2(acc[0], acc[1], c0, c1, cbv);
+    else ff_mfma4(acc[0], c0, cbv);
+  });
+}
+
 __global__ __launch_bounds__(256) void t0_fwd_fused_kernel(const float* __restrict__ TT, float* __restrict__ QP,
                                                            const float* __restrict__ RK, float* __restrict__ W,
                                                            const float* __restrict__ kd, const float* __restrict__ Lz,
@@ -401,35 +464,8 @@ __global__ __launch_bounds__(256) void t0_fwd_fused_kernel(const float* __restri
   for (int u = 0; u < 2; ++u)
 #pragma unroll
     for (int r = 0; r < 16; ++r) accP[u][r] = 0.f;
-  {
-    const int kend0 = min(kFusedK, 32 * rbs[0] + 32), kend1 = min(kFusedK, 32 * rbs[1] + 32);     // kend0 <= kend1
-    const float* arow0 = sT + (32 * rbs[0] + li) * kFusedTS + 4 * lh;
-    const float* arow1 = sT + (32 * rbs[1] + li) * kFusedTS + 4 * lh;
-    const float* bcol = sK + (4 * lh) * kFusedKS + 32 * cb + li;
-    int k = 0;
-    for (; k < kend0; k += 8) {
-      const float4 a0 = *reinterpret_cast<const float4*>(arow0 + k), a1 = *reinterpret_cast<const float4*>(arow1 + k);
-      const float b0 = bcol[(k + 0) * kFusedKS], b1 = bcol[(k + 1) * kFusedKS], b2 = bcol[(k + 2) * kFusedKS],
-                  b3 = bcol[(k + 3) * kFusedKS];
-      accP[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0, accP[0], 0, 0, 0);
-      accP[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0, accP[1], 0, 0, 0);
-      accP[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b1, accP[0], 0, 0, 0);
-      accP[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1, accP[1], 0, 0, 0);
-      accP[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b2, accP[0], 0, 0, 0);
-      accP[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b2, accP[1], 0, 0, 0);
-      accP[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b3, accP[0], 0, 0, 0);
-      accP[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b3, accP[1], 0, 0, 0);
-    }
-    for (; k < kend1; k += 8) {
-      const float4 a1 = *reinterpret_cast<const float4*>(arow1 + k);
-      const float b0 = bcol[(k + 0) * kFusedKS], b1 = bcol[(k + 1) * kFusedKS], b2 = bcol[(k + 2) * kFusedKS],
-                  b3 = bcol[(k + 3) * kFusedKS];
-      accP[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0, accP[1], 0, 0, 0);
-      accP[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1, accP[1], 0, 0, 0);
-      accP[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b2, accP[1], 0, 0, 0);
-      accP[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b3, accP[1], 0, 0, 0);
-    }
-  }
+  if ((wave >> 1) == 0) ff_product_p<0, 3>(accP, sT, sK, cb, li, lh);
+  else ff_product_p<1, 2>(accP, sT, sK, cb, li, lh);
   FF_STAMP(3);
   __syncthreads();                                // everybody is done with the K_uf tile
   FF_STAMP(4);
@@ -466,36 +502,8 @@ __global__ __launch_bounds__(256) void t0_fwd_fused_kernel(const float* __restri
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int r = 0; r < 16; ++r) accW[u][r] = 0.f;
-    const float* acol0 = sG + (4 * lh) * kFusedGS + 32 * rlo + li;
-    const float* acol1 = sG + (4 * lh) * kFusedGS + 32 * rhi + li;
-    const float* bcol = sK + (4 * lh) * kFusedKS + 32 * cb + li;
-    int k = 32 * rlo;
-    for (; k < 32 * rhi; k += 8) {
-      const float a0 = acol0[(k + 0) * kFusedGS], a1 = acol0[(k + 1) * kFusedGS], a2 = acol0[(k + 2) * kFusedGS],
-                  a3 = acol0[(k + 3) * kFusedGS];
-      const float b0 = bcol[(k + 0) * kFusedKS], b1 = bcol[(k + 1) * kFusedKS], b2 = bcol[(k + 2) * kFusedKS],
-                  b3 = bcol[(k + 3) * kFusedKS];
-      accW[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, accW[0], 0, 0, 0);
-      accW[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, accW[0], 0, 0, 0);
-      accW[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2, accW[0], 0, 0, 0);
-      accW[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b3, accW[0], 0, 0, 0);
-    }
-    for (; k < kFusedK; k += 8) {
-      const float a0 = acol0[(k + 0) * kFusedGS], a1 = acol0[(k + 1) * kFusedGS], a2 = acol0[(k + 2) * kFusedGS],
-                  a3 = acol0[(k + 3) * kFusedGS];
-      const float c0 = acol1[(k + 0) * kFusedGS], c1 = acol1[(k + 1) * kFusedGS], c2 = acol1[(k + 2) * kFusedGS],
-                  c3 = acol1[(k + 3) * kFusedGS];
-      const float b0 = bcol[(k + 0) * kFusedKS], b1 = bcol[(k + 1) * kFusedKS], b2 = bcol[(k + 2) * kFusedKS],
-                  b3 = bcol[(k + 3) * kFusedKS];
-      accW[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, accW[0], 0, 0, 0);
-      accW[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(c0, b0, accW[1], 0, 0, 0);
-      accW[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, accW[0], 0, 0, 0);
-      accW[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(c1, b1, accW[1], 0, 0, 0);
-      accW[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2, accW[0], 0, 0, 0);
-      accW[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(c2, b2, accW[1], 0, 0, 0);
-      accW[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b3, accW[0], 0, 0, 0);
-      accW[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(c3, b3, accW[1], 0, 0, 0);
-    }
+    if ((wave >> 1) == 0) ff_product_w<0, 3>(accW, sG, sK, cb, li, lh);
+    else ff_product_w<1, 2>(accW, sG, sK, cb, li, lh);
     FF_STAMP(6);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
