@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256) void t0_fwd_fused_kernel(const float* __restri
   // P into the tile's place (second product's operand) and out to QP; column sums of P a and P^2 on the way
   const int col = n0 + 32 * cb + li;
   float s_mu = 0.f, s_p2 = 0.f, s_w2 = 0.f;
-  float* Pout = QP + b * MLD + NR;
+  char* Pout_b = reinterpret_cast<char*>(QP + b * MLD + NR);
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     // a[m] for the block's 16 rows first, unconditionally (sa holds 128 entries, zero beyond M; rows of P beyond M are zero
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256) void t0_fwd_fused_kernel(const float* __restri
       const int m = 32 * rbs[u] + (r & 3) + 8 * (r >> 2) + 4 * lh;
       const float v = accP[u][r];
       if (m < kFusedK) sK[m * kFusedKS + 32 * cb + li] = v;
-      if (m < M && col < B) Pout[(int64_t)m * LD + col] = v;
+      if (m < M && col < B) *reinterpret_cast<float*>(Pout_b + 4u * (__umul24((unsigned)m, (unsigned)LD) + (unsigned)col)) = v;   // (32-bit byte offset)
       s_mu = fmaf(v, sav[r], s_mu);
       s_p2 = fmaf(v, v, s_p2);
     }
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(256) void t0_fwd_fused_kernel(const float* __restri
   FF_STAMP(5);
   // ---- W = G^T P: row block rb needs k >= 32 rb (G is lower triangular); rbs[0] < ... the block with the smaller rb starts
   // alone, then both advance together
-  float* Wb = W + b * (int64_t)M * B;
+  char* Wb_b = reinterpret_cast<char*>(W + b * (int64_t)M * B);
   {
     const int rlo = min(rbs[0], rbs[1]), rhi = max(rbs[0], rbs[1]);
     f32x16_t accW[2];        // [0]: row block rlo, [1]: row block rhi
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(256) void t0_fwd_fused_kernel(const float* __restri
         const int m = 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (m < M) {
           const float v = accW[u][r];
-          if (col < B) Wb[(int64_t)m * B + col] = v;
+          if (col < B) *reinterpret_cast<float*>(Wb_b + 4u * (__umul24((unsigned)m, (unsigned)B) + (unsigned)col)) = v;
           s_w2 = fmaf(v, v, s_w2);
         }
       }
