@@ -216,13 +216,15 @@ typedef struct vargp_elbo_t0_desc {
   /* 1 (only when a vargp_elbo_t0_bwd on this workspace follows before scalars[2] is read): for the shapes of the LDS-resident
    * backward with C <= 16 and F <= 16 the forward does NOT launch the Monte-Carlo softmax likelihood; the backward's tile kernel
    * evaluates it (value and gradient) and adds nll into scalars[2], which is therefore valid only after bwd.  Ignored (the
-   * forward evaluates the likelihood as usual) for every other shape. */
+   * forward evaluates the likelihood as usual) for every other shape, and for a caller-supplied eps_f that does not sit on a
+   * 16-byte boundary (the tile kernel reads it as float4). */
   int32_t defer_softmax;
 } vargp_elbo_t0_desc;
 size_t vargp_elbo_t0_workspace_bytes(int S, int C, int M, int D, int B, int F);
 int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t stream);
 /* ONE vargp_elbo_t0_bwd per vargp_elbo_t0_fwd: for the shapes of the LDS-resident backward (M <= 104, M % 4 == 0, B % 4 == 0,
- * D % 4 == 0, S <= 16) the forward clears the accumulators the backward adds into -- there is no clearing launch in bwd.
+ * D % 4 == 0, S <= 16) the forward clears the accumulators the backward adds into (and the tile counters of the backward's
+ * persistent product workgroups) -- there is no clearing launch in bwd.
  * Enforced by the library (host-side state per workspace, checked when the call is issued): a second bwd on one fwd, or a bwd
  * whose z / x alignment differs from its forward's, returns VARGP_EINVAL with a message instead of accumulating into stale sums. */
 int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds, float* g_log_mean, float* g_log_logvar, float* g_z,
