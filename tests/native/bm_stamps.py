@@ -1,5 +1,17 @@
-"""Per-phase cycle accounting of t0_bwd_mid_kernel (a -DBM_STAMPS build of the library, VARGP_HIP_LIB): runs a few Cfg2
-steps and prints the s_memtime differences between the stamps of workgroup (0, 0), thread 0.  GPU box only."""
+"""Per-phase cycle accounting (s_memtime stamps of workgroup 0) of the LDS-resident kernels of the first-task step, in a tuning
+build of the library (VARGP_HIP_LIB=<that .so>).  GPU box only.
+
+    python tests/native/bm_stamps.py          t0_bwd_mid_kernel         -DBM_STAMPS    on elbo_t0.hip
+    python tests/native/bm_stamps.py ff       t0_fwd_fused_kernel       -DFF_STAMPS    on elbo_t0.hip   (per wave)
+    python tests/native/bm_stamps.py tail     t0_puu_final_kernel       -DTAIL_STAMPS  on elbo_t0.hip
+    python tests/native/bm_stamps.py mat      t0_bwd_mat_body (+ wall-clock spans of the two roles of its launch)
+                                                                        -DBMAT_STAMPS  on gemm.hip      (per wave)
+Build recipe (from vargp_amd/csrc, after `make`): compile the one translation unit with the switch and link it with the other
+objects of build/ into a second library, e.g.
+    hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -DFF_STAMPS -c elbo_t0.hip -o /tmp/t0.o
+    hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/libvargp_ff.so build/core.o build/gemm.o build/rbf.o build/chol.o \
+          build/elbo_ops.o /tmp/t0.o build/elbo_tn.o
+The stamps cost nothing in the shipped build (the macros are empty)."""
 import ctypes
 import os
 import sys

@@ -1,6 +1,8 @@
 """Time line of one Cfg2 step as the GPU sees it (a -DSTEP_SPANS build of the library, VARGP_HIP_LIB): wall-clock (100 MHz) of the
 first workgroup's start and the last workgroup's end of each of the eight kernels, in steady state under graph replay, to set
-against the dispatch-to-completion durations rocprofv3 reports.  GPU box only."""
+against the dispatch-to-completion durations rocprofv3 reports.  GPU box only.
+Build: core.hip, gemm.hip and elbo_t0.hip compiled with -DSTEP_SPANS and linked with the other objects of vargp_amd/csrc/build/
+into a second library (recipe: bm_stamps.py)."""
 import ctypes
 import os
 import sys
