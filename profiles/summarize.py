@@ -168,6 +168,8 @@ def main():
         calls, a = int(r['Calls']), float(r['AverageNs']) / 1e3
         if calls < steps // 2:
             continue
+        if r['Name'].startswith('Cijk_'):       # bench.py's device warm-up between set-up and the W warm-up steps (torch.mm on
+            continue                            # scratch tensors, hipBLASLt): not part of a step
         per = calls / steps
         tot += calls * a / steps
         nl += per
