@@ -1,6 +1,6 @@
 """Timeline of the merged factorisation + K_uf launch of the first-task forward (tuning build of gemm.hip with
 -DVARGP_CHOL_PHASES): 100 MHz wall-clock stamps of the phases of the first K_uu chain, the last chain (an S_u matrix), the
-first and the last GEMM tile.  GPU box only:  VARGP_HIP_LIB=tests/native/exp/libvargp_phases.so python tests/native/merged_phases.py"""
+first and the last GEMM tile.  GPU box only:  VARGP_HIP_LIB=<a -DVARGP_CHOL_PHASES build of the library: recipe in bm_stamps.py> python tests/native/merged_phases.py"""
 import ctypes
 import os
 import sys
