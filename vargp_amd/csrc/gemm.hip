@@ -971,6 +971,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   gemm_body<BM, BN, BK, AKC, BKC, VEC, RBF, SCALED>(p, id % (int)gridDim.x, id / (int)gridDim.x, blockIdx.z, lds);
 }
 
+// the same with eight waves per workgroup (two per SIMD on the same tile: gemm_body's NT = 512), plain products only
+template <int BM, int BN, int BK, bool AKC, bool BKC>
+__global__ __launch_bounds__(512) void gemm_kernel_w8(const GemmParams p) {
+  __shared__ __attribute__((aligned(16))) float lds[gemm_lds_floats<BM, BN, BK, AKC, BKC>()];
+  const int lin = (int)(blockIdx.y * gridDim.x + blockIdx.x), total = (int)(gridDim.x * gridDim.y);
+  const int id = p.xcd_remap ? xcd_remap(lin, total) : lin;
+  gemm_body<BM, BN, BK, AKC, BKC, true, false, true, 512>(p, id % (int)gridDim.x, id / (int)gridDim.x, blockIdx.z, lds);
+}
+
 // Two independent problems of the same kernel flavour in ONE launch (1-D grid: the workgroups of problem 0, then
 // those of problem 1).  Mid-size problems that cannot fill the chip alone (K_uu: 120 workgroups, K_uf: 384) share it.
 struct GemmPair { GemmParams p[2]; int nwg0; int tiles[2]; int per_split[2]; };   // per_split = tiles * nbatch
@@ -1007,6 +1016,18 @@ static void dispatch_layout(const GemmParams& p, int transA, int transB, dim3 gr
     if (p.kscale) hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, true, true, VEC, true, true>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, true, true, VEC, true, false>), grid, dim3(256), 0, st, p);
   } else {
+    if constexpr (VEC && BM == 128 && BN == 64 && BK == 32) {
+      // eight waves per 128 x 64 x 32 tile (two per SIMD; VARGP_GEMM_W8=0: four): Permuted-MNIST t = 1 / 4 / 9 step 3.58 -> 3.52 /
+      // 13.82 -> 13.74 / 49.99 -> 49.72 ms, Split-MNIST t = 1 610 -> 608 us
+      static const int w8 = [] { const char* e = getenv("VARGP_GEMM_W8"); return e ? atoi(e) : 1; }();   // tuning aid
+      if (w8) {
+        if (akc && bkc) hipLaunchKernelGGL((gemm_kernel_w8<BM, BN, BK, true, true>), grid, dim3(512), 0, st, p);
+        else if (akc && !bkc) hipLaunchKernelGGL((gemm_kernel_w8<BM, BN, BK, true, false>), grid, dim3(512), 0, st, p);
+        else if (!akc && bkc) hipLaunchKernelGGL((gemm_kernel_w8<BM, BN, BK, false, true>), grid, dim3(512), 0, st, p);
+        else hipLaunchKernelGGL((gemm_kernel_w8<BM, BN, BK, false, false>), grid, dim3(512), 0, st, p);
+        return;
+      }
+    }
     if (akc && bkc) hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, true, true, VEC, false>), grid, dim3(256), 0, st, p);
     else if (akc && !bkc) hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, true, false, VEC, false>), grid, dim3(256), 0, st, p);
     else if (!akc && bkc) hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, false, true, VEC, false>), grid, dim3(256), 0, st, p);
