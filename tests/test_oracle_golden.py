@@ -78,7 +78,7 @@ def test_e2e_loss_grads_predict(name):
 
 
 @pytest.mark.parametrize('name', ['smnist_full_t0', 'pmnist_full_t0', 'pmnist_red_t1', 'pmnist_red_t2', 'smnist_s64_t0',
-                                  'smnist_full_t0_mnist', 'smnist_full_t0_mnist_l25'])
+                                  'smnist_full_t0_mnist', 'smnist_full_t0_mnist_l25', 'smnist_full_t1'])
 def test_e2e_full_size(name):
     """Outputs-only fixtures (inputs regenerated from the seed, outputs from the reference): Cfg2 (S3 F10 C10 M100 D784
     B512), Cfg3 task 0 at full size (S10 M200) and tasks 1, 2 (Mt = 400, 600) at reduced D/B, Cfg4's S = 64 unsharded;
@@ -168,6 +168,29 @@ def load_trajectory(name):
     params, prev, x, y, _ = orc.make_problem(S, F_, C, M, D, B, n_prev=n_prev, seed=seed, kind=str(g['kind']))
     noise_of = lambda k: orc.step_noise(S, F_, C, M, D, B, n_prev, seed, k)
     return g, params, prev, x, y, noise_of, len(g['triples']), float(g['lr']), float(g['beta']), float(g['n_total'])
+
+
+def check_compact_final(final, g, tol):
+    """Final parameters of a full-size trajectory fixture (make_golden.trajectory_case(compact=True)): the small tensors in
+    full, the first inducing points of z / first packed entries of u_tril_vec, and for every tensor the norm of its total
+    displacement from the initial value (the part of the parameter the optimiser produced)."""
+    for k in ('u_mean', 'log_mean', 'log_logvar'):
+        assert rel_l2(final[k], g[f'final_{k}']) < tol, k
+    assert rel_l2(final['z'][:, :4, :], g['final_z_head']) < tol
+    assert rel_l2(final['u_tril_vec'][:, :64], g['final_u_tril_vec_head']) < tol
+    for k, v in final.items():
+        np.testing.assert_allclose(torch.as_tensor(v).double().norm().item(), float(g[f'finalnorm_{k}']), rtol=tol, err_msg=k)
+
+
+def test_adam_trajectory_full_size_matches_reference():
+    """Six Adam steps of the reference at BASELINE config 2's real shape (S3 F10 C10 M100 D784 B512)."""
+    g, params, prev, x, y, noise_of, steps, lr, beta, n_total = load_trajectory('traj_full_t0')
+    triples, final = orc.adam_trajectory(params, prev, x, y, noise_of, steps, lr, beta, n_total)
+    np.testing.assert_allclose(triples.numpy(), g['triples'], rtol=5e-5)
+    check_compact_final(final, g, 1e-4)
+    for k, v in final.items():      # the displacement itself (6 steps of lr 1e-2: ~6e-2 per element), not hidden behind the value
+        d = (v.double() - params[k].double()).norm().item()
+        np.testing.assert_allclose(d, float(g[f'deltanorm_{k}']), rtol=2e-3, err_msg=k)
 
 
 @pytest.mark.parametrize('name', TRAJ)

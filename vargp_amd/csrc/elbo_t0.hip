@@ -724,7 +724,12 @@ static std::mutex g_t0_state_mu;
 static std::unordered_map<const void*, int> g_t0_state;
 static void t0_state_set(const void* ws, int v) {
   std::lock_guard<std::mutex> lock(g_t0_state_mu);
-  if (g_t0_state.size() > 4096) g_t0_state.clear();      // workspaces come and go; the map only has to know the live ones
+  if (g_t0_state.size() > 4096) {
+    // workspaces come and go; the map only has to know the live ones.  Entries between their forward and their backward
+    // (kT0Cleared) are never evicted: dropping one would make that workspace's backward fail with "no forward"
+    for (auto it = g_t0_state.begin(); it != g_t0_state.end();)
+      it = ((it->second & 15) == kT0Cleared && it->first != ws) ? std::next(it) : g_t0_state.erase(it);
+  }
   g_t0_state[ws] = v;
 }
 static int t0_state_get(const void* ws) {

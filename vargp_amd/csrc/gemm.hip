@@ -1243,6 +1243,21 @@ int launch_gemm_pair(const GemmParams& p0, int nbatch0, const GemmParams& p1, in
 
 // factorisations (n in (50, 100], dense n x n matrices) + one RBF GEMM in one launch; false if the shapes do not
 // qualify (the caller then launches them separately)
+static int device_cu_count(int dev) {
+  static std::atomic<int> cus[64] = {};
+  int v = cus[dev].load(std::memory_order_acquire);
+  if (v == 0) {
+    hipDeviceProp_t prop;
+    v = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    cus[dev].store(v, std::memory_order_release);
+  }
+  return v;
+}
+// CUs of the device the calling thread launches on (256 on MI355X)
+static int current_cu_count() {
+  int dev = 0;
+  return (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) ? device_cu_count(dev) : 256;
+}
 static int launch_chol_rbf_gemm_impl(const float* A, float eps, float* L, float* T, int32_t* info, int nchol, int n,
                                      const GemmParams& p, int nbatch, hipStream_t st, const CholExtra& extra, const ZeroJobs& zero);
 bool chol_rbf_gemm_applicable(int n, const GemmParams& p) { return n > 50 && n <= 100 && gemm_vec_ok(p); }
@@ -1272,7 +1287,7 @@ static int launch_chol_rbf_gemm_impl(const float* A, float eps, float* L, float*
   // factorisations leave free (the BASELINE shape: 384 tiles on 216 CUs would need two rounds, 192 need one)
   static const int tile_force = [] { const char* e = getenv("VARGP_MERGED_TILE"); return e ? atoi(e) : 0; }();   // tuning aid
   const int t64 = cdiv(p.M, 64) * cdiv(p.N, 64), t128 = cdiv(p.M, 128) * cdiv(p.N, 64);
-  const int free_cus = 256 - nchol;
+  const int free_cus = current_cu_count() - nchol;
   // (with the 8-wave GEMM role below -- pre-scaled operand, fp32 chains, n > 64 -- the 128 x 64 tile is the better one whenever
   // 64 x 64 tiles need more than one round: S = 16 step 869 -> 831 us, S = 8 477 -> 474, S >= 32 the same)
   static const int f32_env = [] { const char* e = getenv("VARGP_CHOL_F32"); return e ? atoi(e) : kCholF32Default; }();
@@ -1291,7 +1306,8 @@ static int launch_chol_rbf_gemm_impl(const float* A, float eps, float* L, float*
   // with many samples the GEMM dominates and wants both slots (S = 64: 950 -> 676 us).
   static const int pad_force = [] { const char* e = getenv("VARGP_MERGED_PAD"); return e ? atoi(e) : -1; }();   // tuning aid (KB)
   const unsigned pad = pad_force >= 0 ? (unsigned)pad_force * 1024u : (tiles * nbatch <= 1024 ? (big ? 40u : 24u) * 1024u : 0u);
-  // arithmetic of the pivot chains: fp64 (default) or the reference's own fp32 (VARGP_CHOL_F32=1; chol_small3.h)
+  // arithmetic of the pivot chains: the reference's own fp32 (default, kCholF32Default = 1: torch.cholesky is fp32) or fp64
+  // (VARGP_CHOL_F32=0; chol_small3.h).  The stand-alone factorisation (vargp_chol_inv_fwd: predict, the composed path) is fp64.
   // kscale == NULL: the caller's B operand is pre-scaled (x o 1/sigma^2, written once per hyper-sample by the norm role) and the
   // main loop carries no scale loads and multiplies
   static const int exp_unscaled = [] { const char* e = getenv("VARGP_EXP_UNSCALED"); return e ? atoi(e) : 0; }();   // timing only
@@ -1327,7 +1343,7 @@ int launch_chol_rbf_gemm_ld(const float* A, int lda, int64_t sA, float eps, floa
   GemmParams q = p;
   q.splitk = 1;
   const int t64 = cdiv(p.M, 64) * cdiv(p.N, 64), t128 = cdiv(p.M, 128) * cdiv(p.N, 64);
-  const int free_cus = 256 - nchol;
+  const int free_cus = current_cu_count() - nchol;
   const bool big = t64 * nbatch > free_cus && (t128 * nbatch <= free_cus || t64 * nbatch > 1024);
   const int tiles = big ? t128 : t64;
   const int total = nchol + tiles * nbatch;
@@ -1389,16 +1405,6 @@ static bool gemm_persist_ok(const GemmParams& p, int BK, bool AKC, bool BKC) {
   return gemm_vec_ok(p) && p.K >= 4 * BK && p.K % BK == 0 && !p.D && p.triA == 0 && p.triB == 0 && p.triC == 0 && !p.symout &&
          p.splitk <= 1 && (AKC || (p.M % 4 == 0 && p.M >= 4)) && (BKC || (p.N % 4 == 0 && p.N >= 4)) &&
          extA < (1ll << 29) && extB < (1ll << 29);
-}
-static int device_cu_count(int dev) {
-  static std::atomic<int> cus[64] = {};
-  int v = cus[dev].load(std::memory_order_acquire);
-  if (v == 0) {
-    hipDeviceProp_t prop;
-    v = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-    cus[dev].store(v, std::memory_order_release);
-  }
-  return v;
 }
 
 int launch_bwdmat_gemm(const BwdMatArgs& a, int first, int nmat, const GemmParams& p, int nbatch, hipStream_t st,

@@ -25,6 +25,18 @@ class Yogi(torch.optim.Optimizer):
         super().load_state_dict(state_dict)
         self._chunk_cache = {}                 # the moment buffers are new tensors
 
+    def __getstate__(self):
+        # the cache holds ctypes pointer arrays (not picklable, not deep-copyable) of addresses that mean nothing elsewhere
+        state = super().__getstate__() if hasattr(super(), '__getstate__') else dict(self.__dict__)
+        state = dict(state)
+        state.pop('_chunk_cache', None)
+        return state
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._chunk_cache = {}
+        self.__dict__.setdefault('external_step', False)
+
     def step_counter(self, device):
         """The device-side step count of the (single) parameter group."""
         group = self.param_groups[0]
@@ -65,8 +77,11 @@ class Yogi(torch.optim.Optimizer):
                 # per chunk (the eager drop-in loop is host-bound; this call used to cost ~60 us of Python)
                 key = tuple(id(p) for p in chunk)
                 cached = self._chunk_cache.get(key)
-                if cached is None or cached[0] != tuple(p.data_ptr() for p in chunk):
-                    cached = (tuple(p.data_ptr() for p in chunk), arr(chunk), arr([self.state[p]['exp_avg'] for p in chunk]),
+                # valid while the parameters AND both moment buffers sit where they sat when the arrays were built (a moment
+                # tensor replaced through optim.state, state.clear(), a move to another device: rebuilt)
+                where = tuple(t.data_ptr() for p in chunk for t in (p, self.state[p]['exp_avg'], self.state[p]['exp_avg_sq']))
+                if cached is None or cached[0] != where:
+                    cached = (where, arr(chunk), arr([self.state[p]['exp_avg'] for p in chunk]),
                               arr([self.state[p]['exp_avg_sq'] for p in chunk]),
                               (ctypes.c_int64 * k)(*[p.numel() for p in chunk]))
                     self._chunk_cache[key] = cached

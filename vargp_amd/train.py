@@ -86,6 +86,8 @@ class ElboTrainer:
         # models on a native program (fused.T0Program: first task; fused.TnProgram: later tasks, ep_var_mean=True) drive it
         # directly: no autograd graph, gradients written straight into the optimiser's buffers
         is_model = gp is not None and loss_fn is None and params is None and hasattr(gp, 'draw_t0_noise')
+        # which of the two programs a first-task model runs on depends on the minibatch size (VARGP.first_task_as_block):
+        # decided per batch shape in _t0_fwd_bwd, exactly as VARGP.loss routes -- `_tn` describes the most recent step
         self._tn = bool(is_model and gp._use_block_program())                                             # csrc/elbo_tn.hip
         self._t0 = bool(is_model and not gp.prev_params and gp.fused_first_task
                         and type(gp.kernel).__name__ == 'RBFKernel') or self._tn                           # csrc/elbo_t0.hip
@@ -285,6 +287,7 @@ class ElboTrainer:
             eps_theta, eps_f = gp.draw_t0_noise(x)
             eps_theta, eps_f = None if eps_theta is None else eps_theta.contiguous(), eps_f.contiguous()
         shape = T0Program.shape_of(S, gp.z, x, gp.likelihood.n_f)
+        self._tn = bool(gp._use_block_program(x.size(0)))
         if self._tn:
             shape = shape + (len(gp.prev_params) + 1,)
         if self._prog is None or self._prog.shape != shape:
@@ -306,7 +309,12 @@ class ElboTrainer:
                                   x, y, eps_theta, eps_f, bump=self._bump, **extra)
         # (a tensor that is frozen / not among the optimiser's parameters has no .grad: the program still writes all five
         # gradients, those into scratch)
-        gbuf = lambda t: t.grad if t.grad is not None else self._scratch_grads.setdefault(id(t), torch.empty_like(t))
+        def gbuf(t):
+            if t.grad is not None:
+                return t.grad
+            if t not in self._scratch_grads:          # keyed by the tensor itself: holds a reference, allocated once
+                self._scratch_grads[t] = torch.empty_like(t)
+            return self._scratch_grads[t]
         self._prog.backward(self._seeds[key], gbuf(kern.log_mean), gbuf(kern.log_logvar), gbuf(gp.z), gbuf(gp.u_mean),
                             gbuf(gp.u_tril_vec), defer_hyper=defer_hyper)
         return scal
