@@ -39,6 +39,7 @@ S, F_, C, M, D, B = 3, 10, 10, 100, 784, 512
 N_TOTAL, BETA, LR = 12000, 10.0, 3e-3
 N_PREV = 0
 MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32 matrix peak
+PREHEAT_S = 0.3                   # plain matrix products on scratch tensors before the warm-up steps (reported as `preheat_s`)
 DOMINANT_TAG = 'rbf_kuf'       # the K_uf distance GEMM incl. its split-K combine pass (vargp_rbf_gram_fwd)
 
 # Secondary workloads (not the driver's default line): other BASELINE configs, same step definition.
@@ -190,6 +191,65 @@ def stress_cpu_baseline(gp, n_cpu=2048):
     dt = time.perf_counter() - t0
     return dict(value=n_cpu / dt, unit='points/s', cores=threads, kind='port',
                 sample=f'one ELBO + gradient over {n_cpu} points (M=2048 C=10 S=1 D=784), the factorisations included')
+
+
+def survey_flops_fwd(S_, C_, M_, n_prev, B_, D_, F__):
+    """Algorithmic flop of one forward (symmetric work counted once); a step is 3x this."""
+    Mt = M_ * (n_prev + 1)
+    n_S = 1 if n_prev == 0 else S_
+    fl = (2.0 * S_ * C_ * Mt * B_ * D_ + 1.0 * S_ * C_ * Mt * Mt * D_ + S_ * C_ * Mt ** 3 / 3.0 + n_S * C_ * Mt ** 3 / 3.0
+          + 1.0 * S_ * C_ * Mt * Mt * B_ + S_ * C_ * Mt ** 3 / 3.0 + 1.0 * S_ * C_ * Mt * Mt * B_ + 6.0 * S_ * C_ * Mt * B_
+          + S_ * C_ * M_ ** 3 / 3.0 + 12.0 * S_ * F__ * C_ * B_)
+    for i in range(1, n_prev + 1):          # the linear_joint chain, one fold per earlier task (M< = i M)
+        Ml = i * M_
+        fl += S_ * C_ * (4.0 / 3.0 * Ml ** 3 + 4.0 * Ml * Ml * M_ + 2.0 * Ml * M_ * M_)
+    return fl
+
+
+def step_timeline(run, period_us, reps=20, burst=4):
+    """The step as the GPU sees it under graph replay (vargp_prof_spans: wall-clock stamps written by the kernels themselves,
+    the only clock that reaches inside a replayed hipGraph): `burst` replays back to back, the stamps of the LAST one read
+    back; averaged over `reps` bursts.  -> list of dict(kernel, start_us (from the step's first kernel), span_us (first
+    workgroup's start .. last workgroup's end), gap_before_us (previous kernel's end .. this start; for the first kernel:
+    the step period minus the rest), slot_us = gap + span (sums to the step period)), in launch order."""
+    from vargp_amd import _lib
+    acc, n = {}, 0
+    for _ in range(reps):
+        _lib.prof_spans(1)
+        for _ in range(burst):
+            run()
+        torch.cuda.synchronize()
+        t = _lib.prof_spans(0)
+        main = sorted(((k, v) for k, v in t.items() if ':' not in k), key=lambda kv: kv[1][0])
+        if len(main) < 2:
+            continue
+        t0 = main[0][1][0]
+        prev_end = None
+        for k, (a, b) in main:
+            e = acc.setdefault(k, [0.0, 0.0, 0.0])
+            e[0] += a - t0
+            e[1] += b - a
+            e[2] += (a - prev_end) if prev_end is not None else 0.0
+            prev_end = b
+        for k, (a, b) in t.items():
+            if ':' in k:
+                acc.setdefault(k, [0.0, 0.0, 0.0])[1] += b - t[k.split(':')[0]][0]
+        n += 1
+    _lib.prof_spans(2)
+    if not n:
+        return []
+    rows = [dict(kernel=k, start_us=v[0] / n, span_us=v[1] / n, gap_before_us=v[2] / n) for k, v in acc.items() if ':' not in k]
+    rows.sort(key=lambda r: r['start_us'])
+    if rows:
+        rows[0]['gap_before_us'] = max(0.0, period_us - sum(r['span_us'] + r['gap_before_us'] for r in rows))
+    for r in rows:
+        r['slot_us'] = r['span_us'] + r['gap_before_us']
+    marks = {k: v[1] / n for k, v in acc.items() if ':' in k}
+    for r in rows:
+        for k, v in marks.items():
+            if k.split(':')[0] == r['kernel']:
+                r[k.split(':')[1] + '_us'] = v           # e.g. chains_end_us: the role's last workgroup, from the kernel's start
+    return rows
 
 
 def _latest_profile(kind):
@@ -420,7 +480,7 @@ def run_workload(name, args, device, world, rank, use_dist, steps, warmup, prima
     if device.type == 'cuda':
         a_ = torch.empty(4096, 4096, device=device).normal_()
         t_ = time.perf_counter()
-        while time.perf_counter() - t_ < 0.3:
+        while time.perf_counter() - t_ < PREHEAT_S:
             for _ in range(8):
                 torch.mm(a_, a_)
             torch.cuda.synchronize()
@@ -463,14 +523,20 @@ def run_workload(name, args, device, world, rank, use_dist, steps, warmup, prima
         t = torch.tensor([comm_us, comm_iso_us], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         comm_us, comm_iso_us = t.tolist()
-    # Dominant kernels: hipEvents cannot bracket a node of a replayed graph, and an event pair around a single launch
-    # also times the dispatch gap (+10 us here).  So one more (eager) step is run with launch recording on, and the
-    # recorded launches -- same kernels, same shapes, the trainer's live buffers -- are re-launched back to back between
-    # ONE pair of events (vargp_prof_remember / vargp_prof_replay).
-    #   first task: "chol_rbf_gemm" = the longest launch of the step (K_uu / S_u factorisations + the K_uf distance GEMM
-    #   in one launch); "rbf_kuf_bwd_gemm" = the heaviest MFMA launch of the backward (P_uf = W_uf x beside the adjoint
-    #   chains of the factorisations; shapes outside the LDS-resident backward: "rbf_kuu_bwd_gemm", both W.Y products).
-    #   later tasks (composed path): "rbf_kuf_gemm" = the K_uf distance GEMM of compute_pf_diag.
+    # Kernel times, two ways.  (a) IN THE STEP: the kernels of the first-task program stamp the device's wall clock themselves
+    # (vargp_prof_spans) -- the only clock that reaches inside a replayed hipGraph; `roofline` is computed from these.
+    # (b) ISOLATED: one more (eager) step is run with launch recording on, and the recorded launches -- same kernels, same
+    # shapes, the trainer's live buffers -- are re-launched back to back between ONE pair of hipEvents (vargp_prof_remember /
+    # vargp_prof_replay): L2-warm, no neighbours, reported as `frac_isolated`; the only figure for the block program's kernels.
+    #   first task: "chol_rbf_gemm" = K_uu / S_u factorisations + the K_uf distance GEMM in one launch; "rbf_kuf_bwd_gemm" =
+    #   t0_bwdmat_gemm_kernel (P_uf = W_uf x beside the adjoint chains of the factorisations).
+    block_prog = bool(gp._use_block_program(B))      # which native program runs this model (vargp.py)
+    timeline = []
+    if use_graph and not block_prog and not args.no_timeline:
+        try:
+            timeline = step_timeline(run, 1e3 * median_ms)
+        except Exception as e:
+            print(f'[bench] step timeline failed ({type(e).__name__}: {e})', file=sys.stderr)
     _lib.prof_enable(False)
     _lib.prof_read('')
     _lib.prof_remember(True)
@@ -480,7 +546,6 @@ def run_workload(name, args, device, world, rank, use_dist, steps, warmup, prima
     kernels = {}
     flops_kuf = 2.0 * S * C * M * (N_PREV + 1) * B * D     # one K_uf launch of compute_pf_diag
     Mt = M * (N_PREV + 1)
-    block_prog = N_PREV > 0 or gp.first_task_as_block()      # which native program runs this model (vargp.py)
     if not block_prog:
         candidates = [('chol_rbf_gemm', flops_kuf, 'chol_rbf_gemm_kernel (K_uu/S_u factorisations -- register-resident pivot chains, four '
                        'pivots per barrier -- sharing one launch with the K_uf = rbf(z, x) distance GEMM; flops counted: the GEMM)'),
@@ -526,6 +591,32 @@ def run_workload(name, args, device, world, rank, use_dist, steps, warmup, prima
     else:
         dom = max(kernels, key=lambda t: kernels[t][0] if kernels[t][0] == kernels[t][0] else -1.0)
     kern_us, dominant_flops, dominant_desc = kernels[dom]
+    iso_us = kern_us
+    # in-step figures: algorithmic flop of every launch of the step (SURVEY 8d terms: symmetric / triangular work once)
+    tl_info = {'t0_pro_kuu': ('t0_pro_kuu', 1.0 * S * C * M * M * D), 'chol_rbf_gemm': ('chol_rbf_gemm', flops_kuf),
+               'gemm_kernel': (None, 1.0 * S * C * M * M * (M + 2)), 't0_fwd_fused': (None, 2.0 * S * C * M * M * B),
+               't0_bwd_mid': (None, 4.0 * S * C * M * M * B), 't0_bwdmat_gemm': ('rbf_kuf_bwd_gemm', 2.0 * S * C * M * B * D),
+               't0_puu_final': (None, 2.0 * S * C * M * M * D), 'yogi_multi': (None, 0.0)}
+    for r in timeline:
+        tag, fl = tl_info.get(r['kernel'], (None, 0.0))
+        r['flop'] = fl
+        # slot = previous kernel's last workgroup end .. this kernel's last workgroup end: the wall time of the step that belongs
+        # to this launch (launch latency and the previous kernel's cache write-back included; the slots sum to the step period).
+        # rocprofv3's dispatch-to-completion duration lies between span and slot.
+        r['frac'] = fl / (r['slot_us'] * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS if fl > 0 and r['slot_us'] > 0 else None
+        r['isolated_us'] = kernels[tag][0] if tag in kernels else None
+    dom_row = None
+    if timeline:
+        # the roofline object describes the LONGEST launch of the replayed step (by its in-step span)
+        dom_row = max((r for r in timeline if r['flop'] > 0), key=lambda r: r['slot_us'])
+        tag = tl_info[dom_row['kernel']][0]
+        if tag in kernels:
+            dom = tag
+            iso_us, dominant_flops, dominant_desc = kernels[tag]
+        else:
+            dom, iso_us, dominant_flops = dom_row['kernel'], float('nan'), dom_row['flop']
+            dominant_desc = dom_row['kernel'] + '_kernel (algorithmic flop of its products, SURVEY 8d)'
+        kern_us = dom_row['slot_us']
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -562,10 +653,27 @@ def run_workload(name, args, device, world, rank, use_dist, steps, warmup, prima
                                  achieved=achieved, peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
                                  frac=(achieved / MFMA_F32_PEAK_TFLOPS) if achieved else None,
                                  launches=kern_n, avg_us=avg_s * 1e6,
+                                 timing=('in the step: wall-clock stamps written by the kernels inside the replayed hipGraph '
+                                         '(vargp_prof_spans); avg_us = the launch\'s slot = previous kernel\'s last workgroup end .. this '
+                                         'kernel\'s last workgroup end (slots sum to ms_per_step); span_us = first workgroup start .. last '
+                                         'workgroup end; last of 4 back-to-back replays, mean of 20') if dom_row
+                                 else 'isolated: 100 back-to-back re-launches between one hipEvent pair',
+                                 span_us=dom_row['span_us'] if dom_row else None,
+                                 frac_span=(dominant_flops / (dom_row['span_us'] * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS) if dom_row else None,
+                                 frac_isolated=(dominant_flops / (iso_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS)
+                                 if iso_us == iso_us and iso_us > 0 else None,
+                                 isolated_us=iso_us if iso_us == iso_us else None,
                                  traffic=measured_traffic(dom) if cfg2 else None,
-                                 mfma_util=measured_mfma_util(dom) if cfg2 else None,
                                  counters_from=_latest_profile('traffic')[1] if cfg2 else None,
                                  counters_commit=(_latest_profile('traffic')[0] or {}).get('commit') if cfg2 else None))
+        # whole step against the same roof: SURVEY 8(d) algorithmic flop of the step / wall time of the step
+        step_flop = 3.0 * survey_flops_fwd(s_total if strong else S * world, C, M, N_PREV, B, D, F_)
+        res['step_flop'] = step_flop
+        res['step_frac'] = step_flop / (dt / steps) / 1e12 / MFMA_F32_PEAK_TFLOPS / world
+        res['preheat_s'] = PREHEAT_S if device.type == 'cuda' else 0.0
+        if timeline:
+            res['timeline'] = [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in timeline]
+            res['timeline_sum_us'] = dict(spans=sum(r['span_us'] for r in timeline), gaps=sum(r['gap_before_us'] for r in timeline))
         if N_PREV > 0:
             res['roofline_others'] = [dict(kernel=dsc, avg_us=us, achieved=fl / (us * 1e-6) / 1e12,
                                            frac=fl / (us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS)
@@ -576,8 +684,8 @@ def run_workload(name, args, device, world, rank, use_dist, steps, warmup, prima
             res['roofline_gemm'] = dict(bound='mfma', kernel=desc2, achieved=fl2 / (us2 * 1e-6) / 1e12,
                                         peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
                                         frac=fl2 / (us2 * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, launches=kern_n, avg_us=us2,
-                                        traffic=measured_traffic(gtag) if cfg2 else None,
-                                        mfma_util=measured_mfma_util(gtag) if cfg2 else None)
+                                        timing='isolated: back-to-back re-launches between one hipEvent pair',
+                                        traffic=measured_traffic(gtag) if cfg2 else None)
             if not block_prog:
                 res['roofline_others'] = [dict(kernel=dsc, avg_us=us, achieved=fl / (us * 1e-6) / 1e12,
                                                frac=fl / (us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS)
@@ -695,6 +803,8 @@ def main():
     ap.add_argument('--secondary-budget', type=float, default=240.0,
                     help='seconds after which no further secondary workload is started')
     ap.add_argument('--stress-n', type=int, default=1000000)
+    ap.add_argument('--no-timeline', action='store_true',
+                    help='skip the in-step kernel time line (vargp_prof_spans: extra graph replays after the timed region)')
     ap.add_argument('--no-replay', action='store_true',
                     help='skip the back-to-back re-launches that time the dominant kernels (keeps a rocprof trace clean)')
     ap.add_argument('--comm', default='allreduce', choices=['allreduce', 'rsag'],

@@ -369,6 +369,15 @@ int vargp_prof_remember(int on);
  * 1 = 128x128x16, 2 = 128x64x32, 3 = 64x64x64).  Results do not depend on it beyond summation order. */
 int vargp_tune_gemm_tile(int tile);
 int vargp_prof_replay(const char* tag, int iters, double* avg_us, vargp_stream_t stream);
+/* Time line of the first-task step as the GPU sees it -- also inside a replayed hipGraph, where hipEvents cannot bracket a
+ * node: while switched on, every kernel of the step stamps the device's constant 100 MHz wall clock at its first
+ * workgroup's start and (atomic max) at every workgroup's end into a small device table.
+ *   mode 1: clear the table and switch the stamps on;  mode 2: switch them off;
+ *   mode 0: copy the table to out[12][2] = (start, end) ticks of 10 ns per slot, 0 = the slot's kernel did not run.
+ * Slots: 0 t0_pro_kuu, 1 chol_rbf_gemm (9: end of its last factorisation), 2 gemm_kernel (any plain product: the last one
+ * launched), 3 t0_fwd_fused, 4 t0_bwd_mid, 5 t0_bwdmat_gemm (8: end of its last matrix chain), 6 t0_puu_final,
+ * 7 yogi_multi.  Synchronous (hipMemcpy to / from device symbols): call between steps, not inside a capture. */
+int vargp_prof_spans(int mode, unsigned long long* out);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,7 @@ R=$(pwd)
 OUT=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --no-cpu-baseline --no-secondary"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_graph -o p -- $B --steps 100 --warmup 10 > $OUT/${TAG}_graph.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_graph -o p -- $B --no-replay --no-timeline --steps 400 --warmup 20 > $OUT/${TAG}_graph.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_eager -o p -- $B --eager --no-replay --steps 50 --warmup 5 > $OUT/${TAG}_eager.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_replay -o p -- $B --eager --steps 5 --warmup 2 > $OUT/${TAG}_replay.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch -o p -- $B --eager --no-replay --steps 10 --warmup 3 > /dev/null 2>&1

@@ -119,6 +119,7 @@ _SIGNATURES = {
     'vargp_prof_enable': (c_int, [c_int]),
     'vargp_prof_read': (c_int, [c_char_p, POINTER(ctypes.c_double), POINTER(c_int64)]),
     'vargp_prof_remember': (c_int, [c_int]),
+    'vargp_prof_spans': (c_int, [c_int, POINTER(ctypes.c_uint64)]),
     'vargp_tune_gemm_tile': (c_int, [c_int]),
     'vargp_prof_replay': (c_int, [c_char_p, c_int, POINTER(ctypes.c_double), _P]),
     'vargp_yogi_step': (c_int, [_P, _P, _P, _P, c_int64] + [c_float] * 6 + [_P, _P]),
@@ -207,6 +208,21 @@ def prof_read(tag):
     ms, n = ctypes.c_double(0.0), c_int64(0)
     lib().vargp_prof_read(tag.encode(), ctypes.byref(ms), ctypes.byref(n))
     return ms.value, n.value
+
+
+SPAN_SLOTS = {0: 't0_pro_kuu', 1: 'chol_rbf_gemm', 2: 'gemm_kernel', 3: 't0_fwd_fused', 4: 't0_bwd_mid', 5: 't0_bwdmat_gemm',
+              6: 't0_puu_final', 7: 'yogi_multi', 8: 't0_bwdmat_gemm:chains_end', 9: 'chol_rbf_gemm:chains_end'}
+
+
+def prof_spans(mode):
+    """Step time line (vargp_hip.h: vargp_prof_spans).  mode 1: clear + on, 2: off, 0: -> {slot name: (start_us, end_us)} of the
+    slots stamped since the last clear (device wall clock, 10 ns ticks, as microseconds from an arbitrary origin)."""
+    if mode:
+        check(lib().vargp_prof_spans(int(mode), None), 'vargp_prof_spans')
+        return None
+    out = (ctypes.c_uint64 * 24)()
+    check(lib().vargp_prof_spans(0, out), 'vargp_prof_spans')
+    return {SPAN_SLOTS.get(i, str(i)): (out[2 * i] / 100.0, out[2 * i + 1] / 100.0) for i in range(12) if out[2 * i + 1]}
 
 
 def prof_remember(on=True):

@@ -6,34 +6,60 @@
 #include <functional>
 #include "../../include/vargp_hip.h"
 
-// Tuning builds only (-DSTEP_SPANS, tests/native/step_spans.py): wall-clock (100 MHz) of the first workgroup's start and the last
-// workgroup's end of each kernel of the first-task step -- the time line of the step as the GPU sees it, to set against the
-// dispatch-to-completion durations rocprofv3 reports.  One table per translation unit.
-#if defined(STEP_SPANS) && defined(__HIPCC__)
+// Step time line (include/vargp_hip.h: vargp_prof_spans): wall-clock (100 MHz) of the first workgroup's start and the last
+// workgroup's end of each kernel of the first-task step -- the step as the GPU sees it, also inside a replayed hipGraph, where
+// hipEvents cannot bracket a node.  One table per translation unit, switched on at run time (g_spans_on_<tu>: one scalar load
+// per workgroup while off).
+#if defined(__HIPCC__)
 namespace vargp {
+constexpr int kSpanEnds = 4096;      // per-workgroup end stamps of one kernel (plain stores: an atomic max on ONE address from
+                                     // thousands of workgroups serialises in the memory-side cache and stretches the kernel it times)
 struct SpanGuard {
-  unsigned long long* p;
-  __device__ __forceinline__ explicit SpanGuard(unsigned long long* q) : p(q) {
-    // (start: the first workgroup's, a plain store -- an atomic with a result from every workgroup serialises them on one address)
-    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) p[0] = wall_clock64();
+  unsigned long long* p;             // start slot; the kernel's end stamps follow the table at p + kSpanEndsOffset
+  unsigned long long* e;
+  __device__ __forceinline__ SpanGuard(unsigned long long* q, unsigned long long* ends, int on) : p(on ? q : nullptr), e(ends) {
+    if (p && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) p[0] = wall_clock64();
   }
-  __device__ __forceinline__ ~SpanGuard() { if (threadIdx.x == 0) atomicMax(&p[1], wall_clock64()); }
+  __device__ __forceinline__ ~SpanGuard() {
+    if (p && threadIdx.x == 0) {
+      const unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      e[lin & (kSpanEnds - 1)] = wall_clock64();
+    }
+  }
 };
 }  // namespace vargp
+// vargp_debug_spans_<tu>(out, mode): mode 0 = out[12][2] = (start, max of the end stamps) per slot; 1 = clear the tables and
+// switch the stamps on; 2 = switch them off
 #define STEP_SPAN_TABLE(tu)                                                                                      \
   __device__ unsigned long long g_spans_##tu[12][4];                                                              \
-  extern "C" void vargp_debug_spans_##tu(unsigned long long* out, int reset) {                                   \
-    if (reset) {                                                                                                 \
-      unsigned long long init[12][4];                                                                             \
-      for (int i = 0; i < 12; ++i) { init[i][0] = ~0ull; init[i][1] = init[i][2] = init[i][3] = 0; }              \
-      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_spans_##tu), init, sizeof(init));                                     \
+  __device__ unsigned long long g_span_ends_##tu[12][vargp::kSpanEnds];                                           \
+  __device__ int g_spans_on_##tu;                                                                                 \
+  extern "C" void vargp_debug_spans_##tu(unsigned long long* out, int mode) {                                    \
+    if (mode) {                                                                                                  \
+      const int on = mode == 1;                                                                                  \
+      if (on) {                                                                                                  \
+        void* sp = nullptr; void* ep = nullptr;                                                                  \
+        (void)hipGetSymbolAddress(&sp, HIP_SYMBOL(g_spans_##tu));                                                \
+        (void)hipGetSymbolAddress(&ep, HIP_SYMBOL(g_span_ends_##tu));                                            \
+        if (sp) (void)hipMemset(sp, 0, sizeof(unsigned long long) * 12 * 4);                                     \
+        if (ep) (void)hipMemset(ep, 0, sizeof(unsigned long long) * 12 * vargp::kSpanEnds);                      \
+      }                                                                                                          \
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_spans_on_##tu), &on, sizeof(on));                                     \
     } else {                                                                                                     \
-      (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_spans_##tu), 12 * 4 * sizeof(unsigned long long));              \
+      static unsigned long long ends[12][vargp::kSpanEnds];                                                      \
+      unsigned long long st[12][4];                                                                              \
+      (void)hipMemcpyFromSymbol(st, HIP_SYMBOL(g_spans_##tu), sizeof(st));                                       \
+      (void)hipMemcpyFromSymbol(ends, HIP_SYMBOL(g_span_ends_##tu), sizeof(ends));                               \
+      for (int i = 0; i < 12; ++i) {                                                                             \
+        unsigned long long mx = st[i][1];                                                                        \
+        for (int k = 0; k < vargp::kSpanEnds; ++k) mx = ends[i][k] > mx ? ends[i][k] : mx;                       \
+        out[2 * i] = st[i][0]; out[2 * i + 1] = mx;                                                              \
+      }                                                                                                          \
     }                                                                                                            \
   }
-#define STEP_SPAN(tu, i) vargp::SpanGuard step_span_guard_(g_spans_##tu[i])
-// (the end of one role of a multi-role kernel: slot i holds the last workgroup's end)
-#define STEP_SPAN_MARK(tu, i) do { if (threadIdx.x == 0) atomicMax(&g_spans_##tu[i][1], wall_clock64()); } while (0)
+#define STEP_SPAN(tu, i) vargp::SpanGuard step_span_guard_(g_spans_##tu[i], g_span_ends_##tu[i], g_spans_on_##tu)
+// (the end of one role of a multi-role kernel -- a few dozen workgroups: slot i holds the last one's end)
+#define STEP_SPAN_MARK(tu, i) do { if (step_span_guard_.p && threadIdx.x == 0) atomicMax(&g_spans_##tu[i][1], wall_clock64()); } while (0)
 #else
 #define STEP_SPAN_TABLE(tu)
 #define STEP_SPAN(tu, i) do { } while (0)

@@ -268,6 +268,26 @@ extern "C" int vargp_prof_replay(const char* tag, int iters, double* avg_us, var
   return check_launch("prof_replay");
 }
 
+// step time line: one span table per translation unit (common.h: STEP_SPAN_TABLE)
+extern "C" void vargp_debug_spans_gemm(unsigned long long* out, int mode);
+extern "C" void vargp_debug_spans_t0(unsigned long long* out, int mode);
+extern "C" int vargp_prof_spans(int mode, unsigned long long* out) {
+  VARGP_REQUIRE(mode == 1 || mode == 2 || (mode == 0 && out), "prof_spans: mode 0 (read into out[12][2]) / 1 (clear + on) / 2 (off)");
+  void (*fns[3])(unsigned long long*, int) = {vargp_debug_spans_gemm, vargp_debug_spans_t0, vargp_debug_spans_core};
+  if (mode) {
+    for (auto fn : fns) fn(nullptr, mode);
+    return check_launch("prof_spans");
+  }
+  for (int i = 0; i < 24; ++i) out[i] = 0;
+  for (auto fn : fns) {
+    unsigned long long t[24];
+    fn(t, 0);
+    for (int i = 0; i < 12; ++i)
+      if (t[2 * i + 1] != 0) { out[2 * i] = t[2 * i]; out[2 * i + 1] = t[2 * i + 1]; }
+  }
+  return check_launch("prof_spans");
+}
+
 extern "C" int vargp_prof_enable(int on) {
   g_prof_on = on != 0;
   return VARGP_OK;
