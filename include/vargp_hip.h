@@ -219,9 +219,18 @@ typedef struct vargp_elbo_t0_desc {
    * forward evaluates the likelihood as usual) for every other shape, and for a caller-supplied eps_f that does not sit on a
    * 16-byte boundary (the tile kernel reads it as float4). */
   int32_t defer_softmax;
+  /* 1: the Monte-Carlo likelihood is the CALLER's -- a rank of a class-sharded step holds only some of the classes the
+   * softmax couples (likelihoods.py:26-29).  fwd stops at the predictive moments and the KL (scalars[2] stays 0); y and eps_f
+   * are not read (may be NULL), eps_theta must be given unless map_est.  Between fwd and bwd the caller stores
+   * d total / d mu and d total / d var -- ALREADY multiplied by their seed -- into the workspace's gmu, gvar (S, C, B)
+   * (vargp_elbo_t0_lik_buffers); bwd takes them as they are and ignores seeds[2].  defer_softmax is ignored. */
+  int32_t ext_lik;
 } vargp_elbo_t0_desc;
 size_t vargp_elbo_t0_workspace_bytes(int S, int C, int M, int D, int B, int F);
 int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t stream);
+/* Where the program keeps the predictive moments mu, var (S, C, B) of its last fwd and the likelihood gradients gmu, gvar
+ * (S, C, B) its bwd reads (pointers into d->ws; any of the four outputs may be NULL). */
+int vargp_elbo_t0_lik_buffers(const vargp_elbo_t0_desc* d, float** mu, float** var, float** gmu, float** gvar);
 /* ONE vargp_elbo_t0_bwd per vargp_elbo_t0_fwd: for the shapes of the LDS-resident backward (M <= 104, M % 4 == 0, B % 4 == 0,
  * D % 4 == 0, S <= 16) the forward clears the accumulators the backward adds into (and the tile counters of the backward's
  * persistent product workgroups) -- there is no clearing launch in bwd.
@@ -269,6 +278,8 @@ typedef struct vargp_elbo_tn_desc {
   int32_t rng_sample_offset;
   int32_t forward_only; /* 1: workspace sized by vargp_elbo_tn_workspace_bytes_fwd; moments only (y == NULL), no bwd / end */
   int32_t defer_hyper;  /* as vargp_elbo_t0_desc.defer_hyper (vargp_elbo_tn_bwd only) */
+  int32_t ext_lik;      /* as vargp_elbo_t0_desc.ext_lik (vargp_elbo_tn_fwd / _bwd; buffers: vargp_elbo_tn_lik_buffers); y must still be non-NULL
+                         * for fwd to evaluate the KL (it is not dereferenced) */
 } vargp_elbo_tn_desc;
 size_t vargp_elbo_tn_workspace_bytes(int S, int C, int M, int D, int B, int F, int nblk);
 /* Workspace of a program that only ever evaluates predictive moments (VARGP.forward / predict, var_gp/vargp.py:115-131,
@@ -278,6 +289,7 @@ int vargp_elbo_tn_fwd(const vargp_elbo_tn_desc* d, vargp_stream_t stream);
 int vargp_elbo_tn_bwd(const vargp_elbo_tn_desc* d, const float* seeds, float* g_log_mean, float* g_log_logvar, float* g_z,
                       float* g_u_mean, float* g_u_tril_vec, vargp_stream_t stream);
 int vargp_elbo_tn_moments(const vargp_elbo_tn_desc* d, float** mu, float** var);
+int vargp_elbo_tn_lik_buffers(const vargp_elbo_tn_desc* d, float** mu, float** var, float** gmu, float** gvar);
 /* The same ELBO over a data set swept in minibatch tiles (BASELINE config 5: N = 1e6, M = 2048, K_uf tiled in HBM): loss
  * AND gradient, with everything that does not depend on the data (kernel matrix of the inducing points, factorisation,
  * small products, KL) computed once.  Workspace / descriptor as for fwd with d->B = the widest tile; d->y must be non-NULL

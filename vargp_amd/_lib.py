@@ -38,7 +38,7 @@ class ElboT0Desc(Structure):
         ('ws', c_void_p), ('ws_bytes', c_size_t),
         ('bump', c_void_p),
         ('rng_seed', ctypes.c_uint64), ('rng_counter', c_void_p), ('rng_sample_offset', c_int32),
-        ('defer_hyper', c_int32), ('defer_softmax', c_int32),
+        ('defer_hyper', c_int32), ('defer_softmax', c_int32), ('ext_lik', c_int32),
     ]
 
 
@@ -63,7 +63,7 @@ class ElboTnDesc(Structure):
         ('ws', c_void_p), ('ws_bytes', c_size_t),
         ('bump', c_void_p),
         ('rng_seed', ctypes.c_uint64), ('rng_counter', c_void_p), ('rng_sample_offset', c_int32),
-        ('forward_only', c_int32), ('defer_hyper', c_int32),
+        ('forward_only', c_int32), ('defer_hyper', c_int32), ('ext_lik', c_int32),
     ]
 
 
@@ -105,6 +105,8 @@ _SIGNATURES = {
     'vargp_hyper_kl_bwd': (c_int, [_P] * 7 + [c_int, _P]),
     'vargp_elbo_t0_workspace_bytes': (c_size_t, [c_int] * 6),
     'vargp_elbo_t0_fwd': (c_int, [POINTER(ElboT0Desc), _P]),
+    'vargp_elbo_t0_lik_buffers': (c_int, [POINTER(ElboT0Desc)] + [POINTER(c_void_p)] * 4),
+    'vargp_elbo_tn_lik_buffers': (c_int, [POINTER(ElboTnDesc)] + [POINTER(c_void_p)] * 4),
     'vargp_elbo_t0_bwd': (c_int, [POINTER(ElboT0Desc)] + [_P] * 7),
     'vargp_bias_act_fwd': (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P]),
     'vargp_bias_act_bwd': (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, _P]),

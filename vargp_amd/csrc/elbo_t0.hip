@@ -682,9 +682,9 @@ static int ensure_dynamic_lds(const void* fn, size_t bytes, std::atomic<unsigned
 static int check_desc(const vargp_elbo_t0_desc* d, const char* who) {
   VARGP_REQUIRE(d, "%s: null descriptor", who);
   VARGP_REQUIRE(d->S > 0 && d->C > 0 && d->M > 0 && d->D > 0 && d->B > 0 && d->F > 0, "%s: bad dims", who);
-  VARGP_REQUIRE(d->log_mean && d->z && d->u_mean && d->u_tril_vec && d->x && d->y && d->scalars && d->info && d->ws,
+  VARGP_REQUIRE(d->log_mean && d->z && d->u_mean && d->u_tril_vec && d->x && (d->y || d->ext_lik) && d->scalars && d->info && d->ws,
                 "%s: null pointer", who);
-  const bool native = d->eps_f == nullptr;    // the program draws its own noise
+  const bool native = d->eps_f == nullptr && !d->ext_lik;    // the program draws its own noise
   VARGP_REQUIRE(!native || (d->rng_counter && d->eps_theta == nullptr && d->rng_sample_offset >= 0),
                 "%s: native noise needs rng_counter, eps_theta == eps_f == NULL and a sample offset >= 0", who);
   VARGP_REQUIRE(d->map_est ? d->S == 1
@@ -746,6 +746,16 @@ extern "C" size_t vargp_elbo_t0_workspace_bytes(int S, int C, int M, int D, int 
   return carve_t0(nullptr, S, C, M, D, B, F).bytes + 256;
 }
 
+extern "C" int vargp_elbo_t0_lik_buffers(const vargp_elbo_t0_desc* d, float** mu, float** var, float** gmu, float** gvar) {
+  VARGP_REQUIRE(d && d->ws, "elbo_t0_lik_buffers: null pointer");
+  const T0Ws o = carve_t0(d->ws, d->S, d->C, d->M, d->D, d->B, d->F);
+  if (mu) *mu = o.mu;
+  if (var) *var = o.var;
+  if (gmu) *gmu = o.gmu;
+  if (gvar) *gvar = o.gvar;
+  return VARGP_OK;
+}
+
 extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t stream) {
   int rc = check_desc(d, "elbo_t0_fwd");
   if (rc) return rc;
@@ -755,7 +765,7 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
   const int NR = o.NR, LD = o.LD;
   const int64_t MM = (int64_t)M * M, MLD = (int64_t)M * LD;
   const bool fused_softmax = C <= 16;
-  const bool native = d->eps_f == nullptr;
+  const bool native = d->eps_f == nullptr && !d->ext_lik;
   const float* eps_f = native ? o.eps_f : d->eps_f;
 
   // the merged factorisation + K_uf launch also writes L_S into RK; then the prologue writes RK's other small columns
@@ -792,7 +802,7 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
   const bool clear_bwd = bwd_paths.mat_bwd;
   // the likelihood inside the backward's tile kernel (one launch less): only where that kernel runs and its softmax fits
   // (float4 reads of the noise there: a caller's eps_f must sit on a 16-byte boundary, the workspace's own does)
-  const bool defer_softmax = d->defer_softmax && fused_softmax && bwd_paths.fused_bwd && F <= 4 * kBmSmF && C <= kBmSmC &&
+  const bool defer_softmax = d->defer_softmax && !d->ext_lik && fused_softmax && bwd_paths.fused_bwd && F <= 4 * kBmSmF && C <= kBmSmC &&
                              reinterpret_cast<uintptr_t>(eps_f) % 16 == 0;
   t0_state_set(d->ws, (clear_bwd ? kT0Cleared : kT0NoClear) | (defer_softmax ? kT0SoftmaxDeferred : 0));
   if (clear_bwd) {
@@ -929,8 +939,9 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
     hipLaunchKernelGGL(t0_pdiag_kl_fwd_kernel, dim3(npd + nkx * SC), dim3(256), 0, st, o.QP, o.W, o.kd, o.LL, o.Lu, o.mu,
                        o.var, d->scalars + 1, S, C, M, B, NR, LD, nbx, npd, nkx, native ? d->rng_counter : nullptr);
   }
-  if (defer_softmax) {
-    // (nothing: t0_bwd_mid_kernel evaluates the likelihood of its tile -- value into scalars[2], gradient straight into its LDS)
+  if (defer_softmax || d->ext_lik) {
+    // (nothing: t0_bwd_mid_kernel evaluates the likelihood of its tile -- value into scalars[2], gradient straight into its LDS;
+    // ext_lik: the caller evaluates it on the moments of ALL classes and stores the seeded gradients into gmu / gvar)
   } else if (fused_softmax) {
     const int64_t total = (int64_t)S * F * B;
     hipLaunchKernelGGL(t0_softmax_kernel<16>, dim3(cdiv(total, 256)), dim3(256), 0, st, o.mu, o.var, eps_f, d->y,
@@ -953,12 +964,12 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
   const T0Ws o = carve_t0(d->ws, S, C, M, D, B, F);
   const int NR = o.NR, LD = o.LD;
   const int64_t MM = (int64_t)M * M, MLD = (int64_t)M * LD, MB = (int64_t)M * B;
-  const bool fused_softmax = C <= 16;
-  const bool native = d->eps_f == nullptr;
+  const bool fused_softmax = C <= 16 && !d->ext_lik;      // ext_lik: gmu / gvar arrive seeded, as from the generic kernel
+  const bool native = d->eps_f == nullptr && !d->ext_lik;
   const float* eps_f = native ? o.eps_f : d->eps_f;
   const float* eps_theta = native ? o.eps_theta : d->eps_theta;
 
-  if (!fused_softmax) {   // C > 16: gradient of the likelihood from the generic kernel (already scaled by its seed)
+  if (!fused_softmax && !d->ext_lik) {   // C > 16: gradient of the likelihood from the generic kernel (already scaled by its seed)
     rc = vargp_softmax_nll_bwd(o.mu, o.var, eps_f, d->y, seeds + 2, o.gmu, o.gvar, S, F, C, B, stream);
     if (rc) return rc;
   }
@@ -1140,7 +1151,7 @@ extern "C" int vargp_elbo_t0_hyper_desc(const vargp_elbo_t0_desc* d, const float
   const T0Ws o = carve_t0(d->ws, d->S, d->C, d->M, d->D, d->B, d->F);
   out->log_mean = d->log_mean; out->log_logvar = d->log_logvar;
   out->prior_log_mean = d->prior_log_mean; out->prior_log_logvar = d->prior_log_logvar;
-  out->eps_theta = d->eps_f == nullptr ? o.eps_theta : d->eps_theta;
+  out->eps_theta = (d->eps_f == nullptr && !d->ext_lik) ? o.eps_theta : d->eps_theta;
   out->gtheta = o.gtheta; out->g2 = o.g2; out->gkd = o.gkd; out->seeds = seeds;
   out->S = d->S; out->C = d->C; out->D1 = d->D + 1; out->map_est = d->map_est;
   return VARGP_OK;

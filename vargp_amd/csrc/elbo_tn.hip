@@ -423,7 +423,7 @@ static int check_tn(const vargp_elbo_tn_desc* d, const char* who, bool tiled = f
                   "%s: workspace too small", who);
     return VARGP_OK;
   }
-  const bool native = d->eps_f == nullptr && d->y != nullptr;
+  const bool native = d->eps_f == nullptr && d->y != nullptr && !d->ext_lik;
   VARGP_REQUIRE(!native || (d->rng_counter && d->eps_theta == nullptr && d->rng_sample_offset >= 0),
                 "%s: native noise needs rng_counter, eps_theta == eps_f == NULL and a sample offset >= 0", who);
   VARGP_REQUIRE(d->map_est ? d->S == 1
@@ -467,6 +467,16 @@ extern "C" int vargp_elbo_tn_moments(const vargp_elbo_tn_desc* d, float** mu, fl
   return VARGP_OK;
 }
 
+extern "C" int vargp_elbo_tn_lik_buffers(const vargp_elbo_tn_desc* d, float** mu, float** var, float** gmu, float** gvar) {
+  VARGP_REQUIRE(d && d->ws && !d->forward_only, "elbo_tn_lik_buffers: null pointer / forward_only program");
+  const TnWs o = carve_tn(d->ws, d->S, d->C, d->M, d->D, d->B, d->F, d->nblk, false);
+  if (mu) *mu = o.mu;
+  if (var) *var = o.var;
+  if (gmu) *gmu = o.gmu;
+  if (gvar) *gvar = o.gvar;
+  return VARGP_OK;
+}
+
 extern "C" int vargp_elbo_tn_fwd(const vargp_elbo_tn_desc* d, vargp_stream_t stream) {
   int rc = check_tn(d, "elbo_tn_fwd");
   if (rc) return rc;
@@ -476,7 +486,7 @@ extern "C" int vargp_elbo_tn_fwd(const vargp_elbo_tn_desc* d, vargp_stream_t str
   const int Mt = o.Mt, NRs = o.NRs;
   const int64_t MtMt = (int64_t)Mt * Mt, MtB = (int64_t)Mt * B, MtN = (int64_t)Mt * NRs;
   const bool lik = d->y != nullptr;                 // y == NULL: predictive moments only (no likelihood, no KL)
-  const bool native = lik && d->eps_f == nullptr;
+  const bool native = lik && d->eps_f == nullptr && !d->ext_lik;
   const bool fused_softmax = C <= 16;
   const float* eps_f = native ? o.eps_f : d->eps_f;
   {
@@ -619,7 +629,7 @@ extern "C" int vargp_elbo_tn_fwd(const vargp_elbo_tn_desc* d, vargp_stream_t str
                        o.LL, d->rk_all, o.mu, o.var, lik ? d->scalars + 1 : nullptr, d->jitter, S, C, M, Mt, nblk, B, NRs,
                        nbx, npd, nkx, native ? d->rng_counter : nullptr);
   }
-  if (lik) {
+  if (lik && !d->ext_lik) {       // (ext_lik: the caller evaluates the likelihood on the moments of ALL classes, include/vargp_hip.h)
     if (fused_softmax) {
       const int64_t total = (int64_t)S * F * B;
       hipLaunchKernelGGL(t0_softmax_kernel<16>, dim3(cdiv(total, 256)), dim3(256), 0, st, o.mu, o.var, eps_f, d->y,
@@ -644,12 +654,12 @@ extern "C" int vargp_elbo_tn_bwd(const vargp_elbo_tn_desc* d, const float* seeds
   const TnWs o = carve_tn(d->ws, S, C, M, D, B, F, nblk);
   const int Mt = o.Mt, NRs = o.NRs;
   const int64_t MtMt = (int64_t)Mt * Mt, MtB = (int64_t)Mt * B, MtN = (int64_t)Mt * NRs;
-  const bool native = d->eps_f == nullptr;
-  const bool fused_softmax = C <= 16;
+  const bool native = d->eps_f == nullptr && !d->ext_lik;
+  const bool fused_softmax = C <= 16 && !d->ext_lik;      // ext_lik: gmu / gvar arrive seeded, as from the generic kernel
   const float* eps_f = native ? o.eps_f : d->eps_f;
   const float* eps_theta = native ? o.eps_theta : d->eps_theta;
 
-  if (!fused_softmax) {
+  if (!fused_softmax && !d->ext_lik) {
     rc = vargp_softmax_nll_bwd(o.mu, o.var, eps_f, d->y, seeds + 2, o.gmu, o.gvar, S, F, C, B, stream);
     if (rc) return rc;
   }
@@ -813,7 +823,7 @@ extern "C" int vargp_elbo_tn_hyper_desc(const vargp_elbo_tn_desc* d, const float
   const TnWs o = carve_tn(d->ws, d->S, d->C, d->M, d->D, d->B, d->F, d->nblk);
   out->log_mean = d->log_mean; out->log_logvar = d->log_logvar;
   out->prior_log_mean = d->prior_log_mean; out->prior_log_logvar = d->prior_log_logvar;
-  out->eps_theta = d->eps_f == nullptr ? o.eps_theta : d->eps_theta;
+  out->eps_theta = (d->eps_f == nullptr && !d->ext_lik) ? o.eps_theta : d->eps_theta;
   out->gtheta = o.gtheta; out->g2 = o.g2; out->gkd = o.gkd; out->seeds = seeds;
   out->S = d->S; out->C = d->C; out->D1 = d->D + 1; out->map_est = d->map_est;
   return VARGP_OK;

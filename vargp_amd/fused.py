@@ -80,9 +80,21 @@ class T0Program:
     def shape_of(n_v, z, x, n_f):
         return (n_v, z.shape[0], z.shape[1], z.shape[2], x.shape[0], n_f)
 
+    def lik_buffers(self):
+        """(mu, var, gmu, gvar), each (S, C, B): the predictive moments of the last forward and the likelihood-gradient buffers
+        the backward reads (views into the workspace).  With `forward(ext_lik=True)` the caller fills gmu / gvar (seeded)."""
+        S, C, M, D, B, F_ = self.shape[:6]
+        ps = [ctypes.c_void_p() for _ in range(4)]
+        fn = lib().vargp_elbo_tn_lik_buffers if isinstance(self, TnProgram) else lib().vargp_elbo_t0_lik_buffers
+        check(fn(ctypes.byref(self.desc), *(ctypes.byref(q) for q in ps)), 'lik_buffers')
+        base = self.ws.data_ptr()
+        return tuple(self.ws[(q.value - base) // 4:(q.value - base) // 4 + S * C * B].view(S, C, B) for q in ps)
+
     def forward(self, log_mean, log_logvar, prior_log_mean, prior_log_logvar, z, u_mean, u_tril_vec, x, y, eps_theta,
-                eps_f, bump=None, defer_softmax=False):
+                eps_f, bump=None, defer_softmax=False, ext_lik=False):
         """-> scalars (3,) = (kl_hypers, kl_u, nll).  All tensors contiguous fp32 on the ROCm device (y int64).
+        ext_lik: the likelihood is the caller's (class-sharded ranks, include/vargp_hip.h): moments + KL only, nll stays 0;
+        y / eps_f may be None; fill lik_buffers()[2:] before `backward`.
         defer_softmax: the caller runs `backward` right behind this forward and reads nll only afterwards (ElboTrainer): the
         likelihood is then evaluated inside the backward's tile kernel where the shapes allow (include/vargp_hip.h).
         eps_theta = eps_f = None: the program draws the noise itself (see set_rng).  `bump`: optional device float that the forward increments by one (an optimiser's step counter)."""
@@ -92,9 +104,11 @@ class T0Program:
             if t is not None and not t.is_contiguous():
                 raise ValueError('T0Program.forward needs contiguous tensors')
         S, C, M, D, B, F_ = self.shape
-        assert z.shape == (C, M, D) and x.shape == (B, D) and y.dtype == torch.int64
+        assert z.shape == (C, M, D) and x.shape == (B, D) and (ext_lik or y.dtype == torch.int64)
         assert u_mean.numel() == C * M and u_tril_vec.shape == (C, M * (M + 1) // 2) and log_mean.numel() == D + 1
-        if eps_f is None:
+        if ext_lik:
+            assert self.map_est or eps_theta.shape == (S, D + 1)
+        elif eps_f is None:
             assert self._rng is not None and eps_theta is None, 'native noise: call set_rng() and pass no eps tensors'
         else:
             assert eps_f.shape == (S, F_, C, B) and (self.map_est or eps_theta.shape == (S, D + 1))
@@ -105,6 +119,7 @@ class T0Program:
         d.eps_theta, d.eps_f = _p(eps_theta), _p(eps_f)
         d.bump = _p(bump)
         d.defer_softmax = int(bool(defer_softmax))
+        d.ext_lik = int(bool(ext_lik))
         self._keep = tensors + (bump,)   # the descriptor holds raw pointers: keep the tensors alive until backward
         check(lib().vargp_elbo_t0_fwd(ctypes.byref(d), stream_ptr()), 'vargp_elbo_t0_fwd')
         self._bwd_ok = True
@@ -310,9 +325,12 @@ class TnProgram:
               'vargp_elbo_tn_tile')
         return self.moments(x.shape[0])
 
+    lik_buffers = T0Program.lik_buffers
+
     def forward(self, log_mean, log_logvar, prior_log_mean, prior_log_logvar, z, u_mean, u_tril_vec, z_all, rk_all, x, y,
-                eps_theta, eps_f, bump=None):
-        """-> scalars (3,) = (kl_hypers, kl_u, nll) (y given) or None (y None: moments only)."""
+                eps_theta, eps_f, bump=None, ext_lik=False):
+        """-> scalars (3,) = (kl_hypers, kl_u, nll) (y given) or None (y None: moments only).  ext_lik: as T0Program.forward
+        (y must still be given: it switches the KL on)."""
         tensors = (log_mean, log_logvar, prior_log_mean, prior_log_logvar, z, u_mean, u_tril_vec, z_all, rk_all, x, y,
                    eps_theta, eps_f)
         require_device(*tensors)
@@ -323,7 +341,9 @@ class TnProgram:
         assert z.shape == (C, M, D) and x.shape == (B, D) and (y is None or y.dtype == torch.int64)
         assert z_all.shape == (C, nblk * M, D) and rk_all.shape == (C, nblk, M, tn_row_width(M))
         assert u_mean.numel() == C * M and u_tril_vec.shape == (C, M * (M + 1) // 2) and log_mean.numel() == D + 1
-        if y is not None and eps_f is None:
+        if ext_lik:
+            assert y is not None and (self.map_est or eps_theta.shape == (S, D + 1))
+        elif y is not None and eps_f is None:
             assert self._rng is not None and eps_theta is None, 'native noise: call set_rng() and pass no eps tensors'
         elif y is not None:
             assert eps_f.shape == (S, F_, C, B) and (self.map_est or eps_theta.shape == (S, D + 1))
@@ -334,6 +354,7 @@ class TnProgram:
         d.z_all, d.rk_all = _p(z_all), _p(rk_all)
         d.eps_theta, d.eps_f = _p(eps_theta), _p(eps_f)
         d.bump = _p(bump)
+        d.ext_lik = int(bool(ext_lik))
         self._keep = tensors + (bump,)
         check(lib().vargp_elbo_tn_fwd(ctypes.byref(d), stream_ptr()), 'vargp_elbo_tn_fwd')
         ops._note_chol_errors(self.info)

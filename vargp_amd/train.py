@@ -29,14 +29,39 @@ def split_samples(total, world):
     return [total // world + (1 if r < total % world else 0) for r in range(world)]
 
 
+def split_pairs(S, C, world):
+    """One rectangle (s0, s1, c0, c1) of the S x C grid of (hyper-sample, class) problems per rank -- everything before the
+    softmax is independent per (s, c) (var_gp/kernels.py:38-56, gp_utils.py:174-186).  world <= S: whole
+    hyper-samples (all classes: no exchange before the likelihood), the remainder to the first ranks.  world > S: the ranks are
+    dealt to the samples (world // S each, the first world % S samples one more) and every sample's classes are cut into
+    contiguous ranges over its ranks -- a rank then holds ONE sample and some classes (BASELINE config 2, S = 3, C = 10 on 8
+    GPUs: 4 3 3 | 4 3 3 | 5 5 pairs), and the predictive moments are all-gathered before the likelihood."""
+    assert world <= S * C, f'{world} ranks for {S} x {C} (sample, class) problems'
+    if world <= S:
+        out, s0 = [], 0
+        for n in split_samples(S, world):
+            out.append((s0, s0 + n, 0, C))
+            s0 += n
+        return out
+    out = []
+    for s, nr in enumerate(split_samples(world, S)):
+        assert nr <= C
+        c0 = 0
+        for n in split_samples(C, nr):
+            out.append((s, s + 1, c0, c0 + n))
+            c0 += n
+    return out
+
+
 class ElboTrainer:
     """`gp` is a vargp_amd VARGP module.  For tests of the exchange logic on CPU (gloo) the model can be
     replaced by any `loss_fn(x, y) -> (kl_hypers, kl_u, nll)` over an explicit `params` list."""
 
     def __init__(self, gp=None, lr=1e-2, beta=1.0, n_total=None, group=None, noise_seed=1234, optimizer=None,
-                 params=None, loss_fn=None, native_noise=True, sample_counts=None, force_exchange=False, comm='allreduce'):
+                 params=None, loss_fn=None, native_noise=True, sample_counts=None, force_exchange=False, comm='allreduce',
+                 shards=None, pair_fns=None, grid=None, pair_dims=None):
         self.gp = gp
-        self.loss_fn = loss_fn if loss_fn is not None else gp.loss
+        self.loss_fn = loss_fn if loss_fn is not None else (gp.loss if gp is not None else None)
         self.beta = float(beta)
         self.n_total = n_total
         self.group = group
@@ -77,11 +102,40 @@ class ElboTrainer:
         else:
             self.weight = 1.0 / self.world
             self.sample_offset = None          # rank * S, S known at the first step
-        if self.multi:
+        # shards: one rectangle (s0, s1, c0, c1) of the (hyper-sample, class) grid per rank (split_pairs).  Rectangles that cut
+        # the classes put the step on the class-sharded route: moments of the rank's pairs -> all-gather of mu, var (S, C, B)
+        # -> the likelihood of ALL pairs on every rank (S F C B exps: nothing) -> backward of the rank's pairs -> the same
+        # exchange of the flat buffer.  grid = (S, C) of the whole problem; pair_fns = (moments_fn, lik_fn) for models without
+        # a native program (the CPU tests drive the oracle through them).
+        self.shards = None if shards is None else [tuple(int(v) for v in r) for r in shards]
+        self.pair_fns = pair_fns
+        self._pair_dims = pair_dims            # (D + 1, F) for the noise shapes when there is no model object (pair_fns)
+        self.class_split = False
+        if self.shards is not None:
+            assert len(self.shards) == self.world and self.multi
+            self.grid = tuple(grid) if grid is not None else (gp.n_v, gp.z.size(0))
+            St, Ct = self.grid
+            assert sum((r[1] - r[0]) * (r[3] - r[2]) for r in self.shards) == St * Ct, 'shards must tile the (S, C) grid'
+            self.class_split = any(r[3] - r[2] < Ct for r in self.shards)
+            self.rect = self.shards[self.rank]
+            s0, s1, c0, c1 = self.rect
+            if not self.class_split:      # whole samples per rank: the sample-parallel route with these counts
+                self.sample_counts = [r[1] - r[0] for r in self.shards]
+                self.weight = (s1 - s0) / float(St)
+                self.sample_offset = s0
+            else:
+                self.w_kl = (s1 - s0) / float(St)                       # kl_u = sum_r w_kl_r * (mean over the rank's samples)
+                self.w_h = (s1 - s0) * (c1 - c0) / float(St * Ct)       # replicated terms (kl_hypers, nll) counted once in the sum
+                self.max_pairs = max((r[1] - r[0]) * (r[3] - r[2]) for r in self.shards)
+        if self.multi and self.class_split:
+            # class-sharded: every rank draws the WHOLE noise tensors (same seed, same stream) and uses its rows of eps_theta
+            noise.set_shard(0, 1, noise_seed, dev, None)
+        elif self.multi:
             noise.set_shard(self.rank, self.world, noise_seed, dev, self.sample_counts)
 
         self.graph = None
         self.graph_opt = None
+        self.graph_mid = None
         self._captured = {}
         # models on a native program (fused.T0Program: first task; fused.TnProgram: later tasks, ep_var_mean=True) drive it
         # directly: no autograd graph, gradients written straight into the optimiser's buffers
@@ -98,7 +152,7 @@ class ElboTrainer:
         self._bump = None
         # native noise: the program draws eps_theta / eps_f itself (Philox keyed by noise_seed, device-side step
         # counter): no randn launches, and ranks see slices of one global draw by construction
-        self.native_noise = bool(native_noise) and self._t0
+        self.native_noise = bool(native_noise) and self._t0 and not self.class_split
         self.noise_seed = int(noise_seed)
         self._rng_counter = torch.zeros(1, dtype=torch.int32, device=dev) if self.native_noise else None
         if self._t0 and isinstance(self.optim, Yogi) and len(self.optim.param_groups) == 1:
@@ -135,14 +189,23 @@ class ElboTrainer:
             with torch.cuda.graph(self.graph):
                 self._sout = self.step(self._sx, self._sy)
         else:
-            with torch.cuda.graph(self.graph):
-                self._sout = self._local_part(self._sx, self._sy)
+            self.graph_mid = None
+            if self.class_split:
+                # three graphs: moments | all-gather | likelihood + backward | exchange | optimiser
+                with torch.cuda.graph(self.graph):
+                    self._pair_part1(self._sx, self._sy)
+                self.graph_mid = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_mid, pool=self.graph.pool()):
+                    self._sout = self._pair_part2(self._sx, self._sy)
+            else:
+                with torch.cuda.graph(self.graph):
+                    self._sout = self._local_part(self._sx, self._sy)
             self.graph_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_opt, pool=self.graph.pool()):
                 self.optim.step()
         # one captured step per minibatch size (the ragged last batch of an epoch gets its own: experiments/vargp.py); the
         # attributes graph / _sx / _sy / _sout always describe the most recent capture
-        self._captured[int(x.size(0))] = (self.graph, self.graph_opt, self._sx, self._sy, self._sout)
+        self._captured[int(x.size(0))] = (self.graph, self.graph_opt, self._sx, self._sy, self._sout, getattr(self, 'graph_mid', None))
         return self
 
     def captured_sizes(self):
@@ -150,7 +213,7 @@ class ElboTrainer:
 
     def _select_capture(self, nb):
         if self._sx.size(0) != nb:
-            self.graph, self.graph_opt, self._sx, self._sy, self._sout = self._captured[int(nb)]
+            self.graph, self.graph_opt, self._sx, self._sy, self._sout, self.graph_mid = self._captured[int(nb)]
 
     def _snapshot_state(self):
         snap = dict(params=[p.detach().clone() for p in self.params], rng=None, gen=None, opt=[])
@@ -220,6 +283,9 @@ class ElboTrainer:
             self._sy.copy_(y, non_blocking=True)
         self.graph.replay()
         if self.multi:
+            if self.class_split:
+                self.gather_moments()
+                self.graph_mid.replay()
             self.exchange()
             self.graph_opt.replay()
         return self._sout
@@ -280,7 +346,7 @@ class ElboTrainer:
         from .fused import T0Program, TnProgram
         gp, kern = self.gp, self.gp.kernel
         x, y = x.contiguous(), y.contiguous()
-        S = 1 if kern.map_est else gp.n_v
+        S = 1 if kern.map_est else (gp.n_v if self.shards is None else self.rect[1] - self.rect[0])
         if self.native_noise and not noise._injected:
             eps_theta = eps_f = None
         else:
@@ -328,6 +394,10 @@ class ElboTrainer:
             for p in self.params:                      # (re-)attach the gradient views of the flat buffer
                 p.grad = self.flat[off:off + p.numel()].view_as(p)
                 off += p.numel()
+        if self.class_split:
+            self._pair_part1(x, y)
+            self.gather_moments()
+            return self._pair_part2(x, y)
         w = self.weight
         if self._t0:
             scal = self._t0_fwd_bwd(x, y, scale, w)      # overwrites every gradient view of the flat buffer
@@ -341,3 +411,137 @@ class ElboTrainer:
             self.scalars[0] = kl_u.detach() * w
             self.scalars[1] = nll.detach() * w
         return kl_h.detach(), self.scalars[0], self.scalars[1]
+
+    # -- class-sharded route (split_pairs with more ranks than hyper-samples) ---------------------------------------------------
+    def _pair_setup(self, x):
+        """Buffers of the class-sharded route for this minibatch size: the send block (max_pairs, 2, B) of this rank's moments, the
+        gathered (world, max_pairs, 2, B), the row map that puts the gathered rows into (S, C) order, the full moments / gradients."""
+        B, dev = x.size(0), x.device
+        if getattr(self, '_pair_B', None) == B:
+            return
+        bufs = self.__dict__.setdefault('_pair_bufs', {})        # per minibatch size, never freed: captured graphs hold the pointers
+        if B not in bufs:
+            St, Ct = self.grid
+            perm = torch.empty(St * Ct, dtype=torch.int64)
+            for r, (s0, s1, c0, c1) in enumerate(self.shards):
+                k = 0
+                for s_ in range(s0, s1):
+                    for c_ in range(c0, c1):
+                        perm[s_ * Ct + c_] = r * self.max_pairs + k
+                        k += 1
+            bufs[B] = dict(_send=torch.zeros(self.max_pairs, 2, B, device=dev),
+                           _recv=torch.zeros(self.world * self.max_pairs, 2, B, device=dev), _perm=perm.to(dev),
+                           _full=torch.zeros(St * Ct, 2, B, device=dev),          # [:, 0] = mu, [:, 1] = var, rows in (s, c) order
+                           _mom=torch.zeros(2, St, Ct, B, device=dev),            # the same, contiguous per moment
+                           _gfull=torch.zeros(2, St, Ct, B, device=dev),          # seeded d nll / d (mu, var) of ALL pairs
+                           _nll=torch.zeros((), device=dev))
+        self.__dict__.update(bufs[B])
+        self._pair_B = B
+        self.__dict__.setdefault('_lik_seed', {})
+
+    def gather_moments(self):
+        """All-gather of the ranks' predictive moments (the class-sharded route's extra exchange: 2 max_pairs B floats per rank;
+        BASELINE config 2 on 8 GPUs: 20 KB each)."""
+        dist.all_gather_into_tensor(self._recv, self._send, group=self.group)
+
+    def _pair_noise(self, x):
+        St, Ct = self.grid
+        gp = self.gp
+        if gp is not None and hasattr(gp, 'kernel'):
+            D1, F_ = gp.kernel.log_mean.shape[0], gp.likelihood.n_f
+        else:
+            D1, F_ = self._pair_dims
+        eps_theta = noise.draw('eps_theta', (St, D1), x.device)
+        eps_f = noise.draw('eps_f', (St, F_, Ct, x.size(0)), x.device)
+        return eps_theta, eps_f
+
+    def _pair_part1(self, x, y):
+        """Moments and KL of this rank's (sample, class) rectangle -> the send block."""
+        from .fused import T0Program, TnProgram
+        self._pair_setup(x)
+        s0, s1, c0, c1 = self.rect
+        Sl, Cl, B = s1 - s0, c1 - c0, x.size(0)
+        if self.params[0].grad is None or self.params[0].grad.data_ptr() != self.flat.data_ptr():
+            off = 0
+            for p in self.params:
+                p.grad = self.flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+        self.flat.zero_()                           # the program / autograd writes this rank's class rows only
+        eps_theta, self._eps_f = self._pair_noise(x)
+        th = eps_theta[s0:s1].contiguous()
+        if self.pair_fns is not None:               # generic route (autograd): moments_fn(x, rect, eps_theta rows) ->
+            kl_h, kl_u, mu, var = self.pair_fns[0](x, self.rect, th)       # (kl_hypers, kl_u of the rectangle, mu, var (Sl, Cl, B))
+            self._pair_graph = (kl_h, kl_u, mu, var)
+            self._send[:Sl * Cl, 0].copy_(mu.detach().reshape(Sl * Cl, B))
+            self._send[:Sl * Cl, 1].copy_(var.detach().reshape(Sl * Cl, B))
+            return
+        gp, kern = self.gp, self.gp.kernel
+        assert self._t0, 'class-sharded steps need a native program (RBFKernel, ep_var_mean=True) or pair_fns'
+        x = x.contiguous()
+        tn = bool(gp._use_block_program(B))
+        shape = (Sl, Cl, gp.M, gp.z.size(-1), B, gp.likelihood.n_f) + ((len(gp.prev_params) + 1,) if tn else ())
+        if self._prog is None or self._prog.shape != shape:
+            if shape not in self._progs:
+                self._progs[shape] = (TnProgram if tn else T0Program)(*shape, x.device, kern.map_est)
+            self._prog = self._progs[shape]
+        self._tn = tn
+        packed = tuple(t[c0:c1] for t in gp._tn_operands()) if tn else ()
+        self._pair_scal = self._prog.forward(kern.log_mean.detach(), kern.log_logvar.detach(), kern.prior_log_mean,
+                                             kern.prior_log_logvar, gp.z.detach()[c0:c1], gp.u_mean.detach()[c0:c1],
+                                             gp.u_tril_vec.detach()[c0:c1], *packed, x, y.contiguous(),
+                                             None if kern.map_est else th, None, ext_lik=True)
+        mu, var, _, _ = self._prog.lik_buffers()
+        self._send[:Sl * Cl, 0].copy_(mu.view(Sl * Cl, B))
+        self._send[:Sl * Cl, 1].copy_(var.view(Sl * Cl, B))
+
+    def _pair_part2(self, x, y):
+        """The likelihood of ALL pairs from the gathered moments, then the backward of this rank's rectangle; leaves
+        [grads | w kl_u | w nll] in the flat buffer for the exchange.  -> (kl_hypers, kl_u share, nll share)."""
+        from . import _lib
+        St, Ct = self.grid
+        s0, s1, c0, c1 = self.rect
+        Sl, Cl, B = s1 - s0, c1 - c0, x.size(0)
+        scale = (self.n_total if self.n_total is not None else B) / B
+        torch.index_select(self._recv, 0, self._perm, out=self._full)
+        if self.pair_fns is not None:
+            kl_h, kl_u, mu, var = self._pair_graph
+            mu_f = self._full[:, 0].reshape(St, Ct, B).clone().requires_grad_(True)
+            var_f = self._full[:, 1].reshape(St, Ct, B).clone().requires_grad_(True)
+            nll = self.pair_fns[1](mu_f, var_f, y, self._eps_f)
+            gmu, gvar = torch.autograd.grad(scale * nll, [mu_f, var_f])
+            local = (self.beta * self.w_h) * kl_h + self.w_kl * kl_u + (mu * gmu[s0:s1, c0:c1]).sum() + (var * gvar[s0:s1, c0:c1]).sum()
+            local.backward()
+            self._pair_graph = None
+            with torch.no_grad():
+                self.scalars[0] = kl_u.detach() * self.w_kl
+                self.scalars[1] = nll.detach() * self.w_h
+            return kl_h.detach(), self.scalars[0], self.scalars[1]
+        gp, kern = self.gp, self.gp.kernel
+        lib, ptr, st = _lib.lib(), _lib.ptr, _lib.stream_ptr()
+        self._mom.copy_(self._full.view(St, Ct, 2, B).permute(2, 0, 1, 3))         # (static buffer: no allocation under capture)
+        mu_f, var_f = self._mom[0], self._mom[1]
+        eps_f, yc = self._eps_f.contiguous(), y.contiguous()
+        F_ = eps_f.shape[1]
+        if scale not in self._lik_seed:
+            self._lik_seed[scale] = torch.tensor([scale], dtype=torch.float32, device=x.device)
+        _lib.check(lib.vargp_softmax_nll_fwd(ptr(mu_f), ptr(var_f), ptr(eps_f), ptr(yc), ptr(self._nll), St, F_, Ct, B, st),
+                   'vargp_softmax_nll_fwd')
+        _lib.check(lib.vargp_softmax_nll_bwd(ptr(mu_f), ptr(var_f), ptr(eps_f), ptr(yc), ptr(self._lik_seed[scale]),
+                                             ptr(self._gfull[0]), ptr(self._gfull[1]), St, F_, Ct, B, st), 'vargp_softmax_nll_bwd')
+        _, _, gmu, gvar = self._prog.lik_buffers()
+        gmu.copy_(self._gfull[0, s0:s1, c0:c1])
+        gvar.copy_(self._gfull[1, s0:s1, c0:c1])
+        key = ('pair', scale)
+        if key not in self._seeds:
+            self._seeds[key] = torch.tensor([self.beta * self.w_h, self.w_kl, 0.0], dtype=torch.float32, device=x.device)
+        g = lambda t: t.grad[c0:c1]
+        self._prog.backward(self._seeds[key], kern.log_mean.grad, kern.log_logvar.grad if kern.log_logvar.grad is not None
+                            else self._scratch(kern.log_logvar), g(gp.z), g(gp.u_mean), g(gp.u_tril_vec))
+        torch.mul(self._pair_scal[1], self.w_kl, out=self.scalars[0])
+        torch.mul(self._nll, self.w_h, out=self.scalars[1])
+        return self._pair_scal[0], self.scalars[0], self.scalars[1]
+
+    def _scratch(self, t):
+        if t not in self._scratch_grads:
+            self._scratch_grads[t] = torch.empty_like(t)
+        return self._scratch_grads[t]
