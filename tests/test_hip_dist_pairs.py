@@ -81,7 +81,7 @@ def test_class_sharded_ranks_equal_single_process(case, use_graph):
     for p in procs:
         p.start()
     try:
-        outs2, sd2 = q.get(timeout=300)
+        outs2, sd2 = q.get(timeout=120)
     finally:
         for p in procs:
             p.join(timeout=120)

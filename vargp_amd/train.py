@@ -489,7 +489,7 @@ class ElboTrainer:
         self._pair_scal = self._prog.forward(kern.log_mean.detach(), kern.log_logvar.detach(), kern.prior_log_mean,
                                              kern.prior_log_logvar, gp.z.detach()[c0:c1], gp.u_mean.detach()[c0:c1],
                                              gp.u_tril_vec.detach()[c0:c1], *packed, x, y.contiguous(),
-                                             None if kern.map_est else th, None, ext_lik=True)
+                                             None if kern.map_est else th, None, bump=self._bump, ext_lik=True)
         mu, var, _, _ = self._prog.lik_buffers()
         self._send[:Sl * Cl, 0].copy_(mu.view(Sl * Cl, B))
         self._send[:Sl * Cl, 1].copy_(var.view(Sl * Cl, B))
