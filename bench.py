@@ -46,6 +46,7 @@ DOMINANT_TAG = 'rbf_kuf'       # the K_uf distance GEMM incl. its split-K combin
 WORKLOADS = {
     'smnist': dict(S=3, M=100, n_prev=0, desc='BASELINE config 2 (Split-MNIST t=0): S3 F10 C10 M100 D784 B512 ELBO step'),
     'smnist_s64': dict(S=64, M=100, n_prev=0, strong=True, desc='BASELINE config 4 (Split-MNIST t=0, 64 hyper-samples x 10 classes), samples split over the ranks'),
+    'smnist_pairs': dict(S=3, M=100, n_prev=0, pairs=True, desc='BASELINE config 2 (Split-MNIST t=0, S3 C10 M100 D784 B512): its 30 (hyper-sample, class) problems split over the ranks (train.split_pairs: class-sharded, all-gather of the predictive moments before the softmax)'),
     'smnist_s8': dict(S=8, M=100, n_prev=0, desc="one rank's share of BASELINE config 4 on 8 GPUs (Split-MNIST t=0, 8 of the 64 hyper-samples), no exchange"),
     'smnist_s16': dict(S=16, M=100, n_prev=0, desc="one rank's share of BASELINE config 4 on 4 GPUs (16 of the 64 hyper-samples), no exchange"),
     'smnist_s32': dict(S=32, M=100, n_prev=0, desc="one rank's share of BASELINE config 4 on 2 GPUs (32 of the 64 hyper-samples), no exchange"),
@@ -431,7 +432,8 @@ def run_workload(name, args, device, world, rank, use_dist, steps, warmup, prima
     from vargp_amd.train import ElboTrainer, split_samples
     S, M, N_PREV = (WORKLOADS[name][k] for k in ('S', 'M', 'n_prev'))
     strong = bool(WORKLOADS[name].get('strong'))
-    weak_multi = (not strong) and world > 1
+    pairs = bool(WORKLOADS[name].get('pairs')) and world > 1      # (one rank: the plain Cfg2 step)
+    weak_multi = (not strong) and (not pairs) and world > 1
     counts, s_total = None, None
     if strong:       # a fixed sample total divided over the ranks
         s_total = S
@@ -442,9 +444,13 @@ def run_workload(name, args, device, world, rank, use_dist, steps, warmup, prima
     gp, x, y = make_model(device)
     rtol, rtol_on = elbo_check(gp, x, y) if rank == 0 else (None, None)
     p0 = snapshot(gp) if rank == 0 and primary else None     # the CPU baseline runs the same (initial) model
+    shards = None
+    if pairs:        # every rank builds the whole model; the trainer takes its rectangle of the (S, C) grid
+        from vargp_amd.train import split_pairs
+        shards = split_pairs(S, C, world)
     trainer = ElboTrainer(gp, lr=LR, beta=BETA, n_total=N_TOTAL,
-                          sample_counts=(counts if counts is not None else [S] * world) if use_dist else None,
-                          force_exchange=use_dist, comm=args.comm)
+                          sample_counts=None if pairs else ((counts if counts is not None else [S] * world) if use_dist else None),
+                          force_exchange=use_dist, comm=args.comm, shards=shards)
 
     def sync():
         if use_dist:
@@ -532,7 +538,7 @@ def run_workload(name, args, device, world, rank, use_dist, steps, warmup, prima
     #   t0_bwdmat_gemm_kernel (P_uf = W_uf x beside the adjoint chains of the factorisations).
     block_prog = bool(gp._use_block_program(B))      # which native program runs this model (vargp.py)
     timeline = []
-    if use_graph and not block_prog and not args.no_timeline:
+    if use_graph and not block_prog and not args.no_timeline and not use_dist:       # (several ranks: the exchange sits inside the step)
         try:
             timeline = step_timeline(run, 1e3 * median_ms)
         except Exception as e:
@@ -544,7 +550,8 @@ def run_workload(name, args, device, world, rank, use_dist, steps, warmup, prima
     sync()
     _lib.prof_remember(False)
     kernels = {}
-    flops_kuf = 2.0 * S * C * M * (N_PREV + 1) * B * D     # one K_uf launch of compute_pf_diag
+    share = trainer.w_h if pairs else 1.0                  # (class-sharded: this rank's part of the S x C problems)
+    flops_kuf = share * 2.0 * S * C * M * (N_PREV + 1) * B * D     # one K_uf launch of compute_pf_diag
     Mt = M * (N_PREV + 1)
     if not block_prog:
         candidates = [('chol_rbf_gemm', flops_kuf, 'chol_rbf_gemm_kernel (K_uu/S_u factorisations -- register-resident pivot chains, four '
@@ -599,7 +606,7 @@ def run_workload(name, args, device, world, rank, use_dist, steps, warmup, prima
                't0_puu_final': (None, 2.0 * S * C * M * M * D), 'yogi_multi': (None, 0.0)}
     for r in timeline:
         tag, fl = tl_info.get(r['kernel'], (None, 0.0))
-        r['flop'] = fl
+        r['flop'] = fl = fl * (share if r['kernel'] != 'chol_rbf_gemm' else 1.0)
         # slot = previous kernel's last workgroup end .. this kernel's last workgroup end: the wall time of the step that belongs
         # to this launch (launch latency and the previous kernel's cache write-back included; the slots sum to the step period).
         # rocprofv3's dispatch-to-completion duration lies between span and slot.
@@ -628,7 +635,9 @@ def run_workload(name, args, device, world, rank, use_dist, steps, warmup, prima
         avg_s = kern_us * 1e-6
         achieved = dominant_flops / avg_s / 1e12 if kern_us == kern_us and kern_us > 0 else None
         cfg2 = name == 'smnist'
-        if strong:
+        if pairs:
+            unit = 'ELBO steps/s (global steps of the Cfg2 ELBO, %d (sample, class) problems over %d ranks)' % (S * C, world)
+        elif strong:
             unit = 'ELBO steps/s (global steps of the %d-sample ELBO)' % s_total
         elif weak_multi:
             unit = 'ELBO steps/s (global steps of a %d-sample ELBO: %d hyper-samples per GPU)' % (S * world, S)
@@ -637,17 +646,20 @@ def run_workload(name, args, device, world, rank, use_dist, steps, warmup, prima
         res = dict(metric='ELBO steps/sec', value=value, unit=unit,
                    n_gpus=world, steps=steps, warmup=warmup, ms_per_step=1e3 * dt / steps,
                    ms_per_step_median=median_ms,
-                   higher_is_better=True, scaling='strong' if strong and world > 1 else 'weak', vs_baseline=None,
+                   higher_is_better=True, scaling='strong' if (strong or pairs) and world > 1 else 'weak', vs_baseline=None,
                    dtype='f32', data='synthetic',
-                   config=dict(workload=WORKLOADS[name]['desc'], S_per_gpu=counts if strong else S, Mt=M * (N_PREV + 1),
-                               S_total=s_total if strong else S * world, F=F_, C=C, M=M, D=D, B=B, N=N_TOTAL, beta=BETA,
-                               optimizer='yogi', parallelism=f'sample-parallel x{world}',
-                               launch=('hipGraph replay' + (' (2 graphs around the all-reduce)' if use_dist else '')) if use_graph
+                   config=dict(workload=WORKLOADS[name]['desc'], S_per_gpu=counts if strong else (None if pairs else S), Mt=M * (N_PREV + 1),
+                               S_total=s_total if strong else (S if pairs else S * world), F=F_, C=C, M=M, D=D, B=B, N=N_TOTAL, beta=BETA,
+                               shards=shards, shard_weights=([round((r[1] - r[0]) * (r[3] - r[2]) / float(S * C), 6) for r in shards] if shards
+                                                             else ([c / float(s_total) for c in counts] if strong else None)),
+                               optimizer='yogi', parallelism=(f'(sample, class)-parallel x{world}' if pairs else f'sample-parallel x{world}'),
+                               launch=('hipGraph replay' + ((' (3 graphs around the all-gather and the all-reduce)' if pairs else ' (2 graphs around the all-reduce)') if use_dist else '')) if use_graph
                                else 'eager'),
                    elbo_rtol_vs_cpu=rtol, elbo_rtol_checked_on=rtol_on, finite=bool(finite), cholesky_failures=errs,
                    ranks_seen=seen, comm=args.comm if use_dist else None,
                    allreduce_us=comm_us, allreduce_us_isolated=comm_iso_us,
                    allreduce_bytes=trainer.flat.numel() * 4 if use_dist else None,
+                   allgather_bytes=(trainer.max_pairs * 2 * B * 4 * world) if pairs else None,
                    final_loss=dict(kl_hypers=final_loss[0], kl_u=final_loss[1], nll=final_loss[2]),
                    roofline=dict(bound='mfma', kernel=dominant_desc,
                                  achieved=achieved, peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
@@ -667,7 +679,7 @@ def run_workload(name, args, device, world, rank, use_dist, steps, warmup, prima
                                  counters_from=_latest_profile('traffic')[1] if cfg2 else None,
                                  counters_commit=(_latest_profile('traffic')[0] or {}).get('commit') if cfg2 else None))
         # whole step against the same roof: SURVEY 8(d) algorithmic flop of the step / wall time of the step
-        step_flop = 3.0 * survey_flops_fwd(s_total if strong else S * world, C, M, N_PREV, B, D, F_)
+        step_flop = 3.0 * survey_flops_fwd(s_total if strong else (S if pairs else S * world), C, M, N_PREV, B, D, F_)
         res['step_flop'] = step_flop
         res['step_frac'] = step_flop / (dt / steps) / 1e12 / MFMA_F32_PEAK_TFLOPS / world
         res['preheat_s'] = PREHEAT_S if device.type == 'cuda' else 0.0
@@ -826,18 +838,52 @@ def main():
     default_line = args.workload is None
     if args.workload is None:
         args.workload = 'smnist' if (world == 1 or args.scaling == 'weak') else 'smnist_s64'
+    # VARGP_BENCH_ONE_GPU=1 (smoke test on a one-GPU box): all ranks share GPU 0 and gloo carries the exchanges -- the whole
+    # multi-rank path of this file (uneven shards, class-sharded secondary, two / three graphs) without a multi-GPU node
+    one_gpu = os.environ.get('VARGP_BENCH_ONE_GPU', '0') == '1'
+    if one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     # VARGP_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL group, two-graph capture around the all-reduce, barriers)
     # with a single rank -- a smoke test of that path on a one-GPU box
     use_dist = world > 1 or os.environ.get('VARGP_BENCH_FORCE_DIST', '0') == '1'
     if use_dist:
-        dist.init_process_group('nccl', device_id=device)
+        if one_gpu:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=device)
 
     if args.workload == 'stress':
         print(json.dumps(stress(args, device, cpu=not args.no_cpu_baseline)))
         return
-    res = run_workload(args.workload, args, device, world, rank, use_dist, args.steps, args.warmup, primary=True)
+    # (the ranks are counted right after the group is up, so that a failing run still reports who took part)
+    seen0 = ranks_seen(world, rank, device) if use_dist else [0]
+    try:
+        res = run_workload(args.workload, args, device, world, rank, use_dist, args.steps, args.warmup, primary=True)
+    except Exception as e:
+        if rank == 0:
+            print(json.dumps(dict(metric='ELBO steps/sec', value=None, unit='ELBO steps/s', n_gpus=world, steps=args.steps,
+                                  warmup=args.warmup, ranks_seen=seen0, error=f'{type(e).__name__}: {e}'[:500],
+                                  config=dict(workload=args.workload))))
+            sys.stdout.flush()
+        raise
+    if world > 1 and default_line and not args.no_secondary and os.environ.get('VARGP_BENCH_PAIRS', '1') != '0':
+        # several GPUs: besides BASELINE config 4 (64 samples: whole samples per rank), the METRIC's own config 2 -- 3 samples x 10
+        # classes -- over the same ranks: class-sharded when there are more ranks than samples (train.split_pairs).  Every rank runs
+        # it; a failure is reported inside the line, the headline stays.
+        try:
+            r2 = run_workload('smnist_pairs', args, device, world, rank, use_dist, max(20, min(args.steps, 100)), 5, primary=False,
+                              kern_n=20)
+            if rank == 0:
+                keep = ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'scaling', 'elbo_rtol_vs_cpu', 'finite', 'cholesky_failures',
+                        'allreduce_us', 'allreduce_bytes', 'allgather_bytes', 'ranks_seen')
+                res['secondary'] = dict(smnist_pairs=dict({k: r2[k] for k in keep if k in r2}, workload=r2['config']['workload'],
+                                                          shards=r2['config']['shards'], shard_weights=r2['config']['shard_weights'],
+                                                          launch=r2['config']['launch']))
+        except Exception as e:
+            if rank == 0:
+                res['secondary'] = dict(smnist_pairs=dict(error=f'{type(e).__name__}: {e}'[:300]))
     if rank == 0 and world == 1 and default_line and not args.no_secondary and not use_dist:
         # short, driver-timed runs of the other BASELINE configs in the same line (their own step counts are stated)
         t_start = time.perf_counter()

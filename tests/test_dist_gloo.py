@@ -96,6 +96,56 @@ def test_sample_parallel_matches_single_process(n_prev, counts, comm):
         assert err < 1e-4, (k, err)
 
 
+def _worker_stable(rank, port, comm, steps, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD))
+    dist.init_process_group('gloo', rank=rank, world_size=WORLD)
+    try:
+        from vargp_amd import noise
+        from vargp_amd.train import ElboTrainer
+        torch.set_num_threads(1)
+        params, prev, x, y, _ = _problem(0)
+        names = ['z', 'u_mean', 'u_tril_vec', 'log_mean', 'log_logvar']
+        leaves = {k: torch.nn.Parameter(params[k].clone()) for k in names}
+        full = dict(params, **leaves)
+
+        def loss_fn(xb, yb):
+            nz = dict(eps_theta=noise.draw('eps_theta', (S_LOCAL, D + 1), 'cpu'), eps_f=noise.draw('eps_f', (S_LOCAL, F_, C, B), 'cpu'))
+            return orc.loss(full, prev, xb, yb, nz)
+
+        tr = ElboTrainer(None, beta=2.0, n_total=64, noise_seed=SEED, params=[leaves[k] for k in names], loss_fn=loss_fn,
+                         optimizer=lambda ps: torch.optim.SGD(ps, lr=1e-3), comm=comm)
+        for _ in range(steps):
+            tr.step(x, y)
+        out.put((rank, {k: leaves[k].detach().clone().numpy() for k in names}))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rsag_exchange_is_bit_stable_over_50_steps():
+    """Reduce-scatter + all-gather of the flat buffer, 50 SGD steps, two ranks: the ranks' parameters stay BIT-identical to each
+    other (every rank applies the same summed buffer: no drift between replicas), a second run reproduces the first bit for
+    bit, and with two ranks the result equals the one-all-reduce exchange bit for bit (a + b in either order)."""
+    def run(comm):
+        ctx = mp.get_context('spawn')
+        out = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker_stable, args=(r, port, comm, 50, out)) for r in range(WORLD)]
+        for p in procs:
+            p.start()
+        got = dict(out.get(timeout=240) for _ in range(WORLD))
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        return got
+    a, b, c = run('rsag'), run('rsag'), run('allreduce')
+    for k in a[0]:
+        assert np.array_equal(a[0][k], a[1][k]), k            # rank 0 == rank 1
+        assert np.array_equal(a[0][k], b[0][k]), k            # run 1 == run 2
+        assert np.array_equal(a[0][k], c[0][k]), k            # rsag == allreduce (two ranks)
+        assert np.isfinite(a[0][k]).all()
+
+
 def test_split_samples_and_uneven_noise_shards():
     from vargp_amd import noise
     from vargp_amd.train import split_samples
