@@ -118,6 +118,7 @@ class T0Program:
         d.z, d.u_mean, d.u_tril_vec, d.x, d.y = _p(z), _p(u_mean), _p(u_tril_vec), _p(x), _p(y)
         d.eps_theta, d.eps_f = _p(eps_theta), _p(eps_f)
         d.bump = _p(bump)
+        d.scalars = _p(self.scalars)                  # (VARGP.loss hands out a fresh slot of a small ring per forward: fused.elbo_lazy)
         d.defer_softmax = int(bool(defer_softmax))
         d.ext_lik = int(bool(ext_lik))
         self._keep = tensors + (bump,)   # the descriptor holds raw pointers: keep the tensors alive until backward
@@ -354,6 +355,7 @@ class TnProgram:
         d.z_all, d.rk_all = _p(z_all), _p(rk_all)
         d.eps_theta, d.eps_f = _p(eps_theta), _p(eps_f)
         d.bump = _p(bump)
+        d.scalars = _p(self.scalars)
         d.ext_lik = int(bool(ext_lik))
         self._keep = tensors + (bump,)
         check(lib().vargp_elbo_tn_fwd(ctypes.byref(d), stream_ptr()), 'vargp_elbo_tn_fwd')
@@ -453,3 +455,46 @@ def elbo_tn(kernel, z, u_mean, u_tril_vec, x, y, eps_theta, eps_f, prog, z_all, 
     """-> (kl_hypers, kl_u, nll) of VARGP.loss for a model with previous tasks (ep_var_mean = True) as ONE autograd node."""
     return _ElboTn.apply(kernel.log_mean, kernel.log_logvar, z, u_mean, u_tril_vec, x, y, eps_theta, eps_f,
                          kernel.prior_log_mean, kernel.prior_log_logvar, bool(kernel.map_est), prog, z_all, rk_all)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# VARGP.loss on a native program WITHOUT an autograd graph: lazy terms (vargp_amd/lazy.py)
+# ----------------------------------------------------------------------------------------------------------------
+_RING = 8
+
+
+def elbo_lazy(model, x, y, block):
+    """(kl_hypers, kl_u, nll) of `model.loss(x, y)` as lazy terms over ONE forward of the model's cached program; the caller's
+    linear combination and its `.backward()` become one program backward with those coefficients as seeds (lazy.py).
+    Noise: injected / sharded draws if set (noise.py), otherwise the program's own counter-based generator keyed by
+    torch.initial_seed() -- no torch.randn launches on the step."""
+    from . import noise
+    from .lazy import PendingForward, terms_of
+    kern = model.kernel
+    B = x.size(0)
+    prog = model._tn_program(B) if block else model._t0_program(B)
+    if getattr(prog, '_ring', None) is None:
+        prog._ring, prog._ring_i = torch.zeros(_RING, 3, dtype=torch.float32, device=x.device), 0
+    prog._ring_i = (prog._ring_i + 1) % _RING
+    prog.scalars = prog._ring[prog._ring_i]                 # valid until _RING more forwards of this program
+    if noise._injected or noise._shard is not None:
+        eps_theta, eps_f = model.draw_t0_noise(x)
+        eps_theta = None if eps_theta is None else eps_theta.contiguous()
+        eps_f = eps_f.contiguous()
+    else:
+        if prog._rng is None:
+            if getattr(model, '_noise_counter', None) is None or model._noise_counter.device != x.device:
+                model._noise_counter = torch.zeros(1, dtype=torch.int32, device=x.device)
+                model._noise_seed = int(torch.initial_seed()) & 0x7fffffffffffffff
+            prog.set_rng(model._noise_seed, model._noise_counter)
+        eps_theta = eps_f = None
+    x = x if x.is_contiguous() else x.contiguous()
+    y = y if y.is_contiguous() else y.contiguous()
+    args = (kern.log_mean.detach(), kern.log_logvar.detach(), kern.prior_log_mean, kern.prior_log_logvar, model.z.detach(),
+            model.u_mean.detach(), model.u_tril_vec.detach())
+    if block:
+        prog.forward(*args, *model._tn_operands(), x, y, eps_theta, eps_f)
+    else:
+        prog.forward(*args, x, y, eps_theta, eps_f)
+    params = (kern.log_mean, None if kern.map_est else kern.log_logvar, model.z, model.u_mean, model.u_tril_vec)
+    return terms_of(PendingForward(model, prog, prog.scalars, params))

@@ -36,6 +36,10 @@ class VARGP(nn.Module):
         # forward-only program (moments only, no gradient buffers) sized for the widest batch seen, serving narrower ones
         self._tn_ops, self._tn_progs, self._tn_spares, self._tn_eval, self._tn_eval_exact = None, {}, {}, None, {}
         self._t0_progs, self._t0_spares = {}, {}       # first-task programs (csrc/elbo_t0.hip) of the autograd route, per shape
+        # loss() on a native program returns lazy terms (lazy.py: no autograd graph for the caller's linear combination, the
+        # backward is one program call); VARGP_LAZY_LOSS=0 or lazy_loss = False: three autograd tensors of one node, as before
+        self.lazy_loss = os.environ.get('VARGP_LAZY_LOSS', '1') != '0'
+        self._seed_cache, self._gbufs = {}, None
         # frozen earlier tasks: plain dicts, not buffers (same as the reference, vargp.py:17-20);
         # u_tril is materialised lazily on first use because that needs the device the params live on
         self.prev_params = [dict(z=p['z'], u_mean=p['u_mean'], u_tril_vec=p['u_tril_vec'])
@@ -288,10 +292,47 @@ class VARGP(nn.Module):
         eps_f = noise.draw('eps_f', (S, self.likelihood.n_f, self.z.size(0), x.size(0)), x.device)
         return eps_theta, eps_f
 
+    # -- lazy route (lazy.py) ---------------------------------------------------------------------------------------------------
+    def _lazy_ok(self):
+        """The five parameters are plain trainable leaves without hooks: the program's backward may write their .grad itself."""
+        if not (self.lazy_loss and torch.is_grad_enabled()):
+            return False
+        k = self.kernel
+        ps = (k.log_mean, self.z, self.u_mean, self.u_tril_vec) + (() if k.map_est else (k.log_logvar,))
+        return all(p.requires_grad and p.is_leaf and not p._backward_hooks and p.is_cuda for p in ps)
+
+    def _seed_tensor(self, coefs):
+        t = self._seed_cache.get(coefs)
+        if t is None or t.device != self.z.device:
+            if len(self._seed_cache) >= 64:
+                self._seed_cache.clear()
+            t = self._seed_cache[coefs] = torch.tensor(coefs, dtype=torch.float32, device=self.z.device)
+        return t
+
+    def _grad_buffers(self):
+        """([five buffers that become .grad], [five scratch buffers for accumulation into an existing .grad]), shapes of
+        (log_mean, log_logvar, z, u_mean, u_tril_vec); each set is one allocation."""
+        k = self.kernel
+        ps = (k.log_mean, k.log_logvar, self.z, self.u_mean, self.u_tril_vec)
+        if self._gbufs is None or self._gbufs[0][2].device != self.z.device or self._gbufs[0][2].shape != self.z.shape:
+            sets = []
+            for _ in range(2):
+                offs, tot = [], 0
+                for p in ps:
+                    offs.append(tot)
+                    tot += (p.numel() + 63) // 64 * 64
+                flat = torch.empty(tot, dtype=torch.float32, device=self.z.device)
+                sets.append([flat[o:o + p.numel()].view_as(p) for o, p in zip(offs, ps)])
+            self._gbufs = sets
+        return self._gbufs
+
     def loss(self, x, y):
         """(kl_hypers, kl_u, nll); the caller combines beta*kl_hypers + kl_u + (N/B)*nll
         (vargp.py:177-194, experiments/vargp.py:34)."""
         block = self._use_block_program(x.size(0))
+        native_t0 = not self.prev_params and self.fused_first_task and type(self.kernel) is RBFKernel and not block
+        if (native_t0 or block) and self._lazy_ok():
+            return fused.elbo_lazy(self, x, y, block)
         if not self.prev_params and self.fused_first_task and type(self.kernel) is RBFKernel and not block:
             # first task: the native program (csrc/elbo_t0.hip) as one autograd node
             return fused.elbo_t0(self.kernel, self.z, self.u_mean, self.u_tril_vec, x, y, *self.draw_t0_noise(x),
