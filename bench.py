@@ -381,7 +381,7 @@ def dropin_workload(args, device, steps=300, warmup=30):
     out = dict(workload='BASELINE config 2 through the var_gp alias in the reference loop shape (eager; VARGP.loss returns lazy terms: '
                         'the caller\'s combine + backward() = one program call; program-drawn noise; vargp_amd.optim.Yogi)',
                steps=steps, warmup=warmup)
-    for mode in ('raise', 'defer'):
+    for mode in ('raise', 'lazy', 'defer'):
         ops.set_cholesky_error_mode(mode)
         ops.reset_linalg_errors()
         gp, x, y = make_model(device)
@@ -414,12 +414,13 @@ def dropin_workload(args, device, steps=300, warmup=30):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         # host time per phase of the caller's loop (no synchronisation inside: what the Python thread spends issuing the step)
-        out['host_us' if mode == 'raise' else 'host_us_defer'] = dict(
+        sfx = '' if mode == 'raise' else '_' + mode
+        out['host_us' + sfx] = dict(
             total=1e6 * t_host / steps, **{k: 1e6 * a / steps for k, a in zip(('zero_grad', 'loss', 'combine', 'backward', 'optim_step'), acc)})
         out['lazy_terms'] = type(last[0]).__name__ == 'ElboTerm'
         fin = all(bool(torch.isfinite(v)) for v in last)
-        out['value' if mode == 'raise' else 'value_defer'] = steps / dt
-        out['ms_per_step' if mode == 'raise' else 'ms_per_step_defer'] = 1e3 * dt / steps
+        out['value' + sfx] = steps / dt
+        out['ms_per_step' + sfx] = 1e3 * dt / steps
         out['finite'] = bool(out.get('finite', True) and fin)
         out['programs_cached'] = len(gp._t0_progs)
         gp.release_programs()
@@ -486,6 +487,13 @@ def run_workload(name, args, device, world, rank, use_dist, steps, warmup, prima
                 dist.all_reduce(flag)
                 if flag.item() > 0:                 # some other rank failed to capture
                     use_graph = False
+    unroll = args.unroll if (use_graph and not use_dist and args.unroll > 1) else 1
+    if unroll > 1:
+        try:
+            trainer.capture_unrolled(x, y, unroll)
+        except Exception as e:
+            print(f'[bench] unrolled capture failed ({type(e).__name__}: {e}); one step per graph', file=sys.stderr)
+            unroll = 1
     if use_graph:
         run = trainer.step_graph
     else:
@@ -509,15 +517,17 @@ def run_workload(name, args, device, world, rank, use_dist, steps, warmup, prima
     for _ in range(warmup):
         run()
     sync()
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    # EXACTLY `steps` steps: steps // unroll launches of the K-step graph, the remainder as one-step launches
+    plan = [(trainer.step_graph_k, unroll)] * (steps // unroll) + [(run, 1)] * (steps % unroll) if unroll > 1 else [(run, 1)] * steps
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(plan) + 1)]
     t0 = time.perf_counter()
     evs[0].record()
-    for i in range(steps):
-        out = run()
-        evs[i + 1].record()              # per-step device time (median below); `value` uses the wall clock of all K steps
+    for i, (fn, _) in enumerate(plan):
+        out = fn()
+        evs[i + 1].record()              # per-launch device time (median below); `value` uses the wall clock of all K steps
     sync()
     dt = time.perf_counter() - t0
-    per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
+    per_step = sorted(evs[i].elapsed_time(evs[i + 1]) / plan[i][1] for i in range(len(plan)))
     median_ms = per_step[len(per_step) // 2]
     final_loss = [v.item() for v in out]     # read now: the re-launches below include the kernel that resets the accumulators
     finite = all(v == v and abs(v) != float('inf') for v in final_loss)
@@ -553,7 +563,8 @@ def run_workload(name, args, device, world, rank, use_dist, steps, warmup, prima
     timeline = []
     if use_graph and not block_prog and not args.no_timeline and not use_dist:       # (several ranks: the exchange sits inside the step)
         try:
-            timeline = step_timeline(run, 1e3 * median_ms)
+            # (the stamps of the LAST step of a launch are read back: of the K-step graph when that is what was timed)
+            timeline = step_timeline(trainer.step_graph_k if unroll > 1 else run, 1e3 * median_ms, burst=1 if unroll > 1 else 4)
         except Exception as e:
             print(f'[bench] step timeline failed ({type(e).__name__}: {e})', file=sys.stderr)
     _lib.prof_enable(False)
@@ -666,6 +677,7 @@ def run_workload(name, args, device, world, rank, use_dist, steps, warmup, prima
                                shards=shards, shard_weights=([round((r[1] - r[0]) * (r[3] - r[2]) / float(S * C), 6) for r in shards] if shards
                                                              else ([c / float(s_total) for c in counts] if strong else None)),
                                optimizer='yogi', parallelism=(f'(sample, class)-parallel x{world}' if pairs else f'sample-parallel x{world}'),
+                               steps_per_graph_launch=unroll,
                                launch=('hipGraph replay' + ((' (3 graphs around the all-gather and the all-reduce)' if pairs else ' (2 graphs around the all-reduce)') if use_dist else '')) if use_graph
                                else 'eager'),
                    elbo_rtol_vs_cpu=rtol, elbo_rtol_checked_on=rtol_on, finite=bool(finite), cholesky_failures=errs,
@@ -828,6 +840,8 @@ def main():
     ap.add_argument('--secondary-budget', type=float, default=240.0,
                     help='seconds after which no further secondary workload is started')
     ap.add_argument('--stress-n', type=int, default=1000000)
+    ap.add_argument('--unroll', type=int, default=4,
+                    help='one GPU, hipGraph mode: steps per graph launch (ElboTrainer.capture_unrolled; 1 = one step per launch)')
     ap.add_argument('--no-timeline', action='store_true',
                     help='skip the in-step kernel time line (vargp_prof_spans: extra graph replays after the timed region)')
     ap.add_argument('--no-replay', action='store_true',
@@ -909,6 +923,7 @@ def main():
                 if name == 'smnist_dropin':
                     sec[name] = dropin_workload(args, device)
                     sec[name]['vs_trainer'] = sec[name]['value'] / res['value']
+                    sec[name]['vs_trainer_lazy'] = sec[name]['value_lazy'] / res['value']
                     sec[name]['vs_trainer_defer'] = sec[name]['value_defer'] / res['value']
                     continue
                 if name == 'stress':

@@ -170,6 +170,19 @@ def test_program_non_pd_is_flagged():
     ops.set_cholesky_error_mode('raise')
     with pytest.raises(torch.linalg.LinAlgError):
         gp.loss(x.to(DEV), y.to(DEV))
+    # 'lazy': no synchronisation inside loss(); the error surfaces at the first host read of a value of that step ...
+    ops.set_cholesky_error_mode('lazy')
+    try:
+        kl_h, kl_u, nll = gp.loss(x.to(DEV), y.to(DEV))
+        with pytest.raises(torch.linalg.LinAlgError, match='lazily'):
+            nll.item()
+        # ... or at the next factorising call, or on request
+        gp.loss(x.to(DEV), y.to(DEV))
+        torch.cuda.synchronize()
+        with pytest.raises(torch.linalg.LinAlgError, match='lazily'):
+            ops.check_linalg_errors()
+    finally:
+        ops.set_cholesky_error_mode('raise')
 
 
 @pytest.mark.parametrize('n_prev,M,N,tile', [(0, 40, 200, 64), (2, 24, 150, 64), (0, 130, 96, 96)])

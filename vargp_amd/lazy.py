@@ -193,15 +193,19 @@ class ElboTerm:
 
     # -- value only ---------------------------------------------------------------------------------------------------------------
     def item(self):
+        from . import ops
         if self._real is not None:
-            return self._real.item()
-        cache = {}
-        tot = self.const
-        for (fwd, k), c in self.terms.items():
-            if fwd not in cache:
-                cache[fwd] = fwd.values.tolist()           # one read-back per forward (synchronises)
-            tot += c * cache[fwd][k]
-        return tot
+            v = self._real.item()
+        else:
+            cache = {}
+            v = self.const
+            for (fwd, k), c in self.terms.items():
+                if fwd not in cache:
+                    cache[fwd] = fwd.values.tolist()       # one read-back per forward (synchronises)
+                v += c * cache[fwd][k]
+        if ops._pending:                                   # 'lazy' Cholesky error mode: the read-back above waited for the step
+            ops.check_linalg_errors(wait=True)
+        return v
 
     def __float__(self):
         return float(self.item())

@@ -19,10 +19,40 @@ _chol_mode = 'raise'
 _info_ring = []   # 'defer' mode: most recent info tensors (device), inspected on demand
 
 
+_pending = []     # 'lazy' mode: (pinned host copy of an info tensor, event recorded behind the copy)
+
+
 def set_cholesky_error_mode(mode):
+    """What happens when a factorisation meets a matrix that is not positive definite (the reference's torch.cholesky raises,
+    gp_utils.py:5-11 -- which costs it a device synchronisation per call):
+      'raise'  (default) the same: every factorising call waits for its status words and raises torch.linalg.LinAlgError;
+      'lazy'   no wait: the status words are copied to pinned host memory behind the call, and the error is raised by the NEXT
+               factorising call, by the first host read of one of the step's values (ElboTerm.item() / float()), or by
+               check_linalg_errors() -- at most one step late, never lost;
+      'defer'  nothing is read back until linalg_error_count() is asked for (captured hipGraphs: no host work inside a step)."""
     global _chol_mode
-    assert mode in ('raise', 'defer')
+    assert mode in ('raise', 'lazy', 'defer')
+    check_linalg_errors()
     _chol_mode = mode
+
+
+def check_linalg_errors(wait=False):
+    """'lazy' mode: raise for any failed factorisation whose status words have arrived (wait: all of them, synchronising)."""
+    bad = None
+    while _pending:
+        host, ev = _pending[0]
+        if wait:
+            ev.synchronize()
+        elif not ev.query():
+            break
+        _pending.pop(0)
+        n = int((host != 0).sum())
+        if n and bad is None:
+            bad = (n, host.numel(), int(host[host != 0][0]))
+    if bad is not None:
+        del _pending[:]
+        raise torch.linalg.LinAlgError(f'vargp_chol_inv: {bad[0]} of {bad[1]} matrices are not positive-definite '
+                                       f'(first failing leading minor of order {bad[2]}; reported lazily)')
 
 
 def reset_linalg_errors():
@@ -220,6 +250,15 @@ def rbf_gram(theta, X, Y=None, y_shared=False):
 # Cholesky (+ jitter) with inverse factor
 # ------------------------------------------------------------------------------------------------
 def _note_chol_errors(info):
+    if _chol_mode == 'lazy':
+        check_linalg_errors()                      # what earlier calls left behind
+        host = torch.empty(info.shape, dtype=info.dtype, pin_memory=True)
+        host.copy_(info, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        _pending.append((host, ev))
+        del _pending[:-256]
+        return
     if _chol_mode == 'raise':
         bad = int((info != 0).sum().item())
         if bad:

@@ -208,6 +208,33 @@ class ElboTrainer:
         self._captured[int(x.size(0))] = (self.graph, self.graph_opt, self._sx, self._sy, self._sout, getattr(self, 'graph_mid', None))
         return self
 
+    def capture_unrolled(self, x, y, k):
+        """K consecutive steps in ONE hipGraph (one GPU only; after `capture`): a graph launch costs a few microseconds more than
+        a kernel boundary inside a graph, so K steps per launch shave that off K - 1 of every K steps.  The K steps read K
+        static minibatch slots (`step_graph_k(xs, ys)` with xs (K, B, D), ys (K, B); without arguments the slots keep what they
+        hold -- initially K copies of x, y); noise and optimiser step counts advance on the device as in the one-step graph."""
+        assert self.graph is not None and not self.multi and k >= 2 and x.size(0) == self._sx.size(0)
+        self._k = int(k)
+        self._sxk = x.unsqueeze(0).repeat(k, *([1] * x.dim())).contiguous()
+        self._syk = y.unsqueeze(0).repeat(k, *([1] * y.dim())).contiguous()
+        snap = self._snapshot_state()
+        self.graph_k = torch.cuda.CUDAGraph()
+        if noise._shard is not None and not (self._t0 and self.native_noise):
+            self.graph_k.register_generator_state(noise._shard[2])
+        with torch.cuda.graph(self.graph_k, pool=self.graph.pool()):
+            for i in range(k):
+                self._soutk = self.step(self._sxk[i], self._syk[i])
+        self._restore_state(snap)            # (capture itself runs nothing, but keeps the eager bookkeeping honest)
+        return self
+
+    def step_graph_k(self, xs=None, ys=None):
+        """Replay the K-step graph -> the last step's (kl_hypers, kl_u, nll)."""
+        if xs is not None:
+            self._sxk.copy_(xs, non_blocking=True)
+            self._syk.copy_(ys, non_blocking=True)
+        self.graph_k.replay()
+        return self._soutk
+
     def captured_sizes(self):
         return sorted(self._captured)
 
