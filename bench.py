@@ -487,7 +487,10 @@ def run_workload(name, args, device, world, rank, use_dist, steps, warmup, prima
                 dist.all_reduce(flag)
                 if flag.item() > 0:                 # some other rank failed to capture
                     use_graph = False
-    unroll = args.unroll if (use_graph and not use_dist and args.unroll > 1) else 1
+    unroll = args.unroll
+    if unroll == 0:          # auto: the largest K <= 10 that divides the number of timed steps, else 4
+        unroll = next((k for k in range(10, 1, -1) if steps % k == 0), 4)
+    unroll = unroll if (use_graph and not use_dist and unroll > 1) else 1
     if unroll > 1:
         try:
             trainer.capture_unrolled(x, y, unroll)
@@ -516,6 +519,8 @@ def run_workload(name, args, device, world, rank, use_dist, steps, warmup, prima
         time.sleep(0.3)
     for _ in range(warmup):
         run()
+    if unroll > 1:
+        trainer.step_graph_k()           # (untimed: the K-step graph's first launch uploads it)
     sync()
     # EXACTLY `steps` steps: steps // unroll launches of the K-step graph, the remainder as one-step launches
     plan = [(trainer.step_graph_k, unroll)] * (steps // unroll) + [(run, 1)] * (steps % unroll) if unroll > 1 else [(run, 1)] * steps
@@ -840,8 +845,9 @@ def main():
     ap.add_argument('--secondary-budget', type=float, default=240.0,
                     help='seconds after which no further secondary workload is started')
     ap.add_argument('--stress-n', type=int, default=1000000)
-    ap.add_argument('--unroll', type=int, default=4,
-                    help='one GPU, hipGraph mode: steps per graph launch (ElboTrainer.capture_unrolled; 1 = one step per launch)')
+    ap.add_argument('--unroll', type=int, default=0,
+                    help='one GPU, hipGraph mode: steps per graph launch (ElboTrainer.capture_unrolled); 1 = one step per launch, '
+                         '0 (default) = the largest K <= 10 dividing --steps')
     ap.add_argument('--no-timeline', action='store_true',
                     help='skip the in-step kernel time line (vargp_prof_spans: extra graph replays after the timed region)')
     ap.add_argument('--no-replay', action='store_true',
