@@ -172,3 +172,34 @@ def test_trainer_routes_by_batch_size_like_loss():
         np.testing.assert_allclose(out, [sc[k].item() for k in ('kl_hypers', 'kl_u', 'nll')], rtol=RTOL_SCALAR)
         for k, v in _grads(gp).items():
             assert rel_l2(v.cpu(), og[k]) < REL_L2_GRAD, (B, k)
+
+
+def test_k_step_graph_equals_single_step_graphs():
+    """bench.py times K steps per hipGraph launch (ElboTrainer.capture_unrolled): the same K steps as K launches of the one-step
+    graph -- same device-side noise stream (counter-based generator), same optimiser step counts -- at BASELINE config 2's shape."""
+    from vargp_amd import ops
+    from vargp_amd.train import ElboTrainer
+    from gpu_common import build_gp
+    g, params, prev, x, y, nz = load_case('smnist_full_t0')
+    S, F_ = int(g['meta'][0]), int(g['meta'][1])
+    xd, yd = x.to(DEV), y.to(DEV)
+    ops.set_cholesky_error_mode('defer')
+    try:
+        res = []
+        for k in (1, 3):
+            gp = build_gp(params, prev, S, F_)
+            tr = ElboTrainer(gp, lr=3e-3, beta=float(g['beta']), n_total=float(g['n_total']), noise_seed=99)
+            tr.capture(xd, yd)
+            if k > 1:
+                tr.capture_unrolled(xd, yd, k)
+                outs = [[float(v) for v in tr.step_graph_k()] for _ in range(6 // k)]
+            else:
+                outs = [[float(v) for v in tr.step_graph()] for _ in range(6)]
+            torch.cuda.synchronize()
+            res.append((outs[-1], {n: p.detach().cpu().clone() for n, p in gp.named_parameters()}))
+        assert ops.linalg_error_count() == 0
+    finally:
+        ops.set_cholesky_error_mode('raise')
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=1e-5)
+    for n in res[0][1]:
+        assert rel_l2(res[1][1][n], res[0][1][n]) < 1e-5, n
