@@ -324,7 +324,7 @@ extern "C" int vargp_chol_inv_fwd(const float* A, float eps, float* L, float* T,
 // GEMMs consumed (always a prefix co[0 .. *co_done)); the caller launches the rest itself.
 int vargp::chol_inv_fwd_impl(const float* A, float eps, float* L, float* T, float* logdet, int32_t* info, int nbatch,
                              int n, void* ws, size_t ws_bytes, bool zero_info, hipStream_t st, const GemmParams* co,
-                             int co_nbatch, int* co_done, int nco) {
+                             int co_nbatch, int* co_done, int nco, bool chain_f32) {
   VARGP_REQUIRE(A && L, "chol_inv_fwd: null pointer");
   VARGP_REQUIRE(nbatch > 0 && n > 0, "chol_inv_fwd: bad dims");
   const int64_t nn = (int64_t)n * n;
@@ -335,7 +335,7 @@ int vargp::chol_inv_fwd_impl(const float* A, float eps, float* L, float* T, floa
   if (n <= kSmallMax) {
     if (nco > 0 && T && !logdet && info && chol_rbf_gemm_applicable(n, co[0]) && co_gemm_is_comparable(co[0], co_nbatch)) {
       if (co_done) *co_done = 1;
-      return launch_chol_rbf_gemm_ld(A, n, nn, eps, L, n, nn, T, n, nn, info, nbatch, n, co[0], co_nbatch, st);
+      return launch_chol_rbf_gemm_ld(A, n, nn, eps, L, n, nn, T, n, nn, info, nbatch, n, co[0], co_nbatch, st, chain_f32);
     }
     return launch_small(A, n, nn, eps, L, n, nn, T, n, nn, logdet, info, 0, nbatch, n, 0, st);
   }
@@ -399,7 +399,7 @@ int vargp::chol_inv_fwd_impl(const float* A, float eps, float* L, float* T, floa
           co_gemm_is_comparable(co[kpanel], co_nbatch)) {
         // (chol3_body reports a failing pivot as info_base + j + 1; the merged kernel has no info_base: only the first
         // panel's index is exact, later panels report the index within the panel -- non-zero is what callers test)
-        rc = launch_chol_rbf_gemm_ld(W + dkk, n, nn, 0.f, L + dkk, n, nn, Tkk, ldt, sT, info, nbatch, kb, co[kpanel], co_nbatch, st);
+        rc = launch_chol_rbf_gemm_ld(W + dkk, n, nn, 0.f, L + dkk, n, nn, Tkk, ldt, sT, info, nbatch, kb, co[kpanel], co_nbatch, st, chain_f32);
         ++ndone;
       } else {
         rc = launch_small(W + dkk, n, nn, 0.f, L + dkk, n, nn, Tkk, ldt, sT, logdet, info, k0, nbatch, kb, k0 > 0, st);

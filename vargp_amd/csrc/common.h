@@ -206,10 +206,11 @@ int rbf_gram_bwd_impl(const float* theta, const float* X, const float* Y, const 
                       size_t ws_bytes, int sym_gk, hipStream_t st);
 int chol_inv_fwd_impl(const float* A, float eps, float* L, float* T, float* logdet, int32_t* info, int nbatch, int n,
                       void* ws, size_t ws_bytes, bool zero_info, hipStream_t st, const GemmParams* co = nullptr,
-                      int co_nbatch = 0, int* co_done = nullptr, int nco = 1);
+                      int co_nbatch = 0, int* co_done = nullptr, int nco = 1, bool chain_f32 = false);
 // factorisations of nchol matrices (n in (50, 100]) with explicit leading dimensions / batch strides + one RBF GEMM
 int launch_chol_rbf_gemm_ld(const float* A, int lda, int64_t sA, float eps, float* L, int ldl, int64_t sL, float* T, int ldt,
-                            int64_t sT, int32_t* info, int nchol, int n, const GemmParams& p, int nbatch, hipStream_t st);
+                            int64_t sT, int32_t* info, int nchol, int n, const GemmParams& p, int nbatch, hipStream_t st,
+                            bool chain_f32 = false);
 // w = exp(-2 theta) (zero-padded to Dp), g2 = exp(2 theta_D) and the weighted squared row norms of x (xrows x D) and of
 // y (yrows x D, may be 0 rows) for every hyper-sample, in one launch
 // ys / xs (nullable): also write y o w, [S][yrows][D], and x o w, [S][xrows][D] (the pre-scaled operand of an unscaled RBF

@@ -571,7 +571,7 @@ extern "C" int vargp_elbo_tn_fwd(const vargp_elbo_tn_desc* d, vargp_stream_t str
     }
   }
   rc = chol_inv_fwd_impl(o.Kall, d->jitter, o.LL, o.TT, nullptr, d->info, SC, Mt, o.chol, o.chol_bytes, false, st,
-                         nsl ? slices : nullptr, S, &consumed, nsl);
+                         nsl ? slices : nullptr, S, &consumed, nsl, /*chain_f32=*/!d->forward_only && lik);
   if (rc) return rc;
   if (!kuf_done) {
     if (consumed == 0) {

@@ -1331,11 +1331,12 @@ static int launch_chol_rbf_gemm_impl(const float* A, float eps, float* L, float*
 }
 
 int launch_chol_rbf_gemm_ld(const float* A, int lda, int64_t sA, float eps, float* L, int ldl, int64_t sL, float* T, int ldt,
-                            int64_t sT, int32_t* info, int nchol, int n, const GemmParams& p, int nbatch, hipStream_t st) {
+                            int64_t sT, int32_t* info, int nchol, int n, const GemmParams& p, int nbatch, hipStream_t st,
+                            bool chain_f32) {
   if (prof_remembering()) {
     const GemmParams pc = p;
     prof_remember("chol_rbf_gemm", [=](hipStream_t s) {
-      launch_chol_rbf_gemm_ld(A, lda, sA, eps, L, ldl, sL, T, ldt, sT, info, nchol, n, pc, nbatch, s);
+      launch_chol_rbf_gemm_ld(A, lda, sA, eps, L, ldl, sL, T, ldt, sT, info, nchol, n, pc, nbatch, s, chain_f32);
     });
   }
   ProfScope prof("chol_rbf_gemm", st);
@@ -1350,14 +1351,20 @@ int launch_chol_rbf_gemm_ld(const float* A, int lda, int64_t sA, float eps, floa
   // factorising CUs exclusive (see launch_chol_rbf_gemm_impl) only while the GEMM fits one round on the other CUs
   const unsigned pad = tiles * nbatch <= free_cus ? (big ? 40u : 24u) * 1024u : 0u;
   const bool scaled = p.kscale != nullptr;      // NULL: the caller's B operand is pre-scaled (rbf_prep_norm_launch: ys)
-#define VARGP_MERGED(KC, SETS)                                                                                              \
+#define VARGP_MERGED(KC, SETS, R)                                                                                           \
   do {                                                                                                                        \
-    if (big && scaled) hipLaunchKernelGGL((chol_rbf_gemm_kernel<KC, SETS, 128, 32, true>), dim3(total), dim3(256), pad, st, c, q, tiles);   \
-    else if (big) hipLaunchKernelGGL((chol_rbf_gemm_kernel<KC, SETS, 128, 32, false>), dim3(total), dim3(256), pad, st, c, q, tiles);      \
-    else if (scaled) hipLaunchKernelGGL((chol_rbf_gemm_kernel<KC, SETS, 64, 64, true>), dim3(total), dim3(256), pad, st, c, q, tiles);     \
-    else hipLaunchKernelGGL((chol_rbf_gemm_kernel<KC, SETS, 64, 64, false>), dim3(total), dim3(256), pad, st, c, q, tiles);                \
+    if (big && scaled) hipLaunchKernelGGL((chol_rbf_gemm_kernel<KC, SETS, 128, 32, true, R>), dim3(total), dim3(256), pad, st, c, q, tiles);   \
+    else if (big) hipLaunchKernelGGL((chol_rbf_gemm_kernel<KC, SETS, 128, 32, false, R>), dim3(total), dim3(256), pad, st, c, q, tiles);      \
+    else if (scaled) hipLaunchKernelGGL((chol_rbf_gemm_kernel<KC, SETS, 64, 64, true, R>), dim3(total), dim3(256), pad, st, c, q, tiles);     \
+    else hipLaunchKernelGGL((chol_rbf_gemm_kernel<KC, SETS, 64, 64, false, R>), dim3(total), dim3(256), pad, st, c, q, tiles);                \
   } while (0)
-  if (n <= 64) VARGP_MERGED(16, 1); else VARGP_MERGED(25, 2);
+  // pivot chains of the diagonal blocks in the reference's own fp32 (torch.cholesky, gp_utils.py:5-11), as in the first-task
+  // launch above (VARGP_CHOL_F32=0: fp64) -- when the caller asks for it: the TRAINING forward of the block program does
+  // (chain_f32); gradient-free evaluation (predict, accuracy sweeps) and the stand-alone factorisation stay fp64.
+  static const int f32_env = [] { const char* e = getenv("VARGP_CHOL_F32"); return e ? atoi(e) : kCholF32Default; }();
+  if (f32_env && chain_f32) { if (n <= 64) VARGP_MERGED(16, 1, float); else VARGP_MERGED(25, 2, float); }
+  else
+  { if (n <= 64) VARGP_MERGED(16, 1, double); else VARGP_MERGED(25, 2, double); }
 #undef VARGP_MERGED
   return check_launch("chol_rbf_gemm");
 }
