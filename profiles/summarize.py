@@ -46,7 +46,19 @@ KERNELS = {
                      2.0 * S * C * M * M * D),
     't0_fwd_fused': ('void vargp::t0_fwd_fused_kernel', 4 * (S * C * M * B + 2 * S * C * M * M + 2 * S * C * M * B),
                      4.0 * S * C * M * M * B),
+    # small-column product QP[:, :NR] = T RK[:, :NR] (a, G, G2): read T and the NR = 204 small columns, write them
+    'gemm_kernel': ('void vargp::gemm_kernel<64, 64, 64, true, false, true, false, true>', 4 * (S * C * M * M + 2 * S * C * M * 204),
+                    1.0 * S * C * M * M * 204),
+    # optimiser: p, g, m, v read; p, m, v written
+    'yogi_multi': ('void vargp::yogi_multi_kernel', 4 * 7 * (C * M * D + C * M + C * M * (M + 1) // 2 + 2 * (D + 1)), 0.0),
 }
+# ALGORITHMIC flop of each launch of the step (SURVEY 8d terms, symmetric / triangular work once; bench.py: tl_info) and the
+# name bench.py's `timeline` uses for it
+STEP_FLOP = {'t0_pro_kuu': 1.0 * S * C * M * M * D, 'chol_rbf_gemm': 2.0 * S * C * M * B * D, 'gemm_kernel': 1.0 * S * C * M * M * (M + 2),
+             't0_fwd_fused': 2.0 * S * C * M * M * B, 't0_bwd_mid': 4.0 * S * C * M * M * B, 'rbf_kuf_bwd_gemm': 2.0 * S * C * M * B * D,
+             't0_puu_final': 2.0 * S * C * M * M * D, 'yogi_multi': 0.0}
+TIMELINE_NAME = {'rbf_kuf_bwd_gemm': 't0_bwdmat_gemm'}
+PEAK_TF = 157.3
 SECONDARY = ['smnist_s64', 'smnist_t1', 'smnist_t4', 'pmnist_t0', 'pmnist_t1', 'pmnist_t4', 'pmnist_t9', 'stress']
 # kernels of the N = 1e6 sweep (M = 2048, C = 10, S = 1, tile 8192), counters from the short sweep of collect.sh:
 # tag -> (kernel-name prefix, grid size in threads, algorithmic bytes, flops)
@@ -178,6 +190,33 @@ def main():
     with open(os.path.join(OUT, f'{tag}_top_kernels.md'), 'w') as g:
         g.write('| kernel | launches/step | avg µs | µs/step |\n|---|---|---|---|\n' + '\n'.join(out) + '\n\n')
         g.write(f'Sum of kernel time: {tot:.0f} µs per step over {nl:.0f} launches (eager run, {steps} program runs).\n')
+    # the step under GRAPH REPLAY (the mode the metric is timed in), launch by launch: rocprofv3's dispatch-to-completion average
+    # of a run without re-launches and without stamps (collect.sh: --no-replay --no-timeline), next to the in-step span / slot
+    # the kernels stamp themselves (bench line: `timeline`), the algorithmic flop, and PMC traffic against algorithmic bytes
+    grows = {r['Name']: r for r in csv.DictReader(open(src('graph', 'p_kernel_stats.csv')))}
+    tl = {r['kernel']: r for r in (line or {}).get('timeline', [])}
+    tab, tot_us = [], 0.0
+    for name, (prefix, algo, _) in KERNELS.items():
+        bare = prefix[5:] if prefix.startswith('void ') else prefix
+        r = next((v for k, v in grows.items() if k.startswith(prefix) or k.startswith(bare)), None)
+        if r is None:
+            continue
+        us = float(r['AverageNs']) / 1e3
+        tot_us += us
+        fl = STEP_FLOP.get(name, 0.0)
+        t = tl.get(TIMELINE_NAME.get(name, name), {})
+        tr = traffic.get(name, {}).get('traffic_bytes')
+        tab.append((t.get('start_us', 1e9), f"| `{bare[7:45]}` | {us:.1f} | {t.get('span_us', float('nan')):.1f} | {t.get('slot_us', float('nan')):.1f} | "
+                    f"{fl / 1e9:.2f} | {(fl / (us * 1e-6) / 1e12 / PEAK_TF) if fl else float('nan'):.3f} | "
+                    f"{algo / 1e6:.1f} | {(tr / 1e6) if tr else float('nan'):.1f} | {(tr / algo) if tr else float('nan'):.2f} |"))
+    with open(os.path.join(OUT, f'{tag}_top_kernels.md'), 'a') as g:
+        g.write('\nThe same step under graph replay, in launch order (rocprofv3 average of `bench.py --no-replay --no-timeline`; span / slot: '
+                'the in-step wall-clock stamps of the bench line, `timeline`):\n\n'
+                '| kernel | rocprof µs | span µs | slot µs | algorithmic GFLOP | frac of f32-MFMA peak (rocprof µs) | algorithmic MB | '
+                'PMC traffic MB | traffic / algorithmic |\n|---|---|---|---|---|---|---|---|---|\n')
+        g.write('\n'.join(row for _, row in sorted(tab)) + '\n\n')
+        g.write(f'Sum of the rocprofv3 averages: {tot_us:.1f} µs; step (bench line): {1e3 * (line or {}).get("ms_per_step", float("nan")):.1f} µs; '
+                f'whole step {(line or {}).get("step_flop", 0) / 1e9:.2f} GFLOP = {(line or {}).get("step_frac", float("nan")):.3f} of the peak.\n')
     print(json.dumps(dict(traffic=traffic, mfma=mfma), indent=1)[:3000])
     print(open(os.path.join(OUT, f'{tag}_top_kernels.md')).read())
     for w, l in lines.items():
