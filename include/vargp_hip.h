@@ -280,6 +280,13 @@ typedef struct vargp_elbo_tn_desc {
   int32_t defer_hyper;  /* as vargp_elbo_t0_desc.defer_hyper (vargp_elbo_tn_bwd only) */
   int32_t ext_lik;      /* as vargp_elbo_t0_desc.ext_lik (vargp_elbo_tn_fwd / _bwd; buffers: vargp_elbo_tn_lik_buffers); y must still be non-NULL
                          * for fwd to evaluate the KL (it is not dereferenced) */
+  /* ep_var_mean = False (reference var_gp/vargp.py:137-152, VARGP(..., ep_var_mean=False)): the variational mean of the
+   * current task is NOT offset by the conditional prior's mean, so the KL keeps that mean, evaluated at n_v samples
+   * u_<t ~ q(u_<t | theta): eps_u (n_v, S, C, (nblk - 1) M) standard normal, 1 <= n_v <= 16.  no_var_mean = 1 selects it
+   * (nblk > 1, vargp_elbo_tn_fwd / _bwd only; ignored by the tiled calls); 0: ep_var_mean = True, eps_u is not read. */
+  const float* eps_u;
+  int32_t n_v;
+  int32_t no_var_mean;
 } vargp_elbo_tn_desc;
 size_t vargp_elbo_tn_workspace_bytes(int S, int C, int M, int D, int B, int F, int nblk);
 /* Workspace of a program that only ever evaluates predictive moments (VARGP.forward / predict, var_gp/vargp.py:115-131,

@@ -324,3 +324,40 @@ def test_loss_without_backward_does_not_leak_programs():
         assert sum(len(v) for v in gp._tn_spares.values()) == 1     # the spare is cached, not re-allocated
     for k, g in grads_of(gp).items():
         assert rel_l2(g2[k], g) < 1e-5, k
+
+
+@pytest.mark.parametrize('shape', [(3, 2, 3, 24, 40, 48, 1), (2, 3, 2, 56, 36, 64, 2), (5, 2, 2, 100, 64, 128, 1)],
+                         ids=['t1', 't2', 't1_M100'])
+def test_ep_var_mean_false_runs_on_the_block_program(shape):
+    """ep_var_mean=False (reference vargp.py:137-152: the KL keeps the conditional prior's mean at n_v samples of u_<t) is a
+    variant of the SAME native program (tn_nm_* kernels), not the op-by-op composition: loss triple and all five gradients
+    against the fp64 oracle, through VARGP.loss and through the trainer's direct use of the program."""
+    from vargp_amd import noise
+    from vargp_amd.train import ElboTrainer
+    from gpu_common import build_gp, grads_of
+    S, F_, C, M, D, B, n_prev = shape
+    params, prev, x, y, nz = orc.make_problem(S, F_, C, M, D, B, n_prev=n_prev, seed=61, kind='gauss')
+    assert nz['eps_u'].shape == (S, S, C, n_prev * M)
+    d64 = lambda o: {k: v.double() for k, v in o.items()}
+    sc, og = orc.elbo_step(d64(params), [d64(p) for p in prev], x.double(), y, d64(nz), beta=2.0, n_total=7 * B, ep_var_mean=False)
+    sc1, _ = orc.elbo_step(d64(params), [d64(p) for p in prev], x.double(), y, d64(nz), beta=2.0, n_total=7 * B, ep_var_mean=True)
+    assert abs(sc['kl_u'].item() - sc1['kl_u'].item()) > 1e-3 * abs(sc1['kl_u'].item())        # the mean term is not negligible here
+    gp = build_gp(params, prev, S, F_, ep_var_mean=False)
+    assert gp._use_block_program(B) and gp.var_mean_mask == 0.0
+    with noise.inject(**to_dev(nz, DEV)):
+        kl_h, kl_u, nll = gp.loss(x.to(DEV), y.to(DEV))
+        (2.0 * kl_h + kl_u + 7.0 * nll).backward()
+    assert len(gp._tn_progs) == 1 and next(iter(gp._tn_progs.values())).desc.no_var_mean == 1
+    for k, v in [('kl_hypers', kl_h), ('kl_u', kl_u), ('nll', nll)]:
+        np.testing.assert_allclose(v.item(), sc[k].item(), rtol=RTOL_SCALAR, err_msg=k)
+    for k, g in grads_of(gp).items():
+        assert rel_l2(g.cpu(), og[k]) < REL_L2_GRAD, k
+    # the trainer route (program driven directly, gradients into the optimiser's buffers)
+    gp2 = build_gp(params, prev, S, F_, ep_var_mean=False)
+    tr = ElboTrainer(gp2, lr=1e-9, beta=2.0, n_total=7 * B)
+    assert tr._t0 and tr._tn
+    with noise.inject(**to_dev(nz, DEV)):
+        out = [float(v) for v in tr.step(x.to(DEV), y.to(DEV))]
+    np.testing.assert_allclose(out, [sc[k].item() for k in ('kl_hypers', 'kl_u', 'nll')], rtol=RTOL_SCALAR)
+    for k, g in grads_of(gp2).items():
+        assert rel_l2(g.cpu(), og[k]) < REL_L2_GRAD, ('trainer', k)

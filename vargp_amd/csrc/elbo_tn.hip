@@ -22,6 +22,8 @@
 
 namespace vargp {
 
+constexpr int kNmMaxV = 16;       // most u_<t samples (n_v) of the ep_var_mean = False KL
+
 struct TnWs {
   float *theta, *eps_theta, *eps_f;          // first, in this order (vargp_amd/fused.py exposes them as views)
   float *g2, *kd, *w, *na, *nb, *xs, *mu, *var, *gmu, *gvar;   // gmu, gvar adjacent: one zero range (accumulated by the softmax kernel)
@@ -30,6 +32,7 @@ struct TnWs {
   float *gQPs, *gP, *gT, *gKuf, *gK, *gRKt, *gkd, *gz_all;
   float *r_uf, *c_uf, *gtheta;               // adjacent: one zero range (accumulators of the kernel-matrix backward)
   float *r_uu, *Wuu, *Puu, *Puf;             // Wuu aliases gT (dead once the Cholesky backward has consumed it)
+  float *nm_v, *nm_y1, *nm_y2, *nm_d, *nm_gy2, *nm_gy1;   // ep_var_mean = False (tn_nm_* kernels): [b][row][kNmMaxV]
   float* zs;                                 // aliases Puu
   void *chol, *rbf;
   size_t chol_bytes, rbf_bytes;
@@ -65,6 +68,11 @@ static TnWs carve_tn(void* ws, int S, int C, int M, int D, int B, int F, int nbl
   o.r_uf = takeb(SC * Mt); o.c_uf = takeb((int64_t)S * B); o.gtheta = takeb(S * D1);
   o.r_uu = takeb(SC * Mt); o.Wuu = o.gT; o.Puu = take(SC * Mt * D); o.Puf = takeb(SC * Mt * D);
   o.zs = o.Puu;       // z_all o w per hyper-sample (forward only; P_uu is written by the backward)
+  if (nblk > 1) {     // the u_<t samples of the ep_var_mean = False KL and what its backward keeps (small: rows x kNmMaxV)
+    const int64_t Ml = Mt - M;
+    o.nm_v = takeb(SC * Ml * kNmMaxV); o.nm_y1 = takeb(SC * Ml * kNmMaxV); o.nm_gy1 = takeb(SC * Ml * kNmMaxV);
+    o.nm_y2 = takeb(SC * M * kNmMaxV); o.nm_d = takeb(SC * M * kNmMaxV); o.nm_gy2 = takeb(SC * M * kNmMaxV);
+  }
   const size_t cf = vargp_chol_workspace_bytes((int)SC, o.Mt, 0), cb = fwd_only ? 0 : vargp_chol_workspace_bytes((int)SC, o.Mt, 1);
   o.chol_bytes = cf > cb ? cf : cb;
   o.chol = p;
@@ -196,6 +204,217 @@ __global__ __launch_bounds__(256) void tn_prologue_kernel(const TnProArgs a) {
 //   kl[s,c] = sum log diag L_tt - sum log diag Lu_t + 0.5 (|H_t|_F^2 + |a_t|^2 - M),  kl_u = (1/S) sum kl[s,c]  (atomic)
 // COLS = 64 or 32 columns per block ((256 / COLS) row lanes): 32 when 64 would give fewer than two blocks per CU -- every
 // thread then walks half as many rows (Split-MNIST t = 1: 240 blocks of 50 dependent row steps took 22.9 us)
+
+// ---------------------------------------------------------------------------------------------------------------
+// ep_var_mean = False (reference var_gp/vargp.py:137-152): the KL of q(u_t) against p(u_t | u_<t) keeps the conditional
+// prior's MEAN, evaluated at n_v samples u_<t ~ q(u_<t | theta) (eps_u (n_v, S, C, M<)):
+//     kl[s,c] = ... + 0.5 mean_j |d_j|^2   instead of   0.5 |a_t|^2,        d_j = L_tt^-1 (u_mean - prior_mu_j).
+// In the block form (M< = Mt - M rows of earlier tasks, t = the current block):
+//     u_<t = L_<< v,  v = a_< + H_< eps   (L_<< H_< IS the Cholesky factor of S_<t: no second factorisation),
+//     prior_mu = K_t< K'_<<^-1 u_<t = K_t< T_<<^T v,          d = a_t - T_tt (K_t< (T_<<^T v)).
+// Forward: v, y1 = T_<<^T v, y2 = K_t< y1, d (+ the KL term); backward: the transposes, adding to ga / gH of the earlier blocks
+// (gQPs), to the T_tt and T_<< blocks of gT, and -- symmetrically split -- to the (t, <) block of gK.  All of it is
+// matrix-vector sized (n_v <= 16 columns): plain kernels, one thread or one wave per output row.
+// ---------------------------------------------------------------------------------------------------------------
+// v[b][k][j] = a[k] + sum_{l <= k % M} H[k][l] eps[j, s, c, (k / M) M + l]
+__global__ __launch_bounds__(256) void tn_nm_v_kernel(const float* __restrict__ QPs, const float* __restrict__ eps_u,
+                                                      float* __restrict__ v, int S, int C, int M, int Mt, int NRs, int NV) {
+  const int Ml = Mt - M;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)S * C * Ml * NV) return;
+  const int j = e % NV, k = (e / NV) % Ml;
+  const int64_t b = e / ((int64_t)NV * Ml);
+  const int kl = k % M, k0 = k - kl;
+  const float* q = QPs + (b * Mt + k) * NRs;
+  const float* ep = eps_u + ((int64_t)j * S * C + b) * Ml + k0;
+  float acc = q[0];
+  for (int l = 0; l <= kl; ++l) acc = fmaf(q[4 + l], ep[l], acc);
+  v[(b * Ml + k) * kNmMaxV + j] = acc;
+}
+// y1[b][c][j] = sum_{k >= c} T[b][k][c] v[b][k][j]   (c < M<: the leading block of T, transposed)
+__global__ __launch_bounds__(256) void tn_nm_y1_kernel(const float* __restrict__ T, const float* __restrict__ v,
+                                                       float* __restrict__ y1, int64_t SC, int M, int Mt, int NV) {
+  const int Ml = Mt - M;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= SC * Ml * NV) return;
+  const int j = e % NV, c = (e / NV) % Ml;
+  const int64_t b = e / ((int64_t)NV * Ml);
+  const float* t = T + b * Mt * Mt + c;
+  const float* vv = v + b * Ml * kNmMaxV + j;
+  float a0 = 0.f, a1 = 0.f;
+  int k = c;
+  for (; k + 1 < Ml; k += 2) {
+    a0 = fmaf(t[(int64_t)k * Mt], vv[(int64_t)k * kNmMaxV], a0);
+    a1 = fmaf(t[(int64_t)(k + 1) * Mt], vv[(int64_t)(k + 1) * kNmMaxV], a1);
+  }
+  if (k < Ml) a0 = fmaf(t[(int64_t)k * Mt], vv[(int64_t)k * kNmMaxV], a0);
+  y1[(b * Ml + c) * kNmMaxV + j] = a0 + a1;
+}
+// one wave per (b, i): out[b][i][:] = sum_c A[b][row0 + i][c] x[b][c][:]  over c < ncols (<= i + 1 if tri), A row-major (ld Mt)
+__device__ __forceinline__ void nm_row_dot(const float* __restrict__ arow, const float* __restrict__ x, int ncols, int NV, int lane,
+                                           float (&acc)[kNmMaxV]) {
+#pragma unroll
+  for (int j = 0; j < kNmMaxV; ++j) acc[j] = 0.f;
+  for (int c = lane; c < ncols; c += 64) {
+    const float a = arow[c];
+    const float* xr = x + (int64_t)c * kNmMaxV;
+#pragma unroll
+    for (int j = 0; j < kNmMaxV; ++j) if (j < NV) acc[j] = fmaf(a, xr[j], acc[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < kNmMaxV; ++j) if (j < NV) acc[j] = wave_sum(acc[j]);
+}
+// y2[b][i][:] = sum_{c < M<} K[b][r0 + i][c] y1[b][c][:]     (one wave per (b, i))
+__global__ __launch_bounds__(256) void tn_nm_y2_kernel(const float* __restrict__ K, const float* __restrict__ y1,
+                                                       float* __restrict__ y2, int64_t SC, int M, int Mt, int NV) {
+  const int Ml = Mt - M, lane = threadIdx.x & 63;
+  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= SC * M) return;
+  const int i = w % M;
+  const int64_t b = w / M;
+  float acc[kNmMaxV];
+  nm_row_dot(K + (b * Mt + Ml + i) * Mt, y1 + b * Ml * kNmMaxV, Ml, NV, lane, acc);
+  if (lane == 0)
+#pragma unroll
+    for (int j = 0; j < kNmMaxV; ++j) if (j < NV) y2[(b * M + i) * kNmMaxV + j] = acc[j];
+}
+// d[b][i][j] = a_t[i] - sum_{l <= i} T_tt[i][l] y2[b][l][j];  kl_u += 0.5 / (S NV) sum d^2     (one block per b)
+__global__ __launch_bounds__(256) void tn_nm_d_kernel(const float* __restrict__ T, const float* __restrict__ QPs,
+                                                      const float* __restrict__ y2, float* __restrict__ dd,
+                                                      float* __restrict__ kl_u, int S, int M, int Mt, int NRs, int NV) {
+  __shared__ float red[4];
+  const int64_t b = blockIdx.x;
+  const int r0 = Mt - M;
+  float acc2 = 0.f;
+  for (int e = threadIdx.x; e < M * NV; e += 256) {
+    const int j = e % NV, i = e / NV;
+    const float* t = T + (b * Mt + r0 + i) * Mt + r0;
+    const float* yy = y2 + b * M * kNmMaxV + j;
+    float a0 = QPs[(b * Mt + r0 + i) * NRs], a1 = 0.f;
+    int l = 0;
+    for (; l + 1 <= i; l += 2) { a0 = fmaf(-t[l], yy[(int64_t)l * kNmMaxV], a0); a1 = fmaf(-t[l + 1], yy[(int64_t)(l + 1) * kNmMaxV], a1); }
+    if (l <= i) a0 = fmaf(-t[l], yy[(int64_t)l * kNmMaxV], a0);
+    const float dv = a0 + a1;
+    dd[(b * M + i) * kNmMaxV + j] = dv;
+    acc2 = fmaf(dv, dv, acc2);
+  }
+  const float tot = block_sum<256>(acc2, red);
+  if (threadIdx.x == 0) atomicAdd(kl_u, 0.5f * tot / ((float)S * (float)NV));
+}
+// backward, step 1 (one block per b):  gd = g d / NV (g = seed_kl / S);  gy2[l][j] = - sum_{i >= l} T_tt[i][l] gd[i][j];
+//     ga_t[i] += sum_j gd[i][j]  (column 0 of gQPs: the head kernel left the moments' share there)
+__global__ __launch_bounds__(256) void tn_nm_bwd1_kernel(const float* __restrict__ T, const float* __restrict__ dd,
+                                                         const float* __restrict__ seeds, float* __restrict__ gy2,
+                                                         float* __restrict__ gQPs, int S, int M, int Mt, int NRs, int NV) {
+  const int64_t b = blockIdx.x;
+  const int r0 = Mt - M;
+  const float gf = seeds[1] / ((float)S * (float)NV);
+  for (int e = threadIdx.x; e < M * NV; e += 256) {
+    const int j = e % NV, l = e / NV;
+    const float* t = T + (b * Mt + r0) * Mt + r0 + l;
+    const float* dv = dd + b * M * kNmMaxV + j;
+    float a0 = 0.f;
+    for (int i = l; i < M; ++i) a0 = fmaf(t[(int64_t)i * Mt], dv[(int64_t)i * kNmMaxV], a0);
+    gy2[(b * M + l) * kNmMaxV + j] = -gf * a0;
+  }
+  for (int i = threadIdx.x; i < M; i += 256) {
+    float a0 = 0.f;
+    for (int j = 0; j < NV; ++j) a0 += dd[(b * M + i) * kNmMaxV + j];
+    gQPs[(b * Mt + r0 + i) * NRs] += gf * a0;
+  }
+}
+// backward, step 2:  gy1[b][c][j] = sum_i K[b][r0 + i][c] gy2[b][i][j]
+__global__ __launch_bounds__(256) void tn_nm_bwd2_kernel(const float* __restrict__ K, const float* __restrict__ gy2,
+                                                         float* __restrict__ gy1, int64_t SC, int M, int Mt, int NV) {
+  const int Ml = Mt - M;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= SC * Ml * NV) return;
+  const int j = e % NV, c = (e / NV) % Ml;
+  const int64_t b = e / ((int64_t)NV * Ml);
+  const float* kk = K + (b * Mt + Ml) * Mt + c;
+  const float* g = gy2 + b * M * kNmMaxV + j;
+  float a0 = 0.f, a1 = 0.f;
+  int i = 0;
+  for (; i + 1 < M; i += 2) { a0 = fmaf(kk[(int64_t)i * Mt], g[(int64_t)i * kNmMaxV], a0); a1 = fmaf(kk[(int64_t)(i + 1) * Mt], g[(int64_t)(i + 1) * kNmMaxV], a1); }
+  if (i < M) a0 = fmaf(kk[(int64_t)i * Mt], g[(int64_t)i * kNmMaxV], a0);
+  gy1[(b * Ml + c) * kNmMaxV + j] = a0 + a1;
+}
+// backward, step 3 (one wave per (b, k), k < M<):  gv[k][:] = sum_{c <= k} T[k][c] gy1[c][:];
+//     ga_<[k] += sum_j gv[k][j];   gH[k][l] += sum_j gv[k][j] eps[j, s, c, (k / M) M + l]   (l <= k % M)
+__global__ __launch_bounds__(256) void tn_nm_bwd3_kernel(const float* __restrict__ T, const float* __restrict__ gy1,
+                                                         const float* __restrict__ eps_u, float* __restrict__ gQPs, int S, int C,
+                                                         int M, int Mt, int NRs, int NV) {
+  const int Ml = Mt - M, lane = threadIdx.x & 63;
+  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= (int64_t)S * C * Ml) return;
+  const int k = w % Ml;
+  const int64_t b = w / Ml;
+  float gv[kNmMaxV];
+  nm_row_dot(T + (b * Mt + k) * Mt, gy1 + b * Ml * kNmMaxV, k + 1, NV, lane, gv);
+  const int kl = k % M, k0 = k - kl;
+  float* q = gQPs + (b * Mt + k) * NRs;
+  if (lane == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < kNmMaxV; ++j) if (j < NV) t += gv[j];
+    q[0] += t;
+  }
+  for (int l = lane; l <= kl; l += 64) {
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < kNmMaxV; ++j) if (j < NV) t = fmaf(gv[j], eps_u[((int64_t)j * S * C + b) * Ml + k0 + l], t);
+    q[4 + l] += t;
+  }
+}
+// backward, step 4 (after gT is complete, before the Cholesky adjoint):
+//     gT_tt[i][l] -= sum_j gd[i][j] y2[l][j]  (l <= i);      gT_<<[k][c] += sum_j v[k][j] gy1[c][j]  (c <= k)
+__global__ __launch_bounds__(256) void tn_nm_bwd4_kernel(const float* __restrict__ dd, const float* __restrict__ y2,
+                                                         const float* __restrict__ v, const float* __restrict__ gy1,
+                                                         const float* __restrict__ seeds, float* __restrict__ gT, int64_t SC, int S,
+                                                         int M, int Mt, int NV, int64_t n_tt) {
+  const int Ml = Mt - M;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e < n_tt) {                                   // (b, i, l) of the T_tt block
+    const int l = e % M, i = (e / M) % M;
+    const int64_t b = e / ((int64_t)M * M);
+    if (l > i) return;
+    const float gf = seeds[1] / ((float)S * (float)NV);
+    const float* dv = dd + (b * M + i) * kNmMaxV;
+    const float* yy = y2 + (b * M + l) * kNmMaxV;
+    float t = 0.f;
+    for (int j = 0; j < NV; ++j) t = fmaf(dv[j], yy[j], t);
+    gT[(b * Mt + Ml + i) * Mt + Ml + l] -= gf * t;
+    return;
+  }
+  const int64_t f = e - n_tt;                        // (b, k, c) of the leading M< x M< block
+  if (f >= SC * Ml * Ml) return;
+  const int c = f % Ml, k = (f / Ml) % Ml;
+  const int64_t b = f / ((int64_t)Ml * Ml);
+  if (c > k) return;
+  const float* vv = v + (b * Ml + k) * kNmMaxV;
+  const float* g = gy1 + (b * Ml + c) * kNmMaxV;
+  float t = 0.f;
+  for (int j = 0; j < NV; ++j) t = fmaf(vv[j], g[j], t);
+  gT[(b * Mt + k) * Mt + c] += t;
+}
+// backward, step 5 (after the Cholesky adjoint has written the symmetric gK): the direct dependence on K_t<, split over the
+// two mirrored blocks:  gK[r0 + i][c] += h,  gK[c][r0 + i] += h,   h = 0.5 sum_j gy2[i][j] y1[c][j]
+__global__ __launch_bounds__(256) void tn_nm_bwd5_kernel(const float* __restrict__ gy2, const float* __restrict__ y1,
+                                                         float* __restrict__ gK, int64_t SC, int M, int Mt, int NV) {
+  const int Ml = Mt - M;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= SC * M * Ml) return;
+  const int c = e % Ml, i = (e / Ml) % M;
+  const int64_t b = e / ((int64_t)Ml * M);
+  const float* g = gy2 + (b * M + i) * kNmMaxV;
+  const float* yy = y1 + (b * Ml + c) * kNmMaxV;
+  float t = 0.f;
+  for (int j = 0; j < NV; ++j) t = fmaf(g[j], yy[j], t);
+  t *= 0.5f;
+  gK[(b * Mt + Ml + i) * Mt + c] += t;
+  gK[(b * Mt + c) * Mt + Ml + i] += t;
+}
+
 constexpr int kTnKlRows = 8;
 template <int COLS>
 __global__ __launch_bounds__(256) void tn_pdiag_kl_kernel(const float* __restrict__ P, const float* __restrict__ W,
@@ -204,7 +423,7 @@ __global__ __launch_bounds__(256) void tn_pdiag_kl_kernel(const float* __restric
                                                           const float* __restrict__ rk_all, float* __restrict__ mu,
                                                           float* __restrict__ var, float* __restrict__ kl_u, float eps,
                                                           int S, int C, int M, int Mt, int nblk, int B, int NRs, int nbx,
-                                                          int npd, int nkx, uint32_t* rng_counter) {
+                                                          int npd, int nkx, uint32_t* rng_counter, int a_term = 1) {
   constexpr int RL = 256 / COLS;       // row lanes
   __shared__ float red[4][RL][COLS];
   if (rng_counter && blockIdx.x == 0 && threadIdx.x == 0) rng_counter[0] += 1u;   // this step's noise has been drawn
@@ -252,7 +471,7 @@ __global__ __launch_bounds__(256) void tn_pdiag_kl_kernel(const float* __restric
     if (j <= i) { const float v = q[(int64_t)i * NRs + 4 + j]; acc = fmaf(v, v, acc); }
   }
   for (int i = i0 + threadIdx.x; i < i1; i += 256) {
-    const float a = q[(int64_t)i * NRs];
+    const float a = a_term ? q[(int64_t)i * NRs] : 0.f;      // (ep_var_mean = False: tn_nm_d_kernel adds mean_j |d_j|^2 instead)
     acc = fmaf(a, a, acc);
     acc += 2.f * (logf(L[(b * Mt + r0 + i) * Mt + r0 + i]) - logf(rk[(int64_t)i * NRs + 4 + i])) - 1.f;
   }
@@ -277,7 +496,7 @@ __global__ __launch_bounds__(256) void tn_bwd_head_kernel(const float* __restric
                                                           float* __restrict__ gP, float* __restrict__ gQPs,
                                                           float* __restrict__ gkd, float eps, int S, int M, int Mt, int B,
                                                           int NRs, int npd, int nrest, float* __restrict__ zero_begin,
-                                                          int64_t zero_count, int accumulate) {
+                                                          int64_t zero_count, int accumulate, int a_term = 1) {
   __shared__ float red[4];
   const float g = seeds[1] / (float)S;
   if ((int)blockIdx.x >= npd + nrest) {       // zero-fill of the r / c / gtheta accumulators of the kernel-matrix backward
@@ -306,7 +525,7 @@ __global__ __launch_bounds__(256) void tn_bwd_head_kernel(const float* __restric
     if (threadIdx.x == 0) {
       // accumulate (N-tiled ELBO): this minibatch tile's share on top of the earlier tiles'; the KL term comes at the end
       if (accumulate) gQPs[(b * Mt + m) * NRs] += t;
-      else gQPs[(b * Mt + m) * NRs] = t + (m >= Mt - M ? g * am : 0.f);
+      else gQPs[(b * Mt + m) * NRs] = t + ((m >= Mt - M && a_term) ? g * am : 0.f);
     }
     if (m == 0) {
       const float tv = block_sum<256>(accv, red);
@@ -430,6 +649,8 @@ static int check_tn(const vargp_elbo_tn_desc* d, const char* who, bool tiled = f
                            : (d->log_logvar && d->prior_log_mean && d->prior_log_logvar && (native || d->eps_theta)),
                 "%s: hyper-parameter arguments inconsistent with map_est", who);
   VARGP_REQUIRE(!d->forward_only || d->y == nullptr, "%s: a forward_only program evaluates moments only (y must be NULL)", who);
+  VARGP_REQUIRE(!d->no_var_mean || (d->nblk > 1 && d->eps_u && d->n_v >= 1 && d->n_v <= kNmMaxV),
+                "%s: no_var_mean needs earlier tasks (nblk > 1), eps_u and 1 <= n_v <= %d", who, kNmMaxV);
   VARGP_REQUIRE(d->ws_bytes >= carve_tn(nullptr, d->S, d->C, d->M, d->D, d->B, d->F, d->nblk, d->forward_only != 0).bytes,
                 "%s: workspace too small", who);
   return VARGP_OK;
@@ -625,9 +846,18 @@ extern "C" int vargp_elbo_tn_fwd(const vargp_elbo_tn_desc* d, vargp_stream_t str
   {
     const bool narrow = cdiv(B, 64) * SC < 512;
     const int nbx = cdiv(B, narrow ? 32 : 64), npd = nbx * SC, nkx = cdiv(M, kTnKlRows);
+    const bool nomean = lik && d->no_var_mean && nblk > 1;
     hipLaunchKernelGGL(narrow ? tn_pdiag_kl_kernel<32> : tn_pdiag_kl_kernel<64>, dim3(npd + (lik ? nkx * SC : 0)), dim3(256), 0, st, o.P, o.W, o.V2, o.QPs, o.kd,
                        o.LL, d->rk_all, o.mu, o.var, lik ? d->scalars + 1 : nullptr, d->jitter, S, C, M, Mt, nblk, B, NRs,
-                       nbx, npd, nkx, native ? d->rng_counter : nullptr);
+                       nbx, npd, nkx, native ? d->rng_counter : nullptr, nomean ? 0 : 1);
+    if (nomean) {   // the mean term of the KL at the n_v samples of u_<t (tn_nm_* above)
+      const int NV = d->n_v, Ml = Mt - M;
+      const int64_t nvl = (int64_t)SC * Ml * NV;
+      hipLaunchKernelGGL(tn_nm_v_kernel, dim3(cdiv(nvl, 256)), dim3(256), 0, st, o.QPs, d->eps_u, o.nm_v, S, C, M, Mt, NRs, NV);
+      hipLaunchKernelGGL(tn_nm_y1_kernel, dim3(cdiv(nvl, 256)), dim3(256), 0, st, o.TT, o.nm_v, o.nm_y1, (int64_t)SC, M, Mt, NV);
+      hipLaunchKernelGGL(tn_nm_y2_kernel, dim3(cdiv((int64_t)SC * M, 4)), dim3(256), 0, st, o.Kall, o.nm_y1, o.nm_y2, (int64_t)SC, M, Mt, NV);
+      hipLaunchKernelGGL(tn_nm_d_kernel, dim3(SC), dim3(256), 0, st, o.TT, o.QPs, o.nm_y2, o.nm_d, d->scalars + 1, S, M, Mt, NRs, NV);
+    }
   }
   if (lik && !d->ext_lik) {       // (ext_lik: the caller evaluates the likelihood on the moments of ALL classes, include/vargp_hip.h)
     if (fused_softmax) {
@@ -659,6 +889,7 @@ extern "C" int vargp_elbo_tn_bwd(const vargp_elbo_tn_desc* d, const float* seeds
   const float* eps_f = native ? o.eps_f : d->eps_f;
   const float* eps_theta = native ? o.eps_theta : d->eps_theta;
 
+  const bool nomean = d->no_var_mean && nblk > 1;
   if (!fused_softmax && !d->ext_lik) {
     rc = vargp_softmax_nll_bwd(o.mu, o.var, eps_f, d->y, seeds + 2, o.gmu, o.gvar, S, F, C, B, stream);
     if (rc) return rc;
@@ -670,7 +901,15 @@ extern "C" int vargp_elbo_tn_bwd(const vargp_elbo_tn_desc* d, const float* seeds
     const int nz = (int)std::min<int64_t>(64, cdiv(zc, 1024));
     hipLaunchKernelGGL(tn_bwd_head_kernel, dim3(npd + nrest + nz), dim3(256), 0, st, o.P, o.W, o.V2, o.QPs, o.gmu, o.gvar,
                        fused_softmax ? seeds + 2 : nullptr, seeds, o.gP, o.gQPs, o.gkd, d->jitter, S, M, Mt, B, NRs, npd,
-                       nrest, o.r_uf, zc, 0);
+                       nrest, o.r_uf, zc, 0, nomean ? 0 : 1);
+  }
+  if (nomean) {   // ep_var_mean = False: the KL's mean term back to ga / gH of every block (gQPs), keeping gy2 / gy1 for gT and gK
+    const int NV = d->n_v, Ml = Mt - M;
+    const int64_t nvl = (int64_t)SC * Ml * NV;
+    hipLaunchKernelGGL(tn_nm_bwd1_kernel, dim3(SC), dim3(256), 0, st, o.TT, o.nm_d, seeds, o.nm_gy2, o.gQPs, S, M, Mt, NRs, NV);
+    hipLaunchKernelGGL(tn_nm_bwd2_kernel, dim3(cdiv(nvl, 256)), dim3(256), 0, st, o.Kall, o.nm_gy2, o.nm_gy1, (int64_t)SC, M, Mt, NV);
+    hipLaunchKernelGGL(tn_nm_bwd3_kernel, dim3(cdiv((int64_t)SC * Ml, 4)), dim3(256), 0, st, o.TT, o.nm_gy1, d->eps_u, o.gQPs, S, C, M, Mt,
+                       NRs, NV);
   }
   float* gW = o.W;      // in place (tn_bwd_head_kernel)
   float* gV2 = o.V2;
@@ -739,6 +978,12 @@ extern "C" int vargp_elbo_tn_bwd(const vargp_elbo_tn_desc* d, const float* seeds
     rc = launch_gemm(r, 0, 1, SC * nblk, false, st, "tn_gt_diag_gemm");
     if (rc) return rc;
   }
+  if (nomean) {   // ... and to the T_tt and T_<< blocks of gT (complete by now)
+    const int NV = d->n_v, Ml = Mt - M;
+    const int64_t n_tt = (int64_t)SC * M * M, n_ll = (int64_t)SC * Ml * Ml;
+    hipLaunchKernelGGL(tn_nm_bwd4_kernel, dim3(cdiv(n_tt + n_ll, 256)), dim3(256), 0, st, o.nm_d, o.nm_y2, o.nm_v, o.nm_gy1, seeds, o.gT,
+                       (int64_t)SC, S, M, Mt, NV, n_tt);
+  }
   // Cholesky backward.  Only diag(L_tt) is used forward (log-determinant), so gL = diag(g / L_jj) on the current block:
   //   P_low = tril(L^T gL - gT T^T) = g I_t - tril(gT T^T)   (the lower triangle of L^T diag(.) is its diagonal)
   //   Smat  = (Phi(P_low) + Phi(P_low)^T) / 2 = -0.5 sym(tril(gT T^T)) + 0.5 g I_t,     gK = T^T Smat T
@@ -760,6 +1005,11 @@ extern "C" int vargp_elbo_tn_bwd(const vargp_elbo_tn_desc* d, const float* seeds
     r.triA = 2; r.triB = 1; r.triC = 2; r.symout = 1;
     rc = launch_gemm(r, 1, 0, SC, false, st, "tn_chol_bwd3");
     if (rc) return rc;
+  }
+  if (nomean) {   // ... and the direct dependence of prior_mu on K_t<
+    const int NV = d->n_v, Ml = Mt - M;
+    hipLaunchKernelGGL(tn_nm_bwd5_kernel, dim3(cdiv((int64_t)SC * M * Ml, 256)), dim3(256), 0, st, o.nm_gy2, o.nm_y1, o.gK, (int64_t)SC, M,
+                       Mt, NV);
   }
   // kernel matrices -> theta, z  (the fused passes of the first-task program, elbo_shared.h):
   //   W = gK o K for both kernel matrices in one launch (K_uf in place on gK_uf; K_all: gK is symmetric, W + W^T = 2 W),
@@ -905,7 +1155,7 @@ extern "C" int vargp_elbo_tn_begin(const vargp_elbo_tn_desc* d, vargp_stream_t s
   {   // the KL (data-independent): the KL role of the moments kernel alone
     const int nkx = cdiv(M, kTnKlRows);
     hipLaunchKernelGGL(tn_pdiag_kl_kernel<64>, dim3(nkx * SC), dim3(256), 0, st, o.P, o.W, o.V2, o.QPs, o.kd, o.LL, d->rk_all, o.mu,
-                       o.var, d->scalars + 1, d->jitter, S, C, M, Mt, nblk, B, NRs, 1, 0, nkx, (uint32_t*)nullptr);
+                       o.var, d->scalars + 1, d->jitter, S, C, M, Mt, nblk, B, NRs, 1, 0, nkx, (uint32_t*)nullptr, 1);
   }
   return check_launch("elbo_tn_begin");
 }
@@ -972,7 +1222,7 @@ extern "C" int vargp_elbo_tn_tile(const vargp_elbo_tn_desc* d, const float* seed
     const int nbx = cdiv(B, narrow ? 32 : 64), npd = nbx * SC;
     hipLaunchKernelGGL(narrow ? tn_pdiag_kl_kernel<32> : tn_pdiag_kl_kernel<64>, dim3(npd), dim3(256), 0, st, o.P, o.W, o.V2, o.QPs, o.kd, o.LL, d->rk_all, o.mu, o.var,
                        (float*)nullptr, d->jitter, S, C, M, Mt, nblk, B, NRs, nbx, npd, 1,
-                       (native && !moments_only) ? d->rng_counter : nullptr);
+                       (native && !moments_only) ? d->rng_counter : nullptr, 1);
   }
   if (moments_only) return check_launch("elbo_tn_tile");
   if (fused_softmax) {
@@ -987,7 +1237,7 @@ extern "C" int vargp_elbo_tn_tile(const vargp_elbo_tn_desc* d, const float* seed
   {
     const int npd = SC * Mt;
     hipLaunchKernelGGL(tn_bwd_head_kernel, dim3(npd), dim3(256), 0, st, o.P, o.W, o.V2, o.QPs, o.gmu, o.gvar, seeds + 2, seeds, o.gP,
-                       o.gQPs, o.gkd, d->jitter, S, M, Mt, B, NRs, npd, 0, (float*)nullptr, (int64_t)0, 1);
+                       o.gQPs, o.gkd, d->jitter, S, M, Mt, B, NRs, npd, 0, (float*)nullptr, (int64_t)0, 1, 1);
   }
   float* gW = o.W;
   float* gV2 = o.V2;

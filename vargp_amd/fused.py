@@ -329,9 +329,10 @@ class TnProgram:
     lik_buffers = T0Program.lik_buffers
 
     def forward(self, log_mean, log_logvar, prior_log_mean, prior_log_logvar, z, u_mean, u_tril_vec, z_all, rk_all, x, y,
-                eps_theta, eps_f, bump=None, ext_lik=False):
+                eps_theta, eps_f, bump=None, ext_lik=False, eps_u=None):
         """-> scalars (3,) = (kl_hypers, kl_u, nll) (y given) or None (y None: moments only).  ext_lik: as T0Program.forward
-        (y must still be given: it switches the KL on)."""
+        (y must still be given: it switches the KL on).  eps_u (n_v, S, C, (nblk - 1) M): ep_var_mean = False -- the KL keeps the
+        conditional prior's mean at these n_v samples of u_<t (include/vargp_hip.h: no_var_mean)."""
         tensors = (log_mean, log_logvar, prior_log_mean, prior_log_logvar, z, u_mean, u_tril_vec, z_all, rk_all, x, y,
                    eps_theta, eps_f)
         require_device(*tensors)
@@ -357,7 +358,13 @@ class TnProgram:
         d.bump = _p(bump)
         d.scalars = _p(self.scalars)
         d.ext_lik = int(bool(ext_lik))
-        self._keep = tensors + (bump,)
+        if eps_u is not None:
+            require_device(eps_u)
+            assert nblk > 1 and eps_u.is_contiguous() and eps_u.dim() == 4 and eps_u.shape[1:] == (S, C, (nblk - 1) * M), eps_u.shape
+            d.eps_u, d.n_v, d.no_var_mean = _p(eps_u), int(eps_u.shape[0]), 1
+        else:
+            d.eps_u, d.n_v, d.no_var_mean = None, 0, 0
+        self._keep = tensors + (bump, eps_u)
         check(lib().vargp_elbo_tn_fwd(ctypes.byref(d), stream_ptr()), 'vargp_elbo_tn_fwd')
         ops._note_chol_errors(self.info)
         return self.scalars if y is not None else None
@@ -417,11 +424,12 @@ class TnProgram:
 class _ElboTn(Function):
     @staticmethod
     def forward(ctx, log_mean, log_logvar, z, u_mean, u_tril_vec, x, y, eps_theta, eps_f, prior_log_mean,
-                prior_log_logvar, map_est, prog, z_all, rk_all):
+                prior_log_logvar, map_est, prog, z_all, rk_all, eps_u=None):
         args = [t.contiguous() if t is not None else None
                 for t in (log_mean, log_logvar, prior_log_mean, prior_log_logvar, z, u_mean, u_tril_vec)]
         scal = prog.forward(*args, z_all, rk_all, x.contiguous(), y.contiguous(),
-                            None if eps_theta is None else eps_theta.contiguous(), eps_f.contiguous())
+                            None if eps_theta is None else eps_theta.contiguous(), eps_f.contiguous(),
+                            eps_u=None if eps_u is None else eps_u.contiguous())
         # The workspace is owned by this node until its backward has run -- or until the node dies without one (validation
         # ELBO under no_grad: no graph is recorded and ctx is released as soon as apply() returns; a dropped graph; a
         # skipped step).  grad mode is always off inside Function.forward, so the node's lifetime is the signal.
@@ -448,13 +456,13 @@ class _ElboTn(Function):
         prog.backward(seeds, g_mean, g_logvar, g_z, g_um, g_uv)
         _release(prog, ctx.gen)
         ctx.prog = None
-        return (g_mean, None if ctx.map_est else g_logvar, g_z, g_um, g_uv) + (None,) * 10
+        return (g_mean, None if ctx.map_est else g_logvar, g_z, g_um, g_uv) + (None,) * 11
 
 
-def elbo_tn(kernel, z, u_mean, u_tril_vec, x, y, eps_theta, eps_f, prog, z_all, rk_all):
-    """-> (kl_hypers, kl_u, nll) of VARGP.loss for a model with previous tasks (ep_var_mean = True) as ONE autograd node."""
+def elbo_tn(kernel, z, u_mean, u_tril_vec, x, y, eps_theta, eps_f, prog, z_all, rk_all, eps_u=None):
+    """-> (kl_hypers, kl_u, nll) of VARGP.loss for a model with previous tasks as ONE autograd node (eps_u: ep_var_mean = False)."""
     return _ElboTn.apply(kernel.log_mean, kernel.log_logvar, z, u_mean, u_tril_vec, x, y, eps_theta, eps_f,
-                         kernel.prior_log_mean, kernel.prior_log_logvar, bool(kernel.map_est), prog, z_all, rk_all)
+                         kernel.prior_log_mean, kernel.prior_log_logvar, bool(kernel.map_est), prog, z_all, rk_all, eps_u)
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -477,7 +485,8 @@ def elbo_lazy(model, x, y, block):
         prog._ring, prog._ring_i = torch.zeros(_RING, 3, dtype=torch.float32, device=x.device), 0
     prog._ring_i = (prog._ring_i + 1) % _RING
     prog.scalars = prog._ring[prog._ring_i]                 # valid until _RING more forwards of this program
-    if noise._injected or noise._shard is not None:
+    eps_u = model.draw_u_noise(x) if block else None          # ep_var_mean = False only (None otherwise)
+    if noise._injected or noise._shard is not None or eps_u is not None:
         eps_theta, eps_f = model.draw_t0_noise(x)
         eps_theta = None if eps_theta is None else eps_theta.contiguous()
         eps_f = eps_f.contiguous()
@@ -493,7 +502,7 @@ def elbo_lazy(model, x, y, block):
     args = (kern.log_mean.detach(), kern.log_logvar.detach(), kern.prior_log_mean, kern.prior_log_logvar, model.z.detach(),
             model.u_mean.detach(), model.u_tril_vec.detach())
     if block:
-        prog.forward(*args, *model._tn_operands(), x, y, eps_theta, eps_f)
+        prog.forward(*args, *model._tn_operands(), x, y, eps_theta, eps_f, eps_u=eps_u)
     else:
         prog.forward(*args, x, y, eps_theta, eps_f)
     params = (kern.log_mean, None if kern.map_est else kern.log_logvar, model.z, model.u_mean, model.u_tril_vec)

@@ -19,6 +19,7 @@ _chol_mode = 'raise'
 _info_ring = []   # 'defer' mode: most recent info tensors (device), inspected on demand
 
 
+_lazy_rings = {}
 _pending = []     # 'lazy' mode: (pinned host copy of an info tensor, event recorded behind the copy)
 
 
@@ -252,12 +253,17 @@ def rbf_gram(theta, X, Y=None, y_shared=False):
 def _note_chol_errors(info):
     if _chol_mode == 'lazy':
         check_linalg_errors()                      # what earlier calls left behind
-        host = torch.empty(info.shape, dtype=info.dtype, pin_memory=True)
+        # pinned landing buffers and events are recycled (a ring per status-word count: allocating them per call cost ~40 us)
+        ring = _lazy_rings.setdefault(info.numel(), [[], 0])
+        if len(ring[0]) < 16:
+            ring[0].append((torch.empty(info.shape, dtype=info.dtype, pin_memory=True), torch.cuda.Event()))
+        host, ev = ring[0][ring[1] % len(ring[0])]
+        ring[1] += 1
+        if any(h is host for h, _ in _pending):    # the ring has come round to a copy that has not been looked at: wait for it
+            check_linalg_errors(wait=True)
         host.copy_(info, non_blocking=True)
-        ev = torch.cuda.Event()
         ev.record()
         _pending.append((host, ev))
-        del _pending[:-256]
         return
     if _chol_mode == 'raise':
         bad = int((info != 0).sum().item())

@@ -374,7 +374,8 @@ class ElboTrainer:
         gp, kern = self.gp, self.gp.kernel
         x, y = x.contiguous(), y.contiguous()
         S = 1 if kern.map_est else (gp.n_v if self.shards is None else self.rect[1] - self.rect[0])
-        if self.native_noise and not noise._injected:
+        eps_u = gp.draw_u_noise(x) if hasattr(gp, 'draw_u_noise') else None      # ep_var_mean = False models only
+        if self.native_noise and not noise._injected and eps_u is None:
             eps_theta = eps_f = None
         else:
             eps_theta, eps_f = gp.draw_t0_noise(x)
@@ -396,7 +397,7 @@ class ElboTrainer:
         packed = gp._tn_operands() if self._tn else ()
         # (first-task program: forward and backward are issued back to back here and nll is read after both, so the
         # likelihood may be left to the backward's tile kernel -- one launch less)
-        extra = {} if self._tn else dict(defer_softmax=os.environ.get('VARGP_DEFER_SOFTMAX', '1') != '0')
+        extra = dict(eps_u=eps_u) if self._tn else dict(defer_softmax=os.environ.get('VARGP_DEFER_SOFTMAX', '1') != '0')
         scal = self._prog.forward(kern.log_mean.detach(), kern.log_logvar.detach(), kern.prior_log_mean,
                                   kern.prior_log_logvar, gp.z.detach(), gp.u_mean.detach(), gp.u_tril_vec.detach(), *packed,
                                   x, y, eps_theta, eps_f, bump=self._bump, **extra)

@@ -139,7 +139,10 @@ class VARGP(nn.Module):
         if not self._tn_applicable():
             return False
         if self.prev_params:
-            return self.var_mean_mask == 1.0
+            # ep_var_mean = False (the KL keeps the conditional prior's mean at n_v samples of u_<t): the same program with its
+            # tn_nm_* kernels (csrc/elbo_tn.hip), for up to 16 samples
+            n_v = 1 if self.kernel.map_est else self.n_v
+            return self.var_mean_mask == 1.0 or (self.var_mean_mask == 0.0 and n_v <= 16)
         return self.fused_first_task and self.first_task_as_block(B)
 
     def _tn_operands(self):
@@ -326,6 +329,15 @@ class VARGP(nn.Module):
             self._gbufs = sets
         return self._gbufs
 
+    def draw_u_noise(self, x):
+        """eps_u (n_v, S, C, M<) of the u_<t ~ q(u_<t | theta) samples the ep_var_mean = False KL is averaged over (reference
+        vargp.py:137-138); None for ep_var_mean = True models and first-task models."""
+        if not self.prev_params or self.var_mean_mask == 1.0:
+            return None
+        S = 1 if self.kernel.map_est else self.n_v
+        n_lt = sum(p['z'].shape[-2] for p in self.prev_params)
+        return noise.draw('eps_u', (self.n_v, S, self.z.size(0), n_lt), x.device, sample_dim=1).contiguous()
+
     def loss(self, x, y):
         """(kl_hypers, kl_u, nll); the caller combines beta*kl_hypers + kl_u + (N/B)*nll
         (vargp.py:177-194, experiments/vargp.py:34)."""
@@ -341,7 +353,7 @@ class VARGP(nn.Module):
             # later tasks: the block-structured program (csrc/elbo_tn.hip) as one autograd node
             eps_theta, eps_f = self.draw_t0_noise(x)
             return fused.elbo_tn(self.kernel, self.z, self.u_mean, self.u_tril_vec, x, y, eps_theta, eps_f,
-                                 self._tn_program(x.size(0)), *self._tn_operands())
+                                 self._tn_program(x.size(0)), *self._tn_operands(), eps_u=self.draw_u_noise(x))
         loss_cache = dict()
         pred_mu, pred_var = self(x, loss_cache=loss_cache)
         nll = self.likelihood.loss(pred_mu, pred_var, y)
