@@ -721,7 +721,9 @@ def run_workload(name, args, device, world, rank, use_dist, steps, warmup, prima
                                            frac=fl / (us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS)
                                       for t, (us, fl, dsc) in kernels.items() if t != dom and us == us and fl > 0]
         gtag = next((t for t in ('rbf_kuf_bwd_gemm', 'rbf_kuu_bwd_gemm') if t in kernels), None)
-        if N_PREV == 0 and gtag and dom != gtag:       # the heaviest MFMA launch of the backward
+        if gtag == dom and 'chol_rbf_gemm' in kernels:
+            gtag = 'chol_rbf_gemm'                     # (the backward's launch is `roofline` itself: report the forward's here)
+        if N_PREV == 0 and gtag and dom != gtag:       # the other GEMM-carrying launch of the step
             us2, fl2, desc2 = kernels[gtag]
             res['roofline_gemm'] = dict(bound='mfma', kernel=desc2, achieved=fl2 / (us2 * 1e-6) / 1e12,
                                         peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
