@@ -70,3 +70,16 @@ for (s0, s1, c0, c1) in [(0, 1, 0, 3), (0, 1, 0, 4), (0, 1, 0, 5), (0, 1, 0, 10)
     torch.cuda.synchronize()
     print('rectangle %d sample(s) x %2d classes (%2d of 30 problems): %.1f us per step without the collectives'
           % (Sl, Cl, Sl * Cl, e0.elapsed_time(e1) / 200 * 1e3))
+    # the time line of the last step of a launch (vargp_prof_spans): how long each launch takes when it has almost nothing to do
+    acc = {}
+    for _ in range(10):
+        _lib.prof_spans(1)
+        g.replay()
+        torch.cuda.synchronize()
+        for k, (a, b) in _lib.prof_spans(0).items():
+            if ':' not in k:
+                acc.setdefault(k, [0.0, 0.0])
+                acc[k][0] += a
+                acc[k][1] += b - a
+    _lib.prof_spans(2)
+    print('    spans (us): ' + '  '.join('%s %.1f' % (k, v[1] / 10) for k, v in sorted(acc.items(), key=lambda kv: kv[1][0])))
