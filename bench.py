@@ -235,6 +235,8 @@ def step_timeline(run, period_us, reps=20, burst=4):
         for k, (a, b) in t.items():
             if ':' in k:
                 acc.setdefault(k, [0.0, 0.0, 0.0])[1] += b - t[k.split(':')[0]][0]
+                if a:        # (a role that also stamps its LAST workgroup's start)
+                    acc[k][0] += a - t[k.split(':')[0]][0]
         n += 1
     _lib.prof_spans(2)
     if not n:
@@ -245,11 +247,13 @@ def step_timeline(run, period_us, reps=20, burst=4):
         rows[0]['gap_before_us'] = max(0.0, period_us - sum(r['span_us'] + r['gap_before_us'] for r in rows))
     for r in rows:
         r['slot_us'] = r['span_us'] + r['gap_before_us']
-    marks = {k: v[1] / n for k, v in acc.items() if ':' in k}
+    marks = {k: v for k, v in acc.items() if ':' in k}
     for r in rows:
         for k, v in marks.items():
             if k.split(':')[0] == r['kernel']:
-                r[k.split(':')[1] + '_us'] = v           # e.g. chains_end_us: the role's last workgroup, from the kernel's start
+                r[k.split(':')[1] + '_us'] = v[1] / n    # e.g. chains_end_us: the role's last workgroup, from the kernel's start
+                if v[0]:
+                    r[k.split(':')[1].replace('_end', '_last_start') + '_us'] = v[0] / n
     return rows
 
 

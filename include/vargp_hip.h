@@ -395,7 +395,7 @@ int vargp_prof_replay(const char* tag, int iters, double* avg_us, vargp_stream_t
  *   mode 0: copy the table to out[12][2] = (start, end) ticks of 10 ns per slot, 0 = the slot's kernel did not run.
  * Slots: 0 t0_pro_kuu, 1 chol_rbf_gemm (9: end of its last factorisation), 2 gemm_kernel (any plain product: the last one
  * launched), 3 t0_fwd_fused, 4 t0_bwd_mid, 5 t0_bwdmat_gemm (8: end of its last matrix chain), 6 t0_puu_final,
- * 7 yogi_multi.  Synchronous (hipMemcpy to / from device symbols): call between steps, not inside a capture. */
+ * 7 yogi_multi; 10 / 11: end of the Gram / row-norm role of t0_pro_kuu.  Synchronous (hipMemcpy to / from device symbols): call between steps, not inside a capture. */
 int vargp_prof_spans(int mode, unsigned long long* out);
 
 #ifdef __cplusplus

@@ -25,6 +25,7 @@ from vargp_amd.train import ElboTrainer  # noqa: E402
 
 dev = torch.device('cuda', 0)
 ops.set_cholesky_error_mode('defer')
+bench.S = int(os.environ.get('VARGP_BM_S', '3'))      # hyper-samples (8: 640 tile workgroups, 2.5 per CU)
 gp, x, y = bench.make_model(dev)
 tr = ElboTrainer(gp, lr=bench.LR, beta=bench.BETA, n_total=bench.N_TOTAL)
 for _ in range(5):
@@ -47,7 +48,8 @@ if len(sys.argv) > 1 and sys.argv[1] == 'ff':       # t0_fwd_fused_kernel (a -DF
     fn = _lib.lib().vargp_debug_ff_stamps
     fn.restype, fn.argtypes = None, [ctypes.c_void_p]
     fn(out)
-    names = {(0, 1): 'KL loads + sums', (1, 2): 'stage T, G, K_uf tile + barrier', (2, 3): 'P = T K_uf', (3, 4): 'barrier',
+    names = {(0, 1): 'KL loads + sums', (1, 2): 'stage T, G, K_uf tile + barrier', (1, 10): '  all loads issued', (10, 11): '  T in LDS (first wait)',
+             (11, 12): '  G, K_uf tile in LDS', (12, 13): '  KL arithmetic', (13, 2): '  barrier', (2, 3): 'P = T K_uf', (3, 4): 'barrier',
              (4, 5): 'P -> LDS, global; column sums + barrier', (5, 6): 'W = G^T P', (6, 7): 'W out, sums', (7, 8): 'column reductions, mu / var',
              (8, 9): 'KL block sum'}
     v = [list(out)[16 * w:16 * w + 16] for w in range(4)]

@@ -32,6 +32,6 @@ rows = bench.step_timeline(tr.step_graph, period, reps=int(os.environ.get('REPS'
 print('step period %.1f us' % period)
 print('%-18s %9s %9s %9s %9s' % ('kernel', 'start', 'span', 'gap<', 'slot'))
 for r in rows:
-    extra = ' '.join('%s=%.1f' % (k, v) for k, v in r.items() if k.endswith('_end_us'))
+    extra = ' '.join('%s=%.1f' % (k, v) for k, v in r.items() if k.endswith('_end_us') or k.endswith('_last_start_us'))
     print('%-18s %9.2f %9.2f %9.2f %9.2f  %s' % (r['kernel'], r['start_us'], r['span_us'], r['gap_before_us'], r['slot_us'], extra))
 print('sum of spans %.1f us, of gaps %.1f us' % (sum(r['span_us'] for r in rows), sum(r['gap_before_us'] for r in rows)))

@@ -214,7 +214,8 @@ def prof_read(tag):
 
 
 SPAN_SLOTS = {0: 't0_pro_kuu', 1: 'chol_rbf_gemm', 2: 'gemm_kernel', 3: 't0_fwd_fused', 4: 't0_bwd_mid', 5: 't0_bwdmat_gemm',
-              6: 't0_puu_final', 7: 'yogi_multi', 8: 't0_bwdmat_gemm:chains_end', 9: 'chol_rbf_gemm:chains_end'}
+              6: 't0_puu_final', 7: 'yogi_multi', 8: 't0_bwdmat_gemm:chains_end', 9: 'chol_rbf_gemm:chains_end',
+              10: 't0_pro_kuu:gram_end', 11: 't0_pro_kuu:norms_end'}
 
 
 def prof_spans(mode):

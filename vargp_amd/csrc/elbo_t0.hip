@@ -251,7 +251,10 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 #ifdef FF_STAMPS   // tuning builds only: s_memtime of workgroup 0 (lane 0 of each wave) after each phase (tests/native/bm_stamps.py ff)
 __device__ unsigned long long g_ff_stamps[4][16];
 extern "C" void vargp_debug_ff_stamps(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ff_stamps), sizeof(g_ff_stamps)); }
-#define FF_STAMP(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) g_ff_stamps[threadIdx.x >> 6][i] = __builtin_amdgcn_s_memtime(); } while (0)
+#ifndef FF_STAMP_BLOCK
+#define FF_STAMP_BLOCK 0u      // which workgroup stamps (-DFF_STAMP_BLOCK=...: a late one finds the kernel's code in the instruction cache)
+#endif
+#define FF_STAMP(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == (FF_STAMP_BLOCK)) g_ff_stamps[threadIdx.x >> 6][i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define FF_STAMP(i) do { } while (0)
 #endif
@@ -319,6 +322,7 @@ __device__ __forceinline__ void ff_product_w(f32x16_t (&acc)[2], const float* __
   });
 }
 
+template <bool VEC4>
 __global__ __launch_bounds__(256) void t0_fwd_fused_kernel(const float* __restrict__ TT, float* __restrict__ QP,
                                                            const float* __restrict__ RK, float* __restrict__ W,
                                                            const float* __restrict__ kd, const float* __restrict__ Lz,
@@ -357,75 +361,93 @@ __global__ __launch_bounds__(256) void t0_fwd_fused_kernel(const float* __restri
   constexpr int NG_ = kFusedK * 32 / 256;                 // 13
   constexpr int NK_ = (kFusedK * 16 + 255) / 256;         // 7 (the last one partly out of range)
   float4 rt[NT_], rg[NG_], rk[NK_];
+  // (32-bit BYTE offsets from uniform bases, as t0_bwd_common.h: bm_load_mat -- with 64-bit element indices every load carried a
+  // v_mad_i64 chain, and with one wave per SIMD the 45 loads of this front took 10.8k cycles just to ISSUE)
+  const char* Tbb = reinterpret_cast<const char*>(Tb);
+  const char* Qbb = reinterpret_cast<const char*>(Qb);
+  const char* Kbb = reinterpret_cast<const char*>(Kb);
 #pragma unroll
   for (int u = 0; u < NT_; ++u) {
     const int e = tid + 256 * u;
     const int i = e / (kFusedK / 4), k = (e - i * (kFusedK / 4)) * 4;
-    rt[u] = *reinterpret_cast<const float4*>(Tb + (int64_t)min(i, M - 1) * M + min(k, M - 4));
+    const int ic = min(i, M - 1);      // (T is lower triangular: a float4 wholly above the diagonal is not fetched, bm_load_mat<true>)
+    rt[u] = *reinterpret_cast<const float4*>(Tbb + 4u * (__umul24((unsigned)ic, (unsigned)M) + (unsigned)min(k, min(M - 4, ic & ~3))));
   }
 #pragma unroll
   for (int u = 0; u < NG_; ++u) {
     const int e = tid + 256 * u;
     const int k = e >> 5, i = (e & 31) * 4;
-    rg[u] = *reinterpret_cast<const float4*>(Qb + (int64_t)min(k, M - 1) * LD + 4 + min(i, M - 4));
+    const int kc = min(k, M - 1);      // (G = T L_S likewise: G[k][i] = 0 for i > k)
+    rg[u] = *reinterpret_cast<const float4*>(Qbb + 4u * (__umul24((unsigned)kc, (unsigned)LD) + 4u + (unsigned)min(i, min(M - 4, kc & ~3))));
   }
-  {
-    const bool full = n0 + 64 <= B;                         // (uniform) all 64 columns exist: plain float4 loads
+  // K_uf tile.  B % 4 == 0 (VEC4; every BASELINE shape): a float4 lies wholly inside or outside the matrix, so the column is
+  // clamped and the padding selected in when the value is stored -- NO branch: the previous form, `if (full) float4 else
+  // per-element`, left a branch around every one of the seven loads, and the compiler put an s_waitcnt vmcnt(0) at each join:
+  // seven memory round trips in a row, each also waiting for the 26 loads of T and G in front of it (10.5k of this kernel's
+  // 36k cycles went by before the first LDS store).  Other B: the per-element form, in its own instantiation.
 #pragma unroll
-    for (int u = 0; u < NK_; ++u) {
-      const int e = min(tid + 256 * u, kFusedK * 16 - 1);
-      const int k = e >> 4, n = (e & 15) * 4;
-      const float* src = Kb + (int64_t)min(k, M - 1) * LD;
-      if (full) rk[u] = *reinterpret_cast<const float4*>(src + n);
-      else {
-        rk[u].x = n0 + n < B ? src[n] : 0.f;         rk[u].y = n0 + n + 1 < B ? src[n + 1] : 0.f;
-        rk[u].z = n0 + n + 2 < B ? src[n + 2] : 0.f; rk[u].w = n0 + n + 3 < B ? src[n + 3] : 0.f;
-      }
+  for (int u = 0; u < NK_; ++u) {
+    const int e = min(tid + 256 * u, kFusedK * 16 - 1);
+    const int k = e >> 4, n = (e & 15) * 4;
+    const unsigned ro = 4u * __umul24((unsigned)min(k, M - 1), (unsigned)LD);
+    if constexpr (VEC4) {
+      rk[u] = *reinterpret_cast<const float4*>(Kbb + ro + 4u * (unsigned)min(n, B - 4 - n0));
+    } else {
+      const float* src = reinterpret_cast<const float*>(Kbb + ro);
+      rk[u].x = n0 + n < B ? src[n] : 0.f;         rk[u].y = n0 + n + 1 < B ? src[n + 1] : 0.f;
+      rk[u].z = n0 + n + 2 < B ? src[n + 2] : 0.f; rk[u].w = n0 + n + 3 < B ? src[n + 3] : 0.f;
     }
   }
-  const float av = tid < 128 ? Qb[(int64_t)min(tid, M - 1) * LD] : 0.f;
+  const float av = tid < 128 ? *reinterpret_cast<const float*>(Qbb + 4u * __umul24((unsigned)min(tid, M - 1), (unsigned)LD)) : 0.f;
   // ---- KL of q(u) against p(u) for this (s, c) (vargp.py:182-190), its rows shared out over the tile workgroups:
   //      kl[s,c] = sum log diag Lz - sum log diag Lu + (|G2|_F^2 + |a|^2 - M) / 2,   kl_u = (1/S) sum kl[s,c]
   const int c_kl = b % C;
   const int per = (M + ntile - 1) / ntile, i0 = tile_x * per, i1 = min(M, i0 + per);
   const int nkl = max((i1 - i0) * M, 0);
+  const unsigned mdiv = ((1u << 20) + (unsigned)M - 1u) / (unsigned)M;      // (uniform: one scalar division instead of eight per thread)
   float kv[8];                                            // first round of G2 entries (clamped; eight loads in flight per round)
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
     const int e = min(tid + 256 * u, max(nkl - 1, 0));
-    kv[u] = Qb[(int64_t)min(i0 + e / M, M - 1) * LD + 4 + M + e % M];
+    const int ei = (int)(((unsigned)e * mdiv) >> 20);     // e / M (exact: e < 2^11, M <= 104, mdiv = ceil(2^20 / M))
+    kv[u] = *reinterpret_cast<const float*>(Qbb + 4u * (__umul24((unsigned)min(i0 + ei, M - 1), (unsigned)LD) + 4u + (unsigned)M + (unsigned)(e - ei * M)));
   }
   // the diagonal terms: thread t < i1 - i0 takes row i0 + t (rows beyond: clamped loads, masked)
   const int idg = min(i0 + tid, M - 1);
-  const float dga = Qb[(int64_t)idg * LD], dlz = Lz[(b * M + idg) * M + idg], dlu = Lu[((int64_t)c_kl * M + idg) * M + idg];
+  const float dga = *reinterpret_cast<const float*>(Qbb + 4u * __umul24((unsigned)idg, (unsigned)LD));
+  const float dlz = Lz[(b * M + idg) * M + idg], dlu = Lu[((int64_t)c_kl * M + idg) * M + idg];
+  FF_STAMP(10);
   // ---- LDS stores (zero-padded: rows / inner indices >= M, columns >= B)
 #pragma unroll
   for (int u = 0; u < NT_; ++u) {
     const int e = tid + 256 * u;
     const int i = e / (kFusedK / 4), k = (e - i * (kFusedK / 4)) * 4;
-    const bool ok = i < M && k < M;
+    const bool ok = i < M && k < M && k <= i;
     *reinterpret_cast<float4*>(&sT[i * kFusedTS + k]) = ok ? rt[u] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  FF_STAMP(11);
 #pragma unroll
   for (int u = 0; u < NG_; ++u) {
     const int e = tid + 256 * u;
     const int k = e >> 5, i = (e & 31) * 4;
-    *reinterpret_cast<float4*>(&sG[k * kFusedGS + i]) = (k < M && i < M) ? rg[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(&sG[k * kFusedGS + i]) = (k < M && i < M && i <= k) ? rg[u] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 #pragma unroll
   for (int u = 0; u < NK_; ++u) {
     const int e = tid + 256 * u;
     if (e < kFusedK * 16) {
       const int k = e >> 4, n = (e & 15) * 4;
-      *reinterpret_cast<float4*>(&sK[k * kFusedKS + n]) = k < M ? rk[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(&sK[k * kFusedKS + n]) = (k < M && (!VEC4 || n0 + n < B)) ? rk[u] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
+  FF_STAMP(12);
   // ---- KL arithmetic (further rounds of loads only when a workgroup's share exceeds 2048 entries)
   float kl_acc = 0.f;
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
     const int e = tid + 256 * u;
-    const int i = i0 + e / M, j = e % M;
+    const int ei = (int)(((unsigned)e * mdiv) >> 20);
+    const int i = i0 + ei, j = e - ei * M;
     kl_acc = fmaf((e < nkl && j <= i) ? kv[u] : 0.f, kv[u], kl_acc);      // upper entries are stored zeros
   }
   for (int e0 = 8 * 256; e0 < nkl; e0 += 8 * 256) {
@@ -453,6 +475,7 @@ __global__ __launch_bounds__(256) void t0_fwd_fused_kernel(const float* __restri
   }
   if (tid < 128) sa[tid] = tid < M ? av : 0.f;
   if (tid < 192) red[tid] = 0.f;
+  FF_STAMP(13);
   __syncthreads();
   FF_STAMP(2);
   const int cb = wave & 1;
@@ -917,11 +940,18 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
     p.triA = 1;
     rc = launch_gemm(p, 0, 0, SC, false, st, "t0_qps_gemm");
     if (rc) return rc;
-    static std::atomic<unsigned> attr_set_mask[2] = {};      // 64 device ordinals
-    rc = ensure_dynamic_lds(reinterpret_cast<const void*>(t0_fwd_fused_kernel), kFusedLdsBytes, attr_set_mask, "elbo_t0_fwd");
-    if (rc) return rc;
-    hipLaunchKernelGGL(t0_fwd_fused_kernel, dim3(8 * cdiv(SC, 8) * ntile), dim3(256), kFusedLdsBytes, st, o.TT, o.QP, o.RK, o.W, o.kd, o.LL,
-                       o.Lu, o.mu, o.var, d->scalars + 1, S, C, M, B, NR, LD, ntile, native ? d->rng_counter : nullptr);
+    static std::atomic<unsigned> attr_set_mask[2] = {}, attr_set_mask_s[2] = {};      // 64 device ordinals
+    if (B % 4 == 0) {
+      rc = ensure_dynamic_lds(reinterpret_cast<const void*>(t0_fwd_fused_kernel<true>), kFusedLdsBytes, attr_set_mask, "elbo_t0_fwd");
+      if (rc) return rc;
+      hipLaunchKernelGGL(t0_fwd_fused_kernel<true>, dim3(8 * cdiv(SC, 8) * ntile), dim3(256), kFusedLdsBytes, st, o.TT, o.QP, o.RK, o.W, o.kd,
+                         o.LL, o.Lu, o.mu, o.var, d->scalars + 1, S, C, M, B, NR, LD, ntile, native ? d->rng_counter : nullptr);
+    } else {
+      rc = ensure_dynamic_lds(reinterpret_cast<const void*>(t0_fwd_fused_kernel<false>), kFusedLdsBytes, attr_set_mask_s, "elbo_t0_fwd");
+      if (rc) return rc;
+      hipLaunchKernelGGL(t0_fwd_fused_kernel<false>, dim3(8 * cdiv(SC, 8) * ntile), dim3(256), kFusedLdsBytes, st, o.TT, o.QP, o.RK, o.W, o.kd,
+                         o.LL, o.Lu, o.mu, o.var, d->scalars + 1, S, C, M, B, NR, LD, ntile, native ? d->rng_counter : nullptr);
+    }
   } else {
     {  // QP = T RK
       GemmParams p = flat_gemm(o.TT, M, MM, o.RK, LD, MLD, o.QP, LD, MLD, M, NR + B, M);

@@ -1178,7 +1178,10 @@ __global__ __launch_bounds__(256) void t0_pro_kuu_kernel(const ProArgs a, const 
   if (blk >= ngemm) {      // (the other order -- short roles first -- measured 26.9 us against 20.3 us)
     blk -= ngemm;
     if (blk < npro) t0_prologue_body(a, blk, lds);
-    else t0_norm_body(a, nr, blk - npro, lds);
+    else {
+      if (step_span_guard_.p && threadIdx.x == 0) atomicMax(&g_spans_gemm[11][0], wall_clock64());      // (slot 11: LAST start .. last end)
+      t0_norm_body(a, nr, blk - npro, lds); STEP_SPAN_MARK(gemm, 11);
+    }
     return;
   }
   const int per = ngemm / p.splitk;            // tiles * nbatch
@@ -1188,11 +1191,17 @@ __global__ __launch_bounds__(256) void t0_pro_kuu_kernel(const ProArgs a, const 
     const int s = batch / (p.nb2 * p.nb1);
     const int nslab = (p.K + BK - 1) / BK, share = (nslab + p.splitk - 1) / p.splitk;
     const int ks = min(p.K, split * share * BK), ke = min(p.K, (split + 1) * share * BK);
-    for (int k = ks + (int)threadIdx.x; k < ke; k += 256) a.w[s * a.Dp + k] = expf(-2.f * t0_theta_at(a, s, k, false));
+    for (int k0 = ks + (int)threadIdx.x; k0 < ke; k0 += 512) {      // (two entries per thread and round trip: t0_theta_batch)
+      float tb[2];
+      t0_theta_batch<2>(a, s, k0, false, tb);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) if (k0 + 256 * u < ke) a.w[s * a.Dp + k0 + 256 * u] = expf(-2.f * tb[u]);
+    }
     __threadfence_block();
     __syncthreads();
   }
   gemm_body<64, 64, BK, true, true, true, true, true>(p, tile, batch, split, lds);
+  STEP_SPAN_MARK(gemm, 10);
 }
 
 int launch_pro_kuu(const ProArgs& a, int npro, const NormArgs& n, const GemmParams& ps, int nbatch, hipStream_t st) {

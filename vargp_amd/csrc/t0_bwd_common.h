@@ -56,13 +56,20 @@ constexpr int kBmNA = (kBmKP * kBmNQ + 255) / 256;        // float4 per thread o
 // (uniform) base: the load then takes its address as SGPR pair + one VGPR, and the address arithmetic stays 32-bit -- with
 // 64-bit element indices every load carried a v_mad_i64 / v_lshl_add_u64 chain (a third of the instructions in front of the
 // first barrier of t0_bwd_mid_kernel).  A matrix spans far less than 4 GB.
+// TRI: the matrix is lower triangular (T, G): a float4 wholly above the diagonal is not fetched -- its load is pointed at the
+// row's diagonal float4, which is fetched anyway, and the value is dropped when it is stored (bm_store_mat<true>).  The staging
+// fronts are bound by the cache lines a CU can have in flight (10.8k cycles to ISSUE the 45 loads of t0_fwd_fused_kernel's
+// front, whatever the address arithmetic), so lines not asked for are time saved; the instruction count does not change.
+template <bool TRI = false>
 __device__ __forceinline__ void bm_load_mat(const float* __restrict__ base, int ld, int M, int tid, float4 (&dst)[kBmNA]) {
   const char* bp = reinterpret_cast<const char*>(base);
 #pragma unroll
   for (int u = 0; u < kBmNA; ++u) {
     const int e = min(tid + 256 * u, kBmKP * kBmNQ - 1);
     const int i = e / kBmNQ, j = (e - i * kBmNQ) * 4;
-    const unsigned off = 4u * (__umul24((unsigned)min(i, M - 1), (unsigned)ld) + (unsigned)min(j, M - 4));
+    const int ic = min(i, M - 1);
+    const int jc = TRI ? min(j, min(M - 4, ic & ~3)) : min(j, M - 4);
+    const unsigned off = 4u * (__umul24((unsigned)ic, (unsigned)ld) + (unsigned)jc);
     dst[u] = *reinterpret_cast<const float4*>(bp + off);
   }
 }

@@ -219,12 +219,13 @@ __device__ __forceinline__ void bm_store_tile(float* __restrict__ dst, const flo
 }
 
 // registers -> LDS [i][j] (stride kBmSA), rows / columns >= M zero
+template <bool TRI = false>
 __device__ __forceinline__ void bm_store_mat(float* __restrict__ dst, const float4 (&src)[kBmNA], int M, int tid) {
 #pragma unroll
   for (int u = 0; u < kBmNA; ++u) {
     const int e = tid + 256 * u;
     const int i = e / kBmNQ, j = (e - i * kBmNQ) * 4;
-    const float4 v = (i < M && j < M) ? src[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 v = (i < M && j < M && (!TRI || j <= i)) ? src[u] : make_float4(0.f, 0.f, 0.f, 0.f);
     if (e < kBmKP * kBmNQ) *reinterpret_cast<float4*>(&dst[i * kBmSA + j]) = v;
   }
 }
@@ -293,14 +294,14 @@ __global__ __launch_bounds__(256) void t0_bwd_mid_kernel(const float* __restrict
   }
   //      G, the P and W tiles now; T and the K_uf tile stay in registers until the first two products are done
   float4 rg[NA_], rp[NT_], rw[NT_], rt[NA_], rk[NT_];
-  bm_load_mat(Qb + 4, LD, M, tid, rg);
+  bm_load_mat<true>(Qb + 4, LD, M, tid, rg);          // G = T L_S: lower triangular
   bm_load_tile(Qb + NR, LD, M, n0, B, tid, rp);
   bm_load_tile(Wb, B, M, n0, B, tid, rw);
   const float av = tid < 128 ? Qb[(int64_t)min(tid, M - 1) * LD] : 0.f;
   const int ncl = min(n0 + (tid & 63), B - 1);
   float gmv = 0.f, gvv = 0.f;
   if (!sm.eps) { gmv = gmu[b * B + ncl]; gvv = gvar[b * B + ncl]; }
-  bm_load_mat(Tb, M, M, tid, rt);
+  bm_load_mat<true>(Tb, M, M, tid, rt);
   bm_load_tile(Kb, LD, M, n0, B, tid, rk);
   BM_STAMP(13);
   if (sm.eps) {
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(256) void t0_bwd_mid_kernel(const float* __restrict
 
   BM_STAMP(1);
   // ---- phase 0: G, P, W, a, gmu, gvar into LDS ------------------------------------------------------------------------------
-  bm_store_mat(sA, rg, M, tid);
+  bm_store_mat<true>(sA, rg, M, tid);
   bm_store_tile(sP, rp, M, n0, B, tid);
   bm_store_tile(sW, rw, M, n0, B, tid);
   if (tid < 128) sa[tid] = tid < M ? av : 0.f;
@@ -462,7 +463,7 @@ __global__ __launch_bounds__(256) void t0_bwd_mid_kernel(const float* __restrict
       const int m = 32 * rbs[u] + (r & 3) + 8 * (r >> 2) + 4 * lh;
       if (m < kBmKP) sP[m * kBmST + 32 * cbh + li] = m < M ? accP[u][r] : 0.f;
     }
-  bm_store_mat(sA, rt, M, tid);
+  bm_store_mat<true>(sA, rt, M, tid);
   bm_store_tile(sW, rk, M, n0, B, tid);
   __syncthreads();
   BM_STAMP(7);

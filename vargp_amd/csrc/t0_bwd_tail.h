@@ -187,12 +187,6 @@ __global__ __launch_bounds__(256, 2) void t0_puu_final_kernel(const TailArgs a, 
   const int64_t zrows = (int64_t)a.C * M;
   const float* zc = a.z + (int64_t)c * M * D;
   TAIL_STAMP(0);
-  // --- r_uu + r_uf of the block's 32 rows, every sample -> LDS (this wave's slice) --------------------------------------------
-  for (int e = lane; e < 32 * (S == 0 ? a.S : S); e += 64) {
-    const int s = e >> 5, row = min(r0 + (e & 31), M - 1);
-    const int64_t sr = (int64_t)s * zrows + (int64_t)c * M + row;
-    rsl[wave][s][e & 31] = a.r_uu[sr] + a.r_uf[sr];
-  }
   // --- this lane's 16 output positions: rows rbase + 8 (r / 4) + r % 4, column d -------------------------------------------
   const int d = d0 + li;
   const bool dok = d < D;
@@ -222,6 +216,14 @@ __global__ __launch_bounds__(256, 2) void t0_puu_final_kernel(const TailArgs a, 
     const int64_t ro = (int64_t)min(rowof(r), M - 1) * D;
     p2[r] = pufp[ro];
     ga[r] = 0.f;
+  }
+  // --- r_uu + r_uf of the block's 32 rows, every sample -> LDS (this wave's slice).  BEHIND the fragment loads: as the first
+  // thing in the kernel its load -> add -> LDS-store iterations were two memory round trips before any other load was issued;
+  // the sums are only needed by the first sample's epilogue, after the first MFMA group.
+  for (int e = lane; e < 32 * (S == 0 ? a.S : S); e += 64) {
+    const int s = e >> 5, row = min(r0 + (e & 31), M - 1);
+    const int64_t sr = (int64_t)s * zrows + (int64_t)c * M + row;
+    rsl[wave][s][e & 31] = a.r_uu[sr] + a.r_uf[sr];
   }
   TAIL_STAMP(1);
 

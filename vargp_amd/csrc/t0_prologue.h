@@ -43,6 +43,40 @@ __device__ __forceinline__ float t0_theta_at(const ProArgs& a, int s, int d, boo
   return a.mean[d] + e * expf(0.5f * a.logvar[d]);
 }
 
+// The same for U entries d0, d0 + 256, ... of one thread, every load of the batch issued BEFORE the first use (entries past D are
+// clamped and come out as theta[D]; the caller masks).  t0_theta_at in a loop is one memory round trip per iteration -- the
+// loads sit behind the map_est / native branches -- and every workgroup of the front launch that needs 1 / sigma^2 paid two to
+// four of them before its own loads could start (t0_pro_kuu_kernel: 20 us of which the product is 7).
+template <int U>
+__device__ __forceinline__ void t0_theta_batch(const ProArgs& a, int s, int d0, bool keep, float (&out)[U]) {
+  const int D1 = a.D + 1;
+  float mv[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) mv[u] = a.mean[min(d0 + 256 * u, a.D)];
+  if (a.map_est) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) out[u] = mv[u];
+    return;
+  }
+  float lv[U], ev[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) lv[u] = a.logvar[min(d0 + 256 * u, a.D)];
+  if (a.native) {
+    const uint32_t step = a.rng_counter[0];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int d = min(d0 + 256 * u, a.D);
+      ev[u] = normal1(a.seed, kStreamTheta, (uint64_t)(a.g0_theta + (int64_t)s * D1 + d), step);
+      if (keep && d0 + 256 * u < D1) a.eps_theta_out[s * D1 + d] = ev[u];
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < U; ++u) ev[u] = a.eps_theta[s * D1 + min(d0 + 256 * u, a.D)];
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) out[u] = mv[u] + ev[u] * expf(0.5f * lv[u]);
+}
+
 // Multi-role prologue, role by block index:
 //   block 0            kl_hypers (kernels.py:70-77) -> scalars[0]; scalars[1..2] = 0 (kl_u, nll accumulate); info = 0;
 //                      *bump += 1 if the caller asked for it
@@ -70,17 +104,20 @@ __device__ __forceinline__ void t0_prologue_body(const ProArgs& a, const int blk
   }
   if (blk <= a.S) {
     const int s = blk - 1;
-    for (int d = tid; d < D1 || d < a.Dp; d += 256) {
-      float t = 0.f;
-      if (d < D1) {
-        t = t0_theta_at(a, s, d, true);
-        a.theta[s * D1 + d] = t;
-      }
-      if (d < a.Dp) a.w[s * a.Dp + d] = d < a.D ? expf(-2.f * t) : 0.f;
-      if (d == a.D) {
-        const float g = expf(2.f * t);
-        a.g2[s] = g;
-        for (int c = 0; c < a.C; ++c) a.kd[s * a.C + c] = g;
+    for (int d0 = tid; d0 < D1 || d0 < a.Dp; d0 += 1024) {      // four entries per thread and round trip
+      float tb[4];
+      t0_theta_batch<4>(a, s, d0, true, tb);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int d = d0 + 256 * u;
+        const float t = d < D1 ? tb[u] : 0.f;
+        if (d < D1) a.theta[s * D1 + d] = t;
+        if (d < a.Dp) a.w[s * a.Dp + d] = d < a.D ? expf(-2.f * t) : 0.f;
+        if (d == a.D) {
+          const float g = expf(2.f * t);
+          a.g2[s] = g;
+          for (int c = 0; c < a.C; ++c) a.kd[s * a.C + c] = g;
+        }
       }
     }
     return;
@@ -173,7 +210,12 @@ struct NormArgs {
 __device__ __forceinline__ void t0_norm_body(const ProArgs& a, const NormArgs& n, const int id, float* __restrict__ wl) {
   const int s = id / n.nrow_blocks, rb = id - s * n.nrow_blocks;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int d = tid; d < a.D; d += 256) wl[d] = expf(-2.f * t0_theta_at(a, s, d, false));
+  for (int d0 = tid; d0 < a.D; d0 += 1024) {
+    float tb[4];
+    t0_theta_batch<4>(a, s, d0, false, tb);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (d0 + 256 * u < a.D) wl[d0 + 256 * u] = expf(-2.f * tb[u]);
+  }
   __syncthreads();
   // the wave's rows (wave, wave + 4, ...) four at a time, all their loads in flight together
   const int64_t nrows = n.zrows + n.xrows, last = nrows - 1;
