@@ -110,18 +110,19 @@ __global__ __launch_bounds__(256) void rbf_prep_norm_kernel(const float* __restr
   const float* xr = isx ? x + row * D : y + (row - xrows) * D;
   float* yo = isx ? (xs ? xs + ((int64_t)s * xrows + row) * D : nullptr)
                   : (ys ? ys + ((int64_t)s * yrows + (row - xrows)) * D : nullptr);
-  // four 64-wide chunks per batch, their loads first (clamped index), then the stores: a plain load / store loop is
-  // D / 64 memory round trips in a row (a load behind a store waits for the store as well)
+  // sixteen 64-wide chunks per pass, ALL their loads first (clamped index), then the arithmetic and the stores: D = 784 is one
+  // pass -- one memory round trip for the row instead of D / 256 with a store's acknowledgement in front of every next load
+  // (vmcnt retires in order)
   float acc0 = 0.f, acc1 = 0.f;
-  for (int d0 = 0; d0 < D; d0 += 256) {
-    float xv[4], tv[4];
+  for (int d0 = 0; d0 < D; d0 += 1024) {
+    float xv[16], tv[16];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 16; ++q) {
       const int d = min(d0 + 64 * q + lane, D - 1);
       xv[q] = xr[d]; tv[q] = th[d];
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 16; ++q) {
       const int d = d0 + 64 * q + lane;
       const float wv = expf(-2.f * tv[q]);
       const float v = d < D ? xv[q] : 0.f;
