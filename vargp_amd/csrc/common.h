@@ -211,6 +211,10 @@ int chol_inv_fwd_impl(const float* A, float eps, float* L, float* T, float* logd
 int launch_chol_rbf_gemm_ld(const float* A, int lda, int64_t sA, float eps, float* L, int ldl, int64_t sL, float* T, int ldt,
                             int64_t sT, int32_t* info, int nchol, int n, const GemmParams& p, int nbatch, hipStream_t st,
                             bool chain_f32 = false);
+// pivot chains of nchol diagonal blocks (fp64, info_base as the stand-alone kernel) || a plain NN product they do not feed
+bool chol_nn_gemm_applicable(int n, const GemmParams& p);
+int launch_chol_nn_gemm(const float* A, int lda, int64_t sA, float eps, float* L, int ldl, int64_t sL, float* T, int ldt, int64_t sT,
+                        int32_t* info, int info_base, int nchol, int n, const GemmParams& p, int nbatch, hipStream_t st);
 // w = exp(-2 theta) (zero-padded to Dp), g2 = exp(2 theta_D) and the weighted squared row norms of x (xrows x D) and of
 // y (yrows x D, may be 0 rows) for every hyper-sample, in one launch
 // ys / xs (nullable): also write y o w, [S][yrows][D], and x o w, [S][xrows][D] (the pre-scaled operand of an unscaled RBF

@@ -1117,6 +1117,22 @@ extern "C" void vargp_debug_chol_phases(unsigned long long* out, int last) {
 }
 #endif
 
+// Stand-alone blocked factorisation (chol.hip): the pivot chains of one diagonal block (one workgroup per matrix: TEN of the 256
+// CUs at BASELINE config 5) next to a plain NN product that does not depend on them -- block row K of T = L^-1 to the LEFT of
+// the outer block, B1 = L[K, 0:K0] T[0:K0, 0:K0], which only needs earlier panels.  fp64 chains (R) with the caller's
+// info_base, exactly as chol_inv_small3_kernel; 64 x 64 x 64 tiles as gemm_kernel.
+template <int KC, int SETS, class R>
+__global__ __launch_bounds__(256) void chol_nn_gemm_kernel(const CholArgs c, const GemmParams p, const int tiles, const int info_base) {
+  __shared__ __attribute__((aligned(16))) float lds[cmax(gemm_lds_floats<64, 64, 64, true, false>(), chol3_stage_floats<KC>())];
+  if ((int)blockIdx.x < c.nchol) {
+    chol3_body<KC, SETS, R>(blockIdx.x, c.A, c.lda, c.sA, c.eps, c.L, c.ldl, c.sL, c.T, c.ldt, c.sT, nullptr, c.info, info_base, c.n,
+                            0, lds, nullptr);
+    return;
+  }
+  const int id = xcd_remap((int)blockIdx.x - c.nchol, (int)gridDim.x - c.nchol);
+  gemm_body<64, 64, 64, true, false, true, false>(p, id % tiles, id / tiles, 0, lds);
+}
+
 // One launch, two independent roles (like chol_rbf_gemm_kernel in the forward): workgroups [0, nmat) walk the chain of
 // M x M products of one matrix of the first-task backward (t0_bwd_mat.h: ~20 us on nmat CUs), the others are 64 x 64 tiles of a
 // plain NN product the chain does not feed (P_uf = W_uf x next to the K_uu matrices, P_uu = W_uu z next to the S_u ones).
@@ -1376,6 +1392,23 @@ int launch_chol_rbf_gemm_ld(const float* A, int lda, int64_t sA, float eps, floa
   { if (n <= 64) VARGP_MERGED(16, 1, double); else VARGP_MERGED(25, 2, double); }
 #undef VARGP_MERGED
   return check_launch("chol_rbf_gemm");
+}
+
+// chains of nchol diagonal blocks (n in (50, 100], fp64) || the plain NN product p over nbatch matrices (see chol_nn_gemm_kernel)
+bool chol_nn_gemm_applicable(int n, const GemmParams& p) {
+  return n > 50 && n <= 100 && gemm_vec_ok(p) && p.splitk <= 1 && p.M > 0 && p.N > 0 && p.K > 0;
+}
+int launch_chol_nn_gemm(const float* A, int lda, int64_t sA, float eps, float* L, int ldl, int64_t sL, float* T, int ldt, int64_t sT,
+                        int32_t* info, int info_base, int nchol, int n, const GemmParams& p, int nbatch, hipStream_t st) {
+  ProfScope prof("chol_nn_gemm", st);
+  CholArgs c{A, lda, sA, eps, L, ldl, sL, T, ldt, sT, info, n, nchol, CholExtra{}, ZeroJobs{}, 0};
+  GemmParams q = p;
+  q.splitk = 1; q.nofast = 0; q.group_m = 0; q.xcd_remap = 1;
+  const int tiles = cdiv(p.M, 64) * cdiv(p.N, 64);
+  const int total = nchol + tiles * nbatch;
+  if (n <= 64) hipLaunchKernelGGL((chol_nn_gemm_kernel<16, 1, double>), dim3(total), dim3(256), 0, st, c, q, tiles, info_base);
+  else hipLaunchKernelGGL((chol_nn_gemm_kernel<25, 2, double>), dim3(total), dim3(256), 0, st, c, q, tiles, info_base);
+  return check_launch("chol_nn_gemm");
 }
 
 // two plain products with their own transposition flags in one launch; the layout pairs the ELBO program uses are
