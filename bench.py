@@ -17,10 +17,14 @@ M=100, D=784, B=512, synthetic data resident in HBM.  One step = zero_grad + VAR
 `secondary` object: short runs of the other BASELINE configs (Cfg3 Permuted-MNIST tasks 0 / 1 / 4 / 9, Split-MNIST task 1,
 Cfg4's 64 samples on one GPU = the base of the multi-GPU curve, Cfg5 stress sweep), each with ms_per_step, roofline.frac
 and elbo_rtol_vs_cpu (`--no-secondary` skips them).
-N>1 (default): BASELINE config 4 as north_star states it — a FIXED total of 64 hyper-samples x 10 classes split over the N
-ranks (`smnist_s64`, STRONG scaling, uneven shards if 64 % N != 0), `value` = global ELBO steps / s; its N=1 base is
-`secondary.smnist_s64` of the N=1 line.  `--scaling weak` instead gives every rank its own 3 samples of a 3N-sample step
-(`value` = global steps / s of that growing step; nothing is multiplied by the world size).
+N>1 (default, `scaling: "weak"`): every rank evaluates the metric's own config-2 ELBO + gradient on ITS OWN 3 hyper-samples
+(same minibatch, rank-sliced global noise), ONE exchange sums the flat [grads | kl_u | nll] buffer, every rank takes the same Yogi
+step: an optimizer step over 3N hyper-samples.  The unit of the N=1 line is one ELBO + gradient over 3 hyper-samples x 10 classes;
+an N-rank step processes N of them, so `value` = N x optimizer steps / s (`optimizer_steps_per_s` is in the line as well), directly
+comparable with the N=1 line.  The same line's `secondary` carries BASELINE config 4 as north_star states it -- a FIXED total of 64
+hyper-samples x 10 classes split over the N ranks (`smnist_s64`, STRONG scaling, uneven shards if 64 % N != 0; value = global
+steps / s, base = `secondary.smnist_s64` of the N=1 line) -- and config 2's 30 (sample, class) problems class-sharded over the
+ranks (`smnist_pairs`).  `--scaling strong` makes config 4 the headline of the N>1 line instead.
 Prints ONE JSON line (rank 0).
 """
 import argparse
@@ -583,7 +587,8 @@ def run_workload(name, args, device, world, rank, use_dist, steps, warmup, prima
     sync()
     _lib.prof_remember(False)
     kernels = {}
-    share = trainer.w_h if pairs else 1.0                  # (class-sharded: this rank's part of the S x C problems)
+    # (config 2 over several ranks: this rank's part of the S x C problems -- a class range, or whole samples when world <= S)
+    share = ((trainer.rect[1] - trainer.rect[0]) * (trainer.rect[3] - trainer.rect[2]) / float(S * C)) if pairs else 1.0
     flops_kuf = share * 2.0 * S * C * M * (N_PREV + 1) * B * D     # one K_uf launch of compute_pf_diag
     Mt = M * (N_PREV + 1)
     if not block_prog:
@@ -664,7 +669,10 @@ def run_workload(name, args, device, world, rank, use_dist, steps, warmup, prima
     errs = ops.linalg_error_count()
     res = None
     if rank == 0:
-        value = steps / dt                         # GLOBAL steps per second (strong and weak alike)
+        # strong / class-sharded: GLOBAL steps per second of the fixed job.  weak: every rank processes one config-2-sized ELBO +
+        # gradient (its own S hyper-samples) per step -- the units all ranks processed per second
+        opt_steps = steps / dt
+        value = opt_steps * world if weak_multi else opt_steps
         avg_s = kern_us * 1e-6
         achieved = dominant_flops / avg_s / 1e12 if kern_us == kern_us and kern_us > 0 else None
         cfg2 = name == 'smnist'
@@ -673,12 +681,13 @@ def run_workload(name, args, device, world, rank, use_dist, steps, warmup, prima
         elif strong:
             unit = 'ELBO steps/s (global steps of the %d-sample ELBO)' % s_total
         elif weak_multi:
-            unit = 'ELBO steps/s (global steps of a %d-sample ELBO: %d hyper-samples per GPU)' % (S * world, S)
+            unit = ('ELBO steps/s (ELBO + gradient evaluations over %d hyper-samples x %d classes, summed over the %d ranks: '
+                    '%d x the optimizer steps/s of the %d-sample step)' % (S, C, world, world, S * world))
         else:
             unit = 'ELBO steps/s (%s step: S=%d hyper-samples)' % ('Cfg2' if cfg2 else name, S)
         res = dict(metric='ELBO steps/sec', value=value, unit=unit,
                    n_gpus=world, steps=steps, warmup=warmup, ms_per_step=1e3 * dt / steps,
-                   ms_per_step_median=median_ms,
+                   ms_per_step_median=median_ms, optimizer_steps_per_s=opt_steps,
                    higher_is_better=True, scaling='strong' if (strong or pairs) and world > 1 else 'weak', vs_baseline=None,
                    dtype='f32', data='synthetic',
                    config=dict(workload=WORKLOADS[name]['desc'], S_per_gpu=counts if strong else (None if pairs else S), Mt=M * (N_PREV + 1),
@@ -687,13 +696,13 @@ def run_workload(name, args, device, world, rank, use_dist, steps, warmup, prima
                                                              else ([c / float(s_total) for c in counts] if strong else None)),
                                optimizer='yogi', parallelism=(f'(sample, class)-parallel x{world}' if pairs else f'sample-parallel x{world}'),
                                steps_per_graph_launch=unroll,
-                               launch=('hipGraph replay' + ((' (3 graphs around the all-gather and the all-reduce)' if pairs else ' (2 graphs around the all-reduce)') if use_dist else '')) if use_graph
+                               launch=('hipGraph replay' + ((' (3 graphs around the all-gather and the all-reduce)' if (pairs and trainer.class_split) else ' (2 graphs around the all-reduce)') if use_dist else '')) if use_graph
                                else 'eager'),
                    elbo_rtol_vs_cpu=rtol, elbo_rtol_checked_on=rtol_on, finite=bool(finite), cholesky_failures=errs,
                    ranks_seen=seen, comm=args.comm if use_dist else None,
                    allreduce_us=comm_us, allreduce_us_isolated=comm_iso_us,
                    allreduce_bytes=trainer.flat.numel() * 4 if use_dist else None,
-                   allgather_bytes=(trainer.max_pairs * 2 * B * 4 * world) if pairs else None,
+                   allgather_bytes=(trainer.max_pairs * 2 * B * 4 * world) if (pairs and trainer.class_split) else None,
                    final_loss=dict(kl_hypers=final_loss[0], kl_u=final_loss[1], nll=final_loss[2]),
                    roofline=dict(bound='mfma', kernel=dominant_desc,
                                  achieved=achieved, peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
@@ -827,7 +836,7 @@ def dry_run(args, world, rank, local):
         ok = True
     if rank == 0:
         print(json.dumps(dict(dry_run=True, ok=ok, n_gpus=world, ranks_seen=seen, backend=backend, comm=args.comm,
-                              workload=args.workload or ('smnist' if world == 1 or args.scaling == 'weak' else 'smnist_s64'),
+                              workload=args.workload or ('smnist_s64' if world > 1 and args.scaling == 'strong' else 'smnist'),
                               devices_visible=n_dev)))
     if world > 1:
         dist.destroy_process_group()
@@ -842,10 +851,10 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eager', action='store_true', help='do not replay the step from a captured hipGraph')
     ap.add_argument('--workload', default=None, choices=sorted(WORKLOADS) + ['stress'],
-                    help='default: the BASELINE metric workload (Cfg2) on one GPU, BASELINE config 4 (smnist_s64, a fixed 64 '
-                         'samples split over the ranks) on several; the others are secondary measurements')
+                    help='default: the BASELINE metric workload (Cfg2), 3 hyper-samples per GPU; the others are secondary '
+                         'measurements (several GPUs: smnist_s64 = BASELINE config 4, a fixed 64 samples split over the ranks)')
     ap.add_argument('--scaling', default=None, choices=['strong', 'weak'],
-                    help='several GPUs only: strong (default) = smnist_s64; weak = Cfg2 with 3 hyper-samples per rank')
+                    help='several GPUs only: weak (default) = Cfg2 with 3 hyper-samples per rank; strong = smnist_s64 (Cfg4) as the headline')
     ap.add_argument('--no-secondary', action='store_true',
                     help='one GPU, default workload: skip the short runs of the other BASELINE configs (`secondary`)')
     ap.add_argument('--secondary-budget', type=float, default=240.0,
@@ -876,7 +885,7 @@ def main():
         dry_run(args, world, rank, local)        # does not return
     default_line = args.workload is None
     if args.workload is None:
-        args.workload = 'smnist' if (world == 1 or args.scaling == 'weak') else 'smnist_s64'
+        args.workload = 'smnist_s64' if (world > 1 and args.scaling == 'strong') else 'smnist'
     # VARGP_BENCH_ONE_GPU=1 (smoke test on a one-GPU box): all ranks share GPU 0 and gloo carries the exchanges -- the whole
     # multi-rank path of this file (uneven shards, class-sharded secondary, two / three graphs) without a multi-GPU node
     one_gpu = os.environ.get('VARGP_BENCH_ONE_GPU', '0') == '1'
@@ -908,21 +917,27 @@ def main():
             sys.stdout.flush()
         raise
     if world > 1 and default_line and not args.no_secondary and os.environ.get('VARGP_BENCH_PAIRS', '1') != '0':
-        # several GPUs: besides BASELINE config 4 (64 samples: whole samples per rank), the METRIC's own config 2 -- 3 samples x 10
-        # classes -- over the same ranks: class-sharded when there are more ranks than samples (train.split_pairs).  Every rank runs
-        # it; a failure is reported inside the line, the headline stays.
-        try:
-            r2 = run_workload('smnist_pairs', args, device, world, rank, use_dist, max(20, min(args.steps, 100)), 5, primary=False,
-                              kern_n=20)
-            if rank == 0:
-                keep = ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'scaling', 'elbo_rtol_vs_cpu', 'finite', 'cholesky_failures',
-                        'allreduce_us', 'allreduce_bytes', 'allgather_bytes', 'ranks_seen')
-                res['secondary'] = dict(smnist_pairs=dict({k: r2[k] for k in keep if k in r2}, workload=r2['config']['workload'],
-                                                          shards=r2['config']['shards'], shard_weights=r2['config']['shard_weights'],
-                                                          launch=r2['config']['launch']))
-        except Exception as e:
-            if rank == 0:
-                res['secondary'] = dict(smnist_pairs=dict(error=f'{type(e).__name__}: {e}'[:300]))
+        # several GPUs, besides the headline: (1) BASELINE config 4 as north_star states it -- a FIXED 64 hyper-samples x 10 classes,
+        # whole samples per rank (strong scaling; skipped when it IS the headline); (2) the metric's config 2 -- 3 samples x 10
+        # classes -- class-sharded over the same ranks (train.split_pairs).  Every rank runs them; a failure is reported inside the
+        # line, the headline stays.
+        keep = ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'scaling', 'elbo_rtol_vs_cpu', 'finite', 'cholesky_failures',
+                'allreduce_us', 'allreduce_us_isolated', 'allreduce_bytes', 'allgather_bytes', 'ranks_seen', 'step_frac')
+        sec = {}
+        for wname in (['smnist_s64'] if args.workload != 'smnist_s64' else []) + ['smnist_pairs']:
+            try:
+                r2 = run_workload(wname, args, device, world, rank, use_dist, max(20, min(args.steps, 100)), 5, primary=False,
+                                  kern_n=20)
+                if rank == 0:
+                    sec[wname] = dict({k: r2[k] for k in keep if k in r2}, workload=r2['config']['workload'],
+                                      S_per_gpu=r2['config']['S_per_gpu'], shards=r2['config']['shards'],
+                                      shard_weights=r2['config']['shard_weights'], launch=r2['config']['launch'])
+            except Exception as e:
+                if rank == 0:
+                    sec[wname] = dict(error=f'{type(e).__name__}: {e}'[:300])
+                torch.cuda.empty_cache()
+        if rank == 0:
+            res['secondary'] = sec
     if rank == 0 and world == 1 and default_line and not args.no_secondary and not use_dist:
         # short, driver-timed runs of the other BASELINE configs in the same line (their own step counts are stated)
         t_start = time.perf_counter()

@@ -193,7 +193,7 @@ def test_bench_self_launch_dry_run():
     assert len(lines) == 1, r.stdout
     line = json.loads(lines[0])
     assert line['dry_run'] and line['ok'] and line['n_gpus'] == 2 and line['ranks_seen'] == [0, 1]
-    assert line['comm'] == 'rsag' and line['workload'] == 'smnist_s64'
+    assert line['comm'] == 'rsag' and line['workload'] == 'smnist'
     # a WORLD_SIZE that contradicts --gpus is an error message and a non-zero exit code, not an assertion trace
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run'],
                        env=dict(env, RANK='0', WORLD_SIZE='1'), capture_output=True, text=True, timeout=120)
