@@ -243,23 +243,19 @@ static int launch_small(const float* A, int lda, int64_t sA, float eps, float* L
   return check_launch("chol_inv_small");
 }
 
-// Prologue of the blocked path in one pass, by nb x nb block (nb = panel width):
-//   blocks on / below the diagonal: W[b] = A[b] + eps I -- the factorisation never reads above the diagonal blocks, and
-//       everything of L and T there is written later (diagonal blocks by the pivot-chain kernel incl. their zeros, the
-//       rest by the panel products);
-//   blocks above the diagonal: L[b] = 0, T[b] = 0 -- the products that read the factors clip K per TILE, so the zeros
-//       next to the diagonal blocks must be real zeros.
-// Half the traffic of copying and zero-filling everything.
-__global__ void chol_prep_kernel(const float* __restrict__ A, float* __restrict__ W, float* __restrict__ L,
-                                 float* __restrict__ T, int n, float eps, int nb) {
+// Prologue of the blocked path, by nb x nb block (nb = panel width): blocks above the diagonal, L[b] = 0, T[b] = 0 -- the
+// products that read the factors clip K per TILE, so the zeros next to the diagonal blocks must be real zeros.  Everything of
+// L and T on / below the block diagonal is written later (diagonal blocks by the pivot-chain kernel incl. their zeros, the
+// rest by the panel products).  There is no working COPY of A any more (round 5: it was a pass over the whole matrix, 128 us of
+// the 2.3 ms at n = 2048 x 10): block column 0 is read from A itself, and the first update of every other region of the
+// trailing matrix reads A and writes the workspace W (D = A, C = W); the jitter is added by the pivot-chain kernels.
+__global__ void chol_zero_upper_kernel(float* __restrict__ L, float* __restrict__ T, int n, int nb) {
   const int64_t b = blockIdx.y;
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (int64_t)n * n) return;
   const int i = e / n, j = e % n;
-  const int64_t o = b * n * n + e;
-  if (j / nb <= i / nb) {
-    W[o] = A[o] + (i == j ? eps : 0.f);
-  } else {
+  if (j / nb > i / nb) {
+    const int64_t o = b * n * n + e;
     L[o] = 0.f;
     if (T) T[o] = 0.f;
   }
@@ -348,7 +344,18 @@ int vargp::chol_inv_fwd_impl(const float* A, float eps, float* L, float* T, floa
   const int NB2 = outer_panel_width(n, kNbSmall);       // == kNbSmall: one level
   const int64_t stmp = (int64_t)n * NB2;
   float* Tout = T;
-  hipLaunchKernelGGL(chol_prep_kernel, dim3(cdiv(nn, 256), nbatch), dim3(256), 0, st, A, W, L, Tout, n, eps, kNbSmall);
+  // zeros above the block diagonal of L and T: a third role of the FIRST pivot-chain launch (which leaves most of the chip idle)
+  // when that launch has roles; else the plain kernel
+  ZeroJobs zj{};
+  zj.j[0] = ZeroJob{L, (int64_t)nbatch * n, n, n, n, kNbSmall};
+  if (Tout) zj.j[1] = ZeroJob{Tout, (int64_t)nbatch * n, n, n, n, kNbSmall};
+  static const int zrole_env = [] { const char* e = getenv("VARGP_CHOL_ZERO_ROLE"); return e ? atoi(e) : 1; }();   // tuning aid
+  const int kb0 = kNbSmall < n ? kNbSmall : n;
+  const bool co0 = nco > 0 && Tout && !logdet && info && chol_rbf_gemm_applicable(kb0, co[0]) && co_gemm_is_comparable(co[0], co_nbatch);
+  const GemmParams none{};
+  const bool zero_in_chain = zrole_env && Tout && info && !logdet && (co0 || (kb0 > 50 && kb0 <= 100));
+  if (!zero_in_chain)
+    hipLaunchKernelGGL(chol_zero_upper_kernel, dim3(cdiv(nn, 256), nbatch), dim3(256), 0, st, L, Tout, n, kNbSmall);
   int rc = VARGP_OK;
   // batched product on sub-blocks of the [nbatch, n, n] buffers (ld n, batch stride nn) or of tmp (ld ldtmp, stride stmp)
   auto mk = [&](const float* A_, int lda, const float* B_, int ldb, float* C_, int ldc, const float* D_, float alpha, float beta,
@@ -410,29 +417,37 @@ int vargp::chol_inv_fwd_impl(const float* A, float eps, float* L, float* T, floa
       const int ldt = Tout ? n : kb;
       const int64_t sT = Tout ? nn : stmp;
       const int kpanel = k0 / kNbSmall;
+      // block column 0 has seen no update: it is read from A itself; the first update of a region of the trailing matrix
+      // reads A and writes W (`first`: nothing has touched W[k1:, k1:] yet)
+      const float* Wk = k0 == 0 ? A : W;
+      const bool first = k0 == 0;
       if (kpanel < nco && Tout && !logdet && info && chol_rbf_gemm_applicable(kb, co[kpanel]) &&
           co_gemm_is_comparable(co[kpanel], co_nbatch)) {
         // (chol3_body reports a failing pivot as info_base + j + 1; the merged kernel has no info_base: only the first
         // panel's index is exact, later panels report the index within the panel -- non-zero is what callers test)
-        rc = launch_chol_rbf_gemm_ld(W + dkk, n, nn, 0.f, L + dkk, n, nn, Tkk, ldt, sT, info, nbatch, kb, co[kpanel], co_nbatch, st, chain_f32);
+        rc = launch_chol_rbf_gemm_ld(Wk + dkk, n, nn, eps, L + dkk, n, nn, Tkk, ldt, sT, info, nbatch, kb, co[kpanel], co_nbatch, st, chain_f32,
+                                     (k0 == 0 && zero_in_chain) ? &zj : nullptr);
         ++ndone;
       } else {
-        if (la && pend_i < pend.size() && chol_nn_gemm_applicable(kb, pend[pend_i])) {
-          rc = launch_chol_nn_gemm(W + dkk, n, nn, 0.f, L + dkk, n, nn, Tkk, ldt, sT, info, k0, nbatch, kb, pend[pend_i], nbatch, st);
+        if (k0 == 0 && zero_in_chain) {       // first block, nothing to take along but the zero-fills
+          rc = launch_chol_nn_gemm(Wk + dkk, n, nn, eps, L + dkk, n, nn, Tkk, ldt, sT, info, k0, nbatch, kb, none, 0, st, &zj);
+        } else if (la && pend_i < pend.size() && chol_nn_gemm_applicable(kb, pend[pend_i])) {
+          rc = launch_chol_nn_gemm(Wk + dkk, n, nn, eps, L + dkk, n, nn, Tkk, ldt, sT, info, k0, nbatch, kb, pend[pend_i], nbatch, st);
           ++pend_i;
         } else {
-          rc = launch_small(W + dkk, n, nn, 0.f, L + dkk, n, nn, Tkk, ldt, sT, logdet, info, k0, nbatch, kb, k0 > 0, st);
+          rc = launch_small(Wk + dkk, n, nn, eps, L + dkk, n, nn, Tkk, ldt, sT, logdet, info, k0, nbatch, kb, k0 > 0, st);
         }
       }
       if (rc) return rc;
       float* W22 = W + (int64_t)k1 * n + k1;
+      const float* D22 = first ? A + (int64_t)k1 * n + k1 : W22;
       if (!Tout) {
         // no T wanted (one level): only (a) runs, T_kk parked in tmp with its own strides
         if (rem > 0) {
-          rc = sq_gemm(W + (int64_t)k1 * n + k0, n, nn, 0, 0, tmp, kb, stmp, 1, 2, L + (int64_t)k1 * n + k0, n, nn,
+          rc = sq_gemm(Wk + (int64_t)k1 * n + k0, n, nn, 0, 0, tmp, kb, stmp, 1, 2, L + (int64_t)k1 * n + k0, n, nn,
                        nullptr, 1.f, 0.f, rem, kb, kb, 0, nbatch, st);
           if (rc) return rc;
-          rc = sq_gemm(L + (int64_t)k1 * n + k0, n, nn, 0, 0, L + (int64_t)k1 * n + k0, n, nn, 1, 0, W22, n, nn, W22,
+          rc = sq_gemm(L + (int64_t)k1 * n + k0, n, nn, 0, 0, L + (int64_t)k1 * n + k0, n, nn, 1, 0, W22, n, nn, D22,
                        -1.f, 1.f, rem, rem, kb, 2, nbatch, st);
           if (rc) return rc;
         }
@@ -440,9 +455,9 @@ int vargp::chol_inv_fwd_impl(const float* A, float eps, float* L, float* T, floa
       }
       const int kl = k0 - K0;                      // columns of the outer block to the left of this one
       const int ldtmp = kl > 0 ? kl : 1;
-      const GemmParams a1 = mk(W + (int64_t)k1 * n + k0, n, Tkk, n, L + (int64_t)k1 * n + k0, n, nullptr, 1.f, 0.f, rem, kb, kb, 0, 2, 0);
+      const GemmParams a1 = mk(Wk + (int64_t)k1 * n + k0, n, Tkk, n, L + (int64_t)k1 * n + k0, n, nullptr, 1.f, 0.f, rem, kb, kb, 0, 2, 0);
       const GemmParams b1 = mk(L + (int64_t)k0 * n + K0, n, Tout + (int64_t)K0 * n + K0, n, tmp, ldtmp, nullptr, 1.f, 0.f, kb, kl, kl, 0, 1, 0);
-      const GemmParams a2 = mk(L + (int64_t)k1 * n + k0, n, L + (int64_t)k1 * n + k0, n, W22, n, W22, -1.f, 1.f, rem, ncol, kb, 0, 0, 2);
+      const GemmParams a2 = mk(L + (int64_t)k1 * n + k0, n, L + (int64_t)k1 * n + k0, n, W22, n, D22, -1.f, 1.f, rem, ncol, kb, 0, 0, 2);
       const GemmParams b2 = mk(Tkk, n, tmp, ldtmp, Tout + (int64_t)k0 * n + K0, n, nullptr, -1.f, 0.f, kb, kl, kb, 1, 0, 0);
       // the outer panel's own pair (A2 || B2) follows its last block; B1, which only needs earlier outer panels, rides with
       // that block's products (its scratch is the second half of tmp: b1 / b2 of this block use the first)
@@ -474,7 +489,9 @@ int vargp::chol_inv_fwd_impl(const float* A, float eps, float* L, float* T, floa
       if (last) {
         float* TKK = Tout + (int64_t)K0 * n + K0;
         float* W22o = W + (int64_t)K1 * n + K1;
-        const GemmParams A2 = mk(L + (int64_t)K1 * n + K0, n, L + (int64_t)K1 * n + K0, n, W22o, n, W22o, -1.f, 1.f, REM, REM, KB, 0, 0, 2);
+        // (the first outer panel's trailing update is the first touch of W[K1:, K1:])
+        const float* D22o = K0 == 0 ? A + (int64_t)K1 * n + K1 : W22o;
+        const GemmParams A2 = mk(L + (int64_t)K1 * n + K0, n, L + (int64_t)K1 * n + K0, n, W22o, n, D22o, -1.f, 1.f, REM, REM, KB, 0, 0, 2);
         GemmParams B2 = mk(TKK, n, tmpB, ldTMP, Tout + (int64_t)K0 * n, n, nullptr, -1.f, 0.f, KB, K0, KB, 1, 0, 0);
         B2.sB[0] = stmp;
         if (la && K0 > 0) pend.push_back(B2);

@@ -164,7 +164,9 @@ bool chol_rbf_gemm_applicable(int n, const GemmParams& p);
 // (the K-split inner products of an RBF kernel matrix over ONE point set); the factorising workgroup forms
 // K_ij = g2[b / part_C] exp(-(G_ii + G_jj - 2 G_ij) / 2), G = sum_q G_q, exactly g2 on the diagonal, as it loads, and stores
 // Zero-fills that ride in some other launch's spare workgroups: rows x width floats at p, row stride ld (p == NULL: none)
-struct ZeroJob { float* p; int64_t rows, width, ld; };
+// stair_nb > 0 (blocked factorisation, chol.hip): `rows` rows of batched stair_n x stair_n matrices (ld = stair_n); row r gets zeros
+// right of its diagonal block only, columns [((r % stair_n) / stair_nb + 1) stair_nb, stair_n) -- one workgroup per row, float4 stores
+struct ZeroJob { float* p; int64_t rows, width, ld; int stair_n, stair_nb; };
 constexpr int kZeroJobs = 5;
 struct ZeroJobs { ZeroJob j[kZeroJobs]; };
 #ifdef __HIPCC__
@@ -173,6 +175,30 @@ __device__ __forceinline__ void zero_jobs_role(const ZeroJobs& z, int blk, int n
   for (int q = 0; q < kZeroJobs; ++q) {
     const ZeroJob t = z.j[q];
     if (!t.p) continue;
+    if (t.stair_nb > 0) {
+      const int n = t.stair_n;
+      if ((n & 3) == 0 && (t.stair_nb & 3) == 0 && (reinterpret_cast<uintptr_t>(t.p) & 15) == 0) {
+        // q float4 per row; short rows: G = 256 / q rows per pass, one float4 per thread; long rows: one row per pass
+        const int q = n >> 2, G = q >= 256 ? 1 : 256 / q;
+        const int sub = G > 1 ? (int)threadIdx.x / q : 0, l4 = G > 1 ? (int)threadIdx.x - sub * q : (int)threadIdx.x;
+        for (int64_t rb = (int64_t)blk * G; rb < t.rows; rb += (int64_t)nblk * G) {
+          const int64_t r = rb + sub;
+          if (sub < G && r < t.rows) {
+            const int c0 = (((int)(r % n)) / t.stair_nb + 1) * t.stair_nb;
+            float* row = t.p + r * t.ld;
+            for (int c = 4 * l4; c < n; c += 1024)
+              if (c >= c0) *reinterpret_cast<float4*>(row + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
+      } else {
+        for (int64_t r = blk; r < t.rows; r += nblk) {
+          const int c0 = (((int)(r % n)) / t.stair_nb + 1) * t.stair_nb;
+          float* row = t.p + r * t.ld;
+          for (int c = c0 + (int)threadIdx.x; c < n; c += 256) row[c] = 0.f;
+        }
+      }
+      continue;
+    }
     for (int64_t i = (int64_t)blk * 256 + threadIdx.x; i < t.rows * t.width; i += (int64_t)nblk * 256)
       t.p[(i / t.width) * t.ld + i % t.width] = 0.f;
   }
@@ -210,11 +236,12 @@ int chol_inv_fwd_impl(const float* A, float eps, float* L, float* T, float* logd
 // factorisations of nchol matrices (n in (50, 100]) with explicit leading dimensions / batch strides + one RBF GEMM
 int launch_chol_rbf_gemm_ld(const float* A, int lda, int64_t sA, float eps, float* L, int ldl, int64_t sL, float* T, int ldt,
                             int64_t sT, int32_t* info, int nchol, int n, const GemmParams& p, int nbatch, hipStream_t st,
-                            bool chain_f32 = false);
+                            bool chain_f32 = false, const ZeroJobs* zero = nullptr);
 // pivot chains of nchol diagonal blocks (fp64, info_base as the stand-alone kernel) || a plain NN product they do not feed
 bool chol_nn_gemm_applicable(int n, const GemmParams& p);
 int launch_chol_nn_gemm(const float* A, int lda, int64_t sA, float eps, float* L, int ldl, int64_t sL, float* T, int ldt, int64_t sT,
-                        int32_t* info, int info_base, int nchol, int n, const GemmParams& p, int nbatch, hipStream_t st);
+                        int32_t* info, int info_base, int nchol, int n, const GemmParams& p, int nbatch, hipStream_t st,
+                        const ZeroJobs* zero = nullptr);
 // w = exp(-2 theta) (zero-padded to Dp), g2 = exp(2 theta_D) and the weighted squared row norms of x (xrows x D) and of
 // y (yrows x D, may be 0 rows) for every hyper-sample, in one launch
 // ys / xs (nullable): also write y o w, [S][yrows][D], and x o w, [S][xrows][D] (the pre-scaled operand of an unscaled RBF

@@ -1129,7 +1129,12 @@ __global__ __launch_bounds__(256) void chol_nn_gemm_kernel(const CholArgs c, con
                             0, lds, nullptr);
     return;
   }
-  const int id = xcd_remap((int)blockIdx.x - c.nchol, (int)gridDim.x - c.nchol);
+  const int ngemm = (int)gridDim.x - c.nchol - c.nzero;
+  if ((int)blockIdx.x >= c.nchol + ngemm) {       // third role: zero-fills of the caller (the blocked driver's L / T above the block diagonal)
+    zero_jobs_role(c.zero, (int)blockIdx.x - c.nchol - ngemm, c.nzero);
+    return;
+  }
+  const int id = xcd_remap((int)blockIdx.x - c.nchol, ngemm);
   gemm_body<64, 64, 64, true, false, true, false>(p, id % tiles, id / tiles, 0, lds);
 }
 
@@ -1357,22 +1362,26 @@ static int launch_chol_rbf_gemm_impl(const float* A, float eps, float* L, float*
 
 int launch_chol_rbf_gemm_ld(const float* A, int lda, int64_t sA, float eps, float* L, int ldl, int64_t sL, float* T, int ldt,
                             int64_t sT, int32_t* info, int nchol, int n, const GemmParams& p, int nbatch, hipStream_t st,
-                            bool chain_f32) {
+                            bool chain_f32, const ZeroJobs* zero) {
+  const ZeroJobs zj = zero ? *zero : ZeroJobs{};
   if (prof_remembering()) {
     const GemmParams pc = p;
     prof_remember("chol_rbf_gemm", [=](hipStream_t s) {
-      launch_chol_rbf_gemm_ld(A, lda, sA, eps, L, ldl, sL, T, ldt, sT, info, nchol, n, pc, nbatch, s, chain_f32);
+      launch_chol_rbf_gemm_ld(A, lda, sA, eps, L, ldl, sL, T, ldt, sT, info, nchol, n, pc, nbatch, s, chain_f32, &zj);
     });
   }
   ProfScope prof("chol_rbf_gemm", st);
-  CholArgs c{A, lda, sA, eps, L, ldl, sL, T, ldt, sT, info, n, nchol, CholExtra{}, ZeroJobs{}, 0};
+  bool any_zero = false;
+  for (int q = 0; q < kZeroJobs; ++q) any_zero = any_zero || zj.j[q].p != nullptr;
+  // (zero-fills of the blocked driver, chol.hip: 2 x 64 MB at Permuted-MNIST t = 1 -- as many workgroups as CUs)
+  CholArgs c{A, lda, sA, eps, L, ldl, sL, T, ldt, sT, info, n, nchol, CholExtra{}, zj, any_zero ? current_cu_count() : 0};
   GemmParams q = p;
   q.splitk = 1;
   const int t64 = cdiv(p.M, 64) * cdiv(p.N, 64), t128 = cdiv(p.M, 128) * cdiv(p.N, 64);
   const int free_cus = current_cu_count() - nchol;
   const bool big = t64 * nbatch > free_cus && (t128 * nbatch <= free_cus || t64 * nbatch > 1024);
   const int tiles = big ? t128 : t64;
-  const int total = nchol + tiles * nbatch;
+  const int total = nchol + tiles * nbatch + c.nzero;
   // factorising CUs exclusive (see launch_chol_rbf_gemm_impl) only while the GEMM fits one round on the other CUs
   const unsigned pad = tiles * nbatch <= free_cus ? (big ? 40u : 24u) * 1024u : 0u;
   const bool scaled = p.kscale != nullptr;      // NULL: the caller's B operand is pre-scaled (rbf_prep_norm_launch: ys)
@@ -1399,13 +1408,18 @@ bool chol_nn_gemm_applicable(int n, const GemmParams& p) {
   return n > 50 && n <= 100 && gemm_vec_ok(p) && p.splitk <= 1 && p.M > 0 && p.N > 0 && p.K > 0;
 }
 int launch_chol_nn_gemm(const float* A, int lda, int64_t sA, float eps, float* L, int ldl, int64_t sL, float* T, int ldt, int64_t sT,
-                        int32_t* info, int info_base, int nchol, int n, const GemmParams& p, int nbatch, hipStream_t st) {
+                        int32_t* info, int info_base, int nchol, int n, const GemmParams& p, int nbatch, hipStream_t st,
+                        const ZeroJobs* zero) {
   ProfScope prof("chol_nn_gemm", st);
-  CholArgs c{A, lda, sA, eps, L, ldl, sL, T, ldt, sT, info, n, nchol, CholExtra{}, ZeroJobs{}, 0};
+  const ZeroJobs zj = zero ? *zero : ZeroJobs{};
+  bool any_zero = false;
+  for (int q = 0; q < kZeroJobs; ++q) any_zero = any_zero || zj.j[q].p != nullptr;
+  // (zero-fills of the blocked driver: up to 2 x 160 MB at n = 2048 x 10 -- every CU the chains leave free takes part)
+  CholArgs c{A, lda, sA, eps, L, ldl, sL, T, ldt, sT, info, n, nchol, CholExtra{}, zj, any_zero ? current_cu_count() - nchol : 0};
   GemmParams q = p;
   q.splitk = 1; q.nofast = 0; q.group_m = 0; q.xcd_remap = 1;
-  const int tiles = cdiv(p.M, 64) * cdiv(p.N, 64);
-  const int total = nchol + tiles * nbatch;
+  const int tiles = cdiv(p.M, 64) * cdiv(p.N, 64);     // (p.M == 0: no product, chains (+ zero-fills) only)
+  const int total = nchol + tiles * nbatch + c.nzero;
   if (n <= 64) hipLaunchKernelGGL((chol_nn_gemm_kernel<16, 1, double>), dim3(total), dim3(256), 0, st, c, q, tiles, info_base);
   else hipLaunchKernelGGL((chol_nn_gemm_kernel<25, 2, double>), dim3(total), dim3(256), 0, st, c, q, tiles, info_base);
   return check_launch("chol_nn_gemm");
