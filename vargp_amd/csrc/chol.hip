@@ -400,6 +400,7 @@ int vargp::chol_inv_fwd_impl(const float* A, float eps, float* L, float* T, floa
   const bool la = la_env && Tout && !logdet && info && nco == 0 && n >= 800;     // (n = 600: 2 % slower with it; 1000: 3 % faster; 1400: 8 %)
   std::vector<GemmParams> pend;
   size_t pend_i = 0;
+  int b1_early = -1;      // outer panel (its K0) whose B1 already ran next to the first panel's trailing update
   for (int K0 = 0; K0 < n; K0 += NBo) {
     const int K1 = (K0 + NBo < n) ? K0 + NBo : n;
     if (la && K0 > 0) {     // B1 of this outer panel: everything it reads exists (behind the queued B2 of the previous panel)
@@ -467,7 +468,7 @@ int vargp::chol_inv_fwd_impl(const float* A, float eps, float* L, float* T, floa
       float* tmpB = tmp + (int64_t)nbatch * stmp;
       GemmParams B1 = mk(L + (int64_t)K0 * n, n, Tout, n, tmpB, ldTMP, nullptr, 1.f, 0.f, KB, K0, K0, 0, 1, 0);
       B1.sC[0] = stmp; B1.sD[0] = stmp;
-      const bool doB = last && K0 > 0 && !la;          // (look-ahead: B1 went into the queue at the top of the panel)
+      const bool doB = last && K0 > 0 && !la && b1_early != K0;     // (look-ahead: B1 went into the queue at the top of the panel)
       if (kl > 0) {
         rc = run_pair(rem > 0 ? &a1 : nullptr, 0, 1, &b1, 0, 0, "chol_panel");
         if (rc) return rc;
@@ -495,7 +496,18 @@ int vargp::chol_inv_fwd_impl(const float* A, float eps, float* L, float* T, floa
         GemmParams B2 = mk(TKK, n, tmpB, ldTMP, Tout + (int64_t)K0 * n, n, nullptr, -1.f, 0.f, KB, K0, KB, 1, 0, 0);
         B2.sB[0] = stmp;
         if (la && K0 > 0) pend.push_back(B2);
-        rc = run_pair(REM > 0 ? &A2 : nullptr, 0, 1, (K0 > 0 && !la) ? &B2 : nullptr, 0, 0, "chol_trailing");
+        // First outer panel: there is no B2 to keep A2 company, but B1 of the NEXT panel -- L[K1:K1n, 0:K1] T[0:K1, 0:K1] -- reads
+        // only what exists now (the panel's columns of L, its block of T): it takes the free seat, and the next panel's last block
+        // finds it done (Split-MNIST t = 1, two panels: six launches of the factorisation become five)
+        GemmParams B1n{};
+        const bool early = K0 == 0 && !la && REM > 0;
+        if (early) {
+          const int K1n = (K1 + NBo < n) ? K1 + NBo : n;
+          B1n = mk(L + (int64_t)K1 * n, n, Tout, n, tmpB, K1, nullptr, 1.f, 0.f, K1n - K1, K1, K1, 0, 1, 0);
+          B1n.sC[0] = stmp; B1n.sD[0] = stmp;
+          b1_early = K1;
+        }
+        rc = run_pair(REM > 0 ? &A2 : nullptr, 0, 1, early ? &B1n : ((K0 > 0 && !la) ? &B2 : nullptr), 0, 0, "chol_trailing");
         if (rc) return rc;
       }
     }

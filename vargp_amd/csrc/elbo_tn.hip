@@ -948,32 +948,41 @@ extern "C" int vargp_elbo_tn_bwd(const vargp_elbo_tn_desc* d, const float* seeds
     }
   }
   {  // V2 = T^T P:  gP += T gV2
-    GemmParams p = flat_gemm(o.TT, Mt, MtMt, gV2, B, MtB, o.gP, B, MtB, Mt, B, Mt);
-    p.triA = 1; p.D = o.gP; p.beta = 1.f;
-    rc = launch_gemm(p, 0, 0, SC, false, st, "tn_gp_v2_gemm");
-    if (rc) return rc;
-  }
-  {  // gT = tril(gP K_uf^T + P gV2^T)  (P = T K_uf and V2 = T^T P), then the diagonal blocks' share from the small products;
+     // gT = tril(gP K_uf^T + P gV2^T)  (P = T K_uf and V2 = T^T P), then the diagonal blocks' share from the small products;
      // gK_uf = T^T gP and the parameter gradients of the current task, [g m_t | . | g Lu_t] = T_tt^T [ga_t | . | gH_t], do not
-     // depend on gT: at mid-size shapes they ride in the launches of its two big products
+     // depend on gT.  Mid-size shapes (no product fills the chip alone) run the seven products as FOUR launches, ordered by what
+     // each needs:   [gT = P gV2^T  ||  gP += T gV2]  ->  [gT += gP K_uf^T  ||  gK_uf = T^T gP]  ->  [gT_ii += gQP_i RK_i^T  ||  gRK_t]
+     // (P gV2^T needs nothing of this segment, so it leads and the gP product is added on top of it; round 4 ran five launches)
+    GemmParams v = flat_gemm(o.TT, Mt, MtMt, gV2, B, MtB, o.gP, B, MtB, Mt, B, Mt);
+    v.triA = 1; v.D = o.gP; v.beta = 1.f;
     GemmParams p = flat_gemm(o.gP, B, MtB, o.Kuf, B, MtB, o.gT, Mt, MtMt, Mt, Mt, B);
     p.triC = 1;
     GemmParams q = flat_gemm(o.P, B, MtB, gV2, B, MtB, o.gT, Mt, MtMt, Mt, Mt, B);
-    q.triC = 1; q.D = o.gT; q.beta = 1.f;
+    q.triC = 1;
     GemmParams ku = flat_gemm(o.TT, Mt, MtMt, o.gP, B, MtB, o.gKuf, B, MtB, Mt, B, Mt);
     ku.triA = 2;
     const int64_t off = (int64_t)(Mt - M) * Mt + (Mt - M);
     GemmParams rk = flat_gemm(o.TT + off, Mt, MtMt, o.gQPs + (int64_t)(Mt - M) * NRs, NRs, MtN, o.gRKt, NRs, (int64_t)M * NRs, M,
                               NRs, M);
     rk.triA = 2;
+    const int64_t sQ[3] = {C * MtN, MtN, (int64_t)M * NRs}, sR[3] = {0, (int64_t)nblk * M * NRs, (int64_t)M * NRs},
+                  sT[3] = {C * MtMt, MtMt, (int64_t)M * Mt + M};
+    GemmParams r = blk_gemm(o.gQPs, NRs, sQ, d->rk_all, NRs, sR, o.gT, Mt, sT, M, M, NRs, C, nblk);
+    r.triC = 1; r.D = o.gT; r.ldd = Mt; r.beta = 1.f;
     const int64_t wgs = (int64_t)SC * cdiv(Mt, 64) * (cdiv(Mt, 64) + cdiv(B, 64));
     static const int pair_bwd = [] { const char* e = getenv("VARGP_TN_PAIRBWD"); return e ? atoi(e) : 1; }();   // tuning aid
     if (pair_bwd && wgs <= 4096) {
+      p.D = o.gT; p.beta = 1.f;           // on top of q, which leads
+      rc = launch_gemm_pair2(q, 0, 1, SC, v, 0, 0, SC, st, "tn_gt_gemm");
+      if (rc) return rc;
       rc = launch_gemm_pair2(p, 0, 1, SC, ku, 1, 0, SC, st, "tn_gt_gemm");
       if (rc) return rc;
-      rc = launch_gemm_pair2(q, 0, 1, SC, rk, 1, 0, SC, st, "tn_gt_gemm");
+      rc = launch_gemm_pair2(r, 0, 1, SC * nblk, rk, 1, 0, SC, st, "tn_gt_diag_gemm");
       if (rc) return rc;
     } else {
+      q.D = o.gT; q.beta = 1.f;           // on top of p
+      rc = launch_gemm(v, 0, 0, SC, false, st, "tn_gp_v2_gemm");
+      if (rc) return rc;
       rc = launch_gemm(p, 0, 1, SC, false, st, "tn_gt_gemm");
       if (rc) return rc;
       rc = launch_gemm(q, 0, 1, SC, false, st, "tn_gt_gemm");
@@ -982,13 +991,9 @@ extern "C" int vargp_elbo_tn_bwd(const vargp_elbo_tn_desc* d, const float* seeds
       if (rc) return rc;
       rc = launch_gemm(rk, 1, 0, SC, false, st, "tn_grk_gemm");
       if (rc) return rc;
+      rc = launch_gemm(r, 0, 1, SC * nblk, false, st, "tn_gt_diag_gemm");
+      if (rc) return rc;
     }
-    const int64_t sQ[3] = {C * MtN, MtN, (int64_t)M * NRs}, sR[3] = {0, (int64_t)nblk * M * NRs, (int64_t)M * NRs},
-                  sT[3] = {C * MtMt, MtMt, (int64_t)M * Mt + M};
-    GemmParams r = blk_gemm(o.gQPs, NRs, sQ, d->rk_all, NRs, sR, o.gT, Mt, sT, M, M, NRs, C, nblk);
-    r.triC = 1; r.D = o.gT; r.ldd = Mt; r.beta = 1.f;
-    rc = launch_gemm(r, 0, 1, SC * nblk, false, st, "tn_gt_diag_gemm");
-    if (rc) return rc;
   }
   if (nomean) {   // ... and to the T_tt and T_<< blocks of gT (complete by now)
     const int NV = d->n_v, Ml = Mt - M;
