@@ -156,6 +156,34 @@ def test_chol_inv_fwd_bwd(ops, n):
     assert rel_l2(L2.cpu(), L64.detach()) < 1e-5
 
 
+@pytest.mark.parametrize('n,want_t', [(150, True), (250, False), (257, True)])
+def test_chol_blocked_logdet_through_the_c_abi(ops, n, want_t):
+    """The blocked factorisation (n > 100) with the log-determinant output of the C ABI (accumulated block by block), with and
+    without the inverse factor -- arguments `ops` never passes.  (Round 5: the blocked driver has no working copy of A any more;
+    block column 0 and the first update of every other region read A itself.)"""
+    from vargp_amd._lib import check, lib, ptr, scratch, stream_ptr
+    nb = 2
+    A = _spd(nb, n, 70 + n).to(DEV)
+    A0 = A.clone()
+    L = torch.full_like(A, float('nan'))
+    T = torch.full_like(A, float('nan')) if want_t else None
+    logdet = torch.full((nb,), float('nan'), device=DEV)
+    info = torch.zeros(nb, dtype=torch.int32, device=DEV)
+    ws = scratch(lib().vargp_chol_workspace_bytes(nb, n, 0), A.device)
+    ws.fill_(float('nan'))          # nothing may depend on what the workspace held
+    check(lib().vargp_chol_inv_fwd(ptr(A), 1e-4, ptr(L), ptr(T), ptr(logdet), ptr(info), nb, n, ptr(ws), ws.numel() * 4,
+                                   stream_ptr()), 'vargp_chol_inv_fwd')
+    torch.cuda.synchronize()
+    assert torch.equal(A, A0) and int(info.abs().sum()) == 0
+    L64 = torch.linalg.cholesky(A.double().cpu() + 1e-4 * torch.eye(n, dtype=torch.float64))
+    assert rel_l2(L.cpu(), L64) < 1e-5 and torch.equal(L.triu(1), torch.zeros_like(L))
+    # (the ABI's logdet is sum log diag L: half the log-determinant of A + eps I)
+    np.testing.assert_allclose(logdet.cpu().numpy(), L64.diagonal(dim1=-2, dim2=-1).log().sum(-1).numpy(), rtol=1e-5)
+    if want_t:
+        T64 = torch.linalg.solve_triangular(L64, torch.eye(n, dtype=torch.float64).expand(nb, n, n), upper=False)
+        assert rel_l2(T.cpu(), T64) < 1e-4 and torch.equal(T.triu(1), torch.zeros_like(T))
+
+
 @pytest.mark.parametrize('n', [20, 64, 100])
 def test_chol_not_positive_definite(ops, n):
     """n = 20: rows-across-threads kernel; 64 / 100: the register-resident blocked elimination (chol_small3.h) -- a pivot
