@@ -135,6 +135,8 @@ int main(int argc, char** argv) {
         {"W.x       2000x784x512  b3  ", 2000, 784, 512, 0, 0, 3, 0},  {"W.z        200x784x200  b30 ", 200, 784, 200, 0, 0, 30, 0},
         {"blk        200x512x200  b200", 200, 512, 200, 0, 0, 200, 1}, {"blk NT     200x200x512  b200", 200, 200, 512, 0, 1, 200, 0},
         {"blk        100x512x100  b60 ", 100, 512, 100, 0, 0, 60, 1},
+        {"s64 P=T.K  100x512x100  b640", 100, 512, 100, 0, 0, 640, 1}, {"s64 T^T.P  100x512x100  b640", 100, 512, 100, 1, 0, 640, 2},
+        {"s64 NT     100x100x512  b640", 100, 100, 512, 0, 1, 640, 0}, {"s64 dense  100x512x100  b640", 100, 512, 100, 0, 0, 640, 0},
     };
     float* A = dev_rand((size_t)100 * 1000 * 1000, 1.f, 8);
     float* B = dev_rand((size_t)100 * 1000 * 1000, 1.f, 9);
@@ -152,6 +154,12 @@ int main(int argc, char** argv) {
       double us = time_us([&] { gemm(A, B, C, c.M, c.N, c.K, c.tA, c.tB, c.nb, sA, sB, sC, c.triA, 0); }, iters);
       printf("   auto %8.1f us\n", us);
     }
+  }
+  if (which == "stream") {   // what the memory system gives a kernel that reads 157 MB and writes 131 MB (the S = 64 P = T K_uf product)
+    float* X; CK(hipMalloc(&X, (size_t)640 * 100 * 512 * 4));
+    float* Y; CK(hipMalloc(&Y, (size_t)640 * 100 * 512 * 4));
+    double us = time_us([&] { CK(hipMemcpyAsync(Y, X, (size_t)640 * 100 * 512 * 4, hipMemcpyDeviceToDevice, 0)); }, iters);
+    printf("stream copy 131 MB -> 131 MB          %8.1f us  -> %.2f TB/s (read + write)\n", us, 2.0 * 640 * 100 * 512 * 4 / us * 1e-6);
   }
   if (which == "kufbig") {   // the stress-config K_uf tile: [10*2048 x 784] x [8192 x 784]^T, RBF epilogue vs plain NT product
     const int S = 1, C = 10, M = 2048, B = 8192, D = 784;
