@@ -22,7 +22,10 @@ def _d(o):
 # earlier tasks, tiny / degenerate sizes
 SHAPES = [(2, 3, 3, 12, 40, 48, 1), (2, 3, 3, 33, 40, 50, 2), (3, 2, 4, 20, 64, 37, 1), (2, 2, 18, 12, 36, 24, 2),
           (2, 3, 2, 20, 2, 64, 3), (1, 2, 2, 60, 48, 40, 4), (1, 1, 1, 3, 33, 2, 1), (2, 2, 2, 100, 36, 52, 1),
-          (2, 2, 3, 50, 24, 32, 1)]
+          (2, 2, 3, 50, 24, 32, 1),
+          # blocked factorisation with a last panel narrower than 50 (Mt = 144: 100 + 44), four panels (Mt = 312: 3 x 100 + 12),
+          # blocks wider than a panel (M = 120, Mt = 240: the task blocks and the 100-wide panels do not line up)
+          (2, 2, 2, 36, 40, 33, 3), (1, 2, 2, 104, 36, 40, 2), (2, 1, 2, 120, 48, 28, 1)]
 
 
 @pytest.mark.parametrize('shape', SHAPES, ids=[str(s) for s in SHAPES])
