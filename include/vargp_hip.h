@@ -225,6 +225,13 @@ typedef struct vargp_elbo_t0_desc {
    * d total / d mu and d total / d var -- ALREADY multiplied by their seed -- into the workspace's gmu, gvar (S, C, B)
    * (vargp_elbo_t0_lik_buffers); bwd takes them as they are and ignores seeds[2].  defer_softmax is ignored. */
   int32_t ext_lik;
+  /* Optional early hand-over of the Cholesky status (both NULL: none).  Right behind the launch that writes info -- the second of
+   * the forward's four -- fwd enqueues a copy of info[0 .. S*C + C) to info_host (host memory, pinned for the copy to be
+   * asynchronous) and records info_event (a hipEvent_t of the caller's) on the stream.  A caller that has to raise on a failed
+   * factorisation before it returns (the reference raises inside torch.cholesky, gp_utils.py:5-11) waits for that event instead
+   * of the whole forward: the rest of the forward runs while the host carries on.  fwd itself still does not synchronise. */
+  int32_t* info_host;
+  void* info_event;
 } vargp_elbo_t0_desc;
 size_t vargp_elbo_t0_workspace_bytes(int S, int C, int M, int D, int B, int F);
 int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t stream);
@@ -287,6 +294,10 @@ typedef struct vargp_elbo_tn_desc {
   const float* eps_u;
   int32_t n_v;
   int32_t no_var_mean;
+  /* as vargp_elbo_t0_desc.info_host / info_event (vargp_elbo_tn_fwd only): info[0 .. S*C) is copied out and the event recorded
+   * right behind the blocked factorisation, before the products that consume it */
+  int32_t* info_host;
+  void* info_event;
 } vargp_elbo_tn_desc;
 size_t vargp_elbo_tn_workspace_bytes(int S, int C, int M, int D, int B, int F, int nblk);
 /* Workspace of a program that only ever evaluates predictive moments (VARGP.forward / predict, var_gp/vargp.py:115-131,

@@ -39,6 +39,7 @@ class ElboT0Desc(Structure):
         ('bump', c_void_p),
         ('rng_seed', ctypes.c_uint64), ('rng_counter', c_void_p), ('rng_sample_offset', c_int32),
         ('defer_hyper', c_int32), ('defer_softmax', c_int32), ('ext_lik', c_int32),
+        ('info_host', c_void_p), ('info_event', c_void_p),
     ]
 
 
@@ -65,6 +66,7 @@ class ElboTnDesc(Structure):
         ('rng_seed', ctypes.c_uint64), ('rng_counter', c_void_p), ('rng_sample_offset', c_int32),
         ('forward_only', c_int32), ('defer_hyper', c_int32), ('ext_lik', c_int32),
         ('eps_u', c_void_p), ('n_v', c_int32), ('no_var_mean', c_int32),
+        ('info_host', c_void_p), ('info_event', c_void_p),
     ]
 
 

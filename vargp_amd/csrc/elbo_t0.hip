@@ -931,6 +931,13 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
     hipLaunchKernelGGL(t0_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, d->u_mean, o.LL + SC * MM, o.Lu, o.RK, C,
                        M, NR, LD, total);
   }
+  // early hand-over of the Cholesky status (include/vargp_hip.h: info_host / info_event): every factorisation of the forward is
+  // behind us on the stream
+  if (d->info_host && d->info_event) {
+    VARGP_REQUIRE(hipMemcpyAsync(d->info_host, d->info, sizeof(int32_t) * (size_t)(SC + C), hipMemcpyDeviceToHost, st) == hipSuccess &&
+                      hipEventRecord(reinterpret_cast<hipEvent_t>(d->info_event), st) == hipSuccess,
+                  "elbo_t0_fwd: copy / event record of the early Cholesky status failed");
+  }
   static const int fused_env = [] { const char* e = getenv("VARGP_T0_FUSED"); return e ? atoi(e) : 1; }();   // tuning aid
   const int ntile = cdiv(B, 64);
   const bool fused_mid = fused_env && M <= kFusedK && (M % 4) == 0 && (LD % 4) == 0 && (int64_t)SC * ntile <= 2048;

@@ -806,6 +806,12 @@ extern "C" int vargp_elbo_tn_fwd(const vargp_elbo_tn_desc* d, vargp_stream_t str
   rc = chol_inv_fwd_impl(o.Kall, d->jitter, o.LL, o.TT, nullptr, d->info, SC, Mt, o.chol, o.chol_bytes, false, st,
                          nsl ? slices : nullptr, S, &consumed, nsl, /*chain_f32=*/!d->forward_only && lik);
   if (rc) return rc;
+  // early hand-over of the Cholesky status (include/vargp_hip.h: info_host / info_event)
+  if (d->info_host && d->info_event) {
+    VARGP_REQUIRE(hipMemcpyAsync(d->info_host, d->info, sizeof(int32_t) * (size_t)SC, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                      hipEventRecord(reinterpret_cast<hipEvent_t>(d->info_event), st) == hipSuccess,
+                  "elbo_tn_fwd: copy / event record of the early Cholesky status failed");
+  }
   if (!kuf_done) {
     if (consumed == 0) {
       rc = launch_gemm(pf, 0, 1, S, true, st, "rbf_kuf_gemm");

@@ -250,6 +250,31 @@ def rbf_gram(theta, X, Y=None, y_shared=False):
 # ------------------------------------------------------------------------------------------------
 # Cholesky (+ jitter) with inverse factor
 # ------------------------------------------------------------------------------------------------
+def raise_slot(n):
+    """(pinned int32 host buffer of n status words, event) for the 'raise' mode, recycled per size.  The event has been recorded
+    once, so that its native handle exists: the first-task program records it itself right behind its factorisation launch
+    (include/vargp_hip.h: info_host / info_event) and the caller waits for THAT, not for the whole forward."""
+    slot = _lazy_rings.get(('raise', n))
+    if slot is None:
+        ev = torch.cuda.Event()
+        ev.record()
+        slot = _lazy_rings[('raise', n)] = (torch.empty(n, dtype=torch.int32, pin_memory=True), ev)
+    return slot
+
+
+def _raise_if_bad(host):
+    nz = host[host != 0]
+    if nz.numel():
+        raise torch.linalg.LinAlgError(
+            f'vargp_chol_inv: {int(nz.numel())} of {host.numel()} matrices are not positive-definite '
+            f'(first failing leading minor of order {int(nz[0])})')
+
+
+def raise_wait(host, ev):
+    ev.synchronize()
+    _raise_if_bad(host)
+
+
 def _note_chol_errors(info):
     if _chol_mode == 'lazy':
         check_linalg_errors()                      # what earlier calls left behind
@@ -266,12 +291,15 @@ def _note_chol_errors(info):
         _pending.append((host, ev))
         return
     if _chol_mode == 'raise':
-        bad = int((info != 0).sum().item())
-        if bad:
-            first = int(info[info != 0][0].item())
-            raise torch.linalg.LinAlgError(
-                f'vargp_chol_inv: {bad} of {info.numel()} matrices are not positive-definite '
-                f'(first failing leading minor of order {first})')
+        # one copy into a (recycled) pinned buffer + an event wait: `(info != 0).sum().item()` was two reduction launches and a
+        # synchronising read on every call
+        if info.is_cuda:
+            host, ev = raise_slot(info.numel())
+            host.copy_(info.view(-1), non_blocking=True)
+            ev.record()
+            raise_wait(host, ev)
+        else:
+            _raise_if_bad(info.view(-1))
     else:
         _info_ring.append(info)
         del _info_ring[:-64]
