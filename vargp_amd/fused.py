@@ -124,18 +124,21 @@ class T0Program:
         self._keep = tensors + (bump,)   # the descriptor holds raw pointers: keep the tensors alive until backward
         # 'raise' mode: the status words are copied out and an event recorded right behind the factorisation launch (the second of
         # four): the host waits for that, and the rest of the forward runs while it carries on (combine, the backward's launch)
-        early = ops._chol_mode == 'raise' and not torch.cuda.is_current_stream_capturing()
+        # ('lazy': the same copy + event, looked at by a later call -- no torch launch for the status words at all)
+        early = ops._chol_mode in ('raise', 'lazy') and not torch.cuda.is_current_stream_capturing()
         if early:
-            host, ev = ops.raise_slot(self.info.numel())
+            host, ev = ops.raise_slot(self.info.numel()) if ops._chol_mode == 'raise' else ops.lazy_slot(self.info.numel())
             d.info_host, d.info_event = host.data_ptr(), ev.cuda_event
         else:
             d.info_host, d.info_event = None, None
         check(lib().vargp_elbo_t0_fwd(ctypes.byref(d), stream_ptr()), 'vargp_elbo_t0_fwd')
         self._bwd_ok = True
-        if early:
+        if not early:
+            ops._note_chol_errors(self.info)
+        elif ops._chol_mode == 'raise':
             ops.raise_wait(host, ev)
         else:
-            ops._note_chol_errors(self.info)
+            ops._pending.append((host, ev))
         return self.scalars
 
     def backward(self, seeds, g_log_mean, g_log_logvar, g_z, g_u_mean, g_u_tril_vec, defer_hyper=False):
@@ -376,17 +379,19 @@ class TnProgram:
         else:
             d.eps_u, d.n_v, d.no_var_mean = None, 0, 0
         self._keep = tensors + (bump, eps_u)
-        early = ops._chol_mode == 'raise' and not torch.cuda.is_current_stream_capturing()      # (as T0Program.forward)
+        early = ops._chol_mode in ('raise', 'lazy') and not torch.cuda.is_current_stream_capturing()      # (as T0Program.forward)
         if early:
-            host, ev = ops.raise_slot(self.info.numel())
+            host, ev = ops.raise_slot(self.info.numel()) if ops._chol_mode == 'raise' else ops.lazy_slot(self.info.numel())
             d.info_host, d.info_event = host.data_ptr(), ev.cuda_event
         else:
             d.info_host, d.info_event = None, None
         check(lib().vargp_elbo_tn_fwd(ctypes.byref(d), stream_ptr()), 'vargp_elbo_tn_fwd')
-        if early:
+        if not early:
+            ops._note_chol_errors(self.info)
+        elif ops._chol_mode == 'raise':
             ops.raise_wait(host, ev)
         else:
-            ops._note_chol_errors(self.info)
+            ops._pending.append((host, ev))
         return self.scalars if y is not None else None
 
     def backward(self, seeds, g_log_mean, g_log_logvar, g_z, g_u_mean, g_u_tril_vec, defer_hyper=False):

@@ -250,6 +250,25 @@ def rbf_gram(theta, X, Y=None, y_shared=False):
 # ------------------------------------------------------------------------------------------------
 # Cholesky (+ jitter) with inverse factor
 # ------------------------------------------------------------------------------------------------
+def lazy_slot(n):
+    """'lazy' mode: raise what earlier calls left behind, then hand out the next (pinned int32 host buffer, event) of the ring for n
+    status words.  The caller gets the status words copied into the buffer and the event recorded behind them -- `_note_chol_errors`
+    with a torch copy, the native programs by themselves (info_host / info_event: no torch launch at all) -- and appends the pair
+    to `_pending`.  Buffers and events are recycled (allocating them per call cost ~40 us); every event has been recorded once,
+    so that its native handle exists."""
+    check_linalg_errors()
+    ring = _lazy_rings.setdefault(n, [[], 0])
+    if len(ring[0]) < 16:
+        ev = torch.cuda.Event()
+        ev.record()
+        ring[0].append((torch.empty(n, dtype=torch.int32, pin_memory=True), ev))
+    host, ev = ring[0][ring[1] % len(ring[0])]
+    ring[1] += 1
+    if any(h is host for h, _ in _pending):        # the ring has come round to a copy that has not been looked at: wait for it
+        check_linalg_errors(wait=True)
+    return host, ev
+
+
 def raise_slot(n):
     """(pinned int32 host buffer of n status words, event) for the 'raise' mode, recycled per size.  The event has been recorded
     once, so that its native handle exists: the first-task program records it itself right behind its factorisation launch
@@ -277,16 +296,8 @@ def raise_wait(host, ev):
 
 def _note_chol_errors(info):
     if _chol_mode == 'lazy':
-        check_linalg_errors()                      # what earlier calls left behind
-        # pinned landing buffers and events are recycled (a ring per status-word count: allocating them per call cost ~40 us)
-        ring = _lazy_rings.setdefault(info.numel(), [[], 0])
-        if len(ring[0]) < 16:
-            ring[0].append((torch.empty(info.shape, dtype=info.dtype, pin_memory=True), torch.cuda.Event()))
-        host, ev = ring[0][ring[1] % len(ring[0])]
-        ring[1] += 1
-        if any(h is host for h, _ in _pending):    # the ring has come round to a copy that has not been looked at: wait for it
-            check_linalg_errors(wait=True)
-        host.copy_(info, non_blocking=True)
+        host, ev = lazy_slot(info.numel())
+        host.copy_(info.view(-1), non_blocking=True)
         ev.record()
         _pending.append((host, ev))
         return
