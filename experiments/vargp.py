@@ -74,10 +74,33 @@ def train(task_id, train_set, val_set, test_set, ep_var_mean=True, map_est_hyper
     captured = set()         # minibatch sizes with a captured step: the full batch and the ragged last one of an epoch
     n_steps, t_train = 0, 0.0
 
+    # --graph on the device-resident loader: the epoch's full minibatches run as graphs of K steps whose steps gather their own
+    # minibatch (ElboTrainer.capture_epoch / run_epoch: the batch index advances on the device); the ragged last batch and every
+    # other combination (--dataloader, no --graph, trainers without a device-side step count) take the per-step loop below
+    epoch_graphs = graph and not dataloader and N >= batch_size
+
     for e in range(epochs):
         torch.cuda.synchronize()
         t_epoch = time.perf_counter()
-        for item in loader:
+        batches = loader
+        if epoch_graphs:
+            order = loader.epoch_order()
+            if batch_size not in captured:
+                torch.cuda.synchronize()
+                t_cap = time.perf_counter()
+                trainer.capture(*loader.take(order[:batch_size]))
+                if trainer.capture_epoch(loader.data, loader.targets) is None:
+                    epoch_graphs = False
+                torch.cuda.synchronize()
+                t_epoch += time.perf_counter() - t_cap              # the one-off captures are not part of the training rate
+                captured.add(batch_size)
+            if epoch_graphs:
+                (kl_hypers, kl_u, lik), done = trainer.run_epoch(order)
+                n_steps += done
+                batches = [order[done * batch_size:]] if done * batch_size < N else []
+            else:
+                batches = [order[i:i + batch_size] for i in range(0, N, batch_size)]
+        for item in batches:
             if dataloader:
                 x, y = item[0].to(device), item[1].to(device)
                 nb = x.size(0)

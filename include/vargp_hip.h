@@ -347,6 +347,15 @@ int vargp_yogi_step_multi_hyper(int ntensors, float* const* p, float* const* g, 
                                 int step_mode, const vargp_hyper_grad_desc* h, int idx_mean, int idx_logvar,
                                 vargp_stream_t stream);
 
+/* Minibatch i of an epoch, gathered on the device: x[r, :] = data[perm[i B + r], :], y[r] = targets[perm[i B + r]], r < B, with
+ * i = (int)(*step_now - *step_base) read from DEVICE memory -- step_now is a step counter some kernel of the step advances (the
+ * `bump` of the ELBO programs' descriptors), step_base its value at the start of the epoch.  Replaces the two index_select
+ * launches per step of the training loop (reference: DataLoader(train_set, batch_size, shuffle=True), experiments/vargp.py:26)
+ * by a launch that can sit INSIDE a captured graph of K steps: the minibatch index advances on the device, the host launches
+ * graphs.  perm: n int64 indices (one permutation per epoch); rows past n clamp to the last index. */
+int vargp_gather_minibatch(const float* data, const int64_t* targets, const int64_t* perm, const float* step_now,
+                           const float* step_base, int64_t n, int B, int D, float* x, int64_t* y, vargp_stream_t stream);
+
 /* Same update for up to 8 tensors in one launch.  `step` (device float) = the step count t.
  * step_mode 0: use t as is.  1: use t + 1 (the caller advances the stored count elsewhere, e.g. through the `bump`
  * pointer of vargp_elbo_t0_desc, so that the optimiser needs no "t += 1" launch of its own). */

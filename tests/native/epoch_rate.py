@@ -61,6 +61,25 @@ def c(sync=True, errs=False, ragged=True):
     return run
 
 
+def d(sync=True, errs=False, n=N):
+    # the epoch-graph route of the driver: gather inside the graph, K = 10 steps per launch, ragged tail per step
+    dd, tt = data[:n].contiguous(), targets[:n].contiguous()
+    tr._select_capture(512)
+    tr.capture_epoch(dd, tt, k=10)
+
+    def run():
+        for e in range(30):
+            order = torch.randperm(n, device='cuda:0')
+            _, done = tr.run_epoch(order)
+            if done * 512 < n:
+                tr.step_graph_gather(dd, tt, order[done * 512:])
+            if sync:
+                torch.cuda.synchronize()
+            if errs:
+                vargp_amd.linalg_error_count()
+    return run
+
+
 timed('graph replay, no input copy', a0, 360)
 timed('step_graph(x, y): copy of a resident batch', a, 360)
 timed('step_graph_gather: index_select into the static inputs', b, 360)
@@ -68,4 +87,7 @@ timed('30 epochs of 11 full batches, no sync', c(False, False, False), 330)
 timed('30 epochs of 11 full + 1 ragged batch, no sync', c(False, False, True), 360)
 timed('... + one synchronize per epoch', c(True, False, True), 360)
 timed('... + linalg_error_count per epoch', c(True, True, True), 360)
+timed('epoch graphs (gather in the graph, K = 10): 30 epochs of 11 full + 1 ragged, no sync', d(False, False), 360)
+timed('... + one synchronize per epoch', d(True, False), 360)
+timed('... + linalg_error_count per epoch', d(True, True), 360)
 print('info ring entries:', len(ops._info_ring))

@@ -164,6 +164,61 @@ def test_graph_survives_ragged_eager_step_and_capture_keeps_state():
         ops.set_cholesky_error_mode('raise')
 
 
+@pytest.mark.parametrize('n_prev', [0, 1])
+def test_epoch_graphs_equal_the_per_step_loop(n_prev):
+    """ElboTrainer.capture_epoch / run_epoch -- the minibatch gather inside the graph (vargp_gather_minibatch: batch index read
+    from the device-side step count), K steps per launch -- against the per-step loop (index_select + one-step graph per
+    minibatch) over the same permutations: the same parameters (to rounding) after two epochs with a ragged tail, for a first-task model
+    and a model with one previous task (block program)."""
+    from vargp_amd import ops
+    from vargp_amd.kernels import RBFKernel
+    from vargp_amd.likelihoods import MulticlassSoftmax
+    from vargp_amd.synthetic import mnist_like
+    from vargp_amd.train import ElboTrainer
+    from vargp_amd.vargp import VARGP
+    C, M, B, D, N = 3, 20, 32, 40, 240          # 7 full minibatches + a ragged one of 16; K = 3: 2 three-step launches + 1 one-step
+    ops.set_cholesky_error_mode('defer')
+    try:
+        xall, yall = mnist_like(N, D, C, kind='gauss', seed=3)
+        data, targets = xall.to(DEV).contiguous(), yall.to(DEV).contiguous()
+        gen = torch.Generator().manual_seed(5)
+        perms = [torch.randperm(N, generator=gen).to(DEV) for _ in range(2)]
+        res = []
+        for mode in ('per_step', 'epoch_graphs'):
+            torch.manual_seed(0)
+            z = torch.stack([xall[yall == c][:M] for c in range(C)])
+            prev = []
+            if n_prev:
+                zp = torch.stack([xall[yall == c][M:2 * M] for c in range(C)])
+                prev = [dict(z=zp.to(DEV), u_mean=0.1 * torch.randn(C, M, 1).to(DEV),
+                             u_tril_vec=(0.05 * torch.randn(C, M * (M + 1) // 2)).to(DEV))]
+            gp = VARGP(z, RBFKernel(D), MulticlassSoftmax(n_f=4), n_var_samples=2, prev_params=prev).to(DEV)
+            tr = ElboTrainer(gp, lr=3e-3, beta=2.0, n_total=N, noise_seed=17)
+            tr.capture(data[:B], targets[:B])
+            if mode == 'epoch_graphs':
+                assert tr.capture_epoch(data, targets, k=3) is tr
+            tr.capture(data[:N % B], targets[:N % B])
+            for perm in perms:
+                if mode == 'epoch_graphs':
+                    out, done = tr.run_epoch(perm)
+                    assert done == N // B
+                else:
+                    for i in range(N // B):
+                        out = tr.step_graph_gather(data, targets, perm[i * B:(i + 1) * B])
+                out = tr.step_graph_gather(data, targets, perm[(N // B) * B:])
+            torch.cuda.synchronize()
+            assert ops.linalg_error_count() == 0
+            res.append(([o.item() for o in out], {k: v.detach().cpu().clone() for k, v in gp.state_dict().items()}))
+        # (same kernels on the same minibatches in the same order; float atomics inside them make two runs of EITHER loop agree to
+        # rounding, not to the bit)
+        np.testing.assert_allclose(np.array(res[1][0]), np.array(res[0][0]), rtol=1e-5)
+        for k in res[0][1]:
+            assert rel_l2(res[1][1][k], res[0][1][k]) < 1e-5, k
+            assert torch.isfinite(res[0][1][k]).all()
+    finally:
+        ops.set_cholesky_error_mode('raise')
+
+
 @pytest.mark.parametrize('shape,map_est', [((3, 3, 4, 56, 784, 64), False), ((2, 3, 3, 24, 40, 32), False),
                                           ((1, 3, 3, 56, 300, 64), True)])
 def test_deferred_hyper_backward_equals_its_own_launch(shape, map_est, monkeypatch):

@@ -128,6 +128,7 @@ _SIGNATURES = {
     'vargp_tune_gemm_tile': (c_int, [c_int]),
     'vargp_prof_replay': (c_int, [c_char_p, c_int, POINTER(ctypes.c_double), _P]),
     'vargp_yogi_step': (c_int, [_P, _P, _P, _P, c_int64] + [c_float] * 6 + [_P, _P]),
+    'vargp_gather_minibatch': (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, c_int, _P, _P, _P]),
 }
 EXPORTS = sorted(_SIGNATURES)
 

@@ -311,6 +311,38 @@ extern "C" int vargp_prof_read(const char* tag, double* total_ms, int64_t* launc
   return VARGP_OK;
 }
 
+// Minibatch gather with the batch index read from device memory (include/vargp_hip.h: vargp_gather_minibatch): one wave per row
+namespace vargp {
+__global__ __launch_bounds__(256) void gather_minibatch_kernel(const float* __restrict__ data, const int64_t* __restrict__ targets,
+                                                               const int64_t* __restrict__ perm, const float* __restrict__ step_now,
+                                                               const float* __restrict__ step_base, int64_t n, int B, int D,
+                                                               float* __restrict__ x, int64_t* __restrict__ y) {
+  const int r = (int)blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= B) return;
+  const int64_t i = (int64_t)(step_now[0] - step_base[0]);
+  int64_t pos = i * B + r;
+  pos = pos < 0 ? 0 : (pos >= n ? n - 1 : pos);
+  const int64_t src = perm[pos];
+  const float* s = data + src * D;
+  float* dst = x + (int64_t)r * D;
+  if ((D & 3) == 0 && ((reinterpret_cast<uintptr_t>(data) | reinterpret_cast<uintptr_t>(x)) & 15) == 0) {
+    for (int d = 4 * lane; d < D; d += 256) *reinterpret_cast<float4*>(dst + d) = *reinterpret_cast<const float4*>(s + d);
+  } else {
+    for (int d = lane; d < D; d += 64) dst[d] = s[d];
+  }
+  if (lane == 0) y[r] = targets[src];
+}
+}  // namespace vargp
+
+extern "C" int vargp_gather_minibatch(const float* data, const int64_t* targets, const int64_t* perm, const float* step_now,
+                                      const float* step_base, int64_t n, int B, int D, float* x, int64_t* y,
+                                      vargp_stream_t stream) {
+  VARGP_REQUIRE(data && targets && perm && step_now && step_base && x && y && n > 0 && B > 0 && D > 0, "gather_minibatch: bad arguments");
+  hipLaunchKernelGGL(vargp::gather_minibatch_kernel, dim3(cdiv(B, 4)), dim3(256), 0, as_stream(stream), data, targets, perm, step_now,
+                     step_base, n, B, D, x, y);
+  return check_launch("gather_minibatch");
+}
+
 // up to 8 parameter tensors in ONE launch (the VAR-GP model has 5); step = device pointer to the step count t
 extern "C" int vargp_yogi_step_multi(int ntensors, float* const* p, const float* const* g, float* const* m,
                                      float* const* v, const int64_t* n, float lr, float beta1, float beta2, float eps,

@@ -40,9 +40,13 @@ class DeviceBatches:
     def __len__(self):
         return (self.n + self.batch_size - 1) // self.batch_size
 
+    def epoch_order(self):
+        """The epoch's order of the training points (device int64): one on-device permutation, or range(n) without shuffling."""
+        return (torch.randperm(self.n, device=self.data.device) if self.shuffle
+                else torch.arange(self.n, device=self.data.device))
+
     def __iter__(self):
-        order = (torch.randperm(self.n, device=self.data.device) if self.shuffle
-                 else torch.arange(self.n, device=self.data.device))
+        order = self.epoch_order()
         for i in range(0, self.n, self.batch_size):
             yield order[i:i + self.batch_size]
 
