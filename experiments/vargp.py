@@ -77,7 +77,7 @@ def train(task_id, train_set, val_set, test_set, ep_var_mean=True, map_est_hyper
     # --graph on the device-resident loader: the epoch's full minibatches run as graphs of K steps whose steps gather their own
     # minibatch (ElboTrainer.capture_epoch / run_epoch: the batch index advances on the device); the ragged last batch and every
     # other combination (--dataloader, no --graph, trainers without a device-side step count) take the per-step loop below
-    epoch_graphs = graph and not dataloader and N >= batch_size
+    epoch_graphs = graph and not dataloader and N >= batch_size and os.environ.get('VARGP_EPOCH_GRAPHS', '1') != '0'
 
     for e in range(epochs):
         torch.cuda.synchronize()
