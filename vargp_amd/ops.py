@@ -257,7 +257,7 @@ def lazy_slot(n):
     to `_pending`.  Buffers and events are recycled (allocating them per call cost ~40 us); every event has been recorded once,
     so that its native handle exists."""
     check_linalg_errors()
-    ring = _lazy_rings.setdefault(n, [[], 0])
+    ring = _lazy_rings.setdefault((torch.cuda.current_device(), n), [[], 0])       # (events belong to a device)
     if len(ring[0]) < 16:
         ev = torch.cuda.Event()
         ev.record()
@@ -273,11 +273,12 @@ def raise_slot(n):
     """(pinned int32 host buffer of n status words, event) for the 'raise' mode, recycled per size.  The event has been recorded
     once, so that its native handle exists: the first-task program records it itself right behind its factorisation launch
     (include/vargp_hip.h: info_host / info_event) and the caller waits for THAT, not for the whole forward."""
-    slot = _lazy_rings.get(('raise', n))
+    key = ('raise', torch.cuda.current_device(), n)                                 # (events belong to a device)
+    slot = _lazy_rings.get(key)
     if slot is None:
         ev = torch.cuda.Event()
         ev.record()
-        slot = _lazy_rings[('raise', n)] = (torch.empty(n, dtype=torch.int32, pin_memory=True), ev)
+        slot = _lazy_rings[key] = (torch.empty(n, dtype=torch.int32, pin_memory=True), ev)
     return slot
 
 
