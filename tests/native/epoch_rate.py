@@ -62,10 +62,10 @@ def c(sync=True, errs=False, ragged=True):
 
 
 def d(sync=True, errs=False, n=N):
-    # the epoch-graph route of the driver: gather inside the graph, K = 10 steps per launch, ragged tail per step
+    # the epoch-graph route of the driver: gather inside the graph, the epoch's 11 full batches in one launch, ragged tail per step
     dd, tt = data[:n].contiguous(), targets[:n].contiguous()
     tr._select_capture(512)
-    tr.capture_epoch(dd, tt, k=10)
+    tr.capture_epoch(dd, tt)
 
     def run():
         for e in range(30):
@@ -87,7 +87,7 @@ timed('30 epochs of 11 full batches, no sync', c(False, False, False), 330)
 timed('30 epochs of 11 full + 1 ragged batch, no sync', c(False, False, True), 360)
 timed('... + one synchronize per epoch', c(True, False, True), 360)
 timed('... + linalg_error_count per epoch', c(True, True, True), 360)
-timed('epoch graphs (gather in the graph, K = 10): 30 epochs of 11 full + 1 ragged, no sync', d(False, False), 360)
+timed('epoch graphs (gather in the graph, 11 steps per launch): 30 epochs of 11 full + 1 ragged, no sync', d(False, False), 360)
 timed('... + one synchronize per epoch', d(True, False), 360)
 timed('... + linalg_error_count per epoch', d(True, True), 360)
 print('info ring entries:', len(ops._info_ring))

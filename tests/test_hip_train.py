@@ -176,7 +176,7 @@ def test_epoch_graphs_equal_the_per_step_loop(n_prev):
     from vargp_amd.synthetic import mnist_like
     from vargp_amd.train import ElboTrainer
     from vargp_amd.vargp import VARGP
-    C, M, B, D, N = 3, 20, 32, 40, 240          # 7 full minibatches + a ragged one of 16; K = 3: 2 three-step launches + 1 one-step
+    C, M, B, D, N = 3, 20, 32, 40, 240          # 7 full minibatches + a ragged one of 16; K = 3: two three-step launches + the one-step rest
     ops.set_cholesky_error_mode('defer')
     try:
         xall, yall = mnist_like(N, D, C, kind='gauss', seed=3)

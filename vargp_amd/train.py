@@ -236,13 +236,14 @@ class ElboTrainer:
         return self._soutk
 
     # -- device-resident epochs: the minibatch gather inside the graph, K steps per launch ------------------------------
-    def capture_epoch(self, data, targets, k=10):
+    def capture_epoch(self, data, targets, k=32):
         """After `capture(x, y)` for the full batch size (one GPU, first-task / block program with our Yogi: the optimiser's step
         count lives on the device and is advanced by the program's first kernel): two more graphs whose steps START with the
         gather of their own minibatch out of the device-resident training set -- `vargp_gather_minibatch`: batch index =
-        (device step count) - (its value at the start of the epoch), rows = `perm[index * B + r]` -- a one-step graph and a
-        K-step graph.  `run_epoch(perm)` then trains a whole epoch's full batches with ceil(n / K) graph launches and no other
-        launch at all (the per-step form: two index_select launches + one graph launch per step).  -> self, or None when the
+        (device step count) - (its value at the start of the epoch), rows = `perm[index * B + r]` -- a graph of K = min(k, full
+        batches per epoch) steps and one of the (full batches mod K) steps left over.  `run_epoch(perm)` then trains a whole
+        epoch's full batches with ceil(full batches / K) graph launches and no other launch at all (the per-step form: two
+        index_select launches + one graph launch per step).  -> self, or None when the
         trainer cannot (no device step counter, several ranks): the caller keeps `step_graph_gather`."""
         if self.graph is None or self.multi or self._bump is None or not self._t0:
             return None
@@ -250,7 +251,9 @@ class ElboTrainer:
         B, D = self._sx.shape
         n = int(targets.size(0))
         assert data.is_contiguous() and targets.is_contiguous() and data.shape == (n, D) and targets.dtype == torch.int64
-        self._ep = dict(data=data, targets=targets, n=n, B=int(B), k=int(k),
+        nfull = n // int(B)
+        k = max(1, min(int(k), nfull))
+        self._ep = dict(data=data, targets=targets, n=n, B=int(B), k=k, r=nfull % k,
                         perm=torch.arange(n, dtype=torch.int64, device=data.device),
                         base=torch.zeros(1, dtype=torch.float32, device=data.device))
         ep = self._ep
@@ -260,7 +263,9 @@ class ElboTrainer:
                                                int(D), ptr(self._sx), ptr(self._sy), stream_ptr()), 'vargp_gather_minibatch')
 
         snap = self._snapshot_state()
-        for name, steps in (('g1', 1), ('gk', int(k))):
+        for name, steps in (('gk', k), ('gr', ep['r'])):
+            if steps == 0:
+                continue
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=self.graph.pool()):
                 for _ in range(steps):
@@ -279,8 +284,8 @@ class ElboTrainer:
         nfull = ep['n'] // ep['B']
         for _ in range(nfull // ep['k']):
             ep['gk'].replay()
-        for _ in range(nfull % ep['k']):
-            ep['g1'].replay()
+        if ep['r']:
+            ep['gr'].replay()
         return ep['out'], nfull
 
     def captured_sizes(self):
