@@ -184,6 +184,26 @@ def test_chol_blocked_logdet_through_the_c_abi(ops, n, want_t):
         assert rel_l2(T.cpu(), T64) < 1e-4 and torch.equal(T.triu(1), torch.zeros_like(T))
 
 
+@pytest.mark.parametrize('D,B,n', [(784, 512, 6000), (37, 30, 100), (40, 64, 70)])
+def test_gather_minibatch_follows_the_device_step_count(ops, D, B, n):
+    """vargp_gather_minibatch: minibatch i = (*step_now - *step_base) of a permutation, read on the DEVICE -- float4 rows and the
+    scalar form (D % 4 != 0), positions past the end of the permutation clamp to its last entry."""
+    from vargp_amd._lib import check, lib, ptr, stream_ptr
+    gen = torch.Generator().manual_seed(D + B)
+    data = torch.randn(n, D, generator=gen).to(DEV)
+    targets = torch.randint(0, 10, (n,), generator=gen).to(DEV)
+    perm = torch.randperm(n, generator=gen).to(DEV)
+    now, base = torch.tensor([7.0], device=DEV), torch.tensor([7.0], device=DEV)
+    x = torch.full((B, D), float('nan'), device=DEV)
+    y = torch.full((B,), -1, dtype=torch.int64, device=DEV)
+    for i in range(min(3, (n + B - 1) // B)):
+        check(lib().vargp_gather_minibatch(ptr(data), ptr(targets), ptr(perm), ptr(now), ptr(base), n, B, D, ptr(x), ptr(y),
+                                           stream_ptr()), 'vargp_gather_minibatch')
+        idx = perm[(torch.arange(B, device=DEV) + i * B).clamp(max=n - 1)]
+        assert torch.equal(x, data[idx]) and torch.equal(y, targets[idx]), i
+        now += 1.0               # (what the first kernel of the ELBO programs does through `bump`)
+
+
 @pytest.mark.parametrize('n', [20, 64, 100])
 def test_chol_not_positive_definite(ops, n):
     """n = 20: rows-across-threads kernel; 64 / 100: the register-resident blocked elimination (chol_small3.h) -- a pivot
