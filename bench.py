@@ -467,8 +467,9 @@ def epochs_workload(args, device, n_train=12000, epochs=12):
         out, done = tr.run_epoch(order)
         if tail:
             out = tr.step_graph_gather(data, targets, order[done * B:])
+        failed = ops.linalg_error_count_begin()      # (as the driver: the count rides in front of the epoch's sync)
         torch.cuda.synchronize()
-        return out, ops.linalg_error_count()
+        return out, int(failed)
 
     epoch()
     t0 = time.perf_counter()

@@ -121,11 +121,13 @@ def train(task_id, train_set, val_set, test_set, ep_var_mean=True, map_est_hyper
             else:
                 kl_hypers, kl_u, lik = trainer.step(*(loader.take(item) if not dataloader else (x, y)))
             n_steps += 1
+        # ('defer' mode: the count of failed factorisations rides in front of the epoch's sync, read after it)
+        failed = vargp_amd.linalg_error_count_begin() if graph else None
         torch.cuda.synchronize()             # the one host sync of the epoch
         t_train += time.perf_counter() - t_epoch
         if e == 0 and epochs > 1:            # the first epoch pays the one-off costs (kernel module loads, first allocations,
             n_steps, t_train = 0, 0.0        # program workspaces): the logged rate is the steady state of the later epochs
-        if graph and vargp_amd.linalg_error_count():
+        if graph and int(failed):
             # 'defer' mode never syncs inside a step: failed factorisations are NaN-filled and flagged on the device.
             # The reference raises at once (torch.cholesky, gp_utils.py:10); here the check runs once per epoch.
             raise torch.linalg.LinAlgError(f'task {task_id}, epoch {e + 1}: a Cholesky factorisation met a matrix that is '

@@ -60,6 +60,26 @@ def reset_linalg_errors():
     del _info_ring[:]
 
 
+def linalg_error_count_begin():
+    """'defer' mode, for callers that synchronise anyway (the driver's one sync per epoch): ENQUEUE the count of failed
+    factorisations and its copy to pinned memory on the current stream -> a handle; `int(handle)` after the caller's own
+    synchronisation is the count.  (linalg_error_count() after a sync starts its reductions on an idle GPU and waits for them:
+    ~0.1 ms per epoch that this form hides in the pipeline.)"""
+    uniq = {}
+    for t in _info_ring:
+        uniq[(t.data_ptr(), t.numel())] = t
+    slot = _lazy_rings.get('count')
+    if slot is None:
+        slot = _lazy_rings['count'] = torch.zeros(1, dtype=torch.int64, pin_memory=True)
+    if not uniq:
+        slot.zero_()
+        return slot
+    counts = [torch.count_nonzero(t) for t in uniq.values()]
+    total = torch.stack(counts).sum() if len(counts) > 1 else counts[0]
+    slot.copy_(total.view(1), non_blocking=True)
+    return slot
+
+
 def linalg_error_count():
     """'defer' mode: number of failed factorisations among the most recent calls.  ONE host sync: the ring usually holds the
     same few info tensors many times over (a program's info buffer is appended on every eager call), so they are counted
