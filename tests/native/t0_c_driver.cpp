@@ -53,7 +53,14 @@ int main(int argc, char** argv) {
   float* g[5];
   for (int i = 0; i < 5; ++i) CK(hipMalloc(&g[i], ng[i] * 4));
 
+  // early hand-over of the Cholesky status: pinned host words + an event recorded right behind the factorisation launch
+  int32_t* info_host; CK(hipHostMalloc(&info_host, 4 * (S * C + C)));
+  for (int i = 0; i < S * C + C; ++i) info_host[i] = -7;
+  hipEvent_t info_ev; CK(hipEventCreateWithFlags(&info_ev, hipEventDisableTiming));
+  d.info_host = info_host; d.info_event = info_ev;
   if (vargp_elbo_t0_fwd(&d, nullptr) != VARGP_OK) { fprintf(stderr, "fwd: %s\n", vargp_last_error()); return 3; }
+  CK(hipEventSynchronize(info_ev));                           // (the forward's remaining launches may still be running)
+  int32_t early_bad = 0; for (int i = 0; i < S * C + C; ++i) early_bad += info_host[i] != 0;
   if (vargp_elbo_t0_bwd(&d, seeds, g[0], g[1], g[2], g[3], g[4], nullptr) != VARGP_OK) { fprintf(stderr, "bwd: %s\n", vargp_last_error()); return 3; }
   CK(hipDeviceSynchronize());
 
@@ -62,6 +69,9 @@ int main(int argc, char** argv) {
   float sc[3]; CK(hipMemcpy(sc, scalars, 12, hipMemcpyDeviceToHost));
   std::vector<int32_t> ih(S * C + C); CK(hipMemcpy(ih.data(), info, 4 * ih.size(), hipMemcpyDeviceToHost));
   int32_t bad = 0; for (int32_t v : ih) bad += v != 0;
+  for (size_t i = 0; i < ih.size(); ++i)
+    if (ih[i] != info_host[i]) { fprintf(stderr, "info_host[%zu] = %d, info = %d\n", i, info_host[i], ih[i]); return 4; }
+  if (early_bad != bad) { fprintf(stderr, "early status %d != %d\n", early_bad, bad); return 4; }
   fwrite(sc, 4, 3, o); fwrite(&bad, 4, 1, o);
   for (int i = 0; i < 5; ++i) {
     std::vector<float> h(ng[i]); CK(hipMemcpy(h.data(), g[i], ng[i] * 4, hipMemcpyDeviceToHost));
