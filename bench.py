@@ -43,6 +43,7 @@ S, F_, C, M, D, B = 3, 10, 10, 100, 784, 512
 N_TOTAL, BETA, LR = 12000, 10.0, 3e-3
 N_PREV = 0
 MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32 matrix peak
+PEAK_CLOCK_GHZ = 2.4              # the clock that peak is quoted at (256 CUs x 4 SIMDs x 64 flop/clk x 2.4 GHz)
 PREHEAT_S = 0.3                   # plain matrix products on scratch tensors before the warm-up steps (reported as `preheat_s`)
 DOMINANT_TAG = 'rbf_kuf'       # the K_uf distance GEMM incl. its split-K combine pass (vargp_rbf_gram_fwd)
 
@@ -218,13 +219,17 @@ def step_timeline(run, period_us, reps=20, burst=4):
     workgroup's start .. last workgroup's end), gap_before_us (previous kernel's end .. this start; for the first kernel:
     the step period minus the rest), slot_us = gap + span (sums to the step period)), in launch order."""
     from vargp_amd import _lib
-    acc, n = {}, 0
+    acc, n, clk = {}, 0, {}
     for _ in range(reps):
         _lib.prof_spans(1)
         for _ in range(burst):
             run()
         torch.cuda.synchronize()
         t = _lib.prof_spans(0)
+        for k, ghz in _lib.prof_clocks().items():      # shader clock held under each kernel (its workgroup 0: s_memtime over wall clock)
+            c = clk.setdefault(k, [0.0, 0])
+            c[0] += ghz
+            c[1] += 1
         main = sorted(((k, v) for k, v in t.items() if ':' not in k), key=lambda kv: kv[1][0])
         if len(main) < 2:
             continue
@@ -251,6 +256,8 @@ def step_timeline(run, period_us, reps=20, burst=4):
         rows[0]['gap_before_us'] = max(0.0, period_us - sum(r['span_us'] + r['gap_before_us'] for r in rows))
     for r in rows:
         r['slot_us'] = r['span_us'] + r['gap_before_us']
+        if r['kernel'] in clk and clk[r['kernel']][1]:
+            r['clock_ghz'] = clk[r['kernel']][0] / clk[r['kernel']][1]
     marks = {k: v for k, v in acc.items() if ':' in k}
     for r in rows:
         for k, v in marks.items():
@@ -761,6 +768,12 @@ def run_workload(name, args, device, world, rank, use_dist, steps, warmup, prima
                                          'workgroup end; last of 4 back-to-back replays, mean of 20') if dom_row
                                  else 'isolated: 100 back-to-back re-launches between one hipEvent pair',
                                  span_us=dom_row['span_us'] if dom_row else None,
+                                 # the shader clock MEASURED under this launch (s_memtime against the 100 MHz wall clock, workgroup
+                                 # 0 of the launch, inside the replayed graph); below the 2.4 GHz the peak is quoted at, the
+                                 # fraction of the roof the chip offered at that clock rides along
+                                 clock_ghz=dom_row.get('clock_ghz') if dom_row else None,
+                                 frac_at_held_clock=((achieved / MFMA_F32_PEAK_TFLOPS) * PEAK_CLOCK_GHZ / dom_row['clock_ghz'])
+                                 if (dom_row and achieved and dom_row.get('clock_ghz') and dom_row['clock_ghz'] < PEAK_CLOCK_GHZ) else None,
                                  frac_span=(dominant_flops / (dom_row['span_us'] * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS) if dom_row else None,
                                  frac_isolated=(dominant_flops / (iso_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS)
                                  if iso_us == iso_us and iso_us > 0 else None,

@@ -412,7 +412,9 @@ int vargp_prof_replay(const char* tag, int iters, double* avg_us, vargp_stream_t
  * node: while switched on, every kernel of the step stamps the device's constant 100 MHz wall clock at its first
  * workgroup's start and (atomic max) at every workgroup's end into a small device table.
  *   mode 1: clear the table and switch the stamps on;  mode 2: switch them off;
- *   mode 0: copy the table to out[12][2] = (start, end) ticks of 10 ns per slot, 0 = the slot's kernel did not run.
+ *   mode 0: copy the table to out[12][2] = (start, end) ticks of 10 ns per slot, 0 = the slot's kernel did not run;
+ *   mode 3: out[12][2] = (shader-clock ticks (s_memtime), wall-clock ticks of 10 ns) that went by between the start and the end
+ *           of WORKGROUP 0 of each slot's last launch: 100 MHz x the ratio = the clock the chip held under that kernel.
  * Slots: 0 t0_pro_kuu, 1 chol_rbf_gemm (9: end of its last factorisation), 2 gemm_kernel (any plain product: the last one
  * launched), 3 t0_fwd_fused, 4 t0_bwd_mid, 5 t0_bwdmat_gemm (8: end of its last matrix chain), 6 t0_puu_final,
  * 7 yogi_multi; 10 / 11: end of the Gram / row-norm role of t0_pro_kuu.  Synchronous (hipMemcpy to / from device symbols): call between steps, not inside a capture. */

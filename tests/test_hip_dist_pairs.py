@@ -40,7 +40,10 @@ def _model(S, C, M, D, n_prev, dev='cuda:0'):
     return gp, xall[:B].to(dev), yall[:B].to(dev)
 
 
-def _worker(rank, world, port, case, use_graph, steps, q):
+B2 = 36          # the ragged last minibatch of an epoch: a second captured size
+
+
+def _worker(rank, world, port, case, use_graph, steps, q, two_sizes=False):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.cuda.set_device(0)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -54,9 +57,12 @@ def _worker(rank, world, port, case, use_graph, steps, q):
         assert tr.class_split and tr._t0
         if use_graph:
             tr.capture(x, y, warmup=1)                 # (the warm-up is undone by capture itself)
+            if two_sizes:
+                tr.capture(x[:B2].contiguous(), y[:B2].contiguous(), warmup=1)
         outs = []
-        for _ in range(steps):
-            out = tr.step_graph(x, y) if use_graph else tr.step(x, y)
+        for k in range(steps):
+            xb, yb = (x[:B2].contiguous(), y[:B2].contiguous()) if (two_sizes and k % 2 == 1) else (x, y)
+            out = tr.step_graph(xb, yb) if use_graph else tr.step(xb, yb)
             outs.append([o.item() for o in out])
         torch.cuda.synchronize()
         assert ops.linalg_error_count() == 0
@@ -67,17 +73,24 @@ def _worker(rank, world, port, case, use_graph, steps, q):
         dist.destroy_process_group()
 
 
+def test_class_sharded_two_captured_sizes():
+    """Full minibatch and the ragged last one captured side by side, replayed alternately: the un-captured all-gather between
+    the graphs must work on the pair buffers of the size being replayed (they are per size; a capture or an eager step of another
+    size rebinds them)."""
+    test_class_sharded_ranks_equal_single_process('mfma', True, two_sizes=True)
+
+
 @pytest.mark.parametrize('use_graph', [False, True], ids=['eager', 'three_graphs'])
 @pytest.mark.parametrize('case', list(CASES))
-def test_class_sharded_ranks_equal_single_process(case, use_graph):
-    world, steps = 3, 3
+def test_class_sharded_ranks_equal_single_process(case, use_graph, two_sizes=False):
+    world, steps = 3, (4 if two_sizes else 3)
     S, C, M, D, n_prev = CASES[case]
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, case, use_graph, steps, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, use_graph, steps, q, two_sizes)) for r in range(world)]
     for p in procs:
         p.start()
     try:
@@ -100,11 +113,12 @@ def test_class_sharded_ranks_equal_single_process(case, use_graph):
         gen = torch.Generator(device='cuda:0')
         gen.manual_seed(SEED)
         outs1 = []
-        for _ in range(steps):
+        for k in range(steps):
+            Bk = B2 if (two_sizes and k % 2 == 1) else B
             nz = dict(eps_theta=torch.randn(S, D + 1, device='cuda:0', generator=gen),
-                      eps_f=torch.randn(S, F_, C, B, device='cuda:0', generator=gen))
+                      eps_f=torch.randn(S, F_, C, Bk, device='cuda:0', generator=gen))
             with noise.inject(**nz):
-                outs1.append([o.item() for o in tr.step(x, y)])
+                outs1.append([o.item() for o in tr.step(x[:Bk].contiguous(), y[:Bk].contiguous())])
         sd1 = {k: v.detach().cpu().numpy() for k, v in gp.state_dict().items()}
     finally:
         noise.clear_shard()

@@ -10,7 +10,10 @@ from vargp_amd.lazy import ElboTerm, PendingForward, terms_of
 class _Prog:
     """Stands in for fused.T0Program: backward(seeds, five gradient buffers) fills buffer k with seeds . (k + 1, 10, 100)."""
     def __init__(self):
-        self._gen, self.busy, self.calls = 0, False, []
+        self._gen, self.busy, self.calls, self.reruns = 0, False, [], 0
+
+    def rerun_forward(self):
+        self.reruns += 1
 
     def backward(self, seeds, *outs):
         self.calls.append(seeds.clone())
@@ -48,9 +51,33 @@ def test_reference_loop_combine_and_backward():
         assert p.grad is fwd.model.bufs[0][k]
         assert p.grad[0].item() == pytest.approx(10.0 * (k + 1) + 10.0 + 100 * 12000 / 512)
     assert not prog.busy
-    with pytest.raises(RuntimeError, match='one backward per forward'):
+    with pytest.raises(RuntimeError, match='backward through the graph a second time'):      # as autograd: no retain_graph, no second backward
         loss.backward()
     assert float(loss.detach()) == pytest.approx(loss.item()) and '%.2f' % kl_u == '2.00'
+
+
+def test_retained_graph_takes_a_second_backward():
+    """experiments/vargp.py:35 is ordinary autograd: loss.backward(retain_graph=True) and another backward are legal there.  Here
+    the second one re-evaluates the program's forward (rerun_forward) and accumulates into .grad, and the workspace stays with
+    the retained loss until that is dropped; a later loss() taking the workspace over ends it with a message."""
+    params, prog, fwd, (kl_h, kl_u, lik) = _setup()
+    loss = 2.0 * kl_h + kl_u
+    loss.backward(retain_graph=True)
+    assert prog.busy and prog.reruns == 0 and len(prog.calls) == 1
+    g1 = params[0].grad[0].item()
+    (kl_h + 0.5 * lik).backward(retain_graph=True)               # another combination of the same forward
+    assert prog.reruns == 1 and len(prog.calls) == 2 and prog.calls[1].tolist() == pytest.approx([1.0, 0.0, 0.5])
+    assert params[0].grad[0].item() == pytest.approx(g1 + 1.0 * 1 + 0.5 * 100)
+    loss.backward()                                              # the last one releases the workspace
+    assert prog.reruns == 2 and not prog.busy
+    with pytest.raises(RuntimeError, match='second time'):
+        loss.backward()
+    # the workspace handed on (a later forward of the program) -> a clear error, not stale numbers
+    params, prog, fwd, (a, b, c) = _setup()
+    a.backward(retain_graph=True)
+    prog._gen += 1
+    with pytest.raises(RuntimeError, match='handed to a later loss'):
+        a.backward()
 
 
 def test_arithmetic_stays_lazy_and_accumulates_like_autograd():

@@ -232,6 +232,14 @@ def prof_spans(mode):
     return {SPAN_SLOTS.get(i, str(i)): (out[2 * i] / 100.0, out[2 * i + 1] / 100.0) for i in range(12) if out[2 * i + 1]}
 
 
+def prof_clocks():
+    """{slot name: GHz} -- the shader clock the chip held while workgroup 0 of each slot's last stamped launch ran (vargp_prof_spans
+    mode 3: s_memtime ticks over 100 MHz wall-clock ticks)."""
+    out = (ctypes.c_uint64 * 24)()
+    check(lib().vargp_prof_spans(3, out), 'vargp_prof_spans')
+    return {SPAN_SLOTS.get(i, str(i)): 0.1 * out[2 * i] / out[2 * i + 1] for i in range(12) if out[2 * i + 1]}
+
+
 def prof_remember(on=True):
     """While on, tagged launches keep a copy of their arguments for prof_replay (see vargp_hip.h)."""
     lib().vargp_prof_remember(int(on))

@@ -18,24 +18,39 @@ struct SpanGuard {
   unsigned long long* p;             // start slot; the kernel's end stamps follow the table at p + kSpanEndsOffset
   unsigned long long* e;
   __device__ __forceinline__ SpanGuard(unsigned long long* q, unsigned long long* ends, int on) : p(on ? q : nullptr), e(ends) {
-    if (p && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) p[0] = wall_clock64();
+    // workgroup 0 also reads the SHADER clock (s_memtime) beside the 100 MHz wall clock at its start and at its end: the
+    // ratio of the two differences is the clock the chip held while this workgroup ran (vargp_prof_spans mode 3)
+    if (p && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+      p[0] = wall_clock64();
+      p[2] = __builtin_amdgcn_s_memtime();
+    }
   }
   __device__ __forceinline__ ~SpanGuard() {
     if (p && threadIdx.x == 0) {
       const unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      if (lin == 0) p[3] = __builtin_amdgcn_s_memtime();
       e[lin & (kSpanEnds - 1)] = wall_clock64();
     }
   }
 };
 }  // namespace vargp
 // vargp_debug_spans_<tu>(out, mode): mode 0 = out[12][2] = (start, max of the end stamps) per slot; 1 = clear the tables and
-// switch the stamps on; 2 = switch them off
+// switch the stamps on; 2 = switch them off; 3 = out[12][2] = (shader-clock, wall-clock) ticks of each slot's workgroup 0
 #define STEP_SPAN_TABLE(tu)                                                                                      \
   __device__ unsigned long long g_spans_##tu[12][4];                                                              \
   __device__ unsigned long long g_span_ends_##tu[12][vargp::kSpanEnds];                                           \
   __device__ int g_spans_on_##tu;                                                                                 \
   extern "C" void vargp_debug_spans_##tu(unsigned long long* out, int mode) {                                    \
-    if (mode) {                                                                                                  \
+    if (mode == 3) {         /* out[12][2] = (shader-clock ticks, wall-clock ticks) of workgroup 0 of each slot */ \
+      unsigned long long st[12][4];                                                                              \
+      static unsigned long long ends0[12][vargp::kSpanEnds];                                                     \
+      (void)hipMemcpyFromSymbol(st, HIP_SYMBOL(g_spans_##tu), sizeof(st));                                       \
+      (void)hipMemcpyFromSymbol(ends0, HIP_SYMBOL(g_span_ends_##tu), sizeof(ends0));                             \
+      for (int i = 0; i < 12; ++i) {                                                                             \
+        const bool ok = st[i][3] > st[i][2] && ends0[i][0] > st[i][0] && st[i][0] != 0;                          \
+        out[2 * i] = ok ? st[i][3] - st[i][2] : 0; out[2 * i + 1] = ok ? ends0[i][0] - st[i][0] : 0;            \
+      }                                                                                                          \
+    } else if (mode) {                                                                                           \
       const int on = mode == 1;                                                                                  \
       if (on) {                                                                                                  \
         void* sp = nullptr; void* ep = nullptr;                                                                  \

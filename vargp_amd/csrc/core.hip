@@ -272,8 +272,19 @@ extern "C" int vargp_prof_replay(const char* tag, int iters, double* avg_us, var
 extern "C" void vargp_debug_spans_gemm(unsigned long long* out, int mode);
 extern "C" void vargp_debug_spans_t0(unsigned long long* out, int mode);
 extern "C" int vargp_prof_spans(int mode, unsigned long long* out) {
-  VARGP_REQUIRE(mode == 1 || mode == 2 || (mode == 0 && out), "prof_spans: mode 0 (read into out[12][2]) / 1 (clear + on) / 2 (off)");
+  VARGP_REQUIRE(mode == 1 || mode == 2 || ((mode == 0 || mode == 3) && out),
+                "prof_spans: mode 0 (read into out[12][2]) / 1 (clear + on) / 2 (off) / 3 (clock ticks into out[12][2])");
   void (*fns[3])(unsigned long long*, int) = {vargp_debug_spans_gemm, vargp_debug_spans_t0, vargp_debug_spans_core};
+  if (mode == 3) {
+    for (int i = 0; i < 24; ++i) out[i] = 0;
+    for (auto fn : fns) {
+      unsigned long long t[24];
+      fn(t, 3);
+      for (int i = 0; i < 12; ++i)
+        if (t[2 * i + 1] != 0) { out[2 * i] = t[2 * i]; out[2 * i + 1] = t[2 * i + 1]; }
+    }
+    return check_launch("prof_spans");
+  }
   if (mode) {
     for (auto fn : fns) fn(nullptr, mode);
     return check_launch("prof_spans");

@@ -122,6 +122,7 @@ class T0Program:
         d.defer_softmax = int(bool(defer_softmax))
         d.ext_lik = int(bool(ext_lik))
         self._keep = tensors + (bump,)   # the descriptor holds raw pointers: keep the tensors alive until backward
+        self._ver = tuple(t._version for t in (log_mean, log_logvar, z, u_mean, u_tril_vec))
         # 'raise' mode: the status words are copied out and an event recorded right behind the factorisation launch (the second of
         # four): the host waits for that, and the rest of the forward runs while it carries on (combine, the backward's launch)
         # ('lazy': the same copy + event, looked at by a later call -- no torch launch for the status words at all)
@@ -149,8 +150,7 @@ class T0Program:
         # (the forward clears the accumulators the backward adds into: include/vargp_hip.h, vargp_elbo_t0_bwd)
         if self._keep is None or not getattr(self, '_bwd_ok', False):
             raise RuntimeError('T0Program.backward: one backward per forward (the forward clears the accumulators the backward '
-                               'adds into; a second loss.backward(retain_graph=True) on the same loss is not supported -- '
-                               'call loss() again)')
+                               'adds into); call rerun_forward() first to evaluate the same forward again for another backward')
         self._bwd_ok = False
         for g in (g_log_mean, g_log_logvar, g_z, g_u_mean, g_u_tril_vec):
             assert g.is_contiguous() and g.dtype == torch.float32
@@ -158,6 +158,32 @@ class T0Program:
         self._seeds = seeds
         check(lib().vargp_elbo_t0_bwd(ctypes.byref(self.desc), ptr(seeds), ptr(g_log_mean), ptr(g_log_logvar), ptr(g_z),
                                       ptr(g_u_mean), ptr(g_u_tril_vec), stream_ptr()), 'vargp_elbo_t0_bwd')
+
+    def rerun_forward(self):
+        """The last forward again -- same operands, same noise, no counter advanced, status words not re-reported -- so that a
+        SECOND backward can run on it (`loss.backward(retain_graph=True)` followed by another backward is legal in the
+        reference's loop, experiments/vargp.py:35: ordinary autograd).  The program's backward consumes the accumulators its
+        forward cleared, so the retained "graph" is re-evaluated rather than kept: results equal the first evaluation's up to the
+        order of the float atomics."""
+        if self._keep is None:
+            raise RuntimeError('rerun_forward without a forward')
+        (log_mean, log_logvar, _, _, z, u_mean, u_tril_vec) = self._keep[:7]
+        if tuple(t._version for t in (log_mean, log_logvar, z, u_mean, u_tril_vec)) != self._ver:
+            raise RuntimeError('one of the variables needed for gradient computation has been modified by an inplace operation '
+                               '(a parameter changed between VARGP.loss and this second backward of its retained graph)')
+        d = self.desc
+        if not d.eps_f and not d.ext_lik:                 # the program drew the noise itself: it is still in the workspace
+            et = None if self.map_est else self.eps_theta().clone()
+            ef = self.eps_f().clone()
+            d.eps_theta, d.eps_f = _p(et), _p(ef)
+            self._keep = self._keep + (et, ef)
+        if getattr(self, '_rerun_scal', None) is None:
+            self._rerun_scal = torch.empty(3, dtype=torch.float32, device=self.ws.device)
+        d.bump, d.info_host, d.info_event = None, None, None
+        d.scalars = _p(self._rerun_scal)                  # (the first evaluation's numbers stay where the caller reads them)
+        fn = lib().vargp_elbo_tn_fwd if isinstance(self, TnProgram) else lib().vargp_elbo_t0_fwd
+        check(fn(ctypes.byref(d), stream_ptr()), 'rerun_forward')
+        self._bwd_ok = True
 
     def hyper_desc(self):
         """What the deferred last step of `backward(defer_hyper=True)` needs (pointers into this program's workspace)."""
@@ -173,6 +199,11 @@ class T0Program:
 def _release(prog, gen):
     if prog._gen == gen:
         prog.busy = False
+
+
+_REUSED = ('VARGP.loss: the workspace of this ELBO node has been handed to a later loss() -- its forward cannot be re-evaluated '
+           'for another backward.  Keep the graph with loss.backward(retain_graph=True) (the workspace then stays with this '
+           'loss until it is dropped), or call loss() again')
 
 
 class _ElboT0(Function):
@@ -200,11 +231,11 @@ class _ElboT0(Function):
     @once_differentiable
     def backward(ctx, g_klh, g_klu, g_nll):
         prog = ctx.prog
-        if prog is None or prog._gen != ctx.gen or not getattr(prog, '_bwd_ok', False):
-            raise RuntimeError('VARGP.loss: one backward per forward on the native first-task program (its forward clears the '
-                               'accumulators the backward adds into, and the workspace is handed on once the backward has '
-                               'run); backward(retain_graph=True) followed by a second backward is not supported -- call '
-                               'loss() again')
+        if prog._gen != ctx.gen:
+            raise RuntimeError(_REUSED)
+        if getattr(ctx, 'ran', False):
+            prog.rerun_forward()             # second backward of a retained graph: the forward is evaluated again
+        ctx.ran = True
         seeds = torch.stack([g_klh.reshape(()), g_klu.reshape(()), g_nll.reshape(())]).float()
         sh_mean, sh_z, sh_um, sh_uv = ctx.shapes
         dev = seeds.device
@@ -217,8 +248,7 @@ class _ElboT0(Function):
         flat = torch.empty(tot, dtype=torch.float32, device=dev)
         g_mean, g_logvar, g_z, g_um, g_uv = (flat[o:o + n].view(sh) for o, n, sh in zip(offs, ns, (sh_mean, sh_mean, sh_z, sh_um, sh_uv)))
         prog.backward(seeds, g_mean, g_logvar, g_z, g_um, g_uv)
-        _release(prog, ctx.gen)
-        ctx.prog = None
+        _release(prog, ctx.gen)              # (a later loss() may take the workspace: a further backward of THIS node then raises)
         return (g_mean, None if ctx.map_est else g_logvar, g_z, g_um, g_uv, None, None, None, None, None, None, None, None)
 
 
@@ -341,6 +371,7 @@ class TnProgram:
         return self.moments(x.shape[0])
 
     lik_buffers = T0Program.lik_buffers
+    rerun_forward = T0Program.rerun_forward
 
     def forward(self, log_mean, log_logvar, prior_log_mean, prior_log_logvar, z, u_mean, u_tril_vec, z_all, rk_all, x, y,
                 eps_theta, eps_f, bump=None, ext_lik=False, eps_u=None):
@@ -379,6 +410,7 @@ class TnProgram:
         else:
             d.eps_u, d.n_v, d.no_var_mean = None, 0, 0
         self._keep = tensors + (bump, eps_u)
+        self._ver = tuple(t._version for t in (log_mean, log_logvar, z, u_mean, u_tril_vec))
         early = ops._chol_mode in ('raise', 'lazy') and not torch.cuda.is_current_stream_capturing()      # (as T0Program.forward)
         if early:
             host, ev = ops.raise_slot(self.info.numel()) if ops._chol_mode == 'raise' else ops.lazy_slot(self.info.numel())
@@ -472,7 +504,10 @@ class _ElboTn(Function):
     def backward(ctx, g_klh, g_klu, g_nll):
         prog = ctx.prog
         if prog._gen != ctx.gen:
-            raise RuntimeError('VARGP.loss: the workspace of this ELBO node was reused by a later forward before its backward ran')
+            raise RuntimeError(_REUSED)
+        if getattr(ctx, 'ran', False):
+            prog.rerun_forward()
+        ctx.ran = True
         seeds = torch.stack([g_klh.reshape(()), g_klu.reshape(()), g_nll.reshape(())]).float()
         sh_mean, sh_z, sh_um, sh_uv = ctx.shapes
         dev = seeds.device
@@ -480,7 +515,6 @@ class _ElboTn(Function):
         g_z, g_um, g_uv = torch.empty(sh_z, device=dev), torch.empty(sh_um, device=dev), torch.empty(sh_uv, device=dev)
         prog.backward(seeds, g_mean, g_logvar, g_z, g_um, g_uv)
         _release(prog, ctx.gen)
-        ctx.prog = None
         return (g_mean, None if ctx.map_est else g_logvar, g_z, g_um, g_uv) + (None,) * 11
 
 
@@ -499,8 +533,8 @@ _RING = 8
 def elbo_lazy(model, x, y, block):
     """(kl_hypers, kl_u, nll) of `model.loss(x, y)` as lazy terms over ONE forward of the model's cached program; the caller's
     linear combination and its `.backward()` become one program backward with those coefficients as seeds (lazy.py).
-    Noise: injected / sharded draws if set (noise.py), otherwise the program's own counter-based generator keyed by
-    torch.initial_seed() -- no torch.randn launches on the step."""
+    Noise: injected / sharded draws if set (noise.py), otherwise the program's own counter-based generator under a key drawn
+    from torch's default generator at the model's first step -- no torch.randn launches on the step."""
     from . import noise
     from .lazy import PendingForward, terms_of
     kern = model.kernel
@@ -508,8 +542,16 @@ def elbo_lazy(model, x, y, block):
     prog = model._tn_program(B) if block else model._t0_program(B)
     if getattr(prog, '_ring', None) is None:
         prog._ring, prog._ring_i = torch.zeros(_RING, 3, dtype=torch.float32, device=x.device), 0
+        prog._ring_owner = [None] * _RING
     prog._ring_i = (prog._ring_i + 1) % _RING
-    prog.scalars = prog._ring[prog._ring_i]                 # valid until _RING more forwards of this program
+    # the slot's previous forward, _RING steps back: if a term of it is still alive (`running += lik.detach()` read at the end
+    # of the epoch, losses kept in a list), its three numbers move into a tensor of their own before the slot is reused -- a
+    # term never silently reads another step's values (the copy is queued in front of this forward, same stream)
+    old = prog._ring_owner[prog._ring_i]
+    old = old() if old is not None else None
+    if old is not None and old.values.data_ptr() == prog._ring[prog._ring_i].data_ptr():
+        old.values = old.values.clone()
+    prog.scalars = prog._ring[prog._ring_i]
     eps_u = model.draw_u_noise(x) if block else None          # ep_var_mean = False only (None otherwise)
     if noise._injected or noise._shard is not None or eps_u is not None:
         eps_theta, eps_f = model.draw_t0_noise(x)
@@ -519,7 +561,11 @@ def elbo_lazy(model, x, y, block):
         if prog._rng is None:
             if getattr(model, '_noise_counter', None) is None or model._noise_counter.device != x.device:
                 model._noise_counter = torch.zeros(1, dtype=torch.int32, device=x.device)
-                model._noise_seed = int(torch.initial_seed()) & 0x7fffffffffffffff
+                # the stream's key is DRAWN from torch's default generator when the model takes its first step: it follows
+                # torch.manual_seed like any other draw, and every model of a process (one per task in the continual-learning
+                # driver, the members of an ensemble) gets a stream of its own -- keyed by torch.initial_seed() all of them
+                # replayed the same noise
+                model._noise_seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
             prog.set_rng(model._noise_seed, model._noise_counter)
         eps_theta = eps_f = None
     x = x if x.is_contiguous() else x.contiguous()
@@ -531,4 +577,6 @@ def elbo_lazy(model, x, y, block):
     else:
         prog.forward(*args, x, y, eps_theta, eps_f)
     params = (kern.log_mean, None if kern.map_est else kern.log_logvar, model.z, model.u_mean, model.u_tril_vec)
-    return terms_of(PendingForward(model, prog, prog.scalars, params))
+    fwd = PendingForward(model, prog, prog.scalars, params)
+    prog._ring_owner[prog._ring_i] = weakref.ref(fwd)
+    return terms_of(fwd)

@@ -37,18 +37,27 @@ class PendingForward:
         self.values = values                    # (3,) device view: kl_hypers, kl_u, nll of this forward (a slot of the program's ring)
         self.params = params                    # (log_mean, log_logvar or None, z, u_mean, u_tril_vec): the leaves
         self.done = False
+        self.retained = False                   # the last backward asked for retain_graph: a further one re-evaluates the forward
         prog._gen += 1
         self.gen = prog._gen
         prog.busy = True
         weakref.finalize(self, _release, prog, prog._gen)
 
-    def run_backward(self, coefs):
-        """d total / d (kl_hypers, kl_u, nll) = coefs (host floats) -> gradients into the parameters' .grad."""
-        if self.done or self.prog._gen != self.gen:
-            raise RuntimeError('VARGP.loss: one backward per forward on the native program (its forward clears the accumulators the '
-                               'backward adds into, and the workspace is handed on once the backward has run); '
-                               'backward(retain_graph=True) followed by a second backward is not supported -- call loss() again')
+    def run_backward(self, coefs, retain=False):
+        """d total / d (kl_hypers, kl_u, nll) = coefs (host floats) -> gradients into the parameters' .grad.  A second call is
+        legal after `retain=True` (loss.backward(retain_graph=True), as in autograd): the program's forward is re-evaluated on
+        the same operands and noise (fused.T0Program.rerun_forward) and the workspace stays with this forward until it dies."""
+        if self.prog._gen != self.gen:
+            from .fused import _REUSED
+            raise RuntimeError(_REUSED)
+        if self.done:
+            if not self.retained:
+                raise RuntimeError('Trying to backward through the graph a second time (VARGP.loss on the native program: the '
+                                   'forward is re-evaluated for a second backward only when the first one was called with '
+                                   'retain_graph=True)')
+            self.prog.rerun_forward()
         self.done = True
+        self.retained = bool(retain)
         m = self.model
         seeds = m._seed_tensor(coefs)
         bufs = m._grad_buffers()
@@ -62,7 +71,8 @@ class PendingForward:
                 p.grad = o
             else:
                 p.grad.add_(o.view_as(p.grad))
-        _release(self.prog, self.gen)
+        if not retain:
+            _release(self.prog, self.gen)
 
 
 def _release(prog, gen):
@@ -84,13 +94,17 @@ class _Materialise(Function):
     @once_differentiable
     def backward(ctx, g0, g1, g2):
         fwd = ctx.fwd
-        if fwd.done or fwd.prog._gen != fwd.gen:
-            raise RuntimeError('VARGP.loss: one backward per forward on the native program; call loss() again')
+        if fwd.prog._gen != fwd.gen:
+            from .fused import _REUSED
+            raise RuntimeError(_REUSED)
+        if fwd.done:
+            fwd.prog.rerun_forward()             # retained graph, second backward (autograd itself has let it through)
         fwd.done = True
         seeds = torch.stack([g0.reshape(()), g1.reshape(()), g2.reshape(())]).float()
         outs = [torch.empty_like(p) if p is not None else fwd.model._grad_buffers()[1][i] for i, p in enumerate(fwd.params)]
         fwd.prog.backward(seeds, *outs)
-        _release(fwd.prog, fwd.gen)
+        if not fwd.retained:
+            _release(fwd.prog, fwd.gen)
         return (None,) + tuple(o for o, p in zip(outs, fwd.params) if p is not None)
 
 
@@ -156,12 +170,14 @@ class ElboTerm:
         if self.nograd:
             raise RuntimeError('element 0 of tensors does not require grad and does not have a grad_fn')
         if gradient is not None or create_graph or inputs is not None or self._real is not None:
+            for fwd, _ in self.terms:
+                fwd.retained = bool(retain_graph)
             return self.tensor().backward(gradient, retain_graph, create_graph, inputs)
         per = {}
         for (fwd, k), c in self.terms.items():
             per.setdefault(fwd, [0.0, 0.0, 0.0])[k] += c
         for fwd, coefs in per.items():
-            fwd.run_backward(tuple(coefs))
+            fwd.run_backward(tuple(coefs), retain=bool(retain_graph))
 
     @property
     def requires_grad(self):

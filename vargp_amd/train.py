@@ -153,6 +153,13 @@ class ElboTrainer:
         # native noise: the program draws eps_theta / eps_f itself (Philox keyed by noise_seed, device-side step
         # counter): no randn launches, and ranks see slices of one global draw by construction
         self.native_noise = bool(native_noise) and self._t0 and not self.class_split
+        # ep_var_mean = False models with earlier tasks draw eps_u -- and with it eps_theta / eps_f -- from the torch generator
+        # (noise.draw) on every step, native noise or not: the captures below must register that generator
+        self._draws_u = bool(is_model and gp.prev_params and gp.var_mean_mask != 1.0)
+        if self.class_split and self._draws_u:
+            raise NotImplementedError('class-sharded steps (more ranks than hyper-samples) run ep_var_mean=True models only: the '
+                                      "ablation's KL needs samples of u_<t for every class of a hyper-sample on one rank; use "
+                                      'whole-sample shards (world <= n_var_samples)')
         self.noise_seed = int(noise_seed)
         self._rng_counter = torch.zeros(1, dtype=torch.int32, device=dev) if self.native_noise else None
         if self._t0 and isinstance(self.optim, Yogi) and len(self.optim.param_groups) == 1:
@@ -181,7 +188,7 @@ class ElboTrainer:
         torch.cuda.current_stream().wait_stream(side)
         self._restore_state(snap)
         self.graph = torch.cuda.CUDAGraph()
-        if noise._shard is not None and not (self._t0 and self.native_noise):
+        if noise._shard is not None and not (self._t0 and self.native_noise and not self._draws_u):
             # the composed (t > 0) path draws its noise from the shared torch generator inside the captured region;
             # the first-task program has its own counter-based generator and needs no generator bookkeeping per replay
             self.graph.register_generator_state(noise._shard[2])
@@ -219,7 +226,7 @@ class ElboTrainer:
         self._syk = y.unsqueeze(0).repeat(k, *([1] * y.dim())).contiguous()
         snap = self._snapshot_state()
         self.graph_k = torch.cuda.CUDAGraph()
-        if noise._shard is not None and not (self._t0 and self.native_noise):
+        if noise._shard is not None and not (self._t0 and self.native_noise and not self._draws_u):
             self.graph_k.register_generator_state(noise._shard[2])
         with torch.cuda.graph(self.graph_k, pool=self.graph.pool()):
             for i in range(k):
@@ -294,6 +301,10 @@ class ElboTrainer:
     def _select_capture(self, nb):
         if self._sx.size(0) != nb:
             self.graph, self.graph_opt, self._sx, self._sy, self._sout, self.graph_mid = self._captured[int(nb)]
+        if self.class_split:
+            # the un-captured all-gather between the graphs works on the pair buffers of THIS minibatch size (an eager step or a
+            # capture of another size rebinds them: _pair_setup)
+            self._pair_setup(self._sx)
 
     def _snapshot_state(self):
         snap = dict(params=[p.detach().clone() for p in self.params], rng=None, gen=None, opt=[])
@@ -357,8 +368,8 @@ class ElboTrainer:
 
     def step_graph(self, x=None, y=None):
         """Replay the captured step (optionally on a new minibatch of the captured shape)."""
+        self._select_capture(x.size(0) if x is not None else self._sx.size(0))
         if x is not None:
-            self._select_capture(x.size(0))
             self._sx.copy_(x, non_blocking=True)
             self._sy.copy_(y, non_blocking=True)
         self.graph.replay()
