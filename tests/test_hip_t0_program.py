@@ -31,7 +31,12 @@ SHAPES = [(2, 3, 3, 33, 40, 50), (3, 2, 4, 20, 64, 37), (2, 2, 18, 12, 36, 24), 
           # the persistent P_uf role of the backward's merged launch (gemm_persist_body: more tiles than free CUs, B % 64 == 0,
           # B >= 256): static tile lists with four (the minimum) and five slabs per tile, and the work queue that the finished
           # matrix chains join (many tiles per CU: 8 hyper-samples)
-          (3, 2, 10, 100, 784, 256), (3, 2, 10, 100, 784, 320), (8, 2, 10, 100, 384, 256)]
+          (3, 2, 10, 100, 784, 256), (3, 2, 10, 100, 784, 320), (8, 2, 10, 100, 384, 256),
+          # more (s, c, tile) units than CUs: the multi-tile form of the LDS-resident tile kernels (a workgroup walks several tiles
+          # of its (s, c): T / G staged once, M x M accumulators kept across tiles) -- uneven tile shares (8 tiles over 3
+          # workgroups), a ragged last tile, B % 4 != 0 (the per-element K_uf loads), and one workgroup for all tiles of a matrix
+          (8, 2, 10, 100, 36, 512), (6, 2, 10, 96, 36, 328), (12, 1, 9, 100, 36, 200), (10, 2, 10, 52, 36, 130),
+          (16, 1, 16, 100, 36, 128)]
 
 
 @pytest.mark.parametrize('shape', SHAPES, ids=[str(s) for s in SHAPES])

@@ -231,6 +231,7 @@ struct CholExtra {
   int symmetric_input, diag_only_before_first;
   const float* part; int nsplit; int64_t sSplit; const float* g2; int part_C; float* Kout;
 };
+int vargp_cu_count();       // CUs of the current device (gemm.hip)
 int launch_chol_rbf_gemm(const float* A, float eps, float* L, float* T, int32_t* info, int nchol, int n,
                          const GemmParams& p, int nbatch, hipStream_t st, const CholExtra* extra = nullptr,
                          const ZeroJobs* zero = nullptr);

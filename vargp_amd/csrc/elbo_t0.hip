@@ -23,6 +23,7 @@
 STEP_SPAN_TABLE(t0)
 #include "elbo_shared.h"
 #include "t0_bwd_mid.h"
+#include "t0_bwd_mid_multi.h"
 #include "t0_prologue.h"
 #include "t0_bwd_tail.h"
 
@@ -322,13 +323,18 @@ __device__ __forceinline__ void ff_product_w(f32x16_t (&acc)[2], const float* __
   });
 }
 
-template <bool VEC4>
+// MULTI (throughput-bound shapes: more (s, c, tile) units than the chip has CUs): a workgroup takes `ntile / nparts` consecutive
+// tiles of its (s, c) -- T, G and a are staged ONCE per workgroup instead of once per tile (80 of the 106 KB a tile workgroup
+// pulls), and the next tile's K_uf loads are in flight under the current tile's products.  nparts = workgroups per (s, c)
+// (the single-tile form is nparts == ntile).
+template <bool VEC4, bool MULTI = false>
 __global__ __launch_bounds__(256) void t0_fwd_fused_kernel(const float* __restrict__ TT, float* __restrict__ QP,
                                                            const float* __restrict__ RK, float* __restrict__ W,
                                                            const float* __restrict__ kd, const float* __restrict__ Lz,
                                                            const float* __restrict__ Lu, float* __restrict__ mu,
                                                            float* __restrict__ var, float* __restrict__ kl_u, int S, int C,
-                                                           int M, int B, int NR, int LD, int ntile, uint32_t* rng_counter) {
+                                                           int M, int B, int NR, int LD, int ntile, uint32_t* rng_counter,
+                                                           int nparts) {
   extern __shared__ __attribute__((aligned(16))) float lds_f[];
   STEP_SPAN(t0, 3);
   float* sT = lds_f;                              // [128][TS]   T[i][k]
@@ -340,16 +346,19 @@ __global__ __launch_bounds__(256) void t0_fwd_fused_kernel(const float* __restri
   // 1-D grid, XCD-aware (as t0_bwd_mid_kernel): XCD x works through the matrices b = x, x + 8, ..., all tiles of one before the
   // next, so that the tiles of an (s, c) find its T and G in ONE L2 (grid = 8 ceil(SC / 8) ntile; the surplus exits)
   const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
-  const int64_t b = (int64_t)(idx / ntile) * 8 + xcd;
+  const int64_t b = (int64_t)(idx / nparts) * 8 + xcd;
   const int64_t MM = (int64_t)M * M, MLD = (int64_t)M * LD;
   if (rng_counter && blockIdx.x == 0 && tid == 0) rng_counter[0] += 1u;   // this step's noise has been drawn
   if (b >= (int64_t)S * C) return;
-  const int tile_x = idx % ntile;
-  const int n0 = tile_x * 64;
+  const int part = idx % nparts;
+  // this workgroup's tiles [tile_x, tile_end) of the (s, c) (single-tile form: one)
+  int tile_x = MULTI ? (part * ntile) / nparts : part;
+  const int tile_end = MULTI ? ((part + 1) * ntile) / nparts : part + 1;
+  int n0 = tile_x * 64;
   // ---- stage T, G, the K_uf tile and a (zero-padded: rows / inner indices >= M, columns >= B) ----------------------------
   const float* Tb = TT + b * MM;
   const float* Qb = QP + b * MLD;
-  const float* Kb = RK + b * MLD + NR + n0;
+  const float* Kb = RK + b * MLD + NR;          // (+ n0: per tile)
   FF_STAMP(0);
   FF_STAMP(1);      // (the KL's loads are part of the staging phase now)
   // ---- every global load first: T, G, the K_uf tile, a, and the first round of the KL's operands; then the LDS stores; then
@@ -385,24 +394,28 @@ __global__ __launch_bounds__(256) void t0_fwd_fused_kernel(const float* __restri
   // per-element`, left a branch around every one of the seven loads, and the compiler put an s_waitcnt vmcnt(0) at each join:
   // seven memory round trips in a row, each also waiting for the 26 loads of T and G in front of it (10.5k of this kernel's
   // 36k cycles went by before the first LDS store).  Other B: the per-element form, in its own instantiation.
+  auto load_ktile = [&](const int n0_) {
+    const char* Kt = Kbb + 4 * n0_;
 #pragma unroll
-  for (int u = 0; u < NK_; ++u) {
-    const int e = min(tid + 256 * u, kFusedK * 16 - 1);
-    const int k = e >> 4, n = (e & 15) * 4;
-    const unsigned ro = 4u * __umul24((unsigned)min(k, M - 1), (unsigned)LD);
-    if constexpr (VEC4) {
-      rk[u] = *reinterpret_cast<const float4*>(Kbb + ro + 4u * (unsigned)min(n, B - 4 - n0));
-    } else {
-      const float* src = reinterpret_cast<const float*>(Kbb + ro);
-      rk[u].x = n0 + n < B ? src[n] : 0.f;         rk[u].y = n0 + n + 1 < B ? src[n + 1] : 0.f;
-      rk[u].z = n0 + n + 2 < B ? src[n + 2] : 0.f; rk[u].w = n0 + n + 3 < B ? src[n + 3] : 0.f;
+    for (int u = 0; u < NK_; ++u) {
+      const int e = min(tid + 256 * u, kFusedK * 16 - 1);
+      const int k = e >> 4, n = (e & 15) * 4;
+      const unsigned ro = 4u * __umul24((unsigned)min(k, M - 1), (unsigned)LD);
+      if constexpr (VEC4) {
+        rk[u] = *reinterpret_cast<const float4*>(Kt + ro + 4u * (unsigned)min(n, B - 4 - n0_));
+      } else {
+        const float* src = reinterpret_cast<const float*>(Kt + ro);
+        rk[u].x = n0_ + n < B ? src[n] : 0.f;         rk[u].y = n0_ + n + 1 < B ? src[n + 1] : 0.f;
+        rk[u].z = n0_ + n + 2 < B ? src[n + 2] : 0.f; rk[u].w = n0_ + n + 3 < B ? src[n + 3] : 0.f;
+      }
     }
-  }
+  };
+  load_ktile(n0);
   const float av = tid < 128 ? *reinterpret_cast<const float*>(Qbb + 4u * __umul24((unsigned)min(tid, M - 1), (unsigned)LD)) : 0.f;
   // ---- KL of q(u) against p(u) for this (s, c) (vargp.py:182-190), its rows shared out over the tile workgroups:
   //      kl[s,c] = sum log diag Lz - sum log diag Lu + (|G2|_F^2 + |a|^2 - M) / 2,   kl_u = (1/S) sum kl[s,c]
   const int c_kl = b % C;
-  const int per = (M + ntile - 1) / ntile, i0 = tile_x * per, i1 = min(M, i0 + per);
+  const int per = (M + nparts - 1) / nparts, i0 = part * per, i1 = min(M, i0 + per);
   const int nkl = max((i1 - i0) * M, 0);
   const unsigned mdiv = ((1u << 20) + (unsigned)M - 1u) / (unsigned)M;      // (uniform: one scalar division instead of eight per thread)
   float kv[8];                                            // first round of G2 entries (clamped; eight loads in flight per round)
@@ -432,15 +445,8 @@ __global__ __launch_bounds__(256) void t0_fwd_fused_kernel(const float* __restri
     const int k = e >> 5, i = (e & 31) * 4;
     *reinterpret_cast<float4*>(&sG[k * kFusedGS + i]) = (k < M && i < M && i <= k) ? rg[u] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-#pragma unroll
-  for (int u = 0; u < NK_; ++u) {
-    const int e = tid + 256 * u;
-    if (e < kFusedK * 16) {
-      const int k = e >> 4, n = (e & 15) * 4;
-      *reinterpret_cast<float4*>(&sK[k * kFusedKS + n]) = (k < M && (!VEC4 || n0 + n < B)) ? rk[u] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
-  FF_STAMP(12);
+  if (tid < 128) sa[tid] = tid < M ? av : 0.f;
+  if (tid < 192) red[tid] = 0.f;
   // ---- KL arithmetic (further rounds of loads only when a workgroup's share exceeds 2048 entries)
   float kl_acc = 0.f;
 #pragma unroll
@@ -473,8 +479,19 @@ __global__ __launch_bounds__(256) void t0_fwd_fused_kernel(const float* __restri
       kl_acc += 2.f * (logf(Lz[(b * M + i) * M + i]) - logf(Lu[((int64_t)c_kl * M + i) * M + i])) - 1.f;
     }
   }
-  if (tid < 128) sa[tid] = tid < M ? av : 0.f;
-  if (tid < 192) red[tid] = 0.f;
+  // ---- the tile loop (single-tile form: one pass, straight-line code)
+  do {
+#pragma unroll
+  for (int u = 0; u < NK_; ++u) {
+    const int e = tid + 256 * u;
+    if (e < kFusedK * 16) {
+      const int k = e >> 4, n = (e & 15) * 4;
+      *reinterpret_cast<float4*>(&sK[k * kFusedKS + n]) = (k < M && (!VEC4 || n0 + n < B)) ? rk[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  FF_STAMP(12);
+  // (MULTI) the next tile's K_uf loads: in flight under this tile's products
+  if constexpr (MULTI) { if (tile_x + 1 < tile_end) load_ktile(n0 + 64); }
   FF_STAMP(13);
   __syncthreads();
   FF_STAMP(2);
@@ -549,11 +566,16 @@ __global__ __launch_bounds__(256) void t0_fwd_fused_kernel(const float* __restri
     atomicAdd(&red[32 * cb + li], s_mu); atomicAdd(&red[64 + 32 * cb + li], s_p2); atomicAdd(&red[128 + 32 * cb + li], s_w2);
   }
   __syncthreads();
-  if (tid < 64 && n0 + tid < B) {
-    mu[b * B + n0 + tid] = red[tid];
-    var[b * B + n0 + tid] = kd[b] - red[64 + tid] + red[128 + tid];
+  if (tid < 64) {
+    if (n0 + tid < B) {
+      mu[b * B + n0 + tid] = red[tid];
+      var[b * B + n0 + tid] = kd[b] - red[64 + tid] + red[128 + tid];
+    }
+    if constexpr (MULTI) { red[tid] = 0.f; red[64 + tid] = 0.f; red[128 + tid] = 0.f; }     // (by their reader: no barrier needed)
   }
   FF_STAMP(8);
+  if constexpr (MULTI) { tile_x += 1; n0 += 64; }
+  } while (MULTI && tile_x < tile_end);
   // ---- KL (partial sum from the top of the kernel)
   __syncthreads();
   const float tkl = block_sum<256>(kl_acc, red);
@@ -716,6 +738,23 @@ static int check_desc(const vargp_elbo_t0_desc* d, const char* who) {
   VARGP_REQUIRE(d->ws_bytes >= vargp_elbo_t0_workspace_bytes(d->S, d->C, d->M, d->D, d->B, d->F),
                 "%s: workspace too small", who);
   return VARGP_OK;
+}
+
+// Workgroups per (s, c) of the LDS-resident tile kernels (t0_fwd_fused_kernel, t0_bwd_mid_kernel): one workgroup per CU (their
+// LDS), so with SC * ntile tile units on `cus` CUs the launch takes  rounds x (set-up + tiles per workgroup x tile time).
+// nparts == ntile is the single-tile form (latency-bound shapes: every unit its own CU); fewer, longer workgroups stage T and
+// G once for several tiles and keep the M x M accumulators in registers across them (`setup` = that set-up in tile times).
+static int t0_tile_parts(int64_t SC, int ntile, int cus, float setup) {
+  static const int env = [] { const char* e = getenv("VARGP_T0_PARTS"); return e ? atoi(e) : 0; }();   // tuning aid
+  if (env > 0) return env < ntile ? env : ntile;
+  if (SC * ntile <= cus) return ntile;
+  int best = ntile;
+  float best_t = 1e30f;
+  for (int np = 1; np <= ntile; ++np) {
+    const float t = (float)cdiv(SC * np, (int64_t)cus) * (setup + (float)cdiv(ntile, np));
+    if (t < best_t - 1e-6f) { best_t = t; best = np; }
+  }
+  return best;
 }
 
 // which backward the shapes get (the forward needs to know: it clears the accumulators of the LDS-resident one)
@@ -947,18 +986,22 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
     p.triA = 1;
     rc = launch_gemm(p, 0, 0, SC, false, st, "t0_qps_gemm");
     if (rc) return rc;
-    static std::atomic<unsigned> attr_set_mask[2] = {}, attr_set_mask_s[2] = {};      // 64 device ordinals
-    if (B % 4 == 0) {
-      rc = ensure_dynamic_lds(reinterpret_cast<const void*>(t0_fwd_fused_kernel<true>), kFusedLdsBytes, attr_set_mask, "elbo_t0_fwd");
-      if (rc) return rc;
-      hipLaunchKernelGGL(t0_fwd_fused_kernel<true>, dim3(8 * cdiv(SC, 8) * ntile), dim3(256), kFusedLdsBytes, st, o.TT, o.QP, o.RK, o.W, o.kd,
-                         o.LL, o.Lu, o.mu, o.var, d->scalars + 1, S, C, M, B, NR, LD, ntile, native ? d->rng_counter : nullptr);
-    } else {
-      rc = ensure_dynamic_lds(reinterpret_cast<const void*>(t0_fwd_fused_kernel<false>), kFusedLdsBytes, attr_set_mask_s, "elbo_t0_fwd");
-      if (rc) return rc;
-      hipLaunchKernelGGL(t0_fwd_fused_kernel<false>, dim3(8 * cdiv(SC, 8) * ntile), dim3(256), kFusedLdsBytes, st, o.TT, o.QP, o.RK, o.W, o.kd,
-                         o.LL, o.Lu, o.mu, o.var, d->scalars + 1, S, C, M, B, NR, LD, ntile, native ? d->rng_counter : nullptr);
-    }
+    static std::atomic<unsigned> attr_set_mask[4][2] = {};      // 64 device ordinals per instantiation
+    const int nparts = t0_tile_parts(SC, ntile, vargp_cu_count(), 0.5f);
+    const bool multi = nparts < ntile;
+    const dim3 grid(8 * cdiv(SC, 8) * nparts);
+    uint32_t* rngc = native ? d->rng_counter : nullptr;
+#define VARGP_FF(V4, MT, SLOT)                                                                                                  \
+  do {                                                                                                                          \
+    rc = ensure_dynamic_lds(reinterpret_cast<const void*>(t0_fwd_fused_kernel<V4, MT>), kFusedLdsBytes, attr_set_mask[SLOT],    \
+                            "elbo_t0_fwd");                                                                                     \
+    if (rc) return rc;                                                                                                          \
+    hipLaunchKernelGGL((t0_fwd_fused_kernel<V4, MT>), grid, dim3(256), kFusedLdsBytes, st, o.TT, o.QP, o.RK, o.W, o.kd, o.LL,   \
+                       o.Lu, o.mu, o.var, d->scalars + 1, S, C, M, B, NR, LD, ntile, rngc, nparts);                             \
+  } while (0)
+    if (B % 4 == 0) { if (multi) VARGP_FF(true, true, 0); else VARGP_FF(true, false, 1); }
+    else { if (multi) VARGP_FF(false, true, 2); else VARGP_FF(false, false, 3); }
+#undef VARGP_FF
   } else {
     {  // QP = T RK
       GemmParams p = flat_gemm(o.TT, M, MM, o.RK, LD, MLD, o.QP, LD, MLD, M, NR + B, M);
@@ -1042,15 +1085,24 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
                        mat_bwd ? o.gLL + SC * MM : nullptr);
   }
   if (fused_bwd) {
-    static std::atomic<unsigned> attr_set_mask[2] = {};
-    rc = ensure_dynamic_lds(reinterpret_cast<const void*>(t0_bwd_mid_kernel), kBwdMidLdsBytes, attr_set_mask, "elbo_t0_bwd");
-    if (rc) return rc;
-    {
+    static std::atomic<unsigned> attr_set_mask[2] = {}, attr_set_mask_m[2] = {};
+    // throughput-bound shapes (more tile units than CUs): the multi-tile form (t0_bwd_mid_multi.h)
+    const int nparts = t0_tile_parts(SC, ntile, vargp_cu_count(), 0.35f);
+    const BmSoftmax smx = softmax_deferred ? BmSoftmax{o.mu, o.var, eps_f, d->y, d->scalars + 2, F} : BmSoftmax{};
+    if (nparts < ntile) {
+      rc = ensure_dynamic_lds(reinterpret_cast<const void*>(t0_bwd_mid_multi_kernel), kBwdMidMultiLdsBytes, attr_set_mask_m, "elbo_t0_bwd");
+      if (rc) return rc;
+      ProfScope prof("t0_bwd_mid", st);
+      hipLaunchKernelGGL(t0_bwd_mid_multi_kernel, dim3(8 * cdiv(SC, 8) * nparts), dim3(256), kBwdMidMultiLdsBytes, st, o.TT, o.QP, o.W, o.RK,
+                         o.gmu, o.gvar, fused_softmax ? seeds + 2 : nullptr, o.gQP, o.gTT, o.gRK, o.gkd, o.r_uf, o.c_uf, o.gtheta, S, C, M,
+                         B, D, NR, LD, ntile, nparts, mat_bwd ? g_u_mean : nullptr, C * M, smx);
+    } else {
+      rc = ensure_dynamic_lds(reinterpret_cast<const void*>(t0_bwd_mid_kernel), kBwdMidLdsBytes, attr_set_mask, "elbo_t0_bwd");
+      if (rc) return rc;
       ProfScope prof("t0_bwd_mid", st);
       hipLaunchKernelGGL(t0_bwd_mid_kernel, dim3(8 * cdiv(SC, 8) * ntile), dim3(256), kBwdMidLdsBytes, st, o.TT, o.QP, o.W, o.RK, o.gmu, o.gvar,
                          fused_softmax ? seeds + 2 : nullptr, o.gQP, o.gTT, o.gRK, o.gkd, o.r_uf, o.c_uf, o.gtheta, S, C, M, B, D,
-                         NR, LD, ntile, mat_bwd ? g_u_mean : nullptr, C * M,
-                         softmax_deferred ? BmSoftmax{o.mu, o.var, eps_f, d->y, d->scalars + 2, F} : BmSoftmax{});
+                         NR, LD, ntile, mat_bwd ? g_u_mean : nullptr, C * M, smx);
     }
     if (!mat_bwd) {
       // what the tiles cannot see: the small columns [a | . | G | G2 | .] of QP = T RK (K = NR):

@@ -1288,6 +1288,7 @@ static int current_cu_count() {
   int dev = 0;
   return (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) ? device_cu_count(dev) : 256;
 }
+int vargp_cu_count() { return current_cu_count(); }
 static int launch_chol_rbf_gemm_impl(const float* A, float eps, float* L, float* T, int32_t* info, int nchol, int n,
                                      const GemmParams& p, int nbatch, hipStream_t st, const CholExtra& extra, const ZeroJobs& zero);
 bool chol_rbf_gemm_applicable(int n, const GemmParams& p) { return n > 50 && n <= 100 && gemm_vec_ok(p); }

@@ -181,7 +181,10 @@ __device__ __forceinline__ void bm_tail_atomics(const bm_f32x16 (&acc)[3], float
 #ifdef BM_STAMPS   // per-phase cycle accounting (workgroup (0, 0), thread 0), tuning builds only: tests/native/bm_stamps.py
 __device__ unsigned long long g_bm_stamps[16];
 extern "C" void vargp_debug_bm_stamps(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bm_stamps), 128); }
-#define BM_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_bm_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#ifndef BM_STAMP_BLOCK
+#define BM_STAMP_BLOCK 0u      // which workgroup stamps (-DBM_STAMP_BLOCK=...: a late one, in its CU's second or third round)
+#endif
+#define BM_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == (BM_STAMP_BLOCK)) g_bm_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define BM_STAMP(i) do { } while (0)
 #endif
