@@ -93,6 +93,22 @@ if len(sys.argv) > 1 and sys.argv[1] == 'mat':      # t0_bwd_mat_body (a -DBMAT_
     print('S_u role (first class, wave 0): samples %d, stage gL / T_S / L_S %d, L_S^T gL and S -> X2 %d, tail %d, total %d cycles'
           % (su[1] - su[0], su[2] - su[1], su[3] - su[2], su[4] - su[3], su[4] - su[0]))
     sys.exit(0)
+if os.environ.get('VARGP_BM_MULTI'):     # t0_bwd_mid_multi_kernel: second tile of the stamped workgroup (+ its set-up and whole life), per wave
+    out = (ctypes.c_ulonglong * 96)()
+    fn = _lib.lib().vargp_debug_bmm_stamps
+    fn.restype, fn.argtypes = None, [ctypes.c_void_p]
+    fn(out)
+    v = [list(out)[24 * w:24 * w + 24] for w in range(4)]
+    names = {(20, 21): 'set-up: first tile loads issued, G / T / a staged', (0, 1): 'tile top',
+             (1, 15): 'P, W -> LDS', (15, 2): 'K_uf load issue, gmu / gvar + barrier', (2, 3): 'phase 1 (gW, ga) + barrier',
+             (3, 4): 'phase 2: accG += , gP', (4, 5): 'barrier', (5, 6): 'phase 3: gP / K_uf -> LDS, next P / W loads + barrier',
+             (6, 7): 'phase 4: accT +=, gK_uf', (7, 16): 'W_uf = gK_uf o K_uf', (16, 17): '  barrier', (17, 8): '  W_uf -> LDS, next likelihood loads + barrier',
+             (8, 9): 'W_uf rows out, row / column sums + barrier', (9, 10): 'c_uf atomics', (0, 10): 'second tile, total',
+             (20, 22): 'workgroup, total'}
+    print('%-56s %s' % ('cycles per wave', ''.join('%9s' % ('wave %d' % w) for w in range(4))))
+    for (i, j), n in names.items():
+        print('%-56s %s' % (n, ''.join('%9d' % (v[w][j] - v[w][i]) for w in range(4))))
+    sys.exit(0)
 out = (ctypes.c_ulonglong * 16)()
 fn = _lib.lib().vargp_debug_bm_stamps
 fn.restype, fn.argtypes = None, [ctypes.c_void_p]

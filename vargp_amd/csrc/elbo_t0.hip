@@ -327,6 +327,12 @@ __device__ __forceinline__ void ff_product_w(f32x16_t (&acc)[2], const float* __
 // tiles of its (s, c) -- T, G and a are staged ONCE per workgroup instead of once per tile (80 of the 106 KB a tile workgroup
 // pulls), and the next tile's K_uf loads are in flight under the current tile's products.  nparts = workgroups per (s, c)
 // (the single-tile form is nparts == ntile).
+// barrier of the tile loop: the multi-tile form hands nothing over through global memory inside it, so it waits for LDS
+// operations only and leaves the next tile's loads and this tile's P / W stores in flight (t0_bwd_mid_multi.h)
+template <bool MULTI>
+__device__ __forceinline__ void ff_barrier() {
+  if constexpr (MULTI) bmm_lds_barrier(); else __syncthreads();
+}
 template <bool VEC4, bool MULTI = false>
 __global__ __launch_bounds__(256) void t0_fwd_fused_kernel(const float* __restrict__ TT, float* __restrict__ QP,
                                                            const float* __restrict__ RK, float* __restrict__ W,
@@ -493,7 +499,7 @@ __global__ __launch_bounds__(256) void t0_fwd_fused_kernel(const float* __restri
   // (MULTI) the next tile's K_uf loads: in flight under this tile's products
   if constexpr (MULTI) { if (tile_x + 1 < tile_end) load_ktile(n0 + 64); }
   FF_STAMP(13);
-  __syncthreads();
+  ff_barrier<MULTI>();
   FF_STAMP(2);
   const int cb = wave & 1;
   const int rbs[2] = {(wave >> 1) ? 1 : 0, (wave >> 1) ? 2 : 3};
@@ -507,7 +513,7 @@ __global__ __launch_bounds__(256) void t0_fwd_fused_kernel(const float* __restri
   if ((wave >> 1) == 0) ff_product_p<0, 3>(accP, sT, sK, cb, li, lh);
   else ff_product_p<1, 2>(accP, sT, sK, cb, li, lh);
   FF_STAMP(3);
-  __syncthreads();                                // everybody is done with the K_uf tile
+  ff_barrier<MULTI>();                                // everybody is done with the K_uf tile
   FF_STAMP(4);
   // P into the tile's place (second product's operand) and out to QP; column sums of P a and P^2 on the way
   const int col = n0 + 32 * cb + li;
@@ -530,7 +536,7 @@ __global__ __launch_bounds__(256) void t0_fwd_fused_kernel(const float* __restri
       s_p2 = fmaf(v, v, s_p2);
     }
   }
-  __syncthreads();
+  ff_barrier<MULTI>();
   FF_STAMP(5);
   // ---- W = G^T P: row block rb needs k >= 32 rb (G is lower triangular); rbs[0] < ... the block with the smaller rb starts
   // alone, then both advance together
@@ -565,7 +571,7 @@ __global__ __launch_bounds__(256) void t0_fwd_fused_kernel(const float* __restri
   if (lh == 0) {
     atomicAdd(&red[32 * cb + li], s_mu); atomicAdd(&red[64 + 32 * cb + li], s_p2); atomicAdd(&red[128 + 32 * cb + li], s_w2);
   }
-  __syncthreads();
+  ff_barrier<MULTI>();
   if (tid < 64) {
     if (n0 + tid < B) {
       mu[b * B + n0 + tid] = red[tid];
@@ -744,6 +750,7 @@ static int check_desc(const vargp_elbo_t0_desc* d, const char* who) {
 // LDS), so with SC * ntile tile units on `cus` CUs the launch takes  rounds x (set-up + tiles per workgroup x tile time).
 // nparts == ntile is the single-tile form (latency-bound shapes: every unit its own CU); fewer, longer workgroups stage T and
 // G once for several tiles and keep the M x M accumulators in registers across them (`setup` = that set-up in tile times).
+constexpr float kBwdMidSetup = 0.35f;      // set-up of a t0_bwd_mid_multi_kernel workgroup (G / T staging + its round of atomics) in tile times
 static int t0_tile_parts(int64_t SC, int ntile, int cus, float setup) {
   static const int env = [] { const char* e = getenv("VARGP_T0_PARTS"); return e ? atoi(e) : 0; }();   // tuning aid
   if (env > 0) return env < ntile ? env : ntile;
@@ -864,8 +871,11 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
   const bool clear_bwd = bwd_paths.mat_bwd;
   // the likelihood inside the backward's tile kernel (one launch less): only where that kernel runs and its softmax fits
   // (float4 reads of the noise there: a caller's eps_f must sit on a 16-byte boundary, the workspace's own does)
-  const bool defer_softmax = d->defer_softmax && !d->ext_lik && fused_softmax && bwd_paths.fused_bwd && F <= 4 * kBmSmF && C <= kBmSmC &&
-                             reinterpret_cast<uintptr_t>(eps_f) % 16 == 0;
+  // (not on throughput-bound shapes -- the multi-tile form of that kernel, t0_bwd_mid_multi.h: the evaluation is C-fold redundant
+  //  there, 11k cycles of vector work per tile that such a launch cannot hide; those shapes keep the softmax launch)
+  const bool bwd_multi = bwd_paths.fused_bwd && t0_tile_parts(SC, cdiv(B, 64), vargp_cu_count(), kBwdMidSetup) < cdiv(B, 64);
+  const bool defer_softmax = d->defer_softmax && !d->ext_lik && fused_softmax && bwd_paths.fused_bwd && !bwd_multi &&
+                             F <= 4 * kBmSmF && C <= kBmSmC && reinterpret_cast<uintptr_t>(eps_f) % 16 == 0;
   t0_state_set(d->ws, (clear_bwd ? kT0Cleared : kT0NoClear) | (defer_softmax ? kT0SoftmaxDeferred : 0));
   if (clear_bwd) {
     // accumulators of the LDS-resident backward (atomics of t0_bwd_mid.h / t0_bwd_mat.h / t0_bwd_tail.h), cleared in the forward,
@@ -1087,15 +1097,16 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
   if (fused_bwd) {
     static std::atomic<unsigned> attr_set_mask[2] = {}, attr_set_mask_m[2] = {};
     // throughput-bound shapes (more tile units than CUs): the multi-tile form (t0_bwd_mid_multi.h)
-    const int nparts = t0_tile_parts(SC, ntile, vargp_cu_count(), 0.35f);
+    const int nparts = t0_tile_parts(SC, ntile, vargp_cu_count(), kBwdMidSetup);
     const BmSoftmax smx = softmax_deferred ? BmSoftmax{o.mu, o.var, eps_f, d->y, d->scalars + 2, F} : BmSoftmax{};
     if (nparts < ntile) {
+      VARGP_REQUIRE(!softmax_deferred, "elbo_t0_bwd: the multi-tile backward does not evaluate a deferred likelihood");
       rc = ensure_dynamic_lds(reinterpret_cast<const void*>(t0_bwd_mid_multi_kernel), kBwdMidMultiLdsBytes, attr_set_mask_m, "elbo_t0_bwd");
       if (rc) return rc;
       ProfScope prof("t0_bwd_mid", st);
       hipLaunchKernelGGL(t0_bwd_mid_multi_kernel, dim3(8 * cdiv(SC, 8) * nparts), dim3(256), kBwdMidMultiLdsBytes, st, o.TT, o.QP, o.W, o.RK,
                          o.gmu, o.gvar, fused_softmax ? seeds + 2 : nullptr, o.gQP, o.gTT, o.gRK, o.gkd, o.r_uf, o.c_uf, o.gtheta, S, C, M,
-                         B, D, NR, LD, ntile, nparts, mat_bwd ? g_u_mean : nullptr, C * M, smx);
+                         B, D, NR, LD, ntile, nparts, mat_bwd ? g_u_mean : nullptr, C * M);
     } else {
       rc = ensure_dynamic_lds(reinterpret_cast<const void*>(t0_bwd_mid_kernel), kBwdMidLdsBytes, attr_set_mask, "elbo_t0_bwd");
       if (rc) return rc;

@@ -39,6 +39,11 @@ __device__ __forceinline__ void bm_mfma4(bm_f32x16& acc, const float4 a, const f
   acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
 }
 
+// Workgroup barrier for LDS hand-overs only: waits for this wave's LDS operations, NOT for its outstanding global loads, stores
+// and atomics (__syncthreads() = s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier drains them all: a prefetch issued in front of it is
+// waited for on the spot, a round of float atomics likewise).  Nothing in this kernel hands data over through global memory.
+__device__ __forceinline__ void bmm_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // compile-time loop: f(integral_constant<int, I>) for I in [I0, I1)
 template <int I0, int I1, class F>
 __device__ __forceinline__ void bm_for(F&& f) {

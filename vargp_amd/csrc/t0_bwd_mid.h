@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256) void t0_bwd_mid_kernel(const float* __restrict
   BM_STAMP(4);
   BM_CUT_AT(2);
   BM_STAMP(5);
-  __syncthreads();                                  // everybody is done with P, gW and G
+  bmm_lds_barrier();                                // everybody is done with P, gW and G (LDS only: the atomics of phase 2 stay in flight)
   BM_STAMP(6);
   BM_CUT_AT(3);
   // ---- phase 3: gP into P's place, T into G's place, the K_uf tile into gW's place ---------------------------------------------
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256) void t0_bwd_mid_kernel(const float* __restrict
     }
   bm_store_mat<true>(sA, rt, M, tid);
   bm_store_tile(sW, rk, M, n0, B, tid);
-  __syncthreads();
+  bmm_lds_barrier();
   BM_STAMP(7);
   BM_CUT_AT(4);
   // ---- phase 4: gT += tril(gP K_uf^T)  (atomics),  gK_uf = T^T gP,  W_uf = gK_uf o K_uf --------------------------------------
@@ -502,7 +502,9 @@ __global__ __launch_bounds__(256) void t0_bwd_mid_kernel(const float* __restrict
         wv[u][r] = m < M ? acc[u][r] * sW[min(m, kBmKP - 1) * kBmST + n] : 0.f;      // K_uf is zero in the columns past B
       }
     }
-    __syncthreads();
+    // (LDS-only barriers from here on: __syncthreads() would drain the tail atomics issued just above -- they are left to
+    //  finish under the epilogue; nothing below is handed over through global memory)
+    bmm_lds_barrier();
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int rb = u ? rhi : rlo;
@@ -514,7 +516,7 @@ __global__ __launch_bounds__(256) void t0_bwd_mid_kernel(const float* __restrict
     }
   }
   BM_STAMP(10);
-  __syncthreads();
+  bmm_lds_barrier();
   BM_STAMP(11);
   {
     float* Gout = gRK + b * MLD + NR + n0;
@@ -546,7 +548,7 @@ __global__ __launch_bounds__(256) void t0_bwd_mid_kernel(const float* __restrict
     t += __shfl_xor(t, 1, 64);
     if (h == 0 && m < M) atomicAdd(&r_uf[b * M + m], t);          // b * M + m == s * C * M + c * M + m
   }
-  __syncthreads();
+  bmm_lds_barrier();
   {
     const int s = (int)(b / C);
     float cv = 0.f;

@@ -7,8 +7,12 @@
 //     round of float atomics per workgroup (nparts per (s, c)) instead of one per tile (ntile per (s, c)) -- and none of them
 //     inside the MFMA loops;
 //   * ga, gkd, the row sums r_uf and the gtheta share accumulate in registers likewise;
-//   * the next tile's P / W tiles are requested before the current tile's last product and land under it, its likelihood inputs
-//     during the epilogue, its K_uf tile (needed in phase 3 only) at its own top.
+//   * the next tile's P / W tiles are requested before the current tile's last product and land under it, its K_uf tile (needed
+//     in phase 3 only) at its own top; the barriers inside the tile loop wait for LDS operations only (bmm_lds_barrier), so
+//     neither these loads nor the last tile's round of atomics are drained at a barrier;
+//   * the likelihood is NOT evaluated here (the single-tile kernel can: every (s, c, tile) workgroup then redoes the softmax over
+//     all classes of its columns -- C-fold redundant vector work, 11k cycles per tile, which a throughput-bound launch cannot
+//     hide): the forward runs its own softmax launch for these shapes and this kernel reads gmu / gvar.
 // Same arithmetic per tile as the single-tile kernel (same MFMA block tables: t0_bwd_mid.h); sums over tiles are taken in
 // registers instead of by atomics, i.e. in a fixed order.
 #pragma once
@@ -16,9 +20,16 @@
 
 namespace vargp {
 
+#ifdef BM_STAMPS      // per-wave stamps (lane 0 of each wave of workgroup BM_STAMP_BLOCK): its second tile, its set-up and its whole life
+__device__ unsigned long long g_bmm_stamps[4][24];
+extern "C" void vargp_debug_bmm_stamps(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bmm_stamps), sizeof(g_bmm_stamps)); }
+#define BMM_STAMP(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == (BM_STAMP_BLOCK) && (tile == tile0 + 1 || (i) >= 20)) g_bmm_stamps[threadIdx.x >> 6][i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BMM_STAMP(i) do { } while (0)
+#endif
+
 constexpr size_t kBwdMidMultiLdsBytes =
-    sizeof(float) * (2 * kBmKP * kBmSA + 2 * kBmKP * kBmST + 128 /*a*/ + 64 + 64 /*gmu, gvar*/ + 64 /*column sums*/ + 8 +
-                     3 * 4 * 64 /*deferred softmax: partial sums of the four f-groups*/);
+    sizeof(float) * (2 * kBmKP * kBmSA + 2 * kBmKP * kBmST + 128 /*a*/ + 64 + 64 /*gmu, gvar*/ + 64 /*column sums*/ + 8);
 
 // acc[u] += X[rows of block rb(u)] Y[rows of block cb(u)]^T over the 64 columns of two M x 64 LDS tiles (no clearing: the blocks
 // accumulate over the tiles of the workgroup)
@@ -150,6 +161,9 @@ __device__ __forceinline__ void bmm_flush_tri(const bm_f32x16 (&acc)[3], float* 
 }
 __device__ __forceinline__ void bmm_flush(const int wave, const bm_f32x16 (&acc)[3], float* __restrict__ dst, int ldd, int M,
                                           int li, int lh) {
+  // (M made opaque: as a loop invariant every one of the ~400 uniform tests `32 rb + rl < M` of the four wave variants is
+  //  hoisted out of the tile loop and kept in scalar registers across it -- 300+ spilled SGPRs, then spilled vector registers)
+  asm volatile("" : "+s"(M));
   if (wave == 0) bmm_flush_tri<0>(acc, dst, ldd, M, li, lh);
   else if (wave == 1) bmm_flush_tri<1>(acc, dst, ldd, M, li, lh);
   else if (wave == 2) bmm_flush_tri<2>(acc, dst, ldd, M, li, lh);
@@ -164,7 +178,7 @@ __global__ __launch_bounds__(256) void t0_bwd_mid_multi_kernel(const float* __re
                                                                float* __restrict__ gkd, float* __restrict__ r_uf,
                                                                float* __restrict__ c_uf, float* __restrict__ gtheta, int S, int C,
                                                                int M, int B, int D, int NR, int LD, int ntile, int nparts,
-                                                               float* __restrict__ zero_out, int zero_n, const BmSoftmax sm) {
+                                                               float* __restrict__ zero_out, int zero_n) {
   extern __shared__ __attribute__((aligned(16))) float bm_lds[];
   STEP_SPAN(t0, 4);
   if (blockIdx.x == 0 && zero_out)
@@ -177,7 +191,6 @@ __global__ __launch_bounds__(256) void t0_bwd_mid_multi_kernel(const float* __re
   float* sgm = sa + 128;                            // [64]       seed * gmu of the tile
   float* sgv = sgm + 64;                            // [64]       seed * gvar
   float* scs = sgv + 64;                            // [64]       column sums of W_uf
-  float* sred = scs + 64 + 8;                       // [3][4][64] deferred softmax: partial sums of the four f-groups
   const int tid_k = threadIdx.x, tid = tid_k, lane = tid & 63, wave = tid >> 6;
   // 1-D grid, XCD-aware as the single-tile kernel: XCD x works through the matrices b = x, x + 8, ..., all workgroups of one
   // before the next (grid = 8 ceil(SC / 8) nparts; the surplus exits)
@@ -192,44 +205,24 @@ __global__ __launch_bounds__(256) void t0_bwd_mid_multi_kernel(const float* __re
   const float* Wb = Wf + b * (int64_t)M * B;
   const float* Kb = RK + b * MLD + NR;
   const float gs = gscale ? gscale[0] : 1.f;
-  const int s = (int)(b / C), cme = (int)(b % C);
+  const int s = (int)(b / C);
   constexpr int NA_ = kBmNA, NT_ = kBmNT;
+  { [[maybe_unused]] const int tile = -9; BMM_STAMP(20); }
 
   // ---- per-tile loads into registers (clamped indices; padding is selected in when the values are stored)
-  float4 sev[kBmSmC], mu4, var4;
-  int yq[4];
   float4 rp[NT_], rw[NT_], rk[NT_];
   float gmv, gvv;
   // (two groups with different live ranges: the likelihood's inputs are consumed at the top of the tile, the three tiles
   //  during it -- requested together they would hold 160 registers across the last product of the previous tile)
-  auto load_softmax_inputs = [&](const int n0, const int tid) {
-    const int q4 = tid & 15, fs = tid >> 4;
-    if (sm.eps) {
-      const int nq = min(n0 + 4 * q4, B - 4);          // B % 4 == 0: a column quad lies wholly inside or outside
-      const int64_t rc = ((int64_t)s * C + min(fs, C - 1)) * B + nq;
-      mu4 = *reinterpret_cast<const float4*>(sm.mu + rc);
-      var4 = *reinterpret_cast<const float4*>(sm.var + rc);
-      const float* ep = sm.eps + ((int64_t)s * sm.F + min(fs, sm.F - 1)) * C * B + nq;
-#pragma unroll
-      for (int c = 0; c < kBmSmC; ++c) sev[c] = *reinterpret_cast<const float4*>(ep + (int64_t)min(c, C - 1) * B);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) yq[j] = (int)sm.y[nq + j];
-    }
-  };
   auto load_tiles = [&](const int n0, const int tid) {
-    if (!sm.eps) {
-      const int ncl = min(n0 + (tid & 63), B - 1);
-      gmv = gmu[b * B + ncl]; gvv = gvar[b * B + ncl];
-    }
+    const int ncl = min(n0 + (tid & 63), B - 1);
+    gmv = gmu[b * B + ncl]; gvv = gvar[b * B + ncl];
     bm_load_tile(Qb + NR, LD, M, n0, B, tid, rp);
     bm_load_tile(Wb, B, M, n0, B, tid, rw);
   };
 
   // ---- once per workgroup: the first tile's inputs (its likelihood loads first: vmcnt retires in order), then G, T, a
-  mu4 = var4 = make_float4(0.f, 0.f, 0.f, 0.f);
   gmv = gvv = 0.f;
-  yq[0] = yq[1] = yq[2] = yq[3] = 0;
-  load_softmax_inputs(tile0 * 64, tid);
   load_tiles(tile0 * 64, tid);
   {
     float4 rg[NA_], rt[NA_];
@@ -240,6 +233,7 @@ __global__ __launch_bounds__(256) void t0_bwd_mid_multi_kernel(const float* __re
     bm_store_mat<true>(sT, rt, M, tid);
     if (tid < 128) sa[tid] = tid < M ? av : 0.f;
   }
+  { [[maybe_unused]] const int tile = -9; BMM_STAMP(21); }
 
   bm_f32x16 accG[3], accT[3];
 #pragma unroll
@@ -254,93 +248,16 @@ __global__ __launch_bounds__(256) void t0_bwd_mid_multi_kernel(const float* __re
     //  addresses derived from them out of the loop and spills them -- 1.7 KB of scratch per lane)
     int tid = tid_k;
     asm volatile("" : "+v"(tid));
+    asm volatile("" : "+s"(M), "+s"(B), "+s"(LD), "+s"(NR), "+s"(C));      // (likewise the uniform shape parameters)
     const int lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const int q4 = tid & 15, fs = tid >> 4;
     const int cbh = wave & 1;
     const int rbs[2] = {(wave >> 1) ? 1 : 0, (wave >> 1) ? 2 : 3};
-    // ---- the likelihood of this tile's columns (deferred softmax: see t0_bwd_mid_kernel), from the registers loaded a tile ago
-    if (sm.eps) {
-      const float sc1 = 1.f / (float)(S * sm.F);
-      float* smu = sP;                                  // [kBmSmC][64] mu, then [kBmSmC][64] sd = sqrt(var)  (P's place: free here)
-      float* ssd = sP + kBmSmC * 64;
-      *reinterpret_cast<float4*>(&smu[fs * 64 + 4 * q4]) = mu4;
-      *reinterpret_cast<float4*>(&ssd[fs * 64 + 4 * q4]) = make_float4(sqrtf(var4.x), sqrtf(var4.y), sqrtf(var4.z), sqrtf(var4.w));
-      __syncthreads();
-      float pm[4] = {0.f, 0.f, 0.f, 0.f}, pv[4] = {0.f, 0.f, 0.f, 0.f}, ct[4] = {0.f, 0.f, 0.f, 0.f};
-      if (4 * wave < sm.F) {                            // uniform: a wave holds four likelihood samples
-        const bool live = n0 + 4 * q4 < B && fs < sm.F;
-        float mx[4], fy[4] = {0.f, 0.f, 0.f, 0.f}, sdme[4] = {1.f, 1.f, 1.f, 1.f};
-        float eme[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) mx[j] = -INFINITY;
-#pragma unroll
-        for (int cg = 0; cg < kBmSmC / 4; ++cg) {
-          if (4 * cg >= C) continue;
-#pragma unroll
-          for (int c = 4 * cg; c < 4 * cg + 4; ++c) {
-            const float4 m4 = *reinterpret_cast<const float4*>(&smu[c * 64 + 4 * q4]);
-            const float4 s4 = *reinterpret_cast<const float4*>(&ssd[c * 64 + 4 * q4]);
-            const float e[4] = {sev[c].x, sev[c].y, sev[c].z, sev[c].w};
-            const float m_[4] = {m4.x, m4.y, m4.z, m4.w}, s_[4] = {s4.x, s4.y, s4.z, s4.w};
-            float v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              v[j] = c < C ? fmaf(s_[j], e[j], m_[j]) : -INFINITY;
-              mx[j] = fmaxf(mx[j], v[j]);
-              if (c == yq[j]) fy[j] = v[j];
-              if (c == cme) { eme[j] = e[j]; sdme[j] = s_[j]; }
-            }
-            sev[c] = make_float4(v[0], v[1], v[2], v[3]);
-          }
-        }
-        float se[4] = {0.f, 0.f, 0.f, 0.f}, vme[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int cg = 0; cg < kBmSmC / 4; ++cg) {
-          if (4 * cg >= C) continue;
-#pragma unroll
-          for (int c = 4 * cg; c < 4 * cg + 4; ++c) {
-            const float v[4] = {sev[c].x, sev[c].y, sev[c].z, sev[c].w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const float e = c < C ? expf(v[j] - mx[j]) : 0.f;
-              se[j] += e;
-              if (c == cme) vme[j] = e;
-            }
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float pc = vme[j] * (sc1 / se[j]) - (cme == yq[j] ? sc1 : 0.f);
-          pm[j] = live ? pc : 0.f;
-          pv[j] = live ? pc * eme[j] * (0.5f / sdme[j]) : 0.f;
-          ct[j] = live ? -(fy[j] - (mx[j] + logf(se[j]))) * sc1 : 0.f;
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        pm[j] += __shfl_xor(pm[j], 16, 64); pm[j] += __shfl_xor(pm[j], 32, 64);
-        pv[j] += __shfl_xor(pv[j], 16, 64); pv[j] += __shfl_xor(pv[j], 32, 64);
-        ct[j] += __shfl_xor(ct[j], 16, 64); ct[j] += __shfl_xor(ct[j], 32, 64);
-      }
-      if (lane < 16) {
-        *reinterpret_cast<float4*>(&sred[(0 * 4 + wave) * 64 + 4 * q4]) = make_float4(pm[0], pm[1], pm[2], pm[3]);
-        *reinterpret_cast<float4*>(&sred[(1 * 4 + wave) * 64 + 4 * q4]) = make_float4(pv[0], pv[1], pv[2], pv[3]);
-        *reinterpret_cast<float4*>(&sred[(2 * 4 + wave) * 64 + 4 * q4]) = make_float4(ct[0], ct[1], ct[2], ct[3]);
-      }
-      __syncthreads();
-      if (tid < 64) {
-        gmv = sred[tid] + sred[64 + tid] + sred[128 + tid] + sred[192 + tid];
-        gvv = sred[256 + tid] + sred[320 + tid] + sred[384 + tid] + sred[448 + tid];
-        if (cme == 0) {
-          float t = sred[512 + tid] + sred[576 + tid] + sred[640 + tid] + sred[704 + tid];
-          t = wave_sum(t);
-          if (tid == 0) atomicAdd(sm.nll, t);
-        }
-      }
-    }
+    BMM_STAMP(0);
     // ---- phase 0: P, W, gmu, gvar into LDS -------------------------------------------------------------------------------------
+    BMM_STAMP(1);
     bm_store_tile(sP, rp, M, n0, B, tid);
     bm_store_tile(sW, rw, M, n0, B, tid);
+    BMM_STAMP(15);
     bm_load_tile(Kb, LD, M, n0, B, tid, rk);          // this tile's K_uf: needed in phase 3, lands under phases 1 and 2
     if (tid < 64) {
       const bool ok = n0 + tid < B;
@@ -348,7 +265,8 @@ __global__ __launch_bounds__(256) void t0_bwd_mid_multi_kernel(const float* __re
       sgv[tid] = ok ? gs * gvv : 0.f;
       scs[tid] = 0.f;
     }
-    __syncthreads();
+    bmm_lds_barrier();
+    BMM_STAMP(2);
     // ---- phase 1: gW = 2 W gvar in place; ga += P gmu; gkd += sum gvar ---------------------------------------------------------
 #pragma unroll
     for (int u = 0; u < NT_; ++u) {
@@ -374,16 +292,19 @@ __global__ __launch_bounds__(256) void t0_bwd_mid_multi_kernel(const float* __re
       ga_acc += acc0 + acc1;
       if (wave == 0) gkd_acc += sgv[lane];
     }
-    __syncthreads();
+    bmm_lds_barrier();
+    BMM_STAMP(3);
     // ---- phase 2: accG += tril(P gW^T),  gP = a gmu^T - 2 P gvar + G gW -----------------------------------------------------------
     bm_f32x16 accP[2];
     if (wave == 0) bmm_phase2<0>(sG, sP, sW, sa, sgm, sgv, li, lh, accP, accG);
     else if (wave == 1) bmm_phase2<1>(sG, sP, sW, sa, sgm, sgv, li, lh, accP, accG);
     else if (wave == 2) bmm_phase2<2>(sG, sP, sW, sa, sgm, sgv, li, lh, accP, accG);
     else bmm_phase2<3>(sG, sP, sW, sa, sgm, sgv, li, lh, accP, accG);
+    BMM_STAMP(4);
     // (last tile: the G block is complete -- its round of atomics / stores drains under phases 3 and 4)
     if (tile + 1 == tile1) bmm_flush(wave, accG, gQP + b * MLD + 4, LD, M, li, lh);
-    __syncthreads();                                  // everybody is done with P and gW
+    bmm_lds_barrier();                                  // everybody is done with P and gW
+    BMM_STAMP(5);
     // ---- phase 3: gP into P's place, the K_uf tile into gW's place; then the NEXT tile's loads (they land under phase 4) -----------
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -394,7 +315,8 @@ __global__ __launch_bounds__(256) void t0_bwd_mid_multi_kernel(const float* __re
       }
     bm_store_tile(sW, rk, M, n0, B, tid);
     if (tile + 1 < tile1) load_tiles(n0 + 64, tid);
-    __syncthreads();
+    bmm_lds_barrier();
+    BMM_STAMP(6);
     // ---- phase 4: accT += tril(gP K_uf^T),  gK_uf = T^T gP,  W_uf = gK_uf o K_uf ---------------------------------------------------
     {
       bm_f32x16 acc[2];      // [0]: row block rbs[0], [1]: row block rbs[1]
@@ -402,6 +324,7 @@ __global__ __launch_bounds__(256) void t0_bwd_mid_multi_kernel(const float* __re
       else if (wave == 1) bmm_phase4<1>(sT, sP, sW, li, lh, acc, accT);
       else if (wave == 2) bmm_phase4<2>(sT, sP, sW, li, lh, acc, accT);
       else bmm_phase4<3>(sT, sP, sW, li, lh, acc, accT);
+      BMM_STAMP(7);
       if (tile + 1 == tile1) bmm_flush(wave, accT, gTT + b * MM, M, M, li, lh);      // drains under the epilogue
       const int n = 32 * cbh + li;
       float wv[2][16];
@@ -412,7 +335,9 @@ __global__ __launch_bounds__(256) void t0_bwd_mid_multi_kernel(const float* __re
           const int m = 32 * rbs[u] + (r & 3) + 8 * (r >> 2) + 4 * lh;
           wv[u][r] = m < M ? acc[u][r] * sW[min(m, kBmKP - 1) * kBmST + n] : 0.f;      // K_uf is zero in the columns past B
         }
-      __syncthreads();                                // everybody is done with gP as an operand
+      BMM_STAMP(16);
+      bmm_lds_barrier();                                // everybody is done with gP as an operand
+      BMM_STAMP(17);
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -421,8 +346,8 @@ __global__ __launch_bounds__(256) void t0_bwd_mid_multi_kernel(const float* __re
           if (m < kBmKP) sP[m * kBmST + n] = wv[u][r];
         }
     }
-    if (tile + 1 < tile1) load_softmax_inputs(n0 + 64, tid);      // the next tile's likelihood inputs: under the rest of the epilogue
-    __syncthreads();
+    bmm_lds_barrier();
+    BMM_STAMP(8);
     {
       // W_uf rows out (coalesced float4), column sums, row sums
       float* Gout = gRK + b * MLD + NR + n0;
@@ -451,12 +376,14 @@ __global__ __launch_bounds__(256) void t0_bwd_mid_multi_kernel(const float* __re
       }
       ruf_acc += a0 + a1;
     }
-    __syncthreads();
+    bmm_lds_barrier();
+    BMM_STAMP(9);
     if (tid < 64) {
       const float cv = scs[tid];
       if (n0 + tid < B) atomicAdd(&c_uf[(int64_t)s * B + n0 + tid], cv);
       gth_acc += cv;                                    // (wave 0: summed over its lanes at the end)
     }
+    BMM_STAMP(10);
     // (no barrier here: the next iteration's first LDS writes -- the likelihood's scratch in P's place, then P / W -- touch what
     //  everybody stopped reading before the barrier above, and scs is cleared by the threads that have just read it)
   }
@@ -479,6 +406,7 @@ __global__ __launch_bounds__(256) void t0_bwd_mid_multi_kernel(const float* __re
       }
     }
   }
+  { [[maybe_unused]] const int tile = -9; BMM_STAMP(22); }
 }
 
 }  // namespace vargp
