@@ -31,143 +31,133 @@ extern "C" void vargp_debug_bmm_stamps(unsigned long long* out) { (void)hipMemcp
 constexpr size_t kBwdMidMultiLdsBytes =
     sizeof(float) * (2 * kBmKP * kBmSA + 2 * kBmKP * kBmST + 128 /*a*/ + 64 + 64 /*gmu, gvar*/ + 64 /*column sums*/ + 8);
 
-// acc[u] += X[rows of block rb(u)] Y[rows of block cb(u)]^T over the 64 columns of two M x 64 LDS tiles (no clearing: the blocks
-// accumulate over the tiles of the workgroup)
+// ---- f32 MFMA 16x16x4 blocking: M <= 104 is SEVEN 16-row blocks (112 rows: 1.25x padding work for M = 100) instead of four 32-row
+// blocks (128 rows: 1.64x).  Lane (l16, q) = (lane & 15, lane >> 4); the four MFMAs of one k-group of 16 take k = 16 g + 4 q + j,
+// j < 4, from lane group q (one b128 read per lane for a K-contiguous operand, four b32 reads for a k-major one); accumulator
+// register r of a block holds row 16 rb + 4 q + r, column 16 cb + l16.  Rows / inner indices 104 .. 111 do not exist in LDS:
+// row indices are clamped (the results of those rows are never stored), inner indices are masked to zero.
+typedef float bm_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kB16NB = 7;       // 16-row blocks of an M-long dimension
+__device__ __forceinline__ void b16_mfma4(bm_f32x4& acc, const float4 a, const float4 b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+}
+__device__ __forceinline__ float4 b16_mask(const float4 v, const bool ok) {
+  return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+// The 28 blocks of the lower triangle of an M x M result, seven per wave: wave WV holds block row 6 - WV (7 - WV blocks) and, for
+// WV > 0, block row WV - 1 (WV blocks) -- the column blocks of the second row are a subset of the first's, so one k-group needs at
+// most eight fragment reads for its 28 MFMAs.
+template <int WV> struct B16Tri {
+  static constexpr int RA = 6 - WV, NA = 7 - WV, RB = WV > 0 ? WV - 1 : 0, NBk = WV;
+  __host__ __device__ static constexpr int rb(int u) { return u < NA ? RA : RB; }
+  __host__ __device__ static constexpr int cb(int u) { return u < NA ? u : u - NA; }
+};
+// acc[u] += X[rows of block rb(u)] Y[rows of block cb(u)]^T over the 64 columns of two M x 64 LDS tiles ([row][col], stride kBmST)
 template <int WV>
-__device__ __forceinline__ void bmm_tri_mfma_acc(const float* __restrict__ sX, const float* __restrict__ sY, int li, int lh,
-                                                 bm_f32x16 (&acc)[3]) {
-  using W = BmWave<WV>;
-  const float* xr[3];
-  const float* yr[3];
+__device__ __forceinline__ void b16_tri_acc(const float* __restrict__ sX, const float* __restrict__ sY, int l16, int q,
+                                            bm_f32x4 (&acc)[kB16NB]) {
+  using W = B16Tri<WV>;
+  const float* xa = sX + min(16 * W::RA + l16, kBmKP - 1) * kBmST + 4 * q;
+  const float* xb = sX + min(16 * W::RB + l16, kBmKP - 1) * kBmST + 4 * q;
+  const float* yr[W::NA];
 #pragma unroll
-  for (int u = 0; u < 3; ++u) {
-    xr[u] = sX + min(32 * W::rb(u < W::NB ? u : 0) + li, kBmKP - 1) * kBmST + 4 * lh;
-    yr[u] = sY + min(32 * W::cb(u < W::NB ? u : 0) + li, kBmKP - 1) * kBmST + 4 * lh;
+  for (int c = 0; c < W::NA; ++c) yr[c] = sY + min(16 * c + l16, kBmKP - 1) * kBmST + 4 * q;
+  float4 nxa = bm_frag_kc(xa, 0), nxb = nxa, ny[W::NA];
+  if constexpr (W::NBk > 0) nxb = bm_frag_kc(xb, 0);
+#pragma unroll
+  for (int c = 0; c < W::NA; ++c) ny[c] = bm_frag_kc(yr[c], 0);
+  bm_for<0, 4>([&](auto gi) {
+    constexpr int g = decltype(gi)::value;
+    const float4 cxa = nxa, cxb = nxb;
+    float4 cy[W::NA];
+#pragma unroll
+    for (int c = 0; c < W::NA; ++c) cy[c] = ny[c];
+    if constexpr (g + 1 < 4) {                         // next group's fragments: in flight under this group's MFMAs
+      nxa = bm_frag_kc(xa, 16 * (g + 1));
+      if constexpr (W::NBk > 0) nxb = bm_frag_kc(xb, 16 * (g + 1));
+#pragma unroll
+      for (int c = 0; c < W::NA; ++c) ny[c] = bm_frag_kc(yr[c], 16 * (g + 1));
+    }
+#pragma unroll
+    for (int c = 0; c < W::NA; ++c) b16_mfma4(acc[c], cxa, cy[c]);
+#pragma unroll
+    for (int c = 0; c < W::NBk; ++c) b16_mfma4(acc[W::NA + c], cxb, cy[c]);
+  });
+}
+// An M x 64 result, 16 columns per wave (column block CW = wave), all seven row blocks:
+//   LOWER:  acc[i] += sum_{k <= row} A[row][k] B[k][n]      A = sA[row][k] (lower triangular, K-contiguous rows, stride kBmSA)
+//   !LOWER: acc[i] += sum_{k >= row} A[k][row] B[k][n]      A = sA[k][row] (the transpose of a lower triangular matrix, k-major)
+// B = sB[k][n] (k-major, stride kBmST).  Row block i takes part in the k-groups g <= i (LOWER) / g >= i.
+template <bool LOWER>
+__device__ __forceinline__ void b16_prod(const float* __restrict__ sA, const float* __restrict__ sB, int cw, int l16, int q,
+                                         bm_f32x4 (&acc)[kB16NB]) {
+  const float* ap[kB16NB];
+#pragma unroll
+  for (int i = 0; i < kB16NB; ++i)
+    ap[i] = LOWER ? sA + min(16 * i + l16, kBmKP - 1) * kBmSA + 4 * q : sA + (4 * q) * kBmSA + min(16 * i + l16, kBmKP - 1);
+  const float* bcol = sB + (4 * q) * kBmST + 16 * cw + l16;
+  auto afrag = [&](const int i, const int g) -> float4 {
+    // (the last k-group holds k = 96 .. 111: lane groups 2, 3 are past the 104 rows / columns that exist)
+    if (LOWER) return g == 6 ? b16_mask(bm_frag_kc(ap[i], 16 * g - (q >= 2 ? 8 : 0)), q < 2) : bm_frag_kc(ap[i], 16 * g);
+    return g == 6 ? b16_mask(bm_frag_km(ap[i], 16 * g - (q >= 2 ? 8 : 0), kBmSA), q < 2) : bm_frag_km(ap[i], 16 * g, kBmSA);
+  };
+  auto bfrag = [&](const int g) -> float4 {
+    return g == 6 ? b16_mask(bm_frag_km(bcol, 16 * g - (q >= 2 ? 8 : 0), kBmST), q < 2) : bm_frag_km(bcol, 16 * g, kBmST);
+  };
+  constexpr int G0 = 0, G1 = kB16NB;
+  float4 nb = bfrag(G0), na[kB16NB];
+#pragma unroll
+  for (int i = 0; i < kB16NB; ++i) na[i] = (LOWER ? i >= G0 : i <= G0) ? afrag(i, G0) : make_float4(0.f, 0.f, 0.f, 0.f);
+  bm_for<G0, G1>([&](auto gi) {
+    constexpr int g = decltype(gi)::value;
+    const float4 bb = nb;
+    float4 ca[kB16NB];
+#pragma unroll
+    for (int i = 0; i < kB16NB; ++i) ca[i] = na[i];
+    if constexpr (g + 1 < G1) {
+      nb = bfrag(g + 1);
+#pragma unroll
+      for (int i = 0; i < kB16NB; ++i)
+        if (LOWER ? i >= g + 1 : i <= g + 1) na[i] = afrag(i, g + 1);
+    }
+#pragma unroll
+    for (int i = 0; i < kB16NB; ++i)
+      if (LOWER ? i >= g : i <= g) b16_mfma4(acc[i], ca[i], bb);
+  });
+}
+// register A (flat index u * 4 + r) of a wave's lower-triangle blocks, added to dst[row * ldd + col] (col <= row < M)
+template <int WV, int A>
+__device__ __forceinline__ void b16_tri_atomic(const bm_f32x4 (&acc)[kB16NB], float* __restrict__ dst, int ldd, int M, int l16, int q) {
+  using W = B16Tri<WV>;
+  constexpr int u = A / 4, r = A % 4, rb = W::rb(u), cb = W::cb(u);
+  if (16 * rb + r < M) {                                // (uniform) the register holds at least one row < M
+    const int row = 16 * rb + 4 * q + r, col = 16 * cb + l16;
+    if (row < M && (rb != cb || col <= row)) atomicAdd(&dst[(int64_t)row * ldd + col], acc[u][r]);
   }
-  // fragments one k-group ahead of their MFMAs
-  float4 nx[3], ny[3];
-#pragma unroll
-  for (int u = 0; u < W::NB; ++u) { nx[u] = bm_frag_kc(xr[u], 0); ny[u] = bm_frag_kc(yr[u], 0); }
-  bm_for<0, 8>([&](auto gi) {
-    constexpr int g = decltype(gi)::value;
-    float4 cx[3], cy[3];
-#pragma unroll
-    for (int u = 0; u < W::NB; ++u) { cx[u] = nx[u]; cy[u] = ny[u]; }
-    if constexpr (g + 1 < 8) {
-#pragma unroll
-      for (int u = 0; u < W::NB; ++u) { nx[u] = bm_frag_kc(xr[u], 8 * (g + 1)); ny[u] = bm_frag_kc(yr[u], 8 * (g + 1)); }
-    }
-#pragma unroll
-    for (int u = 0; u < W::NB; ++u) bm_mfma4(acc[u], cx[u], cy[u]);
-  });
 }
-
-// phase 2 of wave WV:  accG += tril(P gW^T),  accP = a gmu^T - 2 P gvar + G gW
 template <int WV>
-__device__ __forceinline__ void bmm_phase2(const float* __restrict__ sG, const float* __restrict__ sP, const float* __restrict__ sW,
-                                           const float* __restrict__ sa, const float* __restrict__ sgm,
-                                           const float* __restrict__ sgv, int li, int lh, bm_f32x16 (&accP)[2],
-                                           bm_f32x16 (&accG)[3]) {
-  using W = BmWave<WV>;
-  bmm_tri_mfma_acc<WV>(sP, sW, li, lh, accG);
-  constexpr int R[2] = {W::R0, W::R1};
-  const int n = 32 * W::CBH + li;
-  {
-    const float gmn = sgm[n], gvn = sgv[n];
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = 32 * R[u] + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int mc = min(m, kBmKP - 1);
-        accP[u][r] = m < kBmKP ? fmaf(sa[mc], gmn, -2.f * sP[mc * kBmST + n] * gvn) : 0.f;
-      }
-  }
-  constexpr int G0 = bm_min(kBmKP, 32 * W::R0 + 32) / 8, G1 = bm_min(kBmKP, 32 * W::R1 + 32) / 8;     // G lower: k <= row; G0 < G1
-  const float* arow0 = sG + min(32 * W::R0 + li, kBmKP - 1) * kBmSA + 4 * lh;
-  const float* arow1 = sG + min(32 * W::R1 + li, kBmKP - 1) * kBmSA + 4 * lh;
-  const float* bcol = sW + (4 * lh) * kBmST + n;
-  float4 nb = bm_frag_km(bcol, 0, kBmST), na0 = bm_frag_kc(arow0, 0), na1 = bm_frag_kc(arow1, 0);
-  bm_for<0, G1>([&](auto gi) {
-    constexpr int g = decltype(gi)::value;
-    const float4 bb = nb, a0 = na0, a1 = na1;
-    if constexpr (g + 1 < G1) {                        // next group's fragments: in flight under this group's MFMAs
-      nb = bm_frag_km(bcol, 8 * (g + 1), kBmST);
-      na1 = bm_frag_kc(arow1, 8 * (g + 1));
-      if constexpr (g + 1 < G0) na0 = bm_frag_kc(arow0, 8 * (g + 1));
-    }
-    if constexpr (g < G0) {
-      // the two blocks' MFMAs alternate (independent accumulators)
-      accP[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, bb.x, accP[1], 0, 0, 0);
-      accP[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bb.x, accP[0], 0, 0, 0);
-      accP[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, bb.y, accP[1], 0, 0, 0);
-      accP[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bb.y, accP[0], 0, 0, 0);
-      accP[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, bb.z, accP[1], 0, 0, 0);
-      accP[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, bb.z, accP[0], 0, 0, 0);
-      accP[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, bb.w, accP[1], 0, 0, 0);
-      accP[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bb.w, accP[0], 0, 0, 0);
-    } else {
-      bm_mfma4(accP[1], a1, bb);
-    }
-  });
+__device__ __forceinline__ void b16_flush_tri(const bm_f32x4 (&acc)[kB16NB], float* __restrict__ dst, int ldd, int M, int l16, int q) {
+  bm_for<0, 4 * kB16NB>([&](auto ai) { b16_tri_atomic<WV, decltype(ai)::value>(acc, dst, ldd, M, l16, q); });
 }
-
-// phase 4 of wave WV:  accT += tril(gP K_uf^T),  accK = T^T gP  ([0]: row block R0, [1]: row block R1)
-template <int WV>
-__device__ __forceinline__ void bmm_phase4(const float* __restrict__ sT, const float* __restrict__ sP, const float* __restrict__ sW,
-                                           int li, int lh, bm_f32x16 (&accK)[2], bm_f32x16 (&accT)[3]) {
-  using W = BmWave<WV>;
-  bmm_tri_mfma_acc<WV>(sP, sW, li, lh, accT);
-#pragma unroll
-  for (int u = 0; u < 2; ++u)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accK[u][r] = 0.f;
-  constexpr int GS0 = 4 * W::R0, GS1 = 4 * W::R1, GE = kBmKP / 8;       // T lower: (T^T gP)[m] sums k >= m
-  const int n = 32 * W::CBH + li;
-  const float* acol0 = sT + (4 * lh) * kBmSA + min(32 * W::R0 + li, kBmKP - 1);
-  const float* acol1 = sT + (4 * lh) * kBmSA + min(32 * W::R1 + li, kBmKP - 1);
-  const float* bcol = sP + (4 * lh) * kBmST + n;
-  float4 nb = bm_frag_km(bcol, 8 * GS0, kBmST), na0 = bm_frag_km(acol0, 8 * GS0, kBmSA), na1 = na0;
-  if constexpr (GS1 == GS0) na1 = bm_frag_km(acol1, 8 * GS0, kBmSA);
-  bm_for<GS0, GE>([&](auto gi) {
-    constexpr int g = decltype(gi)::value;
-    const float4 bb = nb, a0 = na0, a1 = na1;
-    if constexpr (g + 1 < GE) {
-      nb = bm_frag_km(bcol, 8 * (g + 1), kBmST);
-      na0 = bm_frag_km(acol0, 8 * (g + 1), kBmSA);
-      if constexpr (g + 1 >= GS1) na1 = bm_frag_km(acol1, 8 * (g + 1), kBmSA);
-    }
-    if constexpr (g >= GS1) {
-      accK[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bb.x, accK[0], 0, 0, 0);
-      accK[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, bb.x, accK[1], 0, 0, 0);
-      accK[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bb.y, accK[0], 0, 0, 0);
-      accK[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, bb.y, accK[1], 0, 0, 0);
-      accK[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, bb.z, accK[0], 0, 0, 0);
-      accK[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, bb.z, accK[1], 0, 0, 0);
-      accK[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bb.w, accK[0], 0, 0, 0);
-      accK[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, bb.w, accK[1], 0, 0, 0);
-    } else {
-      bm_mfma4(accK[0], a0, bb);
-    }
-  });
-}
-
-// every block register of a wave's M x M accumulators out: dst[row * ldd + col] += acc  (col <= row < M; float atomics:
-// nparts workgroups per (s, c) add into the same block, which the forward has cleared)
-template <int WV>
-__device__ __forceinline__ void bmm_flush_tri(const bm_f32x16 (&acc)[3], float* __restrict__ dst, int ldd, int M, int li, int lh) {
-  using W = BmWave<WV>;
-  bm_for<0, 16 * W::NB>([&](auto ai) { bm_tri_atomic<WV, decltype(ai)::value>(acc, dst, ldd, M, li, lh); });
-}
-__device__ __forceinline__ void bmm_flush(const int wave, const bm_f32x16 (&acc)[3], float* __restrict__ dst, int ldd, int M,
-                                          int li, int lh) {
-  // (M made opaque: as a loop invariant every one of the ~400 uniform tests `32 rb + rl < M` of the four wave variants is
-  //  hoisted out of the tile loop and kept in scalar registers across it -- 300+ spilled SGPRs, then spilled vector registers)
+__device__ __forceinline__ void b16_flush(const int wave, const bm_f32x4 (&acc)[kB16NB], float* __restrict__ dst, int ldd, int M,
+                                          int l16, int q) {
+  // (M made opaque: as a loop invariant every uniform test `16 rb + r < M` of the four wave variants is hoisted out of the tile
+  //  loop and kept in scalar registers across it)
   asm volatile("" : "+s"(M));
-  if (wave == 0) bmm_flush_tri<0>(acc, dst, ldd, M, li, lh);
-  else if (wave == 1) bmm_flush_tri<1>(acc, dst, ldd, M, li, lh);
-  else if (wave == 2) bmm_flush_tri<2>(acc, dst, ldd, M, li, lh);
-  else bmm_flush_tri<3>(acc, dst, ldd, M, li, lh);
+  if (wave == 0) b16_flush_tri<0>(acc, dst, ldd, M, l16, q);
+  else if (wave == 1) b16_flush_tri<1>(acc, dst, ldd, M, l16, q);
+  else if (wave == 2) b16_flush_tri<2>(acc, dst, ldd, M, l16, q);
+  else b16_flush_tri<3>(acc, dst, ldd, M, l16, q);
+}
+__device__ __forceinline__ void b16_tri(const int wave, const float* __restrict__ sX, const float* __restrict__ sY, int l16, int q,
+                                        bm_f32x4 (&acc)[kB16NB]) {
+  if (wave == 0) b16_tri_acc<0>(sX, sY, l16, q, acc);
+  else if (wave == 1) b16_tri_acc<1>(sX, sY, l16, q, acc);
+  else if (wave == 2) b16_tri_acc<2>(sX, sY, l16, q, acc);
+  else b16_tri_acc<3>(sX, sY, l16, q, acc);
 }
 
 __global__ __launch_bounds__(256) void t0_bwd_mid_multi_kernel(const float* __restrict__ TT, const float* __restrict__ QP,
@@ -235,11 +225,11 @@ __global__ __launch_bounds__(256) void t0_bwd_mid_multi_kernel(const float* __re
   }
   { [[maybe_unused]] const int tile = -9; BMM_STAMP(21); }
 
-  bm_f32x16 accG[3], accT[3];
+  bm_f32x4 accG[kB16NB], accT[kB16NB];
 #pragma unroll
-  for (int u = 0; u < 3; ++u)
+  for (int u = 0; u < kB16NB; ++u)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { accG[u][r] = 0.f; accT[u][r] = 0.f; }
+    for (int r = 0; r < 4; ++r) { accG[u][r] = 0.f; accT[u][r] = 0.f; }
   float ga_acc = 0.f, ruf_acc = 0.f, gkd_acc = 0.f, gth_acc = 0.f;      // per thread (m, h) / wave 0: sums over the tiles
 
   for (int tile = tile0; tile < tile1; ++tile) {
@@ -249,9 +239,8 @@ __global__ __launch_bounds__(256) void t0_bwd_mid_multi_kernel(const float* __re
     int tid = tid_k;
     asm volatile("" : "+v"(tid));
     asm volatile("" : "+s"(M), "+s"(B), "+s"(LD), "+s"(NR), "+s"(C));      // (likewise the uniform shape parameters)
-    const int lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const int cbh = wave & 1;
-    const int rbs[2] = {(wave >> 1) ? 1 : 0, (wave >> 1) ? 2 : 3};
+    const int lane = tid & 63, wave = tid >> 6, l16 = lane & 15, q = lane >> 4;
+    const int n = 16 * wave + l16;                     // this lane's column of the M x 64 results
     BMM_STAMP(0);
     // ---- phase 0: P, W, gmu, gvar into LDS -------------------------------------------------------------------------------------
     BMM_STAMP(1);
@@ -295,23 +284,31 @@ __global__ __launch_bounds__(256) void t0_bwd_mid_multi_kernel(const float* __re
     bmm_lds_barrier();
     BMM_STAMP(3);
     // ---- phase 2: accG += tril(P gW^T),  gP = a gmu^T - 2 P gvar + G gW -----------------------------------------------------------
-    bm_f32x16 accP[2];
-    if (wave == 0) bmm_phase2<0>(sG, sP, sW, sa, sgm, sgv, li, lh, accP, accG);
-    else if (wave == 1) bmm_phase2<1>(sG, sP, sW, sa, sgm, sgv, li, lh, accP, accG);
-    else if (wave == 2) bmm_phase2<2>(sG, sP, sW, sa, sgm, sgv, li, lh, accP, accG);
-    else bmm_phase2<3>(sG, sP, sW, sa, sgm, sgv, li, lh, accP, accG);
+    b16_tri(wave, sP, sW, l16, q, accG);
+    bm_f32x4 accP[kB16NB];
+    {
+      const float gmn = sgm[n], gvn = sgv[n];
+#pragma unroll
+      for (int i = 0; i < kB16NB; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = 16 * i + 4 * q + r, mc = min(m, kBmKP - 1);
+          accP[i][r] = m < kBmKP ? fmaf(sa[mc], gmn, -2.f * sP[mc * kBmST + n] * gvn) : 0.f;
+        }
+    }
+    b16_prod<true>(sG, sW, wave, l16, q, accP);
     BMM_STAMP(4);
-    // (last tile: the G block is complete -- its round of atomics / stores drains under phases 3 and 4)
-    if (tile + 1 == tile1) bmm_flush(wave, accG, gQP + b * MLD + 4, LD, M, li, lh);
+    // (last tile: the G block is complete -- its round of atomics drains under phases 3 and 4)
+    if (tile + 1 == tile1) b16_flush(wave, accG, gQP + b * MLD + 4, LD, M, l16, q);
     bmm_lds_barrier();                                  // everybody is done with P and gW
     BMM_STAMP(5);
     // ---- phase 3: gP into P's place, the K_uf tile into gW's place; then the NEXT tile's loads (they land under phase 4) -----------
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int i = 0; i < kB16NB; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = 32 * rbs[u] + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m < kBmKP) sP[m * kBmST + 32 * cbh + li] = m < M ? accP[u][r] : 0.f;
+      for (int r = 0; r < 4; ++r) {
+        const int m = 16 * i + 4 * q + r;
+        if (m < kBmKP) sP[m * kBmST + n] = m < M ? accP[i][r] : 0.f;
       }
     bm_store_tile(sW, rk, M, n0, B, tid);
     if (tile + 1 < tile1) load_tiles(n0 + 64, tid);
@@ -319,31 +316,32 @@ __global__ __launch_bounds__(256) void t0_bwd_mid_multi_kernel(const float* __re
     BMM_STAMP(6);
     // ---- phase 4: accT += tril(gP K_uf^T),  gK_uf = T^T gP,  W_uf = gK_uf o K_uf ---------------------------------------------------
     {
-      bm_f32x16 acc[2];      // [0]: row block rbs[0], [1]: row block rbs[1]
-      if (wave == 0) bmm_phase4<0>(sT, sP, sW, li, lh, acc, accT);
-      else if (wave == 1) bmm_phase4<1>(sT, sP, sW, li, lh, acc, accT);
-      else if (wave == 2) bmm_phase4<2>(sT, sP, sW, li, lh, acc, accT);
-      else bmm_phase4<3>(sT, sP, sW, li, lh, acc, accT);
+      b16_tri(wave, sP, sW, l16, q, accT);
+      bm_f32x4 acc[kB16NB];
+#pragma unroll
+      for (int i = 0; i < kB16NB; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+      b16_prod<false>(sT, sP, wave, l16, q, acc);
       BMM_STAMP(7);
-      if (tile + 1 == tile1) bmm_flush(wave, accT, gTT + b * MM, M, M, li, lh);      // drains under the epilogue
-      const int n = 32 * cbh + li;
-      float wv[2][16];
+      if (tile + 1 == tile1) b16_flush(wave, accT, gTT + b * MM, M, M, l16, q);      // drains under the epilogue
+      float wv[kB16NB][4];
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int i = 0; i < kB16NB; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = 32 * rbs[u] + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          wv[u][r] = m < M ? acc[u][r] * sW[min(m, kBmKP - 1) * kBmST + n] : 0.f;      // K_uf is zero in the columns past B
+        for (int r = 0; r < 4; ++r) {
+          const int m = 16 * i + 4 * q + r;
+          wv[i][r] = m < M ? acc[i][r] * sW[min(m, kBmKP - 1) * kBmST + n] : 0.f;      // K_uf is zero in the columns past B
         }
       BMM_STAMP(16);
       bmm_lds_barrier();                                // everybody is done with gP as an operand
       BMM_STAMP(17);
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int i = 0; i < kB16NB; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = 32 * rbs[u] + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (m < kBmKP) sP[m * kBmST + n] = wv[u][r];
+        for (int r = 0; r < 4; ++r) {
+          const int m = 16 * i + 4 * q + r;
+          if (m < kBmKP) sP[m * kBmST + n] = wv[i][r];
         }
     }
     bmm_lds_barrier();
