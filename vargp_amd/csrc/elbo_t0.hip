@@ -501,6 +501,65 @@ __global__ __launch_bounds__(256) void t0_fwd_fused_kernel(const float* __restri
   FF_STAMP(13);
   ff_barrier<MULTI>();
   FF_STAMP(2);
+  if constexpr (MULTI) {
+    // ---- throughput-bound shapes: f32 MFMA 16x16x4 blocks (t0_bwd_mid_multi.h: M = 100 is seven 16-row blocks, 1.25x padded work
+    // instead of 1.64x), 16 columns of the tile per wave, all seven row blocks: both products carry the same work on every wave
+    const int l16 = lane & 15, q = lane >> 4, n = 16 * wave + l16, col = n0 + n;
+    bm_f32x4 accP[kB16NB];
+#pragma unroll
+    for (int i = 0; i < kB16NB; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) accP[i][r] = 0.f;
+    b16_prod<true, kFusedTS>(sT, sK, wave, l16, q, accP);        // P = T K: row block i takes the k-groups g <= i
+    ff_barrier<true>();                               // everybody is done with the K_uf tile
+    float s_mu = 0.f, s_p2 = 0.f, s_w2 = 0.f;
+    char* Pout_b = reinterpret_cast<char*>(QP + b * MLD + NR);
+#pragma unroll
+    for (int i = 0; i < kB16NB; ++i) {
+      float sav[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sav[r] = sa[16 * i + 4 * q + r];      // (128 entries, zero beyond M)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = 16 * i + 4 * q + r;
+        const float v = m < M ? accP[i][r] : 0.f;       // (rows 104 .. 111 hold clamped reads of row 103)
+        if (m < kFusedK) sK[m * kFusedKS + n] = v;
+        if (m < M && col < B) *reinterpret_cast<float*>(Pout_b + 4u * (__umul24((unsigned)m, (unsigned)LD) + (unsigned)col)) = v;
+        s_mu = fmaf(v, sav[r], s_mu);
+        s_p2 = fmaf(v, v, s_p2);
+      }
+    }
+    ff_barrier<true>();
+    char* Wb_b = reinterpret_cast<char*>(W + b * (int64_t)M * B);
+    bm_f32x4 accW[kB16NB];
+#pragma unroll
+    for (int i = 0; i < kB16NB; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) accW[i][r] = 0.f;
+    b16_prod<false, kFusedGS>(sG, sK, wave, l16, q, accW);       // W = G^T P: row block i takes the k-groups g >= i
+#pragma unroll
+    for (int i = 0; i < kB16NB; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = 16 * i + 4 * q + r;
+        if (m < M) {
+          const float v = accW[i][r];
+          if (col < B) *reinterpret_cast<float*>(Wb_b + 4u * (__umul24((unsigned)m, (unsigned)B) + (unsigned)col)) = v;
+          s_w2 = fmaf(v, v, s_w2);
+        }
+      }
+    // column reductions: the four lane groups hold different rows of the same column; a column belongs to ONE wave
+    s_mu += __shfl_xor(s_mu, 16, 64); s_p2 += __shfl_xor(s_p2, 16, 64); s_w2 += __shfl_xor(s_w2, 16, 64);
+    s_mu += __shfl_xor(s_mu, 32, 64); s_p2 += __shfl_xor(s_p2, 32, 64); s_w2 += __shfl_xor(s_w2, 32, 64);
+    if (q == 0) { red[n] = s_mu; red[64 + n] = s_p2; red[128 + n] = s_w2; }
+    ff_barrier<true>();
+    if (tid < 64 && n0 + tid < B) {
+      mu[b * B + n0 + tid] = red[tid];
+      var[b * B + n0 + tid] = kd[b] - red[64 + tid] + red[128 + tid];
+    }
+    tile_x += 1; n0 += 64;
+    // (the next pass writes red only after two more barriers; sK after the one above)
+  } else {
   const int cb = wave & 1;
   const int rbs[2] = {(wave >> 1) ? 1 : 0, (wave >> 1) ? 2 : 3};
   // ---- P = T K: row block rb needs k < 32 rb + 32.  The wave's two blocks advance together (two independent accumulators:
@@ -577,10 +636,9 @@ __global__ __launch_bounds__(256) void t0_fwd_fused_kernel(const float* __restri
       mu[b * B + n0 + tid] = red[tid];
       var[b * B + n0 + tid] = kd[b] - red[64 + tid] + red[128 + tid];
     }
-    if constexpr (MULTI) { red[tid] = 0.f; red[64 + tid] = 0.f; red[128 + tid] = 0.f; }     // (by their reader: no barrier needed)
   }
   FF_STAMP(8);
-  if constexpr (MULTI) { tile_x += 1; n0 += 64; }
+  }
   } while (MULTI && tile_x < tile_end);
   // ---- KL (partial sum from the top of the kernel)
   __syncthreads();

@@ -88,21 +88,21 @@ __device__ __forceinline__ void b16_tri_acc(const float* __restrict__ sX, const 
   });
 }
 // An M x 64 result, 16 columns per wave (column block CW = wave), all seven row blocks:
-//   LOWER:  acc[i] += sum_{k <= row} A[row][k] B[k][n]      A = sA[row][k] (lower triangular, K-contiguous rows, stride kBmSA)
+//   LOWER:  acc[i] += sum_{k <= row} A[row][k] B[k][n]      A = sA[row][k] (lower triangular, K-contiguous rows, stride SA)
 //   !LOWER: acc[i] += sum_{k >= row} A[k][row] B[k][n]      A = sA[k][row] (the transpose of a lower triangular matrix, k-major)
 // B = sB[k][n] (k-major, stride kBmST).  Row block i takes part in the k-groups g <= i (LOWER) / g >= i.
-template <bool LOWER>
+template <bool LOWER, int SA = kBmSA>
 __device__ __forceinline__ void b16_prod(const float* __restrict__ sA, const float* __restrict__ sB, int cw, int l16, int q,
                                          bm_f32x4 (&acc)[kB16NB]) {
   const float* ap[kB16NB];
 #pragma unroll
   for (int i = 0; i < kB16NB; ++i)
-    ap[i] = LOWER ? sA + min(16 * i + l16, kBmKP - 1) * kBmSA + 4 * q : sA + (4 * q) * kBmSA + min(16 * i + l16, kBmKP - 1);
+    ap[i] = LOWER ? sA + min(16 * i + l16, kBmKP - 1) * SA + 4 * q : sA + (4 * q) * SA + min(16 * i + l16, kBmKP - 1);
   const float* bcol = sB + (4 * q) * kBmST + 16 * cw + l16;
   auto afrag = [&](const int i, const int g) -> float4 {
     // (the last k-group holds k = 96 .. 111: lane groups 2, 3 are past the 104 rows / columns that exist)
     if (LOWER) return g == 6 ? b16_mask(bm_frag_kc(ap[i], 16 * g - (q >= 2 ? 8 : 0)), q < 2) : bm_frag_kc(ap[i], 16 * g);
-    return g == 6 ? b16_mask(bm_frag_km(ap[i], 16 * g - (q >= 2 ? 8 : 0), kBmSA), q < 2) : bm_frag_km(ap[i], 16 * g, kBmSA);
+    return g == 6 ? b16_mask(bm_frag_km(ap[i], 16 * g - (q >= 2 ? 8 : 0), SA), q < 2) : bm_frag_km(ap[i], 16 * g, SA);
   };
   auto bfrag = [&](const int g) -> float4 {
     return g == 6 ? b16_mask(bm_frag_km(bcol, 16 * g - (q >= 2 ? 8 : 0), kBmST), q < 2) : bm_frag_km(bcol, 16 * g, kBmST);
