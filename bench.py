@@ -998,6 +998,13 @@ def main():
                 torch.cuda.empty_cache()
         if rank == 0:
             res['secondary'] = sec
+            # The headline of an N-rank line is WEAK scaling (per-GPU work fixed: `value` = N x the optimizer steps/s, as its unit
+            # says): so that nobody reads it as the step rate of a fixed job, the two fixed jobs' global step rates ride at the top
+            # level under their own names -- these are the STRONG-scaling figures comparable with secondary.smnist_s64 /
+            # the headline of the N = 1 line.
+            res['optimizer_steps_per_s_headline'] = res.get('optimizer_steps_per_s')
+            res['value_strong_fixed_64_samples'] = sec.get('smnist_s64', {}).get('value')
+            res['value_strong_cfg2_30_problems'] = sec.get('smnist_pairs', {}).get('value')
     if rank == 0 and world == 1 and default_line and not args.no_secondary and not use_dist:
         # short, driver-timed runs of the other BASELINE configs in the same line (their own step counts are stated)
         t_start = time.perf_counter()

@@ -808,6 +808,11 @@ static int check_desc(const vargp_elbo_t0_desc* d, const char* who) {
 // LDS), so with SC * ntile tile units on `cus` CUs the launch takes  rounds x (set-up + tiles per workgroup x tile time).
 // nparts == ntile is the single-tile form (latency-bound shapes: every unit its own CU); fewer, longer workgroups stage T and
 // G once for several tiles and keep the M x M accumulators in registers across them (`setup` = that set-up in tile times).
+// VARGP_T0_MULTI (tuning aid): 1 = the multi-tile kernels also where every tile has a workgroup of its own (nparts == ntile)
+static bool t0_force_multi() {
+  static const int env = [] { const char* e = getenv("VARGP_T0_MULTI"); return e ? atoi(e) : 0; }();
+  return env == 1;
+}
 constexpr float kBwdMidSetup = 0.35f;      // set-up of a t0_bwd_mid_multi_kernel workgroup (G / T staging + its round of atomics) in tile times
 static int t0_tile_parts(int64_t SC, int ntile, int cus, float setup) {
   static const int env = [] { const char* e = getenv("VARGP_T0_PARTS"); return e ? atoi(e) : 0; }();   // tuning aid
@@ -931,7 +936,7 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
   // (float4 reads of the noise there: a caller's eps_f must sit on a 16-byte boundary, the workspace's own does)
   // (not on throughput-bound shapes -- the multi-tile form of that kernel, t0_bwd_mid_multi.h: the evaluation is C-fold redundant
   //  there, 11k cycles of vector work per tile that such a launch cannot hide; those shapes keep the softmax launch)
-  const bool bwd_multi = bwd_paths.fused_bwd && t0_tile_parts(SC, cdiv(B, 64), vargp_cu_count(), kBwdMidSetup) < cdiv(B, 64);
+  const bool bwd_multi = bwd_paths.fused_bwd && (t0_tile_parts(SC, cdiv(B, 64), vargp_cu_count(), kBwdMidSetup) < cdiv(B, 64) || t0_force_multi());
   const bool defer_softmax = d->defer_softmax && !d->ext_lik && fused_softmax && bwd_paths.fused_bwd && !bwd_multi &&
                              F <= 4 * kBmSmF && C <= kBmSmC && reinterpret_cast<uintptr_t>(eps_f) % 16 == 0;
   t0_state_set(d->ws, (clear_bwd ? kT0Cleared : kT0NoClear) | (defer_softmax ? kT0SoftmaxDeferred : 0));
@@ -1056,7 +1061,7 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
     if (rc) return rc;
     static std::atomic<unsigned> attr_set_mask[4][2] = {};      // 64 device ordinals per instantiation
     const int nparts = t0_tile_parts(SC, ntile, vargp_cu_count(), 0.5f);
-    const bool multi = nparts < ntile;
+    const bool multi = nparts < ntile || t0_force_multi();
     const dim3 grid(8 * cdiv(SC, 8) * nparts);
     uint32_t* rngc = native ? d->rng_counter : nullptr;
 #define VARGP_FF(V4, MT, SLOT)                                                                                                  \
@@ -1157,7 +1162,7 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
     // throughput-bound shapes (more tile units than CUs): the multi-tile form (t0_bwd_mid_multi.h)
     const int nparts = t0_tile_parts(SC, ntile, vargp_cu_count(), kBwdMidSetup);
     const BmSoftmax smx = softmax_deferred ? BmSoftmax{o.mu, o.var, eps_f, d->y, d->scalars + 2, F} : BmSoftmax{};
-    if (nparts < ntile) {
+    if (nparts < ntile || t0_force_multi()) {
       VARGP_REQUIRE(!softmax_deferred, "elbo_t0_bwd: the multi-tile backward does not evaluate a deferred likelihood");
       rc = ensure_dynamic_lds(reinterpret_cast<const void*>(t0_bwd_mid_multi_kernel), kBwdMidMultiLdsBytes, attr_set_mask_m, "elbo_t0_bwd");
       if (rc) return rc;

@@ -270,7 +270,14 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 // hand over a pre-scaled B operand (x o w, written once per hyper-sample by the norm pass) pass kscale = NULL and get the
 // unscaled instantiation: the scale loads and multiplies sit in the main loop, where nothing overlaps them with the MFMAs
 // (stress K_uf tile [20480 x 784] x [8192 x 784]^T: 93 TFLOP/s scaled in the loop, 133 as a plain product).
-template <int BM, int BN, int BK, bool AKC, bool BKC, bool VEC, bool RBF, bool SCALED = true, int NT = 256>
+// PIN: the fragment reads of group g + PF are pinned in front of group g's MFMAs (sched_barrier).  Left alone the scheduler sinks
+// them behind the MFMAs to save eight registers -- `ds_read, s_waitcnt lgkmcnt(0), 4 MFMAs` per group, the LDS latency exposed
+// every time.  Worth it where occupancy is fixed anyway or the launch is latency-bound (the merged factorisation + K_uf launch,
+// the 64 x 64 x 64 tiles of the small batched products: Cfg2 step 197 -> 193.5 us, Split-MNIST t = 1 1754 -> 1794 steps/s);
+// the 128-row tiles of the throughput-bound products lose occupancy to the extra live registers (S = 64: 314 -> 301 steps/s) and
+// keep the compiler's schedule.
+template <int BM, int BN, int BK, bool AKC, bool BKC, bool VEC, bool RBF, bool SCALED = true, int NT = 256,
+          bool PIN = (BM == 64 && BN == 64)>
 __device__ __forceinline__ void gemm_body(const GemmParams& p, const int tile_id_, const int batch_id_, const int split_id_,
                                           float* __restrict__ lds) {
   // The workgroup's tile / batch / split indices are wave-uniform, but they come out of integer divisions that the
@@ -398,6 +405,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int tile_id
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       if (g + PF < NG) frag(g + PF);
+      if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);      // (see PIN above)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -485,10 +493,20 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int tile_id
         });
         __syncthreads();
       };
-      for (int sl = 0; sl < nfull; sl += 2) {
+      // Two things keep the compiler's wait-count pass from putting `s_waitcnt vmcnt` at the loop HEADER, where it would wait,
+      // every pair of slabs, for loads issued a few hundred cycles earlier (found in the ISA: `s_waitcnt vmcnt(2)` / `vmcnt(1)`
+      // in front of the first two fragment reads -- one exposed L2 round trip per two slabs): (i) the fragment registers of the
+      // first half alias register set X, which is dead there in the steady state but still pending on any path that reaches the
+      // header with set X's loads in flight -- the loop entry (slab 1's loads) and, statically, an exit test between the two
+      // halves that leaves through the latch.  So: slab 1's loads are waited for BEFORE the loop (once per tile), and the loop
+      // body is always both halves; an odd last slab runs behind the loop.
+      __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0) only (expcnt / lgkmcnt fields: no wait)
+      int sl = 0;
+      for (; sl + 1 < nfull; sl += 2) {
         iteration(std::integral_constant<int, 0>{}, sl, ra, rb, rs, ra2, rb2, rs2);
-        if (sl + 1 < nfull) iteration(std::integral_constant<int, 1>{}, sl + 1, ra2, rb2, rs2, ra, rb, rs);
+        iteration(std::integral_constant<int, 1>{}, sl + 1, ra2, rb2, rs2, ra, rb, rs);
       }
+      if (sl < nfull) iteration(std::integral_constant<int, 0>{}, sl, ra, rb, rs, ra2, rb2, rs2);
       kdone = ks + nfull * BK;
     }
   }
@@ -849,6 +867,7 @@ __device__ __forceinline__ void gemm_persist_body(const GemmParams& p, int* __re
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       if (g + PF < NG) frag(g + PF);
+      __builtin_amdgcn_sched_barrier(0);      // fragment prefetch stays in front of the MFMAs (gemm_body: PIN)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -877,6 +896,9 @@ __device__ __forceinline__ void gemm_persist_body(const GemmParams& p, int* __re
   load_set(ra, rb);                                        // slab 1 -> set X
   advance_load();
   __syncthreads();
+  // (slab 1's loads are waited for here, once per workgroup: pending at the loop entry they make the compiler put `s_waitcnt
+  //  vmcnt` in front of the first fragment reads of EVERY iteration -- the fragment registers alias set X -- see gemm_body)
+  __builtin_amdgcn_s_waitcnt(0x0F70);
 
   int sM = 0;                                              // slab being multiplied (of tile idM)
   int fetched = 0;                                         // thread 0: the queue's answer, in flight
@@ -1104,7 +1126,7 @@ __global__ __launch_bounds__(NT) void chol_rbf_gemm_kernel(const CholArgs c, con
   if (threadIdx.x == 0 && ((int)blockIdx.x == c.nchol || (int)blockIdx.x == c.nchol + ngemm - 1))
     g_chol_phase[((int)blockIdx.x == c.nchol ? 32 : 40)] = __builtin_amdgcn_s_memrealtime();
 #endif
-  gemm_body<BM, 64, BK, true, true, true, true, SCALED, NT>(p, id % tiles, id / tiles, 0, lds);
+  gemm_body<BM, 64, BK, true, true, true, true, SCALED, NT, true>(p, id % tiles, id / tiles, 0, lds);
 #ifdef VARGP_CHOL_PHASES
   if (threadIdx.x == 0 && ((int)blockIdx.x == c.nchol || (int)blockIdx.x == c.nchol + ngemm - 1))
     g_chol_phase[((int)blockIdx.x == c.nchol ? 32 : 40) + 1] = __builtin_amdgcn_s_memrealtime();
