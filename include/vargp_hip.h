@@ -239,7 +239,7 @@ int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t stream);
  * (S, C, B) its bwd reads (pointers into d->ws; any of the four outputs may be NULL). */
 int vargp_elbo_t0_lik_buffers(const vargp_elbo_t0_desc* d, float** mu, float** var, float** gmu, float** gvar);
 /* ONE vargp_elbo_t0_bwd per vargp_elbo_t0_fwd: for the shapes of the LDS-resident backward (M <= 104, M % 4 == 0, B % 4 == 0,
- * D % 4 == 0, S <= 16) the forward clears the accumulators the backward adds into (and the tile counters of the backward's
+ * D % 4 == 0, S <= 64) the forward clears the accumulators the backward adds into (and the tile counters of the backward's
  * persistent product workgroups) -- there is no clearing launch in bwd.
  * Enforced by the library (host-side state per workspace, checked when the call is issued): a second bwd on one fwd, or a bwd
  * whose z / x alignment differs from its forward's, returns VARGP_EINVAL with a message instead of accumulating into stale sums. */

@@ -155,12 +155,12 @@ def test_trainer_route_full_size_reference_trajectory(graph):
 
 def test_trainer_routes_by_batch_size_like_loss():
     """the trainer picks its native program from the minibatch it is given, as VARGP.loss does (a first-task model
-    leaves the LDS-resident program when S C ceil(B / 64) exceeds 2048 tiles)."""
+    leaves the LDS-resident program when S C ceil(B / 64) exceeds VARGP.T0_TILE_UNITS_MAX = 16384 tile units)."""
     from vargp_amd import noise
     from vargp_amd.train import ElboTrainer
     from gpu_common import build_gp
-    S, F_, C, M, D = 9, 2, 8, 32, 40
-    for B, want_tn in ((64, False), (2048, True)):
+    S, F_, C, M, D = 16, 2, 16, 32, 40
+    for B, want_tn in ((64, False), (4160, True)):
         params, prev, x, y, nz = orc.make_problem(S, F_, C, M, D, B, n_prev=0, seed=4, kind='gauss')
         gp = build_gp(params, prev, S, F_)
         assert gp._use_block_program(B) == want_tn

@@ -34,6 +34,7 @@ constexpr int kKuuSplit = 2;   // K-splits of the K_uu distance GEMM (few workgr
 #ifndef VARGP_KL_ROWS
 #define VARGP_KL_ROWS 8
 #endif
+constexpr int kT0TileUnitsMax = 16384;   // (S C <= 2048 at the reference's batch of 512; mirrored by vargp_amd/vargp.py)
 constexpr int kKlRows = VARGP_KL_ROWS;     // rows of one (s, c) block per KL workgroup
 
 
@@ -809,6 +810,12 @@ static int check_desc(const vargp_elbo_t0_desc* d, const char* who) {
 // nparts == ntile is the single-tile form (latency-bound shapes: every unit its own CU); fewer, longer workgroups stage T and
 // G once for several tiles and keep the M x M accumulators in registers across them (`setup` = that set-up in tile times).
 // VARGP_T0_MULTI (tuning aid): 1 = the multi-tile kernels also where every tile has a workgroup of its own (nparts == ntile)
+// most (sample, class, 64-column) tile units the LDS-resident middles take (beyond: the round-2 sequences / the block program;
+// vargp_amd/vargp.py: first_task_as_block mirrors it).  VARGP_T0_UNITS: tuning aid
+static int64_t t0_tile_units_max() {
+  static const int64_t env = [] { const char* e = getenv("VARGP_T0_UNITS"); return e ? atoll(e) : (int64_t)kT0TileUnitsMax; }();
+  return env;
+}
 static bool t0_force_multi() {
   static const int env = [] { const char* e = getenv("VARGP_T0_MULTI"); return e ? atoi(e) : 0; }();
   return env == 1;
@@ -836,7 +843,7 @@ static T0BwdPaths t0_bwd_paths(const vargp_elbo_t0_desc* d, const T0Ws& o) {
   const int ntile = cdiv(B, 64);
   T0BwdPaths r;
   r.fused_bwd = fused_bwd_env && M <= kBmKP && M >= 4 && (M % 4) == 0 && (LD % 4) == 0 && (B % 4) == 0 &&
-                (int64_t)S * C * ntile <= 2048;
+                (int64_t)S * C * ntile <= t0_tile_units_max();
   // ... and everything per matrix after it (small columns of gT / gRK, Cholesky adjoint, W_uu) as one LDS-resident workgroup
   // per matrix inside the launch of the P_uf product (t0_bwd_mat.h)
   static const int mat_bwd_env = [] { const char* e = getenv("VARGP_T0_MAT_BWD"); return e ? atoi(e) : 1; }();   // tuning aid
@@ -1052,7 +1059,7 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
   }
   static const int fused_env = [] { const char* e = getenv("VARGP_T0_FUSED"); return e ? atoi(e) : 1; }();   // tuning aid
   const int ntile = cdiv(B, 64);
-  const bool fused_mid = fused_env && M <= kFusedK && (M % 4) == 0 && (LD % 4) == 0 && (int64_t)SC * ntile <= 2048;
+  const bool fused_mid = fused_env && M <= kFusedK && (M % 4) == 0 && (LD % 4) == 0 && (int64_t)SC * ntile <= t0_tile_units_max();
   if (fused_mid) {
     // small columns first (a = T m, G = T L_S, G2 = T Lu: one M x NR x M product per (s, c)), then the LDS-resident kernel
     GemmParams p = flat_gemm(o.TT, M, MM, o.RK, LD, MLD, o.QP, LD, MLD, M, NR, M);

@@ -1,4 +1,4 @@
-// The last launch of the first-task backward (M <= 104, M % 4 == 0, D % 4 == 0, S <= kTailSMax = 16): the product P_uu = W_uu z of the
+// The last launch of the first-task backward (M <= 104, M % 4 == 0, D % 4 == 0, S <= kTailSMax = 64): the product P_uu = W_uu z of the
 // kernel-matrix backward and the finalisation that consumes it, in one kernel -- P_uu never goes to memory.
 // Reference: autograd of kernels.py:24-44 (the RBF kernel matrix of scaled inputs) w.r.t. z and the lengthscales; with
 // W = gK o K, r = row sums of W, P = W y (see rbf.hip for the algebra):
@@ -19,7 +19,7 @@
 
 namespace vargp {
 
-constexpr int kTailSMax = 16;
+constexpr int kTailSMax = 64;
 constexpr int kTailXRows = 64;            // minibatch rows per block of the x role
 constexpr int kTailNG = kBmKP / 8;        // k-groups of 8
 

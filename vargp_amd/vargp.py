@@ -110,23 +110,24 @@ class VARGP(nn.Module):
         return linear_marginal_diag(mu_leq_t, S_leq_t, Kzz, Kzx, Kxx_diag, cache=cache)
 
     # -- the block-structured native program (csrc/elbo_tn.hip) ------------------------------------------------------
+    T0_TILE_UNITS_MAX = 16384      # csrc/elbo_t0.hip: kT0TileUnitsMax
+
     def first_task_as_block(self, B=None):
-        """First-task models outside the range of the LDS-resident forward middle of csrc/elbo_t0.hip (M <= 104 and at most
-        2048 (sample, class, 64-column) tiles, i.e. S C <= 256 at B = 512) run faster as the one-block case of the block
-        program (csrc/elbo_tn.hip: symmetric K_uu tiles, the factorisation's pivot chains beside the K_uf row slices, paired
-        mid-size products).  Measured: Permuted-MNIST task 0 (M = 200, S = 10) 557 -> 572 steps/s, the 64-sample Split-MNIST
-        step 254 -> 270; BASELINE config 2 (M = 100, S = 3) stays on elbo_t0 (3120 vs 2740).  VARGP_T0_AS_TN=0 / 1 forces it."""
+        """First-task models outside the range of the LDS-resident middles of csrc/elbo_t0.hip (M <= 104 and at most 16384
+        (sample, class, 64-column) tile units, i.e. S C <= 2048 at B = 512) run as the one-block case of the block program
+        (csrc/elbo_tn.hip: symmetric K_uu tiles, the factorisation's pivot chains beside the K_uf row slices, paired mid-size
+        products).  Measured: Permuted-MNIST task 0 (M = 200, S = 10) 557 -> 572 steps/s.  (Until round 6 the limit was 2048
+        units and the 64-sample Split-MNIST step took the block program: 314 steps/s against 372 on the multi-tile forms of the
+        LDS-resident kernels.)  VARGP_T0_AS_TN=0 / 1 forces it; VARGP_T0_UNITS overrides the limit on both sides."""
         if self.prev_params:
             return False
         env = os.environ.get('VARGP_T0_AS_TN')
         if env is not None:
             return env == '1'
         n_v = 1 if self.kernel.map_est else self.n_v
-        # the LDS-resident middles of csrc/elbo_t0.hip take at most 2048 (sample, class, 64-column) tiles: S C <= 256 at the
-        # reference's batch of 512, <= 64 at B = 2048, <= 1024 at B = 128.  B unknown (the trainer decides its program before
-        # it has seen a batch): the reference's 512.
+        # B unknown (the trainer decides its program before it has seen a batch): the reference's 512.
         ntile = (int(B if B is not None else 512) + 63) // 64
-        return self.M > 104 or n_v * self.z.size(0) * ntile > 2048
+        return self.M > 104 or n_v * self.z.size(0) * ntile > int(os.environ.get('VARGP_T0_UNITS', self.T0_TILE_UNITS_MAX))
 
     def _tn_applicable(self):
         return (self.fused_tasks and type(self.kernel) is RBFKernel and self.z.is_cuda
