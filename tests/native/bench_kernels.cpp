@@ -1,5 +1,5 @@
 // Standalone kernel micro-benchmarks against libvargp_hip.so (no torch): used for tuning under rocprofv3.
-//   ./bench_kernels [case] [iters]      case: all | kuf | gemm4k | small | chol | kufbwd
+//   ./bench_kernels [case] [iters]      case: all | kuf | gemm4k | small | chol | kufbwd | hot | hotS | tiles
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <cmath>
@@ -97,6 +97,24 @@ int main(int argc, char** argv) {
       double b = time_us([&] { gemm(W, X, P, 1000, 784, 512, 0, 0, 3, 1000L * 512, 0, 1000L * 784); }, iters);
       printf("hot tile %d   K_uf-shaped NT [1000x784]x[512x784]^T b3 %7.1f us (%.1f TF)   P_uf-shaped NN [1000x512]x[512x784] b3 %7.1f us (%.1f TF)\n",
              tile, a, 2.408e9 / a * 1e-6, b, 2.408e9 / b * 1e-6);
+    }
+    vargp_tune_gemm_tile(0);
+  }
+  if (which == "hotS") {   // the two big products of the first-task step at many hyper-samples (throughput-bound), every tile shape
+    const int SM = 64;
+    float* Z = dev_rand((size_t)1000 * 784, 1.f, 4);
+    float* X = dev_rand((size_t)SM * 512 * 784, 1.f, 5);
+    float* W = dev_rand((size_t)SM * 1000 * 512, 1.f, 4);
+    float* P; CK(hipMalloc(&P, (size_t)SM * 1000 * 784 * 4));
+    for (int S : {8, 16, 64}) {
+      for (int tile = 0; tile <= 3; ++tile) {
+        vargp_tune_gemm_tile(tile);
+        double a = time_us([&] { gemm(Z, X, P, 1000, 512, 784, 0, 1, S, 0, 512L * 784, 1000L * 512); }, iters);
+        double b = time_us([&] { gemm(W, X, P, 1000, 784, 512, 0, 0, S, 1000L * 512, 0, 1000L * 784); }, iters);
+        const double fl = 2.0 * S * 1000 * 784 * 512;
+        printf("hotS S=%2d tile %d   K_uf-shaped NT [1000x784]x[512x784]^T %8.1f us (%.1f TF = %.2f)   P_uf-shaped NN [1000x512]x[512x784] %8.1f us (%.1f TF = %.2f)\n",
+               S, tile, a, fl / a * 1e-6, fl / a * 1e-6 / 157.3, b, fl / b * 1e-6, fl / b * 1e-6 / 157.3);
+      }
     }
     vargp_tune_gemm_tile(0);
   }

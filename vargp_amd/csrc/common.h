@@ -182,7 +182,7 @@ bool chol_rbf_gemm_applicable(int n, const GemmParams& p);
 // stair_nb > 0 (blocked factorisation, chol.hip): `rows` rows of batched stair_n x stair_n matrices (ld = stair_n); row r gets zeros
 // right of its diagonal block only, columns [((r % stair_n) / stair_nb + 1) stair_nb, stair_n) -- one workgroup per row, float4 stores
 struct ZeroJob { float* p; int64_t rows, width, ld; int stair_n, stair_nb; };
-constexpr int kZeroJobs = 5;
+constexpr int kZeroJobs = 6;
 struct ZeroJobs { ZeroJob j[kZeroJobs]; };
 #ifdef __HIPCC__
 __device__ __forceinline__ void zero_jobs_role(const ZeroJobs& z, int blk, int nblk) {
@@ -280,6 +280,8 @@ struct BwdMatArgs {
   const float* gTT;
   float *gKS, *Wuu, *r_uu, *gtheta;
   float *g_u_mean, *gLu_part;                       // [C][M]: sum over s, accumulated with atomics (pre-zeroed); [S][C][M][M]: per-sample shares (lower triangles written)
+  float* gL_acc;                                    // NULL, or [C][M][M] pre-zeroed: the K_uu roles add their tril(T_s^T gG_s) (atomics) and the S_u
+                                                    // roles -- a LATER launch -- read the sums instead of walking the samples themselves
   int S, C, M, D, NR, LD;
 };
 // queue: 8 ints, zero when the launch starts (work queue of the product's tiles: gemm_persist_body), or NULL

@@ -816,6 +816,15 @@ static int64_t t0_tile_units_max() {
   static const int64_t env = [] { const char* e = getenv("VARGP_T0_UNITS"); return e ? atoll(e) : (int64_t)kT0TileUnitsMax; }();
   return env;
 }
+// Role-merged launches (pivot / adjoint chains of the S C + C matrices beside the big product of the same phase) pay while the
+// chains leave CUs free for the product to hide them under.  With more chains than CUs they fill the chip by themselves, and
+// the product does better as a launch of its own: two workgroups per CU (the merged kernels hold it to one -- the chain role's
+// registers / LDS), 128-row tiles.  Measured (MI355X, Split-MNIST first task, steps/s merged -> apart): S = 16 (170 chains) 1372 ->
+// 1365, S = 32 (330) 697 -> 744, S = 64 (650) 373 -> 413.  VARGP_T0_UNMERGE = chain count from which on (tuning aid).
+static int t0_unmerge_chains() {
+  static const int env = [] { const char* e = getenv("VARGP_T0_UNMERGE"); return e ? atoi(e) : -1; }();
+  return env >= 0 ? env : vargp_cu_count() + 1;
+}
 static bool t0_force_multi() {
   static const int env = [] { const char* e = getenv("VARGP_T0_MULTI"); return e ? atoi(e) : 0; }();
   return env == 1;
@@ -956,6 +965,8 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
     bwd_zero.j[2] = ZeroJob{o.queue, 1, 8, 0};          // work queue of the P_uf tiles (launch_bwdmat_gemm)
     bwd_zero.j[3] = ZeroJob{o.gkd, 1, SC, 0};
     bwd_zero.j[4] = ZeroJob{o.r_uf, 1, o.r_uu - o.r_uf, 0};
+    if (SC + C >= t0_unmerge_chains())                  // per-class sums of the L_S gradient shares (BwdMatArgs::gL_acc; gLL's tail is free on this path)
+      bwd_zero.j[5] = ZeroJob{o.gLL + SC * MM, 1, C * MM, 0};
     if (!merge_chol) {
       a.zero = bwd_zero;
       const int64_t zt = (int64_t)SC * M * (4 + M) + (SC + 2 * C) * MM + (o.r_uu - o.r_uf);
@@ -1031,8 +1042,17 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
       if (front) {   // the matrices b < SC arrive as K-split partial Gram matrices (and leave as K_uu in KS for the backward)
         lx.part = o.kpart; lx.nsplit = ksp; lx.sSplit = SC * MM; lx.g2 = o.g2; lx.part_C = C; lx.Kout = o.KS;
       }
-      rc = launch_chol_rbf_gemm(o.KS, d->jitter, o.LL, o.TT, d->info, SC + C, M, p1, S, st, &lx, clear_bwd ? &bwd_zero : nullptr);
+      // many hyper-samples: the chains fill the chip by themselves and hide nothing -- the product runs as a launch of its own, two
+      // workgroups per CU (the merged launch holds it to one by the chain role's registers): t0_unmerge_chains()
+      const bool unmerge = SC + C >= t0_unmerge_chains();
+      rc = launch_chol_rbf_gemm(o.KS, d->jitter, o.LL, o.TT, d->info, SC + C, M, p1, unmerge ? 0 : S, st, &lx, clear_bwd ? &bwd_zero : nullptr);
       if (rc) return rc;
+      if (unmerge) {
+        static const int kuf_tile = [] { const char* e = getenv("VARGP_T0_KUF_TILE"); return e ? atoi(e) : 0; }();   // tuning aid
+        p1.tile = kuf_tile;
+        rc = launch_gemm(p1, 0, 1, S, true, st, "rbf_kuf_gemm");
+        if (rc) return rc;
+      }
       merged = true;
     } else {
       rc = launch_gemm_pair(p0, SC, p1, S, 0, 1, true, st, "rbf_kuu_gemm", "rbf_kuf_gemm");
@@ -1243,8 +1263,25 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
     ma.g_u_mean = g_u_mean; ma.gLu_part = o.gLL;                 // (gLL is free on this path: no head launch, no Cholesky-adjoint op)
     ma.S = S; ma.C = C; ma.M = M; ma.D = D; ma.NR = NR; ma.LD = LD;
     // all S C + C matrices next to P_uf = W_uf x (which only needs the tile kernel's W_uf) ...
-    rc = launch_bwdmat_gemm(ma, 0, SC + C, p1, S, st, "rbf_kuf_bwd_gemm", reinterpret_cast<int*>(o.queue));
+    // many hyper-samples (as in the forward: vargp_elbo_t0_fwd): the chains fill the chip by themselves, the product runs as a
+    // launch of its own (two workgroups per CU), and the S_u roles -- which would walk all S samples, one workgroup per class,
+    // with nothing left to hide under -- read per-class sums the K_uu roles accumulate (cleared by the forward's zero role)
+    const bool unmerge = SC + C >= t0_unmerge_chains();
+    if (unmerge) {
+      ma.gL_acc = o.gLL + SC * MM;
+      rc = launch_bwdmat_gemm(ma, 0, SC, p1, 0, st, "t0_bwdmat_kuu", nullptr);
+      if (rc) return rc;
+      rc = launch_bwdmat_gemm(ma, SC, C, p1, 0, st, "t0_bwdmat_su", nullptr);
+    } else {
+      rc = launch_bwdmat_gemm(ma, 0, SC + C, p1, S, st, "rbf_kuf_bwd_gemm", reinterpret_cast<int*>(o.queue));
+    }
     if (rc) return rc;
+    if (unmerge) {
+      static const int puf_tile = [] { const char* e = getenv("VARGP_T0_PUF_TILE"); return e ? atoi(e) : 0; }();   // tuning aid
+      p1.tile = puf_tile;
+      rc = launch_gemm(p1, 0, 0, S, false, st, "rbf_kuf_bwd_product");
+      if (rc) return rc;
+    }
     // ... then P_uu = W_uu z; with few samples inside the launch that consumes it (t0_bwd_tail.h)
     static const int tail_env = [] { const char* e = getenv("VARGP_T0_TAIL"); return e ? atoi(e) : 1; }();   // tuning aid
     fused_tail = tail_env && S <= kTailSMax;

@@ -1345,8 +1345,9 @@ static int launch_chol_rbf_gemm_impl(const float* A, float eps, float* L, float*
   // 64 x 64 tiles need more than one round: S = 16 step 869 -> 831 us, S = 8 477 -> 474, S >= 32 the same)
   static const int f32_env = [] { const char* e = getenv("VARGP_CHOL_F32"); return e ? atoi(e) : kCholF32Default; }();
   const bool wide_ok = p.kscale == nullptr && f32_env && n > 64;
-  const bool big = tile_force ? tile_force == 2
-                              : (t64 * nbatch > free_cus && (wide_ok || t128 * nbatch <= free_cus));
+  const bool big = nbatch == 0 ? false
+                   : tile_force ? tile_force == 2
+                                : (t64 * nbatch > free_cus && (wide_ok || t128 * nbatch <= free_cus));
   const int tiles = big ? t128 : t64;
   // VARGP_EXP_MERGED (timing only, wrong results): 1 = the factorisations alone (no GEMM tiles), 2 = the GEMM tiles alone
   static const int exp_role = [] { const char* e = getenv("VARGP_EXP_MERGED"); return e ? atoi(e) : 0; }();
@@ -1358,7 +1359,10 @@ static int launch_chol_rbf_gemm_impl(const float* A, float eps, float* L, float*
   // a co-resident GEMM workgroup competes for its issue slots and stretches the pivot chain (68 -> 77 us measured);
   // with many samples the GEMM dominates and wants both slots (S = 64: 950 -> 676 us).
   static const int pad_force = [] { const char* e = getenv("VARGP_MERGED_PAD"); return e ? atoi(e) : -1; }();   // tuning aid (KB)
-  const unsigned pad = pad_force >= 0 ? (unsigned)pad_force * 1024u : (tiles * nbatch <= 1024 ? (big ? 40u : 24u) * 1024u : 0u);
+  // (no product in the launch -- many hyper-samples, vargp_elbo_t0_fwd -- and more chains than CUs: two chains per CU)
+  const unsigned pad = pad_force >= 0 ? (unsigned)pad_force * 1024u
+                       : (nbatch == 0 ? (nchol > current_cu_count() ? 0u : 24u * 1024u)
+                                      : (tiles * nbatch <= 1024 ? (big ? 40u : 24u) * 1024u : 0u));
   // arithmetic of the pivot chains: the reference's own fp32 (default, kCholF32Default = 1: torch.cholesky is fp32) or fp64
   // (VARGP_CHOL_F32=0; chol_small3.h).  The stand-alone factorisation (vargp_chol_inv_fwd: predict, the composed path) is fp64.
   // kscale == NULL: the caller's B operand is pre-scaled (x o 1/sigma^2, written once per hyper-sample by the norm role) and the

@@ -307,6 +307,17 @@ __device__ __forceinline__ void mat_kuu(const BwdMatArgs& a, int id, float* __re
   if (tid < 128) { sga[tid] = tid < M ? gav : 0.f; smv[tid] = tid < M ? mvv : 0.f; }
   __syncthreads();                                     // everybody is done with gG and L_S; T, ga, m are in place
   BMAT_STAMP(3);
+  if (a.gL_acc) {
+    // many hyper-samples (the S_u roles run as a launch of their own, after this one): this sample's share of the gradient of
+    // L_S, tril(T_s^T gG_s), added into the class's sum -- the S_u role would otherwise walk all S samples by itself
+    bm_f32x16 acx[4];
+    mat_product<false, false, kFamR, WV>(acx, sT, X1, true, li, lh);
+    float* gl = a.gL_acc + (int64_t)c * MM;
+    mat_foreach<kFamR, WV>(li, lh, [&](int u, int rb, int cb, int r, int i, int j) {
+      if (i < M && (rb != cb || j <= i)) atomicAdd(&gl[(int64_t)i * M + j], acx[u][r]);
+    });
+    __syncthreads();                                   // everybody is done with gG (X1 is overwritten next)
+  }
 #pragma unroll
   for (int u = 0; u < kBmNA; ++u) { r1[u].x *= g; r1[u].y *= g; r1[u].z *= g; r1[u].w *= g; }
   mat_store(X1, r1, M, tid);
@@ -393,9 +404,19 @@ __device__ __forceinline__ void mat_su(const BwdMatArgs& a, int id, float* __res
   // gL = sum_s tril(T_s^T gG_s): lower blocks, accumulated over the samples in registers.  The next sample's operands (after
   // the last one: T_S and L_S) are requested before the current product, so that only the first round trip is exposed
   BSU_STAMP(0);
+  if (a.gL_acc) {
+    // the sum over the samples was accumulated by the K_uu roles of an earlier launch
+    bm_load_mat(a.TT + (int64_t)id * MM, M, M, tid, r0);
+    bm_load_mat(a.LL + (int64_t)id * MM, M, M, tid, r1);
+    const float* gl = a.gL_acc + (int64_t)c * MM;
+    mat_foreach<kFamR, WV>(li, lh, [&](int u, int rb, int cb, int r, int i, int j) {
+      acc[u][r] = gl[(int64_t)min(i, M - 1) * M + min(j, M - 1)];
+    });
+  } else {
   bm_load_mat(a.TT + (int64_t)c * MM, M, M, tid, r0);
   bm_load_mat(a.gQP + (int64_t)c * MLD + 4, LD, M, tid, r1);
-  for (int s = 0; s < a.S; ++s) {
+  }
+  for (int s = 0; s < (a.gL_acc ? 0 : a.S); ++s) {
     if (s > 0) __syncthreads();                        // everybody is done with the previous sample's operands
     mat_store(sT, r0, M, tid);
     mat_store(X1, r1, M, tid);
