@@ -164,6 +164,24 @@ struct GemmParams {
   int64_t sSplit;
 };
 
+// Fork / join of a side stream inside one library call (core.hip): independent launches of a call that should overlap on the
+// device.  SideFork(st): the side stream waits for everything issued to `st` so far; side() = the stream to issue the branch to
+// (== st when no side stream is to be had: then the branch simply runs in line); join(): `st` waits for the branch.  One side
+// stream and two events per device, created on first use outside a stream capture (a first use under capture runs in line);
+// under capture the fork / join become graph dependencies.  The issue sequence fork .. join holds a per-device mutex.
+class SideFork {
+ public:
+  explicit SideFork(hipStream_t st, bool want = true);
+  ~SideFork();
+  hipStream_t side() const { return side_; }
+  bool forked() const { return forked_; }
+  int join();
+ private:
+  hipStream_t st_, side_;
+  bool forked_;
+  int dev_;
+};
+
 int launch_gemm(const GemmParams& p, int transA, int transB, int nbatch, bool rbf, hipStream_t st,
                 const char* tag = "bgemm");
 int launch_gemm_pair(const GemmParams& p0, int nbatch0, const GemmParams& p1, int nbatch1, int transA, int transB,

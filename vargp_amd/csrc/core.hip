@@ -1,6 +1,7 @@
 // Error plumbing and small generic kernels (outer-sum reduction, fused Yogi step).
 #include "common.h"
 #include <stdarg.h>
+#include <mutex>
 #include <string>
 #include <vector>
 #include <string.h>
@@ -36,6 +37,50 @@ void zero_async(void* p, size_t bytes, hipStream_t st) {
   int blocks = (int)((n + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(zero_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<uint32_t*>(p), n);
+}
+
+// ---- side stream (SideFork, common.h) ----------------------------------------------------------
+namespace {
+struct SideRes { hipStream_t side = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool ok = false, tried = false; std::mutex mu; };
+SideRes g_side[64];
+}
+SideFork::SideFork(hipStream_t st, bool want) : st_(st), side_(st), forked_(false), dev_(-1) {
+  if (!want) return;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
+  SideRes& r = g_side[dev];
+  r.mu.lock();
+  dev_ = dev;
+  if (!r.tried) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
+    if (!capturing) {            // (resources are not created under a capture: that call runs its branch in line)
+      r.tried = true;
+      r.ok = hipStreamCreateWithFlags(&r.side, hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&r.fork, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&r.join, hipEventDisableTiming) == hipSuccess;
+      if (!r.ok) (void)hipGetLastError();
+    }
+  }
+  if (r.ok && hipEventRecord(r.fork, st) == hipSuccess && hipStreamWaitEvent(r.side, r.fork, 0) == hipSuccess) {
+    side_ = r.side;
+    forked_ = true;
+  } else {
+    (void)hipGetLastError();
+  }
+}
+int SideFork::join() {
+  if (!forked_) return VARGP_OK;
+  forked_ = false;
+  SideRes& r = g_side[dev_];
+  const bool ok = hipEventRecord(r.join, side_) == hipSuccess && hipStreamWaitEvent(st_, r.join, 0) == hipSuccess;
+  side_ = st_;
+  if (!ok) { set_error("side stream: join failed: %s", hipGetErrorString(hipGetLastError())); return VARGP_ELAUNCH; }
+  return VARGP_OK;
+}
+SideFork::~SideFork() {
+  if (forked_) (void)join();
+  if (dev_ >= 0) g_side[dev_].mu.unlock();
 }
 
 // ---- per-kernel event timing ---------------------------------------------------------------

@@ -817,13 +817,20 @@ static int64_t t0_tile_units_max() {
   return env;
 }
 // Role-merged launches (pivot / adjoint chains of the S C + C matrices beside the big product of the same phase) pay while the
-// chains leave CUs free for the product to hide them under.  With more chains than CUs they fill the chip by themselves, and
-// the product does better as a launch of its own: two workgroups per CU (the merged kernels hold it to one -- the chain role's
-// registers / LDS), 128-row tiles.  Measured (MI355X, Split-MNIST first task, steps/s merged -> apart): S = 16 (170 chains) 1372 ->
-// 1365, S = 32 (330) 697 -> 744, S = 64 (650) 373 -> 413.  VARGP_T0_UNMERGE = chain count from which on (tuning aid).
+// chains are few: a latency chain on 40 CUs hides under a product on the other 216.  With many hyper-samples the chains are a
+// throughput problem of their own and the product does better as a launch of its own -- two workgroups per CU (the merged
+// kernels hold it to one: the chain role's registers / LDS), 128-row tiles -- with the chains on a side stream (SideFork) so that
+// the two launches share the chip.  Measured (MI355X, Split-MNIST first task, steps/s merged -> apart in line -> apart on two
+// streams): S = 8 (90 chains) 2472 -> 2226 -> 2400, S = 16 (170) 1372 -> 1366 -> 1418, S = 32 (330) 697 -> 745 -> 783,
+// S = 64 (650) 373 -> 413 -> 421.  Default: apart from half the CU count on.  VARGP_T0_UNMERGE = chain count from which on.
 static int t0_unmerge_chains() {
   static const int env = [] { const char* e = getenv("VARGP_T0_UNMERGE"); return e ? atoi(e) : -1; }();
-  return env >= 0 ? env : vargp_cu_count() + 1;
+  return env >= 0 ? env : vargp_cu_count() / 2 + 1;
+}
+// ... and then the chains go to a side stream (SideFork, common.h).  VARGP_T0_SIDE=0: in line (tuning aid)
+static bool t0_side_stream() {
+  static const int env = [] { const char* e = getenv("VARGP_T0_SIDE"); return e ? atoi(e) : 1; }();
+  return env != 0;
 }
 static bool t0_force_multi() {
   static const int env = [] { const char* e = getenv("VARGP_T0_MULTI"); return e ? atoi(e) : 0; }();
@@ -1045,12 +1052,19 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
       // many hyper-samples: the chains fill the chip by themselves and hide nothing -- the product runs as a launch of its own, two
       // workgroups per CU (the merged launch holds it to one by the chain role's registers): t0_unmerge_chains()
       const bool unmerge = SC + C >= t0_unmerge_chains();
-      rc = launch_chol_rbf_gemm(o.KS, d->jitter, o.LL, o.TT, d->info, SC + C, M, p1, unmerge ? 0 : S, st, &lx, clear_bwd ? &bwd_zero : nullptr);
-      if (rc) return rc;
-      if (unmerge) {
-        static const int kuf_tile = [] { const char* e = getenv("VARGP_T0_KUF_TILE"); return e ? atoi(e) : 0; }();   // tuning aid
-        p1.tile = kuf_tile;
-        rc = launch_gemm(p1, 0, 1, S, true, st, "rbf_kuf_gemm");
+      {
+        // (apart: the chains on a side stream, so that the product's workgroups fill the CUs the chains' rounds leave idle)
+        SideFork fork(st, unmerge && t0_side_stream());
+        rc = launch_chol_rbf_gemm(o.KS, d->jitter, o.LL, o.TT, d->info, SC + C, M, p1, unmerge ? 0 : S, fork.side(), &lx,
+                                  clear_bwd ? &bwd_zero : nullptr);
+        if (rc) return rc;
+        if (unmerge) {
+          static const int kuf_tile = [] { const char* e = getenv("VARGP_T0_KUF_TILE"); return e ? atoi(e) : 0; }();   // tuning aid
+          p1.tile = kuf_tile;
+          rc = launch_gemm(p1, 0, 1, S, true, st, "rbf_kuf_gemm");
+          if (rc) return rc;
+        }
+        rc = fork.join();
         if (rc) return rc;
       }
       merged = true;
@@ -1268,20 +1282,21 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
     // with nothing left to hide under -- read per-class sums the K_uu roles accumulate (cleared by the forward's zero role)
     const bool unmerge = SC + C >= t0_unmerge_chains();
     if (unmerge) {
+      SideFork fork(st, t0_side_stream());               // (the chains on a side stream, as in the forward)
       ma.gL_acc = o.gLL + SC * MM;
-      rc = launch_bwdmat_gemm(ma, 0, SC, p1, 0, st, "t0_bwdmat_kuu", nullptr);
+      rc = launch_bwdmat_gemm(ma, 0, SC, p1, 0, fork.side(), "t0_bwdmat_kuu", nullptr);
       if (rc) return rc;
-      rc = launch_bwdmat_gemm(ma, SC, C, p1, 0, st, "t0_bwdmat_su", nullptr);
-    } else {
-      rc = launch_bwdmat_gemm(ma, 0, SC + C, p1, S, st, "rbf_kuf_bwd_gemm", reinterpret_cast<int*>(o.queue));
-    }
-    if (rc) return rc;
-    if (unmerge) {
+      rc = launch_bwdmat_gemm(ma, SC, C, p1, 0, fork.side(), "t0_bwdmat_su", nullptr);
+      if (rc) return rc;
       static const int puf_tile = [] { const char* e = getenv("VARGP_T0_PUF_TILE"); return e ? atoi(e) : 0; }();   // tuning aid
       p1.tile = puf_tile;
       rc = launch_gemm(p1, 0, 0, S, false, st, "rbf_kuf_bwd_product");
       if (rc) return rc;
+      rc = fork.join();
+    } else {
+      rc = launch_bwdmat_gemm(ma, 0, SC + C, p1, S, st, "rbf_kuf_bwd_gemm", reinterpret_cast<int*>(o.queue));
     }
+    if (rc) return rc;
     // ... then P_uu = W_uu z; with few samples inside the launch that consumes it (t0_bwd_tail.h)
     static const int tail_env = [] { const char* e = getenv("VARGP_T0_TAIL"); return e ? atoi(e) : 1; }();   // tuning aid
     fused_tail = tail_env && S <= kTailSMax;

@@ -1214,16 +1214,19 @@ static bool gemm_vec_ok(const GemmParams& p) {
 // workgroup evaluates the entries it needs itself (same expression, so the copies in `w` agree bit for bit).
 template <int BK>
 __global__ __launch_bounds__(256) void t0_pro_kuu_kernel(const ProArgs a, const int npro, const NormArgs nr, const int nnorm,
-                                                         const GemmParams p, const int tiles, const int ngemm) {
+                                                         const GemmParams p, const int tiles, const int ngemm,
+                                                         const int norms_first) {
   __shared__ __attribute__((aligned(16))) float lds[gemm_lds_floats<64, 64, BK, true, true>()];
   STEP_SPAN(gemm, 0);
   int blk = blockIdx.x;
   if (blk >= ngemm) {      // (the other order -- short roles first -- measured 26.9 us against 20.3 us)
     blk -= ngemm;
-    if (blk < npro) t0_prologue_body(a, blk, lds);
+    // norms_first: the norm role (the longer of the two: 16 rows x S per workgroup, x o w written) in front of the prologue roles
+    const int pblk = norms_first ? blk - nnorm : blk, nblk = norms_first ? blk : blk - npro;
+    if (pblk >= 0 && pblk < npro) t0_prologue_body(a, pblk, lds);
     else {
       if (step_span_guard_.p && threadIdx.x == 0) atomicMax(&g_spans_gemm[11][0], wall_clock64());      // (slot 11: LAST start .. last end)
-      t0_norm_body(a, nr, blk - npro, lds); STEP_SPAN_MARK(gemm, 11);
+      t0_norm_body(a, nr, nblk, lds); STEP_SPAN_MARK(gemm, 11);
     }
     return;
   }
@@ -1260,8 +1263,9 @@ int launch_pro_kuu(const ProArgs& a, int npro, const NormArgs& n, const GemmPara
   q.xcd_remap = 0; q.group_m = 0;
   const int tiles = cdiv(q.M, 64) * cdiv(q.N, 64), ngemm = tiles * nbatch * q.splitk, nnorm = n.nrow_blocks * a.S;
   const dim3 grid(ngemm + npro + nnorm);
-  if (bk == 64) hipLaunchKernelGGL((t0_pro_kuu_kernel<64>), grid, dim3(256), 0, st, a, npro, n, nnorm, q, tiles, ngemm);
-  else hipLaunchKernelGGL((t0_pro_kuu_kernel<32>), grid, dim3(256), 0, st, a, npro, n, nnorm, q, tiles, ngemm);
+  static const int nf = [] { const char* e = getenv("VARGP_PRO_NORMS_FIRST"); return e ? atoi(e) : 0; }();   // tuning aid
+  if (bk == 64) hipLaunchKernelGGL((t0_pro_kuu_kernel<64>), grid, dim3(256), 0, st, a, npro, n, nnorm, q, tiles, ngemm, nf);
+  else hipLaunchKernelGGL((t0_pro_kuu_kernel<32>), grid, dim3(256), 0, st, a, npro, n, nnorm, q, tiles, ngemm, nf);
   return check_launch("pro_kuu");
 }
 

@@ -210,6 +210,61 @@ struct NormArgs {
 __device__ __forceinline__ void t0_norm_body(const ProArgs& a, const NormArgs& n, const int id, float* __restrict__ wl) {
   const int s = id / n.nrow_blocks, rb = id - s * n.nrow_blocks;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (n.rows_per_block <= 16 && (a.D & 3) == 0 && a.D <= 1024 &&
+      ((reinterpret_cast<uintptr_t>(n.z) | reinterpret_cast<uintptr_t>(n.x) | reinterpret_cast<uintptr_t>(n.xs)) & 15) == 0) {
+    // Short rows (the MNIST shapes): the wave's four rows are requested whole, as float4, BEFORE the theta phase -- one memory
+    // round trip beside that phase's own instead of one per 256-column chunk behind it (the role was the long pole of its launch:
+    // 19 us per workgroup against 16.6 for the K-split Gram tiles beside it).
+    const int64_t nrows = n.zrows + n.xrows, last = nrows - 1;
+    const int D4 = a.D >> 2;
+    const float4* xr[4];
+    float4* xo[4];
+    int64_t row[4];
+    bool live[4], xout[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      row[q] = (int64_t)rb * n.rows_per_block + wave + 4 * q;
+      live[q] = wave + 4 * q < n.rows_per_block && row[q] < nrows;
+      const int64_t rc = row[q] < last ? row[q] : last;
+      xr[q] = reinterpret_cast<const float4*>(rc < n.zrows ? n.z + rc * a.D : n.x + (rc - n.zrows) * a.D);
+      xout[q] = n.xs != nullptr && live[q] && row[q] >= n.zrows;
+      xo[q] = reinterpret_cast<float4*>(n.xs + ((int64_t)s * n.xrows + (xout[q] ? row[q] - n.zrows : 0)) * a.D);
+    }
+    float4 xv[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) xv[q][c] = xr[q][min(64 * c + lane, D4 - 1)];
+    for (int d0 = tid; d0 < a.D; d0 += 1024) {
+      float tb[4];
+      t0_theta_batch<4>(a, s, d0, false, tb);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (d0 + 256 * u < a.D) wl[d0 + 256 * u] = expf(-2.f * tb[u]);
+    }
+    __syncthreads();
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int i4 = 64 * c + lane;
+      const bool ok = i4 < D4;
+      const float4 w4 = ok ? reinterpret_cast<const float4*>(wl)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = xv[q][c];
+        const float4 sv = make_float4(v.x * w4.x, v.y * w4.y, v.z * w4.z, v.w * w4.w);
+        acc[q] = fmaf(v.x, sv.x, fmaf(v.y, sv.y, fmaf(v.z, sv.z, fmaf(v.w, sv.w, acc[q]))));
+        if (xout[q] && ok) xo[q][i4] = sv;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float t = wave_sum(acc[q]);
+      if (lane == 0 && live[q]) {
+        if (row[q] < n.zrows) n.na[(int64_t)s * n.zrows + row[q]] = t; else n.nb[(int64_t)s * n.xrows + (row[q] - n.zrows)] = t;
+      }
+    }
+    return;
+  }
   for (int d0 = tid; d0 < a.D; d0 += 1024) {
     float tb[4];
     t0_theta_batch<4>(a, s, d0, false, tb);
