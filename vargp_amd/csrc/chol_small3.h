@@ -34,6 +34,7 @@
 // VARGP_CHOL_BLOCK4 = 0 as the reference point of DESIGN_HISTORY.md's measurements.
 #pragma once
 #include "common.h"
+#include "chol_gram.h"
 #include <math.h>
 #include <type_traits>
 #ifndef STAMP
@@ -367,7 +368,86 @@ __device__ __forceinline__ void chol3_body(const int64_t b, const float* __restr
   const int64_t phase_last_ = (int64_t)gridDim.x < 0 ? 0 : g_chol_phase_last;
 #endif
   CHOL_PHASE(0);
-  if (extra && extra->part && b < extra->first) {
+  bool gram_done = false;
+  if constexpr (KC == 25 && SETS == 2) {
+  if (extra && extra->gram_z && b < extra->first) {
+    gram_done = true;
+    // The workgroup builds its kernel matrix itself (chol_gram.h): weighted Gram matrix of the class's inducing points on the MFMA
+    // (panels inside `stage`), then K_ij = g2 exp(-(G_ii + G_jj - 2 G_ij) / 2), exactly g2 on the diagonal -- the formula of the
+    // partial-sum path below -- out to Kout (float4 rows) and into `stage`, from where every thread picks its entries.
+    static_assert(chol3_stage_floats<KC>() >= kCgLdsFloats, "staging matrix too small for the Gram panels");
+    const int pc = extra->part_C;
+    const int sidx = (int)(b / pc), cidx = (int)(b - (int64_t)sidx * pc);
+    const float* zc = extra->gram_z + (int64_t)cidx * n * extra->gram_D;
+    const float* wv = extra->gram_w + (int64_t)sidx * extra->gram_Dp;
+    float* Kout = extra->Kout + b * (int64_t)n * n;
+    float* diag = reinterpret_cast<float*>(sd);                       // (the pivots' array: free until the elimination has run)
+    {
+      cg_f32x4 acc[7];
+      if (w == 0) cg_gram<0>(zc, wv, n, extra->gram_D, stage, acc, tid);
+      else if (w == 1) cg_gram<1>(zc, wv, n, extra->gram_D, stage, acc, tid);
+      else if (w == 2) cg_gram<2>(zc, wv, n, extra->gram_D, stage, acc, tid);
+      else cg_gram<3>(zc, wv, n, extra->gram_D, stage, acc, tid);
+      // (cg_gram ends on a barrier: nobody reads the panels any more)
+      if (w == 0) cg_store<0>(acc, stage, LS, diag, n, lane);
+      else if (w == 1) cg_store<1>(acc, stage, LS, diag, n, lane);
+      else if (w == 2) cg_store<2>(acc, stage, LS, diag, n, lane);
+      else cg_store<3>(acc, stage, LS, diag, n, lane);
+    }
+    __syncthreads();
+    CHOL_PHASE(5);
+    {
+      const float gam = extra->g2[sidx];
+      constexpr int NQ = (4 * KC * KC + 255) / 256;
+      const int n4 = n >> 2, tot4 = n * n4;
+      const int di4 = 256 / n4, dj4 = 256 - di4 * n4;
+      int i = tid / n4, j4 = tid - i * n4;
+      // every LDS read of the thread first (each element is read by the thread that overwrites it; the diagonal has its own copy)
+      float gij[NQ][4], gi_[NQ], gj_[NQ][4];
+      int qi[NQ], qj[NQ];
+#pragma unroll
+      for (int u = 0; u < NQ; ++u) {
+        const bool ok = tid + 256 * u < tot4;
+        qi[u] = ok ? i : -1; qj[u] = ok ? (j4 << 2) : 0;
+        const int ii = ok ? i : 0, jj = qj[u];
+        gi_[u] = diag[ii];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { gij[u][t] = stage[ii * LS + jj + t]; gj_[u][t] = diag[jj + t]; }
+        i += di4; j4 += dj4;
+        if (j4 >= n4) { j4 -= n4; ++i; }
+      }
+#pragma unroll
+      for (int u = 0; u < NQ; ++u) {
+        const int ii = qi[u], jj = qj[u];
+        if (ii >= 0) {
+          float4 k4;
+          k4.x = ii == jj ? gam : gam * expf(-0.5f * (gi_[u] + gj_[u][0] - 2.f * gij[u][0]));
+          k4.y = ii == jj + 1 ? gam : gam * expf(-0.5f * (gi_[u] + gj_[u][1] - 2.f * gij[u][1]));
+          k4.z = ii == jj + 2 ? gam : gam * expf(-0.5f * (gi_[u] + gj_[u][2] - 2.f * gij[u][2]));
+          k4.w = ii == jj + 3 ? gam : gam * expf(-0.5f * (gi_[u] + gj_[u][3] - 2.f * gij[u][3]));
+          *reinterpret_cast<float4*>(Kout + (int64_t)ii * n + jj) = k4;
+          float* sp = stage + ii * LS + jj;
+          sp[0] = k4.x; sp[1] = k4.y; sp[2] = k4.z; sp[3] = k4.w;
+        }
+      }
+    }
+    CHOL_PHASE(8);
+    __syncthreads();
+    CHOL_PHASE(9);
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+      const int i = 4 * k + w;
+      const int ic = min(i, n - 1);
+      const float sa = stage[ic * LS + min(ca, n - 1)], sb = stage[ic * LS + min(cb, n - 1)];   // unconditional reads
+      v[k].x = (i < n && minea) ? (R)sa + (i == ca ? (R)eps : R(0)) : chol_pad<R>(i, ca, n);
+      v[k].y = (i < n && mineb) ? (R)sb + (i == cb ? (R)eps : R(0)) : chol_pad<R>(i, cb, n);
+    }
+    CHOL_PHASE(7);
+    __syncthreads();      // `stage` is reused for the results
+  }
+  }
+  if (gram_done) {
+  } else if (extra && extra->part && b < extra->first) {
     // K-split partial Gram matrices -> kernel matrix on the way in (CholExtra, common.h).  Summation order and formula of
     // t0_combine_norm_kernel (elbo_t0.hip).  Loads on clamped indices, all of a row's in flight together.
     const float* part = extra->part + b * (int64_t)n * n;

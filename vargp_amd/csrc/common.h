@@ -248,6 +248,9 @@ struct CholExtra {
   float* base; int first; int ld; int64_t stride_b, stride_copy; int ncopy;
   int symmetric_input, diag_only_before_first;
   const float* part; int nsplit; int64_t sSplit; const float* g2; int part_C; float* Kout;
+  // gram_z != NULL (chol_gram.h; instead of `part`): the matrices b < first = (s, c) are built by their factorising workgroup from the
+  // inducing points gram_z [part_C][n][gram_D] and 1/sigma^2 gram_w [S][gram_Dp] (g2, part_C, Kout as for `part`)
+  const float* gram_z; const float* gram_w; int gram_D; int64_t gram_Dp;
 };
 int vargp_cu_count();       // CUs of the current device (gemm.hip)
 int launch_chol_rbf_gemm(const float* A, float eps, float* L, float* T, int32_t* info, int nchol, int n,

@@ -24,6 +24,7 @@ STEP_SPAN_TABLE(t0)
 #include "elbo_shared.h"
 #include "t0_bwd_mid.h"
 #include "t0_bwd_mid_multi.h"
+#include "chol_gram.h"
 #include "t0_prologue.h"
 #include "t0_bwd_tail.h"
 
@@ -933,6 +934,15 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
   // ... and then the prologue shares the launch of the split product (every workgroup evaluates the 1/sigma^2 it needs itself),
   // and the partial products are summed and exponentiated by the factorising workgroups as they load: two launches fewer
   const bool front = split_kuu && front_env && ksp <= kCholPartMax && D <= kProKuuMaxD;
+  // ... with several hyper-samples the Gram matrices are a throughput problem (64 x 64 tiles of a 100-row matrix: 1.64x the work,
+  // partial sums written and re-read) while a factorising workgroup has time to spare under the K_uf product of its launch: it
+  // builds its Gram matrix itself (chol_gram.h: 16-row MFMA blocks, lower triangle) and the front launch keeps prologue + norms.
+  // Not at S = 3: there the chain workgroups ARE the critical path of their launch.
+  // Measured (steps/s without -> with): S = 3 5113 -> 4577, S = 8 2476 -> 2500, S = 16 1405 -> 1441, S = 64 420 -> 434; on from the
+  // chain count at which the merged launches are taken apart (t0_unmerge_chains).  VARGP_T0_GRAM_IN_CHAIN = S from which on (tuning aid)
+  static const int gic_env = [] { const char* e = getenv("VARGP_T0_GRAM_IN_CHAIN"); return e ? atoi(e) : -1; }();
+  const bool gram_in_chain = front && (gic_env >= 0 ? S >= gic_env : SC + C >= t0_unmerge_chains()) && M > 64 && (M % 4) == 0 &&
+                             D <= kCgMaxD && D >= 32;
   ProArgs a{};
   {
     if (merge_chol) { a.RK = o.RK; a.u_mean = d->u_mean; a.NR = NR; a.LD = LD; }
@@ -1028,7 +1038,7 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
           // (the norm role also writes x o 1/sigma_s^2: the K_uf product then runs without scale loads / multiplies in its
           // main loop -- step 209.5 -> 207.7 us at S = 3, 510 -> 494 us at S = 8)
           NormArgs nr{d->z, d->x, o.na, o.nb, zrows, (int64_t)B, 16, (int)cdiv(zrows + B, 16), o.xs};
-          rc = launch_pro_kuu(a, npro, nr, ps, SC, st);
+          rc = launch_pro_kuu(a, npro, nr, ps, gram_in_chain ? 0 : SC, st);
           if (rc) return rc;
           p1.B = o.xs; p1.sB[0] = (int64_t)B * D; p1.kscale = nullptr;
         } else {
@@ -1048,6 +1058,7 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
       CholExtra lx{o.RK + 4, SC, LD, MLD, (int64_t)C * MLD, S, 1, 1};
       if (front) {   // the matrices b < SC arrive as K-split partial Gram matrices (and leave as K_uu in KS for the backward)
         lx.part = o.kpart; lx.nsplit = ksp; lx.sSplit = SC * MM; lx.g2 = o.g2; lx.part_C = C; lx.Kout = o.KS;
+        if (gram_in_chain) { lx.part = nullptr; lx.gram_z = d->z; lx.gram_w = o.w; lx.gram_D = D; lx.gram_Dp = o.Dp; }
       }
       // many hyper-samples: the chains fill the chip by themselves and hide nothing -- the product runs as a launch of its own, two
       // workgroups per CU (the merged launch holds it to one by the chain role's registers): t0_unmerge_chains()

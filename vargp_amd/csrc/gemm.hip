@@ -1251,8 +1251,9 @@ __global__ __launch_bounds__(256) void t0_pro_kuu_kernel(const ProArgs a, const 
 }
 
 int launch_pro_kuu(const ProArgs& a, int npro, const NormArgs& n, const GemmParams& ps, int nbatch, hipStream_t st) {
-  VARGP_REQUIRE(ps.splitk > 1 && ps.kscale == a.w && ps.ks_ld == a.Dp && a.D <= kProKuuMaxD && gemm_vec_ok(ps),
-                "pro_kuu: not applicable");
+  // (nbatch == 0: no product role -- the factorising workgroups of the next launch build their Gram matrices themselves, chol_gram.h)
+  VARGP_REQUIRE(nbatch == 0 || (ps.splitk > 1 && ps.kscale == a.w && ps.ks_ld == a.Dp && gemm_vec_ok(ps)), "pro_kuu: not applicable");
+  VARGP_REQUIRE(a.D <= kProKuuMaxD, "pro_kuu: D = %d out of range", a.D);
   if (prof_remembering()) {
     const ProArgs ac = a; const NormArgs nc = n; const GemmParams pc = ps;
     prof_remember("t0_pro_kuu", [=](hipStream_t s) { launch_pro_kuu(ac, npro, nc, pc, nbatch, s); });
@@ -1261,7 +1262,7 @@ int launch_pro_kuu(const ProArgs& a, int npro, const NormArgs& n, const GemmPara
   static const int bk = [] { const char* e = getenv("VARGP_PRO_KUU_BK"); return e ? atoi(e) : 32; }();   // tuning aid
   GemmParams q = ps;
   q.xcd_remap = 0; q.group_m = 0;
-  const int tiles = cdiv(q.M, 64) * cdiv(q.N, 64), ngemm = tiles * nbatch * q.splitk, nnorm = n.nrow_blocks * a.S;
+  const int tiles = cdiv(q.M, 64) * cdiv(q.N, 64), ngemm = nbatch > 0 ? tiles * nbatch * q.splitk : 0, nnorm = n.nrow_blocks * a.S;
   const dim3 grid(ngemm + npro + nnorm);
   static const int nf = [] { const char* e = getenv("VARGP_PRO_NORMS_FIRST"); return e ? atoi(e) : 0; }();   // tuning aid
   if (bk == 64) hipLaunchKernelGGL((t0_pro_kuu_kernel<64>), grid, dim3(256), 0, st, a, npro, n, nnorm, q, tiles, ngemm, nf);
