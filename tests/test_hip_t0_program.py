@@ -37,11 +37,11 @@ SHAPES = [(2, 3, 3, 33, 40, 50), (3, 2, 4, 20, 64, 37), (2, 2, 18, 12, 36, 24), 
           # workgroups), a ragged last tile, B % 4 != 0 (the per-element K_uf loads), and one workgroup for all tiles of a matrix
           (8, 2, 10, 100, 36, 512), (6, 2, 10, 96, 36, 328), (12, 1, 9, 100, 36, 200), (10, 2, 10, 52, 36, 130),
           (16, 1, 16, 100, 36, 128),
-          # many per-matrix chains (S C + C > half the CUs): the role-merged launches taken apart -- chains alone on a side stream,
+          # many per-matrix chains (S C + C > a third of the CUs): the role-merged launches taken apart -- chains alone on a side stream,
           # K_uf / P_uf as launches of their own, the S_u roles of the backward reading the per-class sums of the L_S gradient shares
           # that the K_uu roles accumulate (BwdMatArgs::gL_acc); 17 and 33 hyper-samples
           (17, 1, 16, 52, 36, 64), (33, 1, 8, 100, 36, 72),
-          # ... from half the CU count on, with the chains on a side stream; D >= 256: behind the K-split front launch (x o w operand)
+          # ... D >= 256: behind the front launch (x o w operand), the Gram matrices built by the chain workgroups (chol_gram.h)
           (13, 1, 10, 100, 256, 128)]
 
 

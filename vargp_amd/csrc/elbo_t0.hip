@@ -823,10 +823,12 @@ static int64_t t0_tile_units_max() {
 // kernels hold it to one: the chain role's registers / LDS), 128-row tiles -- with the chains on a side stream (SideFork) so that
 // the two launches share the chip.  Measured (MI355X, Split-MNIST first task, steps/s merged -> apart in line -> apart on two
 // streams): S = 8 (90 chains) 2472 -> 2226 -> 2400, S = 16 (170) 1372 -> 1366 -> 1418, S = 32 (330) 697 -> 745 -> 783,
-// S = 64 (650) 373 -> 413 -> 421.  Default: apart from half the CU count on.  VARGP_T0_UNMERGE = chain count from which on.
+// S = 64 (650) 373 -> 413 -> 421; with the Gram matrices built by the chain workgroups (chol_gram.h, same rule) apart also wins at
+// S = 8: 2468 merged, 2495 merged + Gram, 2511 apart + Gram.  Default: apart from a third of the CU count on.
+// VARGP_T0_UNMERGE = chain count from which on (tuning aid).
 static int t0_unmerge_chains() {
   static const int env = [] { const char* e = getenv("VARGP_T0_UNMERGE"); return e ? atoi(e) : -1; }();
-  return env >= 0 ? env : vargp_cu_count() / 2 + 1;
+  return env >= 0 ? env : vargp_cu_count() / 3 + 1;
 }
 // ... and then the chains go to a side stream (SideFork, common.h).  VARGP_T0_SIDE=0: in line (tuning aid)
 static bool t0_side_stream() {
