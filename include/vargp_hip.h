@@ -233,6 +233,9 @@ typedef struct vargp_elbo_t0_desc {
   int32_t* info_host;
   void* info_event;
 } vargp_elbo_t0_desc;
+/* Streams: the work is issued to `stream` in order.  With many hyper-samples (S C + C per-matrix chains > a third of the CUs) fwd and
+ * bwd fork a library-owned side stream for the pivot / adjoint chains and join it before they return (events; graph dependencies
+ * under hipGraph capture): to the caller the call is still one unit of work on `stream`.  VARGP_T0_SIDE=0 disables it. */
 size_t vargp_elbo_t0_workspace_bytes(int S, int C, int M, int D, int B, int F);
 int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t stream);
 /* Where the program keeps the predictive moments mu, var (S, C, B) of its last fwd and the likelihood gradients gmu, gvar
