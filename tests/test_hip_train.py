@@ -91,6 +91,51 @@ def test_graph_step_equals_eager_step():
         ops.set_cholesky_error_mode('raise')
 
 
+def test_graph_step_equals_eager_step_with_a_side_stream():
+    """Many hyper-samples (S C + C chains > a third of the CUs): vargp_elbo_t0_fwd / _bwd fork a side stream for the pivot /
+    adjoint chains (SideFork, csrc/core.hip).  Under hipGraph capture the fork / join must become graph dependencies: three
+    replayed steps == three eager steps; and the first use of the side stream may be under capture (fresh process state is not
+    needed: the eager pass below runs second)."""
+    from oracle import vargp_oracle as orc
+    from vargp_amd import noise, ops
+    from vargp_amd.train import ElboTrainer
+    from gpu_common import build_gp
+    S, F_, C, M, D, B = 10, 2, 10, 100, 256, 128          # 110 chains; D >= 256: the Gram matrices built by the chain workgroups
+    params, prev, x, y, nz = orc.make_problem(S, F_, C, M, D, B, n_prev=0, seed=5, kind='gauss')
+    xd, yd = x.to(DEV), y.to(DEV)
+    ops.set_cholesky_error_mode('defer')
+    ops.reset_linalg_errors()
+    try:
+        results = []
+        for mode in ('graph', 'eager'):
+            gp = build_gp(params, prev, S, F_)
+            tr = ElboTrainer(gp, lr=1e-3, beta=2.0, n_total=10 * B)
+            with noise.inject(**to_dev(nz, DEV)):
+                if mode == 'graph':
+                    tr.capture(xd, yd, warmup=1)
+                    for _ in range(3):
+                        out = tr.step_graph()
+                else:
+                    for _ in range(3):
+                        out = tr.step(xd, yd)
+            torch.cuda.synchronize()
+            results.append(({k: v.detach().cpu().clone() for k, v in gp.state_dict().items()}, [o.item() for o in out]))
+        (sd_g, out_g), (sd_e, out_e) = results
+        np.testing.assert_allclose(out_g, out_e, rtol=1e-5)
+        for k in sd_e:
+            assert rel_l2(sd_g[k], sd_e[k]) < 1e-5, k
+        assert ops.linalg_error_count() == 0
+        # ... and the eager result is the oracle's (one step, same noise)
+        gp = build_gp(params, prev, S, F_)
+        tr = ElboTrainer(gp, lr=1e-9, beta=2.0, n_total=10 * B)
+        with noise.inject(**to_dev(nz, DEV)):
+            out = [float(v) for v in tr.step(xd, yd)]
+        sc, _ = orc.elbo_step(params, prev, x, y, nz, beta=2.0, n_total=10 * B)
+        np.testing.assert_allclose(out, [sc[k].item() for k in ('kl_hypers', 'kl_u', 'nll')], rtol=1e-4)
+    finally:
+        ops.set_cholesky_error_mode('raise')
+
+
 @pytest.mark.parametrize('C,M,B,D', [(4, 20, 100, 2), (10, 16, 32, 784), (10, 20, 496, 784)])
 def test_graph_replays_stay_finite(C, M, B, D):
     """Regression: every buffer a captured step accumulates into must be re-zeroed by a node of the graph
