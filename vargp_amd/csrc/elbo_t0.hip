@@ -36,6 +36,7 @@ constexpr int kKuuSplit = 2;   // K-splits of the K_uu distance GEMM (few workgr
 #define VARGP_KL_ROWS 8
 #endif
 constexpr int kT0TileUnitsMax = 16384;   // (S C <= 2048 at the reference's batch of 512; mirrored by vargp_amd/vargp.py)
+constexpr int kTailLdsDefault = 1;
 constexpr int kKlRows = VARGP_KL_ROWS;     // rows of one (s, c) block per KL workgroup
 
 
@@ -1360,6 +1361,19 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
       ta.nx = gx * cdiv(B, kTailXRows); ta.gx = gx;
       ta.nrem = (rem > 0 && rem <= 8) ? C * gx * cdiv(rem, 4) : 0;
       const dim3 grid(ta.nz + ta.nrem + ta.nx);
+      // more than four samples: the per-sample operands of the z role staged through LDS (t0_puu_final_lds_kernel)
+      static const int tail_lds_env = [] { const char* e = getenv("VARGP_T0_TAIL_LDS"); return e ? atoi(e) : kTailLdsDefault; }();   // tuning aid
+      if (S > 4 && tail_lds_env) {
+        static std::atomic<unsigned> attr_set_mask_t[2] = {};
+        rc = ensure_dynamic_lds(reinterpret_cast<const void*>(t0_puu_final_lds_kernel), kTailLdsBytes, attr_set_mask_t, "elbo_t0_bwd");
+        if (rc) return rc;
+        int nzg = C * ta.nrb * cdiv(ta.ncb, 4), ngvw = cdiv(C * (ngr * (ngr + 1) / 2), 4);
+        // VARGP_EXP_TAIL (timing only, wrong results): 1 = the z groups alone, 2 = the other roles alone
+        static const int exp_tail = [] { const char* e = getenv("VARGP_EXP_TAIL"); return e ? atoi(e) : 0; }();
+        if (exp_tail == 1) { ngvw = 0; ta.nrem = 0; ta.nx = 0; }
+        if (exp_tail == 2) nzg = 0;
+        hipLaunchKernelGGL(t0_puu_final_lds_kernel, dim3(nzg + ngvw + ta.nrem + ta.nx), dim3(512), kTailLdsBytes, st, ta, gv, nzg, ngvw);
+      } else
       switch (S) {
         case 1: hipLaunchKernelGGL(t0_puu_final_kernel<1>, grid, dim3(256), 0, st, ta, gv); break;
         case 2: hipLaunchKernelGGL(t0_puu_final_kernel<2>, grid, dim3(256), 0, st, ta, gv); break;

@@ -22,6 +22,7 @@ namespace vargp {
 constexpr int kTailSMax = 64;
 constexpr int kTailXRows = 64;            // minibatch rows per block of the x role
 constexpr int kTailNG = kBmKP / 8;        // k-groups of 8
+static_assert(kBmKP == 104, "t0_puu_final_lds_kernel pads its staged rows to 104 columns");
 
 struct TailArgs {
   const float *z, *x, *Wuu, *Puf, *r_uu, *r_uf, *c_uf, *w;
@@ -280,6 +281,214 @@ __global__ __launch_bounds__(256, 2) void t0_puu_final_kernel(const TailArgs a, 
     if (dok && rowof(r) < M) a.gz[((int64_t)c * M + rowof(r)) * D + d] = ga[r];
   }
   TAIL_STAMP(13);
+}
+
+// ---- more than four hyper-samples: the z role with its per-sample operands staged through LDS by loader waves ---------------------------
+// In the kernel above every wave-block fetches its own fragments of W_uu[s, c] (13 float4 per lane and sample) and its 16 rows of the
+// P_uf block (16 dwords per lane and sample) straight from memory, sample after sample: with many samples the launch is bound by those
+// loads -- 29 vector-memory instructions per lane, sample and block, and the four waves of a workgroup (four neighbouring column
+// blocks of the SAME 32 rows) each pull the same rows of W_uu.  Here a workgroup is (class, 32-row block, group of four 32-column
+// blocks) and has EIGHT waves: four compute waves (one 32 x 32 block each: MFMAs + finalisation on operands in LDS) and four loader
+// waves that stream the 32 x M rows of W_uu[s, c] (once for the four blocks), the four 32 x 32 blocks of P_uf (float4 rows) and the
+// 128 values of 1/sigma_s^2 from memory into double-buffered LDS, two samples ahead in registers of their own.  Why separate waves:
+// staged by the compute waves themselves the float4 of the next sample were spilled to scratch by the compiler (i.e. waited for on
+// the spot), and vmcnt counts in order, so their one scalar load per sample waited for the whole prefetch.  One LDS-only barrier per
+// sample joins the eight waves.  The sums r_uu + r_uf of the 32 rows are shared too.  Roles behind the z groups as in the kernel
+// above, on the first four waves.
+constexpr int kTailWS = 108;              // row stride of the staged W_uu rows (108 / 4 odd: conflict-free b128 fragments)
+constexpr int kTailPS = 40;               // row stride of a staged 32 x 32 block of P_uf (4 rows = 160 words: the two half-waves on disjoint banks)
+constexpr int kTailWBuf = 32 * kTailWS, kTailPBuf = 4 * 32 * kTailPS;
+constexpr size_t kTailLdsBytes = sizeof(float) * (2 * kTailWBuf + 2 * kTailPBuf + 2 * 128 + kTailSMax * 32 + 2 * 4 * 64);
+
+__global__ __launch_bounds__(512) void t0_puu_final_lds_kernel(const TailArgs a, const GvecArgs gv, const int nzg, const int ngvw) {
+  extern __shared__ __attribute__((aligned(16))) float tail_lds[];
+  float* wbuf = tail_lds;                               // [2][32][kTailWS]
+  float* pbuf = wbuf + 2 * kTailWBuf;                   // [2][4][32][kTailPS]
+  float* wtab = pbuf + 2 * kTailPBuf;                   // [2][128]   1/sigma_s^2 of the group's 128 columns
+  float* rsl = wtab + 2 * 128;                          // [S][32]
+  float (*redx)[4][64] = reinterpret_cast<float (*)[4][64]>(rsl + kTailSMax * 32);
+  STEP_SPAN(t0, 6);
+  int blk = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  if (blk >= nzg) {
+    if (tid >= 256) return;                             // (a finished wave no longer counts at s_barrier)
+    blk -= nzg;
+    if (blk < ngvw) {          // lower blocks of the packed-vector gradient, one per wave
+      const int ngr = (gv.M + 31) / 32, nlow = ngr * (ngr + 1) / 2, e = blk * 4 + wave;
+      if (e >= gv.C * nlow) return;
+      int q = e % nlow, rbg = 0;
+      while (q > rbg) { q -= rbg + 1; ++rbg; }
+      tail_gvec_block(gv, e / nlow, rbg, q, li, lh);
+      return;
+    }
+    blk -= ngvw;
+    if (blk < a.nrem) { tail_rem_rows(a, blk, redx); return; }
+    blk -= a.nrem;
+    t0_final_x_body<kTailXRows>(a.x, a.c_uf, a.w, a.gtheta, (int64_t)a.B, a.D, a.Dp, a.S, blk % a.gx, blk / a.gx, redx);
+    return;
+  }
+  const int M = a.M, D = a.D, S = a.S;
+  const int ncg = (a.ncb + 3) >> 2;
+  const int cg = blk % ncg, rb = (blk / ncg) % a.nrb, c = blk / (ncg * a.nrb);
+  const int r0 = 32 * rb;
+  const int64_t zrows = (int64_t)a.C * M;
+  if (tid >= 256) {
+    // ---------------- loader waves: sample s + 1 -> the idle LDS buffer during sample s, from loads issued two samples earlier --------
+    const int t = tid - 256;
+    const int nq = M >> 2;
+    int wrow[4], wq[4];
+    bool wok[4];
+    const float* wptr[4];
+    const float* pptr[4];
+    const float* wsrc = a.Wuu + ((int64_t)c * M) * M;
+    const int prow = t >> 3, pq = (t & 7) << 2;
+    const float* psrc = a.Puf + ((int64_t)c * M + min(r0 + prow, M - 1)) * D;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = t + 256 * u;
+      const int row = e / nq;
+      wq[u] = (e - row * nq) << 2;
+      wok[u] = e < 32 * nq;
+      wrow[u] = min(row, 31);
+      wptr[u] = wsrc + (int64_t)min(r0 + wrow[u], M - 1) * M + wq[u];
+      pptr[u] = psrc + min(32 * (4 * cg + u) + pq, D - 4);
+    }
+    const int64_t wstep = (int64_t)a.C * M * M, pstep = zrows * D;
+    const int wcol = min(128 * cg + (t & 127), D - 1);
+    float4 rwA[4], rpA[4], rwB[4], rpB[4];
+    float wvA, wvB;
+    auto load_sample = [&](int s, float4 (&rw)[4], float4 (&rp)[4], float& wv) {
+      const int sc = min(s, S - 1);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) rw[u] = *reinterpret_cast<const float4*>(wptr[u] + sc * wstep);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) rp[u] = *reinterpret_cast<const float4*>(pptr[u] + sc * pstep);
+      wv = a.w[sc * a.Dp + wcol];
+    };
+    auto store_sample = [&](int buf, const float4 (&rw)[4], const float4 (&rp)[4], const float wv) {
+      float* wb = wbuf + buf * kTailWBuf;
+      float* pb = pbuf + buf * kTailPBuf;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float4 v = r0 + wrow[u] < M ? rw[u] : make_float4(0.f, 0.f, 0.f, 0.f);       // rows past M: zeros
+        if (wok[u]) *reinterpret_cast<float4*>(&wb[wrow[u] * kTailWS + wq[u]]) = v;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) *reinterpret_cast<float4*>(&pb[(u * 32 + prow) * kTailPS + pq]) = rp[u];
+      if (t < 128) wtab[buf * 128 + t] = wv;
+    };
+    load_sample(0, rwA, rpA, wvA);
+    load_sample(1, rwB, rpB, wvB);
+    // columns M .. 107 of the staged rows are only ever multiplied: zeros, written once (the staging never touches them)
+    {
+      const int npad = kTailWS - M;
+      for (int e = t; e < 2 * 32 * npad; e += 256) {
+        const int b2 = e / (32 * npad), r = (e / npad) & 31, k = M + e % npad;
+        wbuf[b2 * kTailWBuf + r * kTailWS + k] = 0.f;
+      }
+    }
+    for (int e = t; e < 32 * S; e += 256) {
+      const int s = e >> 5, row = min(r0 + (e & 31), M - 1);
+      const int64_t sr = (int64_t)s * zrows + (int64_t)c * M + row;
+      rsl[e] = a.r_uu[sr] + a.r_uf[sr];
+    }
+    store_sample(0, rwA, rpA, wvA);
+    load_sample(2, rwA, rpA, wvA);
+    bmm_lds_barrier();                                  // sample 0 is in buffer 0
+    for (int s = 0; s < S; s += 2) {
+      if (s + 1 < S) store_sample(1, rwB, rpB, wvB);    // sample s + 1 (set B, requested two samples ago)
+      load_sample(s + 3, rwB, rpB, wvB);
+      bmm_lds_barrier();                                // end of sample s
+      if (s + 1 < S) {
+        if (s + 2 < S) store_sample(0, rwA, rpA, wvA);  // sample s + 2
+        load_sample(s + 4, rwA, rpA, wvA);
+        bmm_lds_barrier();                              // end of sample s + 1
+      }
+    }
+    return;
+  }
+  // ---------------- compute waves ------------------------------------------------------------------------------------------------
+  const int cb = 4 * cg + wave;
+  const bool active = cb < a.ncb;                       // (wave-uniform; an idle wave still meets the barriers)
+  const int d0 = 32 * cb;
+  const float* zc = a.z + (int64_t)c * M * D;
+  const int d = d0 + li;
+  const bool dok = active && d < D;
+  const int dc = min(d, D - 1);
+  const int rbase = 4 * lh;                             // row of register r inside the block: rbase + 8 (r / 4) + r % 4
+  auto rowl = [rbase](int r) { return rbase + 8 * (r >> 2) + (r & 3); };
+  // B fragments (z[c][k][d]): the same for every sample, in registers
+  float4 bf[kTailNG];
+#pragma unroll
+  for (int g = 0; g < kTailNG; ++g) {
+    const float* zp = zc + (int64_t)min(8 * g + 4 * lh, M - 4) * D + dc;
+    bf[g] = make_float4(zp[0], zp[D], zp[2 * (int64_t)D], zp[3 * (int64_t)D]);
+  }
+  float ga[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) ga[r] = 0.f;
+  // z[row of register r][d] (component j of the B fragment of k-group 4 rb + q, r = 4 q + j; zero where the row or column does
+  // not exist) and the mask itself: the same for every sample
+  float zsel[16];
+  bool zok[16];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 z0 = bf[q], z1 = bf[4 + q], z2 = bf[8 + q], z3 = bf[bm_min(12 + q, kTailNG - 1)];
+    const float zq[4] = {rb == 0 ? z0.x : rb == 1 ? z1.x : rb == 2 ? z2.x : z3.x, rb == 0 ? z0.y : rb == 1 ? z1.y : rb == 2 ? z2.y : z3.y,
+                         rb == 0 ? z0.z : rb == 1 ? z1.z : rb == 2 ? z2.z : z3.z, rb == 0 ? z0.w : rb == 1 ? z1.w : rb == 2 ? z2.w : z3.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      zok[4 * q + j] = dok && r0 + rowl(4 * q + j) < M;
+      zsel[4 * q + j] = zok[4 * q + j] ? zq[j] : 0.f;
+    }
+  }
+  bmm_lds_barrier();                                    // sample 0 is in buffer 0 (and the row sums, the zero padding)
+  for (int s = 0; s < S; ++s) {
+    const int bsel = s & 1;
+    if (active) {
+      const float* wb = wbuf + bsel * kTailWBuf + li * kTailWS + 4 * lh;
+      const float* pb = pbuf + bsel * kTailPBuf + wave * 32 * kTailPS + li;
+      const float wv = dok ? wtab[bsel * 128 + wave * 32 + li] : 0.f;
+      bm_f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      float4 av = *reinterpret_cast<const float4*>(wb);
+#pragma unroll
+      for (int g = 0; g < kTailNG; ++g) {
+        const float4 cur = av;
+        if (g + 1 < kTailNG) av = *reinterpret_cast<const float4*>(wb + 8 * (g + 1));
+        bm_mfma4(acc, cur, bf[g]);
+      }
+      float p2[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) p2[r] = pb[rowl(r) * kTailPS];
+      float th = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 rs4 = *reinterpret_cast<const float4*>(&rsl[s * 32 + 4 * lh + 8 * q]);
+        const float rs[4] = {rs4.x, rs4.y, rs4.z, rs4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = 4 * q + j;
+          const bool okr = zok[r];
+          const float q1 = okr ? acc[r] : 0.f, q2 = okr ? p2[r] : 0.f, zr = zsel[r];
+          const float t = rs[j] * zr - q1 - q2;            // (r_uu z - P_uu) + (r_uf z - P_uf)
+          ga[r] -= wv * t;
+          th += zr * (t - q2);
+        }
+      }
+      th += __shfl_xor(th, 32);
+      if (lh == 0 && dok) atomicAdd(&a.gtheta[(int64_t)s * (D + 1) + d], wv * th);
+    }
+    bmm_lds_barrier();                                  // end of sample s: the loaders have filled the other buffer
+  }
+  if (active) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (dok && r0 + rowl(r) < M) a.gz[((int64_t)c * M + r0 + rowl(r)) * D + d] = ga[r];
+    }
+  }
 }
 
 }  // namespace vargp
