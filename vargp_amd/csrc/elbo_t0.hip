@@ -1363,7 +1363,7 @@ extern "C" int vargp_elbo_t0_bwd(const vargp_elbo_t0_desc* d, const float* seeds
       const dim3 grid(ta.nz + ta.nrem + ta.nx);
       // more than four samples: the per-sample operands of the z role staged through LDS (t0_puu_final_lds_kernel)
       static const int tail_lds_env = [] { const char* e = getenv("VARGP_T0_TAIL_LDS"); return e ? atoi(e) : kTailLdsDefault; }();   // tuning aid
-      if (S > 4 && tail_lds_env) {
+      if ((S > 4 && tail_lds_env) || tail_lds_env == 2) {      // (2: also with few samples -- tuning aid)
         static std::atomic<unsigned> attr_set_mask_t[2] = {};
         rc = ensure_dynamic_lds(reinterpret_cast<const void*>(t0_puu_final_lds_kernel), kTailLdsBytes, attr_set_mask_t, "elbo_t0_bwd");
         if (rc) return rc;

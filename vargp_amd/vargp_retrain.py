@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import gp_utils, noise, ops
-from .gp_utils import vec2tril, rev_cholesky, linear_joint, linear_marginal_diag
+from .gp_utils import vec2tril, rev_cholesky, linear_marginal_diag
 from .kernels import RBFKernel
 from .likelihoods import MulticlassSoftmax
 from .ops import LOWER
@@ -59,29 +59,38 @@ class VARGPRetrain(nn.Module):
                  for k in ('z', 'u_mean', 'u_tril_vec')} for i, p in enumerate(self.prev_params)]
 
     def compute_q(self, theta, prev_params, cache=None):
-        """q(u_<t | theta) and q(u_<=t | theta) by folding the given earlier-task parameters
-        (vargp_retrain.py:38-92).  Returns mu_lt, S_lt, mu_leq_t, S_leq_t, z_lt, z_leq_t."""
-        n_hypers = theta.size(0)
-        z_lt = prev_params[0]['z']
-        mu_lt = prev_params[0]['u_mean'].unsqueeze(0).expand(n_hypers, -1, -1, -1)
-        S_lt = rev_cholesky(vec2tril(prev_params[0]['u_tril_vec'])).unsqueeze(0).expand(n_hypers, -1, -1, -1)
-        for params in prev_params[1:]:
-            Kzx = self.kernel.compute(theta, z_lt, params['z'])
-            Kzz = self.kernel.compute(theta, z_lt)
-            V = rev_cholesky(vec2tril(params['u_tril_vec'])).unsqueeze(0)
-            b = params['u_mean'].unsqueeze(0)
-            mu_lt, S_lt = linear_joint(mu_lt, S_lt, Kzx, Kzz, V, b)
-            z_lt = torch.cat([z_lt, params['z']], dim=-2)
-        Kzx = self.kernel.compute(theta, z_lt, self.z)
-        Kzz = self.kernel.compute(theta, z_lt)
-        V = rev_cholesky(vec2tril(self.u_tril_vec)).unsqueeze(0)
-        b = self.u_mean.unsqueeze(0)
-        cache_leq_t = dict()
-        mu_leq_t, S_leq_t = linear_joint(mu_lt, S_lt, Kzx, Kzz, V, b, cache=cache_leq_t)
-        z_leq_t = torch.cat([z_lt, self.z], dim=-2)
+        """q(u_<t | theta) and q(u_<=t | theta) for the given earlier-task parameters (vargp_retrain.py:38-92; the reference
+        folds the tasks in one by one with gp_utils.linear_joint).  Returns mu_lt, S_lt, mu_leq_t, S_leq_t, z_lt, z_leq_t.
+
+        Evaluated in the block form of DESIGN.md section 3 instead of the chain: ONE kernel matrix K' = K(z_<=t, z_<=t) + eps I
+        over the inducing points of all tasks (task order), one factorisation L = chol(K'), T = L^-1, and with the diagonal
+        blocks T_ii:  a = [T_ii m_i]_i,  H = blockdiag(T_ii Lu_i)  ->  mu_<=t = L a,  S_<=t = (L H)(L H)^T;  the joint over the
+        earlier tasks is the leading block of both (the leading block of a Cholesky factor is the factor of the leading block,
+        and the jitter the reference adds to every K_zz of its chain is the diagonal of K').  The identities are pinned in fp64
+        against the chain by tests/test_block_algorithm.py; gradients flow through ops.* as before."""
+        blocks = list(prev_params) + [dict(z=self.z, u_mean=self.u_mean, u_tril_vec=self.u_tril_vec)]
+        sizes = [p['z'].size(-2) for p in blocks]
+        z_leq_t = torch.cat([p['z'] for p in blocks], dim=-2)
+        z_lt = z_leq_t[..., :sum(sizes[:-1]), :].contiguous()
+        L, T = ops.chol_inv(self.kernel.compute(theta, z_leq_t))                      # (S, C, Mt, Mt)
+        a_blk, lh_blk, o = [], [], 0
+        for p, n in zip(blocks, sizes):
+            T_ii = T[..., o:o + n, o:o + n].contiguous()
+            a_blk.append(ops.matmul(T_ii, p['u_mean'].unsqueeze(0), triA=LOWER))                          # T_ii m_i
+            H_i = ops.matmul(T_ii, vec2tril(p['u_tril_vec']).unsqueeze(0), triA=LOWER, triB=LOWER, triC=LOWER)
+            lh_blk.append(ops.matmul(L[..., :, o:o + n].contiguous(), H_i, triB=LOWER))                   # columns of L H
+            o += n
+        a = torch.cat(a_blk, dim=-2)                                                   # (S, C, Mt, 1)
+        LH = torch.cat(lh_blk, dim=-1)                                                 # (S, C, Mt, Mt), lower
+        n_lt = o - sizes[-1]
+        mu_leq_t = ops.matmul(L, a, triA=LOWER)
+        S_leq_t = ops.matmul(LH, LH.mT)
+        mu_lt = mu_leq_t[..., :n_lt, :].contiguous()
+        S_lt = S_leq_t[..., :n_lt, :n_lt].contiguous()
         if isinstance(cache, dict):
-            cache['Lz_lt'] = cache_leq_t['Lz']
-            cache['Lz_lt_Kz_lt_z_t'] = cache_leq_t['Lz_Kzx']
+            # factor of K(z_<t) + eps I and Lz_<t^-1 K(z_<t, z_t), as the chain's last linear_joint call left them
+            cache['Lz_lt'] = L[..., :n_lt, :n_lt]
+            cache['Lz_lt_Kz_lt_z_t'] = L[..., n_lt:, :n_lt].mT
         return mu_lt, S_lt, mu_leq_t, S_leq_t, z_lt, z_leq_t
 
     def compute_pf_diag(self, theta, x, mu_leq_t, S_leq_t, z_leq_t, cache=None):
