@@ -80,6 +80,28 @@ def linear_joint(m, S, Kzx, Kzz, V, b, cache=None):
     return mu, Sigma
 
 
+def block_joint(K, means, trils):
+    """The chain of linear_joint calls over tasks 0 .. t (vargp.py:35-88: q(u_<=t | theta) folded task by task) in ONE
+    factorisation.  K (S, C, Mt, Mt) = kernel matrix of the inducing points of all tasks in task order; means[i] (C, M_i, 1),
+    trils[i] (C, M_i, M_i) the per-task variational means / Cholesky factors.  With K' = K + eps I, L = chol(K'), T = L^-1 and
+    the diagonal blocks T_ii (identities pinned in fp64 by tests/test_block_algorithm.py):
+        a = [T_ii m_i]_i,   H = blockdiag(T_ii Lu_i),   mu_<=t = L a,   S_<=t = (L H)(L H)^T
+    -- every K_zz factor of the chain is a leading block of L (its per-step jitter is the diagonal of K'), and the joint over
+    the tasks before the last one is the leading block of mu / S.  Returns L, T, mu (S, C, Mt, 1), Sigma (S, C, Mt, Mt)."""
+    L, T = ops.chol_inv(K)
+    a_blk, lh_blk, o = [], [], 0
+    for m, Lu in zip(means, trils):
+        n = m.size(-2)
+        T_ii = T[..., o:o + n, o:o + n].contiguous()
+        a_blk.append(ops.matmul(T_ii, m.unsqueeze(0), triA=LOWER))                                        # T_ii m_i
+        H_i = ops.matmul(T_ii, Lu.unsqueeze(0), triA=LOWER, triB=LOWER, triC=LOWER)
+        lh_blk.append(ops.matmul(L[..., :, o:o + n].contiguous(), H_i, triB=LOWER))                       # columns of L H
+        o += n
+    a = torch.cat(a_blk, dim=-2)
+    LH = torch.cat(lh_blk, dim=-1)                                                                        # lower: chol of S_<=t
+    return L, T, ops.matmul(L, a, triA=LOWER), ops.matmul(LH, LH.mT)
+
+
 def marginal_prepare(m, S, Kzz):
     """The x-independent part of linear_marginal_diag: Lz = chol(Kzz + eps I), Tz = Lz^-1, a = Lz^-1 m,
     G = Lz^-1 chol(S + eps I).  Reusable across minibatch tiles that share the hyper-sample."""

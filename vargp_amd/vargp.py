@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import fused, gp_utils, noise, ops
-from .gp_utils import vec2tril, mat2trilvec, cholesky, rev_cholesky, gp_cond, linear_joint, linear_marginal_diag
+from .gp_utils import vec2tril, mat2trilvec, cholesky, rev_cholesky, gp_cond, block_joint, linear_marginal_diag
 from .kernels import RBFKernel, DeepRBFKernel
 from .likelihoods import MulticlassSoftmax
 from .ops import LOWER
@@ -73,33 +73,22 @@ class VARGP(nn.Module):
     def compute_q(self, theta, cache=None):
         """Fold previous tasks into q(u_<t | theta) and q(u_<=t | theta)  (vargp.py:35-88).
         Returns mu_lt, S_lt, mu_leq_t, S_leq_t, z_leq_t."""
-        n_hypers = theta.size(0)
-        p0 = self._prev(0)
-        z_lt = p0['z']
-        mu_lt = p0['u_mean'].unsqueeze(0).expand(n_hypers, -1, -1, -1)
-        S_lt = rev_cholesky(p0['u_tril']).unsqueeze(0).expand(n_hypers, -1, -1, -1)
-
-        for i in range(1, len(self.prev_params)):
-            p = self._prev(i)
-            Kzx = self.kernel.compute(theta, z_lt, p['z'])
-            Kzz = self.kernel.compute(theta, z_lt)
-            V = rev_cholesky(p['u_tril']).unsqueeze(0)
-            b = p['u_mean'].unsqueeze(0)
-            mu_lt, S_lt = linear_joint(mu_lt, S_lt, Kzx, Kzz, V, b)
-            z_lt = torch.cat([z_lt, p['z']], dim=-2)
-
-        Kzx = self.kernel.compute(theta, z_lt, self.z)
-        Kzz = self.kernel.compute(theta, z_lt)
-        V = rev_cholesky(vec2tril(self.u_tril_vec, self.M)).unsqueeze(0)
-        b = self.u_mean.unsqueeze(0)
-        cache_leq_t = dict()
-        mu_leq_t, S_leq_t = linear_joint(mu_lt, S_lt, Kzx, Kzz, V, b, cache=cache_leq_t)
-        z_leq_t = torch.cat([z_lt, self.z], dim=-2)
-
+        # block form (gp_utils.block_joint, DESIGN.md section 3) instead of the reference's chain of linear_joint calls: one
+        # kernel matrix over the inducing points of all tasks, one factorisation; the joint over the earlier tasks is the
+        # leading block of the joint over all of them
+        prev = [self._prev(i) for i in range(len(self.prev_params))]
+        n_lt = sum(p['z'].size(-2) for p in prev)
+        z_leq_t = torch.cat([p['z'] for p in prev] + [self.z], dim=-2)
+        L, T, mu_leq_t, S_leq_t = block_joint(self.kernel.compute(theta, z_leq_t), [p['u_mean'] for p in prev] + [self.u_mean],
+                                              [p['u_tril'] for p in prev] + [vec2tril(self.u_tril_vec, self.M)])
+        mu_lt = mu_leq_t[..., :n_lt, :].contiguous()
+        S_lt = S_leq_t[..., :n_lt, :n_lt].contiguous()
         if isinstance(cache, dict):
-            cache['Lz_lt'] = cache_leq_t['Lz']
-            cache['Tz_lt'] = cache_leq_t['Tz']
-            cache['Lz_lt_Kz_lt_z_t'] = cache_leq_t['Lz_Kzx']
+            # factors of K(z_<t) + eps I and Lz_<t^-1 K(z_<t, z_t), as the chain's last step left them: leading blocks of L, T
+            # and -- K_{t,<} = L_{t,<} L_<<^T -- the transposed off-diagonal block row of L
+            cache['Lz_lt'] = L[..., :n_lt, :n_lt].contiguous()
+            cache['Tz_lt'] = T[..., :n_lt, :n_lt].contiguous()
+            cache['Lz_lt_Kz_lt_z_t'] = L[..., n_lt:, :n_lt].mT.contiguous()
         return mu_lt, S_lt, mu_leq_t, S_leq_t, z_leq_t
 
     def compute_pf_diag(self, theta, x, mu_leq_t, S_leq_t, z_leq_t, cache=None):

@@ -62,29 +62,15 @@ class VARGPRetrain(nn.Module):
         """q(u_<t | theta) and q(u_<=t | theta) for the given earlier-task parameters (vargp_retrain.py:38-92; the reference
         folds the tasks in one by one with gp_utils.linear_joint).  Returns mu_lt, S_lt, mu_leq_t, S_leq_t, z_lt, z_leq_t.
 
-        Evaluated in the block form of DESIGN.md section 3 instead of the chain: ONE kernel matrix K' = K(z_<=t, z_<=t) + eps I
-        over the inducing points of all tasks (task order), one factorisation L = chol(K'), T = L^-1, and with the diagonal
-        blocks T_ii:  a = [T_ii m_i]_i,  H = blockdiag(T_ii Lu_i)  ->  mu_<=t = L a,  S_<=t = (L H)(L H)^T;  the joint over the
-        earlier tasks is the leading block of both (the leading block of a Cholesky factor is the factor of the leading block,
-        and the jitter the reference adds to every K_zz of its chain is the diagonal of K').  The identities are pinned in fp64
-        against the chain by tests/test_block_algorithm.py; gradients flow through ops.* as before."""
+        Evaluated in the block form of DESIGN.md section 3 instead of the chain (gp_utils.block_joint): one kernel matrix over
+        the inducing points of all tasks, one factorisation, GEMMs; the joint over the earlier tasks is the leading block of the
+        joint over all of them.  Gradients flow through ops.* as before."""
         blocks = list(prev_params) + [dict(z=self.z, u_mean=self.u_mean, u_tril_vec=self.u_tril_vec)]
-        sizes = [p['z'].size(-2) for p in blocks]
+        n_lt = sum(p['z'].size(-2) for p in blocks[:-1])
         z_leq_t = torch.cat([p['z'] for p in blocks], dim=-2)
-        z_lt = z_leq_t[..., :sum(sizes[:-1]), :].contiguous()
-        L, T = ops.chol_inv(self.kernel.compute(theta, z_leq_t))                      # (S, C, Mt, Mt)
-        a_blk, lh_blk, o = [], [], 0
-        for p, n in zip(blocks, sizes):
-            T_ii = T[..., o:o + n, o:o + n].contiguous()
-            a_blk.append(ops.matmul(T_ii, p['u_mean'].unsqueeze(0), triA=LOWER))                          # T_ii m_i
-            H_i = ops.matmul(T_ii, vec2tril(p['u_tril_vec']).unsqueeze(0), triA=LOWER, triB=LOWER, triC=LOWER)
-            lh_blk.append(ops.matmul(L[..., :, o:o + n].contiguous(), H_i, triB=LOWER))                   # columns of L H
-            o += n
-        a = torch.cat(a_blk, dim=-2)                                                   # (S, C, Mt, 1)
-        LH = torch.cat(lh_blk, dim=-1)                                                 # (S, C, Mt, Mt), lower
-        n_lt = o - sizes[-1]
-        mu_leq_t = ops.matmul(L, a, triA=LOWER)
-        S_leq_t = ops.matmul(LH, LH.mT)
+        z_lt = z_leq_t[..., :n_lt, :].contiguous()
+        L, _, mu_leq_t, S_leq_t = gp_utils.block_joint(self.kernel.compute(theta, z_leq_t), [p['u_mean'] for p in blocks],
+                                                       [vec2tril(p['u_tril_vec']) for p in blocks])
         mu_lt = mu_leq_t[..., :n_lt, :].contiguous()
         S_lt = S_leq_t[..., :n_lt, :n_lt].contiguous()
         if isinstance(cache, dict):
