@@ -42,7 +42,10 @@ SHAPES = [(2, 3, 3, 33, 40, 50), (3, 2, 4, 20, 64, 37), (2, 2, 18, 12, 36, 24), 
           # that the K_uu roles accumulate (BwdMatArgs::gL_acc); 17 and 33 hyper-samples
           (17, 1, 16, 52, 36, 64), (33, 1, 8, 100, 36, 72),
           # ... D >= 256: behind the front launch (x o w operand), the Gram matrices built by the chain workgroups (chol_gram.h)
-          (13, 1, 10, 100, 256, 128)]
+          (13, 1, 10, 100, 256, 128),
+          # the tile kernels WITHOUT the per-matrix chains / fused tail (t0_bwd_paths: fused_bwd but not mat_bwd): D % 4 != 0, and
+          # more hyper-samples than the tail kernels take (S > kTailSMax = 64)
+          (3, 2, 2, 52, 38, 40), (65, 1, 2, 52, 36, 40)]
 
 
 @pytest.mark.parametrize('shape', SHAPES, ids=[str(s) for s in SHAPES])
