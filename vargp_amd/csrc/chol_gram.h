@@ -111,8 +111,10 @@ __device__ __forceinline__ void cg_gram(const float* __restrict__ z, const float
     }
     if (s + 1 < nslab) store_slab(s + 1, lds + ((s + 1) & 1) * kCgPanel);
     load_slab(s + 2);
-    __syncthreads();
+    // LDS-only barrier: __syncthreads() = s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier would wait for the loads just issued
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
+  __syncthreads();      // (the caller overwrites the panels)
 }
 
 // acc -> G in the staging matrix (row stride LS, both triangles) and its diagonal in `diag` (>= n floats)
