@@ -35,6 +35,7 @@
 #pragma once
 #include "common.h"
 #include "chol_gram.h"
+#include "chol_blk16.h"
 #include <math.h>
 #include <type_traits>
 #ifndef STAMP
@@ -109,6 +110,11 @@ __device__ __forceinline__ float lane_bcast(float v, int lane) {
 // 1: four pivots per barrier (chol4_steps, below); 0: the rank-1 version (one pivot per barrier)
 #ifndef VARGP_CHOL_BLOCK4
 #define VARGP_CHOL_BLOCK4 1
+#endif
+// 1: fp32 chains of 64 < n <= 100 run the blocked elimination on the matrix core (chol_blk16.h) wherever the matrix passes through
+// the staging area in LDS; 0: the register-resident elimination below everywhere
+#ifndef VARGP_CHOL_BLK16
+#define VARGP_CHOL_BLK16 1
 #endif
 constexpr int kCholBufs = VARGP_CHOL_FLAGSYNC ? 4 : 2;
 template <class R>
@@ -364,6 +370,9 @@ __device__ __forceinline__ void chol3_body(const int64_t b, const float* __restr
 
   const int di = 256 / n, dj = 256 - di * n;   // element e -> e + 256 without a division per element
   chol_v2<R> v[KC];
+  // fp32, 64 < n: the blocked elimination on the matrix core takes the matrix from the staging area (chol_blk16.h)
+  constexpr bool kBlk = VARGP_CHOL_BLK16 && std::is_same<R, float>::value && KC == 25 && SETS == 2;
+  bool in_stage = false;                       // (uniform) the input path has left the whole matrix (lower triangle valid) in `stage`
 #ifdef VARGP_CHOL_PHASES
   const int64_t phase_last_ = (int64_t)gridDim.x < 0 ? 0 : g_chol_phase_last;
 #endif
@@ -434,16 +443,26 @@ __device__ __forceinline__ void chol3_body(const int64_t b, const float* __restr
     CHOL_PHASE(8);
     __syncthreads();
     CHOL_PHASE(9);
+    if constexpr (kBlk) { in_stage = true; } else
+    {
+      // every LDS read first, then the selects: written as one loop the compiler waits for each row's pair of reads before
+      // it issues the next (25 LDS round trips in a row: 1.6 us of the chain's load phase)
+      float sa_[KC], sb_[KC];
 #pragma unroll
-    for (int k = 0; k < KC; ++k) {
-      const int i = 4 * k + w;
-      const int ic = min(i, n - 1);
-      const float sa = stage[ic * LS + min(ca, n - 1)], sb = stage[ic * LS + min(cb, n - 1)];   // unconditional reads
-      v[k].x = (i < n && minea) ? (R)sa + (i == ca ? (R)eps : R(0)) : chol_pad<R>(i, ca, n);
-      v[k].y = (i < n && mineb) ? (R)sb + (i == cb ? (R)eps : R(0)) : chol_pad<R>(i, cb, n);
+      for (int k = 0; k < KC; ++k) {
+        const int ic = min(4 * k + w, n - 1);
+        sa_[k] = stage[ic * LS + min(ca, n - 1)]; sb_[k] = stage[ic * LS + min(cb, n - 1)];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < KC; ++k) {
+        const int i = 4 * k + w;
+        v[k].x = (i < n && minea) ? (R)sa_[k] + (i == ca ? (R)eps : R(0)) : chol_pad<R>(i, ca, n);
+        v[k].y = (i < n && mineb) ? (R)sb_[k] + (i == cb ? (R)eps : R(0)) : chol_pad<R>(i, cb, n);
+      }
     }
     CHOL_PHASE(7);
-    __syncthreads();      // `stage` is reused for the results
+    if (!in_stage) __syncthreads();      // `stage` is reused for the results
   }
   }
   if (gram_done) {
@@ -528,13 +547,23 @@ __device__ __forceinline__ void chol3_body(const int64_t b, const float* __restr
       CHOL_PHASE(8);
       __syncthreads();
       CHOL_PHASE(9);
+      if constexpr (kBlk) { in_stage = true; } else
+      {
+        // every LDS read first, then the selects: written as one loop the compiler waits for each row's pair of reads before
+        // it issues the next (25 LDS round trips in a row: 1.6 us of the chain's load phase)
+        float sa_[KC], sb_[KC];
 #pragma unroll
-      for (int k = 0; k < KC; ++k) {
-        const int i = 4 * k + w;
-        const int ic = min(i, n - 1);
-        const float sa = stage[ic * LS + min(ca, n - 1)], sb = stage[ic * LS + min(cb, n - 1)];   // unconditional reads
-        v[k].x = (i < n && minea) ? (R)sa + (i == ca ? (R)eps : R(0)) : chol_pad<R>(i, ca, n);
-        v[k].y = (i < n && mineb) ? (R)sb + (i == cb ? (R)eps : R(0)) : chol_pad<R>(i, cb, n);
+        for (int k = 0; k < KC; ++k) {
+          const int ic = min(4 * k + w, n - 1);
+          sa_[k] = stage[ic * LS + min(ca, n - 1)]; sb_[k] = stage[ic * LS + min(cb, n - 1)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+          const int i = 4 * k + w;
+          v[k].x = (i < n && minea) ? (R)sa_[k] + (i == ca ? (R)eps : R(0)) : chol_pad<R>(i, ca, n);
+          v[k].y = (i < n && mineb) ? (R)sb_[k] + (i == cb ? (R)eps : R(0)) : chol_pad<R>(i, cb, n);
+        }
       }
     } else {
     const int cac = min(ca, n - 1), cbc = min(cb, n - 1);
@@ -577,8 +606,8 @@ __device__ __forceinline__ void chol3_body(const int64_t b, const float* __restr
     }
     }
     CHOL_PHASE(7);
-    __syncthreads();      // `stage` is reused for the results
-  } else if (extra && extra->symmetric_input) {
+    if (!in_stage) __syncthreads();      // `stage` is reused for the results
+  } else if (extra && extra->symmetric_input && !kBlk) {
     // both triangles valid: row i lies across the lanes, coalesced as it is.  Unconditional loads on clamped indices, all in
     // flight together, then selects (a load inside a bounds branch is its own round trip: 2 KC of them)
     float ra[KC], rb[KC];
@@ -640,18 +669,34 @@ __device__ __forceinline__ void chol3_body(const int64_t b, const float* __restr
     }
     __syncthreads();
     CHOL_PHASE(6);
+    if constexpr (kBlk) { in_stage = true; } else
+    {
+      float sa_[KC], sb_[KC];          // (reads first, selects behind them: see the partial-sum path)
 #pragma unroll
-    for (int k = 0; k < KC; ++k) {
-      const int i = 4 * k + w;
-      const int ic = min(i, n - 1), cac = min(ca, n - 1), cbc = min(cb, n - 1);
-      const float sa = stage[max(ic, cac) * LS + min(ic, cac)], sb = stage[max(ic, cbc) * LS + min(ic, cbc)];   // unconditional
-      v[k].x = (i < n && minea) ? (R)sa + (i == ca ? (R)eps : R(0)) : chol_pad<R>(i, ca, n);
-      v[k].y = (i < n && mineb) ? (R)sb + (i == cb ? (R)eps : R(0)) : chol_pad<R>(i, cb, n);
+      for (int k = 0; k < KC; ++k) {
+        const int ic = min(4 * k + w, n - 1), cac = min(ca, n - 1), cbc = min(cb, n - 1);
+        sa_[k] = stage[max(ic, cac) * LS + min(ic, cac)]; sb_[k] = stage[max(ic, cbc) * LS + min(ic, cbc)];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < KC; ++k) {
+        const int i = 4 * k + w;
+        v[k].x = (i < n && minea) ? (R)sa_[k] + (i == ca ? (R)eps : R(0)) : chol_pad<R>(i, ca, n);
+        v[k].y = (i < n && mineb) ? (R)sb_[k] + (i == cb ? (R)eps : R(0)) : chol_pad<R>(i, cb, n);
+      }
     }
   }
 
   CHOL_PHASE(1);
   int fail = 0;
+  bool blk_done = false;
+  if constexpr (kBlk) {
+    if (in_stage) {                              // (uniform)
+      cb16_factor(stage, LS, sq, sd, n, eps, tid, reinterpret_cast<int*>(red), fail);
+      blk_done = true;
+    }
+  }
+  if (!blk_done) {
 #if VARGP_CHOL_BLOCK4
   {
     // four pivots per barrier (chol4_steps); the LDS of the rank-1 version's row buffers holds the block's four rows
@@ -684,6 +729,7 @@ __device__ __forceinline__ void chol3_body(const int64_t b, const float* __restr
 #ifdef VARGP_CHOL_STAMPS
   if (tid == 0 && b == 0) for (int i = 0; i < 8; ++i) g_chol_stamps[i] = acc_[i];
 #endif
+  }
   CHOL_PHASE(2);
   if (fail) {
     if (tid == 0 && info) { if (info[b] == 0) info[b] = info_base + fail; }
@@ -696,6 +742,7 @@ __device__ __forceinline__ void chol3_body(const int64_t b, const float* __restr
     if (logdet && tid == 0) logdet[b] = qnan;
     return;
   }
+  if (!blk_done) {
   if (tid < n) {   // sq = sqrt(d), sd <- 1 / sqrt(d): once per pivot, not per entry; hardware estimate + two Newton steps
     const double d = sd[tid];                       // (the IEEE sqrt / division sequences are ~10x longer; d > 0 here)
     double r = __builtin_amdgcn_rsq(d);
@@ -720,6 +767,7 @@ __device__ __forceinline__ void chol3_body(const int64_t b, const float* __restr
     }
   }
   __syncthreads();
+  }
   CHOL_PHASE(3);
   const bool diag_only = extra && extra->diag_only_before_first && b < extra->first;   // only diag(L) is wanted (zeros elsewhere)
   // optional extra destination(s) for L (CholExtra, common.h)

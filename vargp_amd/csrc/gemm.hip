@@ -1358,6 +1358,13 @@ static int launch_chol_rbf_gemm_impl(const float* A, float eps, float* L, float*
   static const int exp_role = [] { const char* e = getenv("VARGP_EXP_MERGED"); return e ? atoi(e) : 0; }();
   if (exp_role == 2) { c.nchol = 0; nchol = 0; }
   if (exp_role == 1) nbatch = 0;
+  // the zero-fill role: as many workgroups as CUs are left over (every workgroup of this launch has a CU to itself: registers), so
+  // that they start with the launch -- 64 of them behind 232 others waited for the first chain or tile to end and WERE the end of
+  // the launch (span 37.7 us with the chains done at 31.4 and the tiles at 31)
+  if (any_zero && nbatch > 0) {
+    const int spare = current_cu_count() - nchol - tiles * nbatch;
+    if (spare >= 8) c.nzero = spare < 64 ? spare : 64;
+  }
   const int total = nchol + tiles * nbatch + c.nzero;
   // The kernel needs 68 KB of LDS, so two workgroups fit a CU.  While the GEMM is small enough to finish under the
   // factorisations anyway (the BASELINE shapes), reserving unused dynamic LDS keeps every factorising CU to itself --
