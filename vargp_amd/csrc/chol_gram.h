@@ -46,9 +46,14 @@ __device__ __forceinline__ void cg_mfma4(cg_f32x4& acc, const float4 a, const fl
 
 // z: the class's inducing points [n][D] (16-byte aligned, D % 4 == 0, D <= kCgMaxD); w: the sample's 1/sigma^2 [D];
 // lds: kCgLdsFloats floats.  acc[u]: block (rb(u), cb(u)) of G, register r = row 16 rb + 4 (lane / 16) + r, column 16 cb + lane % 16.
-template <int WV>
+// LOWER: z is lower triangular (n x n, zeros above the diagonal: the Cholesky factor of q(u)): a 16-row block has no entries in
+// the k-groups to the right of it, so block (rb, cb) only takes the k-groups kb <= cb (<= rb) -- 84 of the 196 block products.
+// PACKED (with LOWER): z is that factor's PACKED vector (row i: i + 1 entries at offset i (i + 1) / 2, gp_utils.py:22-49) and
+// `diag` maps the stored diagonal entries to the factor's (softplus); D = n.
+struct CgNoDiag { __device__ __forceinline__ float operator()(float v) const { return v; } };
+template <int WV, bool LOWER = false, bool PACKED = false, class DiagF = CgNoDiag>
 __device__ __forceinline__ void cg_gram(const float* __restrict__ z, const float* __restrict__ w, const int n, const int D,
-                                        float* __restrict__ lds, cg_f32x4 (&acc)[7], const int tid) {
+                                        float* __restrict__ lds, cg_f32x4 (&acc)[7], const int tid, DiagF diag = DiagF()) {
   using W = CgTri<WV>;
   float* sw = lds + 2 * kCgPanel;
   const int lane = tid & 63, l16 = lane & 15, q = lane >> 4;
@@ -67,8 +72,22 @@ __device__ __forceinline__ void cg_gram(const float* __restrict__ z, const float
   float4 rg[4];
   auto load_slab = [&](int s) {
     const int k0 = min(s, nslab - 1) * kCgBK;
+    if constexpr (PACKED) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) rg[u] = *reinterpret_cast<const float4*>(zp[u] + min(k0, D - 4 - sq[u]));
+      for (int u = 0; u < 4; ++u) {
+        const int row = min(srow[u], n - 1), k = min(k0 + sq[u], D - 4);
+        const float* rp = z + (int64_t)row * (row + 1) / 2;
+        float e[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) e[t] = rp[min(k + t, row)];                 // (clamped: entries right of the diagonal are masked)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) e[t] = k + t < row ? e[t] : (k + t == row ? diag(e[t]) : 0.f);
+        rg[u] = make_float4(e[0], e[1], e[2], e[3]);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) rg[u] = *reinterpret_cast<const float4*>(zp[u] + min(k0, D - 4 - sq[u]));
+    }
   };
   auto store_slab = [&](int s, float* __restrict__ buf) {
     const int k0 = s * kCgBK;
@@ -83,7 +102,7 @@ __device__ __forceinline__ void cg_gram(const float* __restrict__ z, const float
     }
   };
   load_slab(0);
-  for (int d = tid; d < D; d += 256) sw[d] = sqrtf(w[d]);
+  for (int d = tid; d < D; d += 256) sw[d] = w ? sqrtf(w[d]) : 1.f;          // (w == NULL: the plain Gram matrix z z^T)
 #pragma unroll
   for (int u = 0; u < 7; ++u) acc[u] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
@@ -104,10 +123,17 @@ __device__ __forceinline__ void cg_gram(const float* __restrict__ z, const float
     frag(1);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
+      const int kb = 2 * s + h;                            // (uniform) the k-group of 16 this half-slab holds
       // (a block row's own fragment is the column fragment of its diagonal block: RA = NA - 1, and RB < NA for every wave)
-      cg_for<0, W::NA>([&](auto ui) { constexpr int u = decltype(ui)::value; cg_mfma4(acc[u], fb[h][W::RA], fb[h][u]); });
+      cg_for<0, W::NA>([&](auto ui) {
+        constexpr int u = decltype(ui)::value;
+        if (!LOWER || u >= kb) cg_mfma4(acc[u], fb[h][W::RA], fb[h][u]);
+      });
       if constexpr (W::NBk > 0)
-        cg_for<0, W::NBk>([&](auto ui) { constexpr int u = decltype(ui)::value; cg_mfma4(acc[W::NA + u], fb[h][W::RB], fb[h][u]); });
+        cg_for<0, W::NBk>([&](auto ui) {
+          constexpr int u = decltype(ui)::value;
+          if (!LOWER || u >= kb) cg_mfma4(acc[W::NA + u], fb[h][W::RB], fb[h][u]);
+        });
     }
     if (s + 1 < nslab) store_slab(s + 1, lds + ((s + 1) & 1) * kCgPanel);
     load_slab(s + 2);
@@ -135,6 +161,26 @@ __device__ __forceinline__ void cg_store(const cg_f32x4 (&acc)[7], float* __rest
         stage[i * LS + j] = v;
         stage[j * LS + i] = v;
         if (i == j) diag[i] = v;
+      }
+    }
+  });
+}
+
+// acc -> a symmetric n x n matrix in memory (row stride ld, both triangles)
+template <int WV>
+__device__ __forceinline__ void cg_store_global(const cg_f32x4 (&acc)[7], float* __restrict__ out, const int ld, const int n, const int lane) {
+  using W = CgTri<WV>;
+  const int l16 = lane & 15, q = lane >> 4;
+  cg_for<0, 7>([&](auto ui) {
+    constexpr int u = decltype(ui)::value;
+    constexpr int rb = W::rb(u), cb = W::cb(u);
+    const int j = 16 * cb + l16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 16 * rb + 4 * q + r;
+      if (i < n && j < n && (rb != cb || j <= i)) {
+        out[(int64_t)i * ld + j] = acc[u][r];
+        out[(int64_t)j * ld + i] = acc[u][r];
       }
     }
   });

@@ -465,6 +465,29 @@ __device__ __forceinline__ void chol3_body(const int64_t b, const float* __restr
     if (!in_stage) __syncthreads();      // `stage` is reused for the results
   }
   }
+  if constexpr (kBlk) {
+    if (!gram_done && extra && extra->su_Lu && b >= extra->first) {
+      // S_u = Lu Lu^T (gp_utils.py:182: the covariance of q(u) from its Cholesky vector) as a Gram matrix on the matrix core, by the
+      // workgroup that factorises it: the 100-long dot products of the prologue's S_u role (391 slow workgroups of the front
+      // launch, whose slots the norm role waited for) are gone
+      gram_done = true;
+      const float* lu = extra->su_Lu + (b - extra->first) * (int64_t)n * n;
+      float* diag = reinterpret_cast<float*>(sd);
+      {
+        cg_f32x4 acc[7];
+        if (w == 0) cg_gram<0, true>(lu, nullptr, n, n, stage, acc, tid);
+        else if (w == 1) cg_gram<1, true>(lu, nullptr, n, n, stage, acc, tid);
+        else if (w == 2) cg_gram<2, true>(lu, nullptr, n, n, stage, acc, tid);
+        else cg_gram<3, true>(lu, nullptr, n, n, stage, acc, tid);
+        if (w == 0) cg_store<0>(acc, stage, LS, diag, n, lane);
+        else if (w == 1) cg_store<1>(acc, stage, LS, diag, n, lane);
+        else if (w == 2) cg_store<2>(acc, stage, LS, diag, n, lane);
+        else cg_store<3>(acc, stage, LS, diag, n, lane);
+      }
+      __syncthreads();
+      in_stage = true;
+    }
+  }
   if (gram_done) {
   } else if (extra && extra->part && b < extra->first) {
     // K-split partial Gram matrices -> kernel matrix on the way in (CholExtra, common.h).  Summation order and formula of

@@ -243,6 +243,11 @@ constexpr int kCholPartMax = 4;
 // (torch.cholesky + triangular_solve in float32, gp_utils.py:5-11; measured accuracy = LAPACK fp32's).  Every other
 // factorisation (stand-alone op, n <= 50 kernel, diagonal blocks of the blocked path) stays fp64.
 constexpr int kCholF32Default = 1;
+// 1: fp32 chains of 64 < n <= 100 run the blocked elimination on the matrix core (chol_blk16.h) wherever the matrix passes through
+// the staging area in LDS; 0: the register-resident elimination of chol_small3.h everywhere
+#ifndef VARGP_CHOL_BLK16
+#define VARGP_CHOL_BLK16 1
+#endif
 constexpr int kProKuuMaxD = 4096;       // launch_pro_kuu: 1/sigma^2 of one hyper-sample staged in LDS by the norm role
 struct CholExtra {
   float* base; int first; int ld; int64_t stride_b, stride_copy; int ncopy;
@@ -251,6 +256,9 @@ struct CholExtra {
   // gram_z != NULL (chol_gram.h; instead of `part`): the matrices b < first = (s, c) are built by their factorising workgroup from the
   // inducing points gram_z [part_C][n][gram_D] and 1/sigma^2 gram_w [S][gram_Dp] (g2, part_C, Kout as for `part`)
   const float* gram_z; const float* gram_w; int gram_D; int64_t gram_Dp;
+  // su_Lu != NULL (fp32 chains of 64 < n <= 100 only): the matrices b >= first are S_u[c] = Lu[c] Lu[c]^T, c = b - first, built by
+  // their factorising workgroup from su_Lu [ncls][n][n] (lower triangular, zeros above) -- nothing is read from A for them
+  const float* su_Lu;
 };
 int vargp_cu_count();       // CUs of the current device (gemm.hip)
 int launch_chol_rbf_gemm(const float* A, float eps, float* L, float* T, int32_t* info, int nchol, int n,

@@ -953,6 +953,17 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
     a.eps_theta = d->eps_theta; a.vec = d->u_tril_vec;
     a.theta = o.theta; a.w = o.w; a.g2 = o.g2; a.kd = o.kd; a.Lu = o.Lu; a.Su = o.KS + SC * MM; a.scalars = d->scalars;
     a.bump = d->bump;
+    // S_u = Lu Lu^T by the workgroup that factorises it (CholExtra::su_Lu, chol_small3.h: fp32 chains of 64 < M <= 100 on the matrix
+    // core) instead of 100-long dot products in the prologue's Lu role.  VARGP_T0_SU_IN_CHAIN=0: off (tuning aid)
+    {
+      static const int f32_env = [] { const char* e = getenv("VARGP_CHOL_F32"); return e ? atoi(e) : kCholF32Default; }();
+      // VARGP_T0_SU=0: the Lu role's dot products (tuning aid).  Measured at Cfg2 (steps/s): 5323 with them; 5375 with the S_u chains
+      // building their matrix and the norm role in front of the (now short) prologue roles -- front launch 22.5 -> 19.0 us, the merged
+      // launch 35.2 -> 37.1 (the S_u chains become its longest); a workgroup per class inside the front launch instead: 5019 (its
+      // packed-vector loads are slow, and the heavier kernel costs the front launch a workgroup slot per SIMD)
+      static const int su_env = [] { const char* e = getenv("VARGP_T0_SU"); return e ? atoi(e) : 1; }();
+      a.su_in_chain = (VARGP_CHOL_BLK16 && su_env && f32_env && merge_chol && M > 64 && (M % 4) == 0 && M <= 100) ? 1 : 0;
+    }
     a.zero_begin = o.gmu; a.zero_count = o.r_uf - o.gmu; a.info = d->info; a.Dp = o.Dp;
     a.S = S; a.C = C; a.M = M; a.D = D; a.ninfo = SC + C; a.map_est = d->map_est;
     a.nzero_blocks = (int)std::min<int64_t>(64, cdiv(a.zero_count, 1024));
@@ -1063,6 +1074,7 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
         lx.part = o.kpart; lx.nsplit = ksp; lx.sSplit = SC * MM; lx.g2 = o.g2; lx.part_C = C; lx.Kout = o.KS;
         if (gram_in_chain) { lx.part = nullptr; lx.gram_z = d->z; lx.gram_w = o.w; lx.gram_D = D; lx.gram_Dp = o.Dp; }
       }
+      if (a.su_in_chain) lx.su_Lu = o.Lu;
       // many hyper-samples: the chains fill the chip by themselves and hide nothing -- the product runs as a launch of its own, two
       // workgroups per CU (the merged launch holds it to one by the chain role's registers): t0_unmerge_chains()
       const bool unmerge = SC + C >= t0_unmerge_chains();

@@ -1264,7 +1264,10 @@ int launch_pro_kuu(const ProArgs& a, int npro, const NormArgs& n, const GemmPara
   q.xcd_remap = 0; q.group_m = 0;
   const int tiles = cdiv(q.M, 64) * cdiv(q.N, 64), ngemm = nbatch > 0 ? tiles * nbatch * q.splitk : 0, nnorm = n.nrow_blocks * a.S;
   const dim3 grid(ngemm + npro + nnorm);
-  static const int nf = [] { const char* e = getenv("VARGP_PRO_NORMS_FIRST"); return e ? atoi(e) : 0; }();   // tuning aid
+  // norms_first: with the Lu role's dot products gone (ProArgs::su_in_chain) the prologue roles are short, and the norm role --
+  // the longest of the small roles -- goes in front of them (VARGP_PRO_NORMS_FIRST overrides: tuning aid)
+  static const int nf_env = [] { const char* e = getenv("VARGP_PRO_NORMS_FIRST"); return e ? atoi(e) : -1; }();
+  const int nf = nf_env >= 0 ? nf_env : (a.su_in_chain ? 1 : 0);
   if (bk == 64) hipLaunchKernelGGL((t0_pro_kuu_kernel<64>), grid, dim3(256), 0, st, a, npro, n, nnorm, q, tiles, ngemm, nf);
   else hipLaunchKernelGGL((t0_pro_kuu_kernel<32>), grid, dim3(256), 0, st, a, npro, n, nnorm, q, tiles, ngemm, nf);
   return check_launch("pro_kuu");

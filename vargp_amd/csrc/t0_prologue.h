@@ -25,6 +25,8 @@ struct ProArgs {
   // accumulators of the BACKWARD that need no seed to be cleared (elbo_t0.hip: the LDS-resident backward then starts without a
   // head launch of its own)
   ZeroJobs zero;
+  int su_in_chain;      // S_u = Lu Lu^T is formed on the matrix core by its factorising workgroup (CholExtra::su_Lu): the Lu role
+                        // here writes Lu / RK only
 };
 
 // theta[s, d] = mean_d + eps[s, d] exp(logvar_d / 2) (kernels.py:62-68; MAP: mean_d): a pure function of the parameters and
@@ -154,7 +156,7 @@ __device__ __forceinline__ void t0_prologue_body(const ProArgs& a, const int blk
   const float* rh = v + (int64_t)hi * (hi + 1) / 2;
   const float* rl = v + (int64_t)lo * (lo + 1) / 2;
   float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;   // independent chains: the loads of a group are in flight together
-  int k = 0;
+  int k = a.su_in_chain ? lo : 0;                          // (su_in_chain: no dot product, no S_u from here)
   for (; k + 4 <= lo; k += 4) {
     acc0 = fmaf(rh[k], rl[k], acc0); acc1 = fmaf(rh[k + 1], rl[k + 1], acc1);
     acc2 = fmaf(rh[k + 2], rl[k + 2], acc2); acc3 = fmaf(rh[k + 3], rl[k + 3], acc3);
@@ -162,7 +164,7 @@ __device__ __forceinline__ void t0_prologue_body(const ProArgs& a, const int blk
   for (; k < lo; ++k) acc0 = fmaf(rh[k], rl[k], acc0);
   const float dl = softplus_t0(rl[lo]);
   const float acc = fmaf(hi == lo ? dl : rh[lo], dl, (acc0 + acc1) + (acc2 + acc3));
-  a.Su[e] = acc;
+  if (!a.su_in_chain) a.Su[e] = acc;
   const float lu = j < i ? v[(int64_t)i * (i + 1) / 2 + j] : (j == i ? dl : 0.f);
   a.Lu[e] = lu;
   if (a.RK) {   // RK[s, c, i, :] = [ m | 0 0 0 | (L_S: by the factorisation) | Lu | 0.. ]
