@@ -398,10 +398,10 @@ __device__ __forceinline__ void chol3_body(const int64_t b, const float* __restr
       else if (w == 2) cg_gram<2>(zc, wv, n, extra->gram_D, stage, acc, tid);
       else cg_gram<3>(zc, wv, n, extra->gram_D, stage, acc, tid);
       // (cg_gram ends on a barrier: nobody reads the panels any more)
-      if (w == 0) cg_store<0>(acc, stage, LS, diag, n, lane);
-      else if (w == 1) cg_store<1>(acc, stage, LS, diag, n, lane);
-      else if (w == 2) cg_store<2>(acc, stage, LS, diag, n, lane);
-      else cg_store<3>(acc, stage, LS, diag, n, lane);
+      if (w == 0) cg_store<0>(acc, stage, LS, diag, n, lane, reinterpret_cast<float*>(sq));
+      else if (w == 1) cg_store<1>(acc, stage, LS, diag, n, lane, reinterpret_cast<float*>(sq));
+      else if (w == 2) cg_store<2>(acc, stage, LS, diag, n, lane, reinterpret_cast<float*>(sq));
+      else cg_store<3>(acc, stage, LS, diag, n, lane, reinterpret_cast<float*>(sq));
     }
     __syncthreads();
     CHOL_PHASE(5);
@@ -479,10 +479,10 @@ __device__ __forceinline__ void chol3_body(const int64_t b, const float* __restr
         else if (w == 1) cg_gram<1, true>(lu, nullptr, n, n, stage, acc, tid);
         else if (w == 2) cg_gram<2, true>(lu, nullptr, n, n, stage, acc, tid);
         else cg_gram<3, true>(lu, nullptr, n, n, stage, acc, tid);
-        if (w == 0) cg_store<0>(acc, stage, LS, diag, n, lane);
-        else if (w == 1) cg_store<1>(acc, stage, LS, diag, n, lane);
-        else if (w == 2) cg_store<2>(acc, stage, LS, diag, n, lane);
-        else cg_store<3>(acc, stage, LS, diag, n, lane);
+        if (w == 0) cg_store<0>(acc, stage, LS, diag, n, lane, reinterpret_cast<float*>(sq));
+        else if (w == 1) cg_store<1>(acc, stage, LS, diag, n, lane, reinterpret_cast<float*>(sq));
+        else if (w == 2) cg_store<2>(acc, stage, LS, diag, n, lane, reinterpret_cast<float*>(sq));
+        else cg_store<3>(acc, stage, LS, diag, n, lane, reinterpret_cast<float*>(sq));
       }
       __syncthreads();
       in_stage = true;
