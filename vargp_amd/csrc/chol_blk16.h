@@ -73,7 +73,7 @@ __device__ __forceinline__ float cb_lane(float v, int lane) {
 // chol3_body's output loop: stage[r * LS + c] = L[r][c] for r > c and T[c][r] for r < c, sq[i] = L_ii, sd[i] = 1 / L_ii.
 template <int WV>
 __device__ __forceinline__ void cb16_wave(float* __restrict__ stage, const int LS, double* __restrict__ sq, double* __restrict__ sd,
-                                          const int n, const float eps, const int lane, int* __restrict__ flag, int& fail) {
+                                          const int n, const float eps, const int lane, int* __restrict__ flag, float* __restrict__ dump, int& fail) {
   using O = CbOwn<WV>;
   const int c = lane & 15, q = lane >> 4;
   cb_f32x4 accU[kCbNB], accX[kCbNB];
@@ -234,6 +234,7 @@ __device__ __forceinline__ void cb16_wave(float* __restrict__ stage, const int L
   CB_STAMP(7, 0);
   cb_barrier();                                          // the exchange areas are dead
   if (fail) return;
+  float* const mine = dump + lane;                       // where the entries that do not exist go (64 floats nobody reads)
   // ---- the factors into `stage`: L below the diagonal (R_ki[4 q + r][c] = L[16 i + c][16 k + 4 q + r]), T transposed above it
   //      (T_ij[4 q + r][c] = T[16 i + 4 q + r][16 j + c] -> stage[16 j + c][16 i + 4 q + r])
   cb_for<0, kCbNB>([&](auto ii) {
@@ -245,7 +246,7 @@ __device__ __forceinline__ void cb16_wave(float* __restrict__ stage, const int L
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int col = 16 * k + 4 * q + r;
-          if (row < n && col < row) stage[row * LS + col] = accU[O::ui(i, k)][r];
+          *((row < n && col < row) ? &stage[row * LS + col] : mine) = accU[O::ui(i, k)][r];      // (no branches: see cg_store)
         }
       });
     }
@@ -256,7 +257,7 @@ __device__ __forceinline__ void cb16_wave(float* __restrict__ stage, const int L
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int trow = 16 * ib + 4 * q + r;          // T's row, the staging matrix's column
-          if (trow < n && col < trow) stage[col * LS + trow] = accX[O::xi(i, ib)][r];
+          *((trow < n && col < trow) ? &stage[col * LS + trow] : mine) = accX[O::xi(i, ib)][r];
         }
       });
     }
@@ -266,13 +267,13 @@ __device__ __forceinline__ void cb16_wave(float* __restrict__ stage, const int L
 
 // All four waves (256 threads).  Returns with `fail` set for every thread (0: fine) and, on success, a barrier behind the results.
 __device__ __forceinline__ void cb16_factor(float* __restrict__ stage, const int LS, double* __restrict__ sq, double* __restrict__ sd,
-                                            const int n, const float eps, const int tid, int* __restrict__ flag, int& fail) {
+                                            const int n, const float eps, const int tid, int* __restrict__ flag, float* __restrict__ dump, int& fail) {
   const int wave = tid >> 6, lane = tid & 63;
   fail = 0;
-  if (wave == 0) cb16_wave<0>(stage, LS, sq, sd, n, eps, lane, flag, fail);
-  else if (wave == 1) cb16_wave<1>(stage, LS, sq, sd, n, eps, lane, flag, fail);
-  else if (wave == 2) cb16_wave<2>(stage, LS, sq, sd, n, eps, lane, flag, fail);
-  else cb16_wave<3>(stage, LS, sq, sd, n, eps, lane, flag, fail);
+  if (wave == 0) cb16_wave<0>(stage, LS, sq, sd, n, eps, lane, flag, dump, fail);
+  else if (wave == 1) cb16_wave<1>(stage, LS, sq, sd, n, eps, lane, flag, dump, fail);
+  else if (wave == 2) cb16_wave<2>(stage, LS, sq, sd, n, eps, lane, flag, dump, fail);
+  else cb16_wave<3>(stage, LS, sq, sd, n, eps, lane, flag, dump, fail);
   __syncthreads();
 }
 

@@ -715,7 +715,12 @@ __device__ __forceinline__ void chol3_body(const int64_t b, const float* __restr
   bool blk_done = false;
   if constexpr (kBlk) {
     if (in_stage) {                              // (uniform)
-      cb16_factor(stage, LS, sq, sd, n, eps, tid, reinterpret_cast<int*>(red), fail);
+#if VARGP_CHOL_BLOCK4
+      float* dump16 = reinterpret_cast<float*>(&rows4[0][0][0]);        // (the row buffers of the register elimination: unused here)
+#else
+      float* dump16 = reinterpret_cast<float*>(&prow[0][0]);
+#endif
+      cb16_factor(stage, LS, sq, sd, n, eps, tid, reinterpret_cast<int*>(red), dump16, fail);
       blk_done = true;
     }
   }
