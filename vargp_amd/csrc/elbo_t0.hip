@@ -954,7 +954,7 @@ extern "C" int vargp_elbo_t0_fwd(const vargp_elbo_t0_desc* d, vargp_stream_t str
     a.theta = o.theta; a.w = o.w; a.g2 = o.g2; a.kd = o.kd; a.Lu = o.Lu; a.Su = o.KS + SC * MM; a.scalars = d->scalars;
     a.bump = d->bump;
     // S_u = Lu Lu^T by the workgroup that factorises it (CholExtra::su_Lu, chol_small3.h: fp32 chains of 64 < M <= 100 on the matrix
-    // core) instead of 100-long dot products in the prologue's Lu role.  VARGP_T0_SU_IN_CHAIN=0: off (tuning aid)
+    // core) instead of 100-long dot products in the prologue's Lu role.  VARGP_T0_SU=0: off (tuning aid)
     {
       static const int f32_env = [] { const char* e = getenv("VARGP_CHOL_F32"); return e ? atoi(e) : kCholF32Default; }();
       // VARGP_T0_SU=0: the Lu role's dot products (tuning aid).  Measured at Cfg2 (steps/s): 5323 with them; 5375 with the S_u chains
